@@ -1,0 +1,114 @@
+"""Pin the CPU oracle (oracle/clip_path.py) against vectors generated from the
+imported reference (tools/gen_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import clip_path as O
+from tests.util import golden, rel_l2, fill_state_from_numpy
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def _state(npz, prefix):
+    return {k[len(prefix):]: T(npz[k]) for k in npz.files if k.startswith(prefix)}
+
+
+def test_patchify_order():
+    g = golden("vit_blocks.npz")
+    assert torch.equal(O.patchify(T(g["patch_in"]), 8), T(g["patch_out"]))
+
+
+def test_attention_block():
+    g = golden("vit_blocks.npz")
+    P = _state(g, "attn:")
+    y = O.self_attention(T(g["x"]), P["to_qkv.weight"], P["to_out.0.weight"], P["to_out.0.bias"], 2)
+    assert rel_l2(y, T(g["attn_out"])) < 2e-6
+    P1 = _state(g, "attn1:")
+    assert "to_out.0.weight" not in P1          # Identity projection (vit.py:34)
+    y1 = O.self_attention(T(g["x"]), P1["to_qkv.weight"], None, None, 1)
+    assert rel_l2(y1, T(g["attn1_out"])) < 2e-6
+
+
+def test_feedforward_and_prenorm():
+    g = golden("vit_blocks.npz")
+    F = _state(g, "ff:")
+    y = O.feedforward(T(g["x"]), F["net.0.weight"], F["net.0.bias"], F["net.3.weight"], F["net.3.bias"])
+    assert rel_l2(y, T(g["ff_out"])) < 2e-6
+    A = _state(g, "attn:")
+    xn = O.layernorm(T(g["x"]), T(g["ln:weight"]), T(g["ln:bias"]))
+    yp = O.self_attention(xn, A["to_qkv.weight"], A["to_out.0.weight"], A["to_out.0.bias"], 2)
+    assert rel_l2(yp, T(g["prenorm_attn_out"])) < 2e-6
+
+
+def test_transformer_fwd_bwd():
+    g = golden("vit_blocks.npz")
+    P = _state(g, "tr:")
+    x = T(g["x"]).clone().requires_grad_(True)
+    y = O.prenorm_transformer(x, P, "", 2, 2)
+    assert rel_l2(y, T(g["tr_out"])) < 2e-6
+    gx = torch.autograd.grad((y * T(g["gy"])).sum(), x)[0]
+    assert rel_l2(gx, T(g["tr_gx"])) < 5e-6
+
+
+def _vivit(npz, P):
+    cfg = {k[4:]: int(npz[k]) for k in npz.files if k.startswith("cfg_")}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    logits = O.vivit_forward(T(npz["x"]), leaves, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
+    loss = O.bce_with_logits(logits, T(npz["target"]))
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    return logits, loss, dict(zip(leaves.keys(), grads))
+
+
+def test_vivit_tiny_end_to_end():
+    g = golden("vivit_tiny.npz")
+    P = _state(g, "w:")
+    logits, loss, grads = _vivit(g, P)
+    assert rel_l2(logits, T(g["logits"])) < 5e-6
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-6
+    for k, gr in grads.items():
+        assert rel_l2(gr, T(g["g:" + k])) < 2e-5, k
+    e = O.linear(O.patchify(T(g["x"]), 8), P["to_patch_embedding.1.weight"], P["to_patch_embedding.1.bias"])
+    assert rel_l2(e, T(g["act:patch_embed"])) < 2e-6
+
+
+def test_vivit_c1_end_to_end():
+    """BASELINE.json configs[0].  Weights are regenerated from the numpy stream
+    (tests/util.fill_state_from_numpy) in the reference's parameter order, which
+    is stored implicitly by the order of the g:* keys in the fixture."""
+    g = golden("vivit_c1.npz")
+    names = [k[2:] for k in g.files if k.startswith("g:")]
+    P = {n: torch.empty(g["g:" + n].shape) for n in names}
+    fill_state_from_numpy(P.items(), int(g["fill_seed"]))
+    logits, loss, grads = _vivit(g, P)
+    assert rel_l2(logits, T(g["logits"])) < 5e-6
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-6
+    for k, gr in grads.items():
+        assert rel_l2(gr, T(g["g:" + k])) < 5e-5, k
+
+
+def test_posenc_base_1000():
+    g = golden("posenc.npz")
+    for d, L in ((896, 14), (2048, 14), (64, 9)):
+        pe = O.sinusoid_table(d, L)
+        assert torch.allclose(pe, T(g[f"pe_{d}_{L}"]), atol=1e-6)
+        assert torch.allclose(torch.ones(L, 2, d) + pe, T(g[f"fwd_{d}_{L}"]), atol=1e-6)
+
+
+def test_encoder_postnorm():
+    g = golden("encoder_postnorm.npz")
+    P = _state(g, "w:")
+    x = T(g["x"]).clone().requires_grad_(True)
+    y = O.transformer_base(x, P, "", 2, int(g["nhead"]))
+    assert rel_l2(y, T(g["y"])) < 5e-6
+    gx = torch.autograd.grad((y * T(g["gy"])).sum(), x)[0]
+    assert rel_l2(gx, T(g["gx"])) < 2e-5
+
+
+def test_losses_against_torch():
+    torch.manual_seed(0)
+    z = torch.randn(5, 19, dtype=torch.float64) * 3
+    y = (torch.rand(5, 19) < 0.3).double()
+    assert abs(float(O.bce_with_logits(z, y)) - float(torch.nn.BCEWithLogitsLoss()(z, y))) < 1e-12
+    t = torch.randn(5, 19, dtype=torch.float64)
+    ref = torch.nn.CrossEntropyLoss()(z, t.argmax(-1))
+    assert abs(float(O.cross_entropy_hard(z, t)) - float(ref)) < 1e-12

@@ -1,0 +1,46 @@
+"""Shared test helpers (no reference code; data plumbing only)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name: str):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def fill_state_from_numpy(named_params, seed: int) -> None:
+    """Deterministic, platform-independent parameter fill (numpy PCG64 stream),
+    consumed in ``named_parameters()`` order.  Used by tools/gen_golden.py on the
+    reference model and by the tests on the build's mirror, so large fixtures
+    do not have to store weights.
+
+    1-D ``*.weight`` (LayerNorm scale) -> 1 + 0.1 n;  1-D other (biases) -> 0.1 n;
+    tokens / positional table -> 0.5 n;  matrices -> 0.05 n.
+    """
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, p in named_params:
+            a = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+            if p.dim() == 1:
+                a = (1.0 + 0.1 * a) if name.endswith("weight") else 0.1 * a
+            elif "token" in name or "pos_embedding" in name:
+                a = 0.5 * a
+            else:
+                a = 0.05 * a
+            p.copy_(torch.from_numpy(a).to(p.dtype))
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    den = float(b.norm())
+    return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+
+def max_abs(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the *imported reference* (build container only).
+
+Run here (never on the GPU box -- /root/reference does not exist there):
+
+    python tools/gen_golden.py
+
+The reference modules are loaded by file path with importlib and are never
+copied into this repository; only inputs / weights / outputs (data) are saved,
+as small ``.npz`` files under ``tests/golden/``.
+
+What is imported:
+  * /root/reference/src/models/vit.py            (ViViT and its blocks)   -- as is
+  * /root/reference/src/models/transformer.py    (PositionalEncoding)     -- needs
+    ``pytorch_lightning``, which is not installed; a 6-line stand-in module whose
+    ``LightningModule`` is ``torch.nn.Module`` is registered in ``sys.modules``
+    for the duration of this script (generator only; nothing of it is shipped).
+  * torch.nn.TransformerEncoderLayer from this container's torch: the
+    reference's arithmetic for ``TransformerBase`` *is* that class
+    (src/models/frame_transformer.py:41-44).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src/models"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+SEED = 1130  # src/main.py:25
+
+
+def _load(name: str, path: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import fill_state_from_numpy  # noqa: E402  (shared with the tests)
+
+
+def fill_from_numpy(model: torch.nn.Module, seed: int) -> None:
+    fill_state_from_numpy(model.named_parameters(), seed)
+
+
+def vivit_case(vit, tag, cfg, batch, store_weights, seed):
+    torch.manual_seed(seed)
+    net = vit.ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["frames"], dim=cfg["dim"],
+                    depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"])
+    fill_from_numpy(net, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    x = torch.from_numpy(rng.standard_normal(
+        (batch, cfg["frames"], 3, cfg["image"], cfg["image"])).astype(np.float32))
+    y = torch.from_numpy((rng.random((batch, cfg["classes"])) < 0.2).astype(np.float32))
+    y[:, 0] = 1.0
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+    out = {"x": x.numpy(), "target": y.numpy(), "logits": logits.detach().numpy(),
+           "loss": loss.detach().numpy()[None]}
+    for k, v in cfg.items():
+        out["cfg_" + k] = np.array(v)
+    out["fill_seed"] = np.array(seed + 1)
+    for name, p in net.named_parameters():
+        if store_weights:
+            out["w:" + name] = p.detach().numpy()
+        out["g:" + name] = p.grad.detach().numpy()
+    # intermediate activations for the tiny case (token assembly, space encoder)
+    if store_weights:
+        with torch.no_grad():
+            e = net.to_patch_embedding(x)
+            out["act:patch_embed"] = e.numpy()
+    np.savez_compressed(os.path.join(OUT, f"vivit_{tag}.npz"), **out)
+    print(f"vivit_{tag}: logits {tuple(logits.shape)} loss {loss.item():.6f}")
+
+
+def block_cases(vit):
+    torch.manual_seed(SEED)
+    out = {}
+    x = torch.randn(3, 10, 64)
+    att = vit.Attention(64, heads=2, dim_head=32)
+    ff = vit.FeedForward(64, 256)
+    ln = torch.nn.LayerNorm(64)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(64)); ln.bias.copy_(0.1 * torch.randn(64))
+    pre = vit.PreNorm(64, att)
+    pre.norm = ln
+    tr = vit.Transformer(64, 2, 2, 32, 128)
+    xg = x.clone().requires_grad_(True)
+    ya = att(xg); yf = ff(xg); yp = pre(xg); yt = tr(xg)
+    out["x"] = x.numpy()
+    out["attn_out"] = ya.detach().numpy(); out["ff_out"] = yf.detach().numpy()
+    out["prenorm_attn_out"] = yp.detach().numpy(); out["tr_out"] = yt.detach().numpy()
+    gy = torch.randn_like(yt)
+    out["gy"] = gy.numpy()
+    out["tr_gx"] = torch.autograd.grad((yt * gy).sum(), xg, retain_graph=True)[0].numpy()
+    out["attn_gx"] = torch.autograd.grad((ya * gy).sum(), xg, retain_graph=True)[0].numpy()
+    out["ff_gx"] = torch.autograd.grad((yf * gy).sum(), xg)[0].numpy()
+    for k, v in att.state_dict().items():
+        out["attn:" + k] = v.numpy()
+    for k, v in ff.state_dict().items():
+        out["ff:" + k] = v.numpy()
+    out["ln:weight"] = ln.weight.detach().numpy(); out["ln:bias"] = ln.bias.detach().numpy()
+    for k, v in tr.state_dict().items():
+        out["tr:" + k] = v.numpy()
+    # heads == 1 and dim_head == dim -> to_out is Identity (vit.py:34,41-44)
+    att1 = vit.Attention(64, heads=1, dim_head=64)
+    out["attn1_out"] = att1(x).detach().numpy()
+    for k, v in att1.state_dict().items():
+        out["attn1:" + k] = v.numpy()
+    # patchify ordering (vit.py:90)
+    from einops import rearrange
+    img = torch.randn(2, 3, 3, 16, 24)
+    out["patch_in"] = img.numpy()
+    out["patch_out"] = rearrange(img, 'b t c (h p1) (w p2) -> b t (h w) (p1 p2 c)', p1=8, p2=8).numpy()
+    np.savez_compressed(os.path.join(OUT, "vit_blocks.npz"), **out)
+    print("vit_blocks: ok")
+
+
+def encoder_layer_case():
+    """torch's own TransformerEncoderLayer == the arithmetic of TransformerBase
+    (frame_transformer.py:41-44): post-norm, ReLU, seq-first, eval mode."""
+    torch.manual_seed(SEED)
+    d, nhead, ff, L, B = 64, 2, 96, 7, 3
+    layer = torch.nn.TransformerEncoderLayer(d, nhead, ff, 0.5)
+    enc = torch.nn.TransformerEncoder(layer, 2, enable_nested_tensor=False)
+    enc.eval()
+    x = torch.randn(L, B, d, requires_grad=True)
+    y = enc(x)
+    gy = torch.randn_like(y)
+    gx = torch.autograd.grad((y * gy).sum(), x)[0]
+    out = {"x": x.detach().numpy(), "y": y.detach().numpy(), "gy": gy.numpy(), "gx": gx.numpy(),
+           "nhead": np.array(nhead)}
+    for k, v in enc.state_dict().items():
+        out["w:transformer." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder_postnorm.npz"), **out)
+    print("encoder_postnorm: ok")
+
+
+def posenc_case():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(torch.nn.Module):  # generator-only stand-in
+        pass
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    try:
+        tr = _load("ref_transformer", os.path.join(REF, "transformer.py"))
+    finally:
+        del sys.modules["pytorch_lightning"]
+    out = {}
+    for d, L in ((896, 14), (2048, 14), (64, 9)):
+        pe = tr.PositionalEncoding(d, 0.0, max_len=L)
+        x = torch.zeros(L, 2, d)
+        out[f"pe_{d}_{L}"] = pe.pe.numpy()
+        out[f"fwd_{d}_{L}"] = pe.eval()(x + 1.0).numpy()
+    np.savez_compressed(os.path.join(OUT, "posenc.npz"), **out)
+    print("posenc: ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    vit = _load("ref_vit", os.path.join(REF, "vit.py"))
+    tiny = dict(image=32, patch=8, classes=19, frames=3, dim=64, depth=2, heads=2, dim_head=32)
+    vivit_case(vit, "tiny", tiny, batch=2, store_weights=True, seed=SEED)
+    # BASELINE.json configs[0]: T=4, 64x64, d=128, 2 layers (plumbing config)
+    c1 = dict(image=64, patch=16, classes=19, frames=4, dim=128, depth=2, heads=2, dim_head=64)
+    vivit_case(vit, "c1", c1, batch=2, store_weights=False, seed=SEED + 10)
+    block_cases(vit)
+    encoder_layer_case()
+    posenc_case()
+
+
+if __name__ == "__main__":
+    main()
