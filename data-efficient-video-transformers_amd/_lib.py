@@ -1,0 +1,115 @@
+"""ctypes binding of libdvt_hip.so (the C ABI declared in include/dvt_hip.h).
+
+The product path has no fallback: if the shared library is missing or a call
+fails, a RuntimeError carrying ``dvt_last_error()`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvt_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_DGELU, EPI_DRELU = range(6)
+
+c_i64 = C.c_int64
+c_f = C.c_float
+c_p = C.c_void_p
+c_int = C.c_int
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_p), ("B", c_p), ("C", c_p),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+        ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("epilogue", C.c_int32), ("accumulate", C.c_int32),
+        ("bias", c_p), ("residual", c_p), ("ldr", c_i64),
+        ("aux", c_p), ("ldaux", c_i64),
+        ("alpha", c_f), ("split_k", C.c_int32),
+        ("workspace", c_p),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p),
+        ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p),
+        ("B", c_i64), ("H", c_i64), ("Lq", c_i64), ("Lk", c_i64), ("dh", c_i64),
+        ("q_sb", c_i64), ("q_sh", c_i64), ("q_sl", c_i64),
+        ("k_sb", c_i64), ("k_sh", c_i64), ("k_sl", c_i64),
+        ("v_sb", c_i64), ("v_sh", c_i64), ("v_sl", c_i64),
+        ("o_sb", c_i64), ("o_sh", c_i64), ("o_sl", c_i64),
+        ("scale", c_f), ("dtype", C.c_int32),
+        ("workspace", c_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/dvt_hip.h
+SIGNATURES = {
+    "dvt_version": (c_int, []),
+    "dvt_last_error": (C.c_char_p, []),
+    "dvt_device_info": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int]),
+    "dvt_cast": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_p]),
+    "dvt_add": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_axpby_f32": (c_int, [c_p, c_int, c_f, c_p, c_f, c_i64, c_p]),
+    "dvt_act_fwd": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p]),
+    "dvt_act_bwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_p]),
+    "dvt_patchify": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_patchify_bwd": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_tokens_assemble_fwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_tokens_assemble_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_rows_gather_fwd": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_rows_gather_bwd": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                  c_i64, c_f, c_int, c_p]),
+    "dvt_layernorm_bwd_workspace_bytes": (C.c_size_t, [c_i64]),
+    "dvt_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64,
+                                  c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "dvt_gemm": (c_int, [C.POINTER(GemmDesc), c_p]),
+    "dvt_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "dvt_colsum": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "dvt_attention_fwd": (c_int, [C.POINTER(AttnDesc), c_p]),
+    "dvt_attention_bwd": (c_int, [C.POINTER(AttnDesc), c_p]),
+    "dvt_bce_logits_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_bce_logits_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_ce_argmax_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
+    "dvt_ce_argmax_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
+    "dvt_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python data-efficient-video-transformers_amd/build.py` (needs hipcc); there is no "
+            "fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dvt_version() != 1:
+        raise RuntimeError(f"libdvt_hip.so ABI version {lib.dvt_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dvt_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdvt_hip {what} failed (status {rc}): {msg}")

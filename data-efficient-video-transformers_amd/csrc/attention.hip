@@ -1,0 +1,680 @@
+// attention.hip -- fused softmax(q k^T * scale) v, forward and backward.
+// Scores are never written to HBM.
+//
+// bf16 fast path (dh == 64, Lk <= 608): one workgroup per (batch, head).
+//   forward   K and V of the head are staged once in LDS as [key][64] images whose
+//             32-byte units are XOR-swizzled by (key>>1)&3 -- conflict-free both
+//             for ds_read_b128 row reads (K as the A operand of S^T = K Q^T) and
+//             for ds_read_b64_tr_b16 transposed reads (V^T as the A operand of
+//             O^T = V^T P^T).  Each wave owns 16-query tiles; the query sits on the
+//             MFMA *column* (lane & 15), so a lane owns one query: the softmax
+//             row-reduce is in-lane plus two wave shuffles (xor 16, 32), and the
+//             S^T accumulators are, converted to bf16, directly the B operand of
+//             the P V product (k order permuted identically on the V^T side).
+//             Online softmax over 32-key steps => any Lk that fits LDS.
+//   backward  two kernels with the same anatomy, no atomics, bitwise reproducible:
+//             dq   (query on the lane; recomputes S^T, dP^T; dQ^T = K^T dS^T)
+//             dkdv (key on the lane; recomputes S, dP; dV^T = dO^T P, dK^T = Q^T dS)
+//             7 MFMA products instead of the minimal 5, in exchange for no
+//             cross-wave reduction of any gradient.
+// generic path: any dtype / head dim / length that fits LDS, fp32 FMA, one wave
+// per row (fp32 parity mode; dh = 448 / 224 / 256 / 32 heads of the reference's
+// 14-token encoders).
+#include "common.h"
+
+namespace {
+
+// LDS hand-off between lanes of ONE wave (its LDS operations complete in order).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct AttnParams {
+  const void *q, *k, *v, *o, *d_o;
+  void *out, *dq, *dk, *dv;
+  float* lse;
+  float* delta;  // workspace [B*H*Lq] (generic bwd)
+  int B, H, Lq, Lk, dh;
+  int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl;
+  float scale;
+  int Lkp;  // Lk rounded up to 32
+  int Lqp;  // Lq rounded up to 32
+};
+
+// ======================================================================= generic
+// forward: one wave per (b, h, i).  LDS per wave: q row [dh] + probabilities [Lk].
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* qs = lds_f + (size_t)wid * (p.dh + p.Lk);
+  float* ps = qs + p.dh;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t total = (int64_t)p.B * p.H * p.Lq;
+  if (row >= total) return;
+  const int i = (int)(row % p.Lq);
+  const int h = (int)((row / p.Lq) % p.H);
+  const int b = (int)(row / ((int64_t)p.Lq * p.H));
+  const T* q = (const T*)p.q + b * p.q_sb + h * p.q_sh + (int64_t)i * p.q_sl;
+  const T* k = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* v = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  T* o = (T*)p.out + b * p.o_sb + h * p.o_sh + (int64_t)i * p.o_sl;
+  for (int e = lane; e < p.dh; e += 64) qs[e] = to_f32<T>(q[e]);
+  wave_lds_sync();
+  float m = -INFINITY;
+  for (int j = lane; j < p.Lk; j += 64) {
+    const T* kj = k + (int64_t)j * p.k_sl;
+    float s = 0.f;
+    for (int e = 0; e < p.dh; ++e) s = fmaf(qs[e], to_f32<T>(kj[e]), s);
+    s *= p.scale;
+    ps[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < p.Lk; j += 64) {
+    const float e = expf(ps[j] - m);
+    ps[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  wave_lds_sync();
+  const float inv = 1.0f / l;
+  for (int e = lane; e < p.dh; e += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < p.Lk; ++j) acc = fmaf(ps[j], to_f32<T>(v[(int64_t)j * p.v_sl + e]), acc);
+    o[e] = from_f32<T>(acc * inv);
+  }
+  if (lane == 0) p.lse[row] = m + logf(l);
+}
+
+// delta[b,h,i] = sum_e dO[i,e] * O[i,e]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t total = (int64_t)p.B * p.H * p.Lq;
+  if (row >= total) return;
+  const int i = (int)(row % p.Lq);
+  const int h = (int)((row / p.Lq) % p.H);
+  const int b = (int)(row / ((int64_t)p.Lq * p.H));
+  const int64_t off = b * p.o_sb + h * p.o_sh + (int64_t)i * p.o_sl;
+  const T* o = (const T*)p.o + off;
+  const T* g = (const T*)p.d_o + off;
+  float s = 0.f;
+  for (int e = lane; e < p.dh; e += 64) s = fmaf(to_f32<T>(o[e]), to_f32<T>(g[e]), s);
+  s = wave_sum(s);
+  if (lane == 0) p.delta[row] = s;
+}
+
+// dq: one wave per (b,h,i).  LDS per wave: q [dh], dO [dh], ds [Lk].
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_generic_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* qs = lds_f + (size_t)wid * (2 * p.dh + p.Lk);
+  float* gs = qs + p.dh;
+  float* ds = gs + p.dh;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t total = (int64_t)p.B * p.H * p.Lq;
+  if (row >= total) return;
+  const int i = (int)(row % p.Lq);
+  const int h = (int)((row / p.Lq) % p.H);
+  const int b = (int)(row / ((int64_t)p.Lq * p.H));
+  const T* q = (const T*)p.q + b * p.q_sb + h * p.q_sh + (int64_t)i * p.q_sl;
+  const T* g = (const T*)p.d_o + b * p.o_sb + h * p.o_sh + (int64_t)i * p.o_sl;
+  const T* k = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* v = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  T* dq = (T*)p.dq + b * p.q_sb + h * p.q_sh + (int64_t)i * p.q_sl;
+  for (int e = lane; e < p.dh; e += 64) {
+    qs[e] = to_f32<T>(q[e]);
+    gs[e] = to_f32<T>(g[e]);
+  }
+  wave_lds_sync();
+  const float lse = p.lse[row], delta = p.delta[row];
+  for (int j = lane; j < p.Lk; j += 64) {
+    const T* kj = k + (int64_t)j * p.k_sl;
+    const T* vj = v + (int64_t)j * p.v_sl;
+    float s = 0.f, dp = 0.f;
+    for (int e = 0; e < p.dh; ++e) {
+      s = fmaf(qs[e], to_f32<T>(kj[e]), s);
+      dp = fmaf(gs[e], to_f32<T>(vj[e]), dp);
+    }
+    const float pr = expf(s * p.scale - lse);
+    ds[j] = pr * (dp - delta) * p.scale;
+  }
+  wave_lds_sync();
+  for (int e = lane; e < p.dh; e += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < p.Lk; ++j) acc = fmaf(ds[j], to_f32<T>(k[(int64_t)j * p.k_sl + e]), acc);
+    dq[e] = from_f32<T>(acc);
+  }
+}
+
+// dk, dv: one wave per (b,h,j).  LDS per wave: k [dh], v [dh], p [Lq], ds [Lq].
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_generic_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* ks = lds_f + (size_t)wid * (2 * p.dh + 2 * p.Lq);
+  float* vs = ks + p.dh;
+  float* ps = vs + p.dh;
+  float* ds = ps + p.Lq;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t total = (int64_t)p.B * p.H * p.Lk;
+  if (row >= total) return;
+  const int j = (int)(row % p.Lk);
+  const int h = (int)((row / p.Lk) % p.H);
+  const int b = (int)(row / ((int64_t)p.Lk * p.H));
+  const T* kj = (const T*)p.k + b * p.k_sb + h * p.k_sh + (int64_t)j * p.k_sl;
+  const T* vj = (const T*)p.v + b * p.v_sb + h * p.v_sh + (int64_t)j * p.v_sl;
+  const T* q = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+  const T* g = (const T*)p.d_o + b * p.o_sb + h * p.o_sh;
+  T* dk = (T*)p.dk + b * p.k_sb + h * p.k_sh + (int64_t)j * p.k_sl;
+  T* dv = (T*)p.dv + b * p.v_sb + h * p.v_sh + (int64_t)j * p.v_sl;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* delta = p.delta + ((int64_t)b * p.H + h) * p.Lq;
+  for (int e = lane; e < p.dh; e += 64) {
+    ks[e] = to_f32<T>(kj[e]);
+    vs[e] = to_f32<T>(vj[e]);
+  }
+  wave_lds_sync();
+  for (int i = lane; i < p.Lq; i += 64) {
+    const T* qi = q + (int64_t)i * p.q_sl;
+    const T* gi = g + (int64_t)i * p.o_sl;
+    float s = 0.f, dp = 0.f;
+    for (int e = 0; e < p.dh; ++e) {
+      s = fmaf(to_f32<T>(qi[e]), ks[e], s);
+      dp = fmaf(to_f32<T>(gi[e]), vs[e], dp);
+    }
+    const float pr = expf(s * p.scale - lse[i]);
+    ps[i] = pr;
+    ds[i] = pr * (dp - delta[i]) * p.scale;
+  }
+  wave_lds_sync();
+  for (int e = lane; e < p.dh; e += 64) {
+    float av = 0.f, ak = 0.f;
+    for (int i = 0; i < p.Lq; ++i) {
+      av = fmaf(ps[i], to_f32<T>(g[(int64_t)i * p.o_sl + e]), av);
+      ak = fmaf(ds[i], to_f32<T>(q[(int64_t)i * p.q_sl + e]), ak);
+    }
+    dv[e] = from_f32<T>(av);
+    dk[e] = from_f32<T>(ak);
+  }
+}
+
+// ======================================================================= MFMA bf16, dh = 64
+constexpr int DH = 64;
+constexpr int kRowBytes = DH * 2;  // 128
+
+// byte offset of 16-byte chunk c (0..7) of row r in a dual-use [rows][64] image
+__device__ __forceinline__ int img_off(int r, int c) {
+  return r * kRowBytes + ((((c >> 1) ^ ((r >> 1) & 3)) << 5) | ((c & 1) << 4));
+}
+
+// stage rows [0, rows_pad) of a [L][64] bf16 matrix (row stride sl) into an image; rows >= L are 0
+__device__ __forceinline__ void stage_image(char* img, const bf16* src, int64_t sl, int L,
+                                            int rows_pad) {
+  for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
+    const int r = idx >> 3, c = idx & 7;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < L) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * sl + c * 8);
+    *reinterpret_cast<bf16x8*>(img + img_off(r, c)) = v;
+  }
+}
+
+// row fragment: lane (g, li) gets M[row0 + li][kk*32 + 8g .. +7]   (MFMA A/B operand, k = feature)
+__device__ __forceinline__ bf16x8 img_row_frag(const char* img, int row0, int kk, int g, int li) {
+  return *reinterpret_cast<const bf16x8*>(img + img_off(row0 + li, kk * 4 + g));
+}
+
+// transposed fragment for a k-step whose 32 reduction rows are the two 16-row tiles
+// ta, tb:  element j of lane (g, li) = M[16*(j<4 ? ta : tb) + 4g + (j&3)][col0 + li]
+// (col0 multiple of 16).  This is the k order of an accumulator pair used as the
+// other operand (see file header).
+__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int ta, int tb, int col0, int g,
+                                              int li) {
+  const int qq = li >> 2, pp = li & 3;
+  const int u = col0 >> 4;
+  bf16x8 out;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int r = 16 * (hf ? tb : ta) + 4 * g + qq;
+    const char* a = img + r * kRowBytes + ((u ^ ((r >> 1) & 3)) << 5) + 8 * pp;
+    const bf16x4 v =
+        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+    out[4 * hf + 0] = v[0];
+    out[4 * hf + 1] = v[1];
+    out[4 * hf + 2] = v[2];
+    out[4 * hf + 3] = v[3];
+  }
+  return out;
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  bf16x8 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    o[r] = (bf16)a[r];
+    o[4 + r] = (bf16)b[r];
+  }
+  return o;
+}
+
+__device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
+  bf16x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = (bf16)(v[r] * s);
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ---------------------------------------------------------------- forward
+__global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  bf16* ob = (bf16*)p.out + b * p.o_sb + h * p.o_sh;
+  float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  char* ks = smem;
+  char* vs = smem + p.Lkp * kRowBytes;
+  stage_image(ks, kb, p.k_sl, p.Lk, p.Lkp);
+  stage_image(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  __syncthreads();
+
+  const float c2 = p.scale * kLog2e;
+  const int nqt = (p.Lq + 15) >> 4, nkp = p.Lkp >> 5;
+  for (int qt = wid; qt < nqt; qt += W) {
+    const int qi = qt * 16 + li;
+    const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int kp = 0; kp < nkp; ++kp) {
+      f32x4 s[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              img_row_frag(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt], 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (2 * kp + tt) * 16 + 4 * g + r;
+          const float val = key < p.Lk ? s[tt][r] * c2 : -INFINITY;
+          s[tt][r] = val;
+          mx = fmaxf(mx, val);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[tt][r] - mn);
+          s[tt][r] = e;
+          ps += e;
+        }
+      l = fmaf(l, alpha, ps);
+      m = mn;
+      const bf16x8 pf = pack_pair(s[0], s[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        o[dt] *= alpha;
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            img_tr_frag(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt], 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(ob + (int64_t)qi * p.o_sl + dt * 16 + 4 * g, o[dt], inv);
+      if (g == 0) lse[qi] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward: dq
+// Query on the lane.  dQ^T[d][q] = sum_key K[key][d] * dS^T[key][q].
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  const bf16* ob = (const bf16*)p.o + b * p.o_sb + h * p.o_sh;
+  const bf16* gb = (const bf16*)p.d_o + b * p.o_sb + h * p.o_sh;
+  bf16* dqb = (bf16*)p.dq + b * p.q_sb + h * p.q_sh;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  char* ks = smem;
+  char* vs = smem + p.Lkp * kRowBytes;
+  stage_image(ks, kb, p.k_sl, p.Lk, p.Lkp);
+  stage_image(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  __syncthreads();
+
+  const float c2 = p.scale * kLog2e;
+  const int nqt = (p.Lq + 15) >> 4, nkp = p.Lkp >> 5;
+  for (int qt = wid; qt < nqt; qt += W) {
+    const int qi = qt * 16 + li;
+    const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+    bf16x8 qf[2], gf[2];
+    float dl = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+      gf[kk] = *reinterpret_cast<const bf16x8*>(gb + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(ob + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl = fmaf((float)gf[kk][j], (float)of[j], dl);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);          // delta of query li
+    const float l2 = lse[qrow] * kLog2e;   // lse in log2 units
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kp = 0; kp < nkp; ++kp) {
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              img_row_frag(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              img_row_frag(vs, (2 * kp + tt) * 16, kk, g, li), gf[kk], dp[tt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (2 * kp + tt) * 16 + 4 * g + r;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2));
+          s[tt][r] = key < p.Lk ? pr * (dp[tt][r] - dl) * p.scale : 0.f;
+        }
+      const bf16x8 dsf = pack_pair(s[0], s[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            img_tr_frag(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li), dsf, acc[dt], 0, 0, 0);
+    }
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(dqb + (int64_t)qi * p.q_sl + dt * 16 + 4 * g, acc[dt], 1.0f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward: dk, dv
+// Key on the lane.  S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO row fragments
+// from LDS images, B = K / V rows straight from HBM);
+// dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key].
+__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  const bf16* ob = (const bf16*)p.o + b * p.o_sb + h * p.o_sh;
+  const bf16* gb = (const bf16*)p.d_o + b * p.o_sb + h * p.o_sh;
+  bf16* dkb = (bf16*)p.dk + b * p.k_sb + h * p.k_sh;
+  bf16* dvb = (bf16*)p.dv + b * p.v_sb + h * p.v_sh;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  char* qs = smem;
+  char* gs = smem + p.Lqp * kRowBytes;
+  float* l2s = reinterpret_cast<float*>(smem + 2 * p.Lqp * kRowBytes);  // lse * log2e, [Lqp]
+  float* dls = l2s + p.Lqp;                                              // delta, [Lqp]
+  stage_image(qs, qb, p.q_sl, p.Lq, p.Lqp);
+  stage_image(gs, gb, p.o_sl, p.Lq, p.Lqp);
+  // per-row statistics: 8 consecutive threads share one query row
+  for (int idx = threadIdx.x; idx < p.Lqp * 8; idx += blockDim.x) {
+    const int r = idx >> 3, c = idx & 7;
+    float d = 0.f;
+    if (r < p.Lq) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(gb + (int64_t)r * p.o_sl + c * 8);
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * p.o_sl + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf((float)a[j], (float)o[j], d);
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0) {
+      dls[r] = d;
+      l2s[r] = r < p.Lq ? lse[r] * kLog2e : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const float c2 = p.scale * kLog2e;
+  const int nkt = (p.Lk + 15) >> 4, nqp = p.Lqp >> 5;
+  for (int kt = wid; kt < nkt; kt += W) {
+    const int kj = kt * 16 + li;
+    const int krow = kj < p.Lk ? kj : p.Lk - 1;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int qp = 0; qp < nqp; ++qp) {
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          // D[row = query 4g+r][col = key li]:  A = Q / dO rows (image), B = K / V rows (regs)
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              img_row_frag(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              img_row_frag(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int q0 = (2 * qp + tt) * 16 + 4 * g;
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(l2s + q0);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(dls + q0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = (q0 + r) < p.Lq ? __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r])) : 0.f;
+          s[tt][r] = pr;
+          dp[tt][r] = pr * (dp[tt][r] - dl[r]) * p.scale;
+        }
+      }
+      const bf16x8 pf = pack_pair(s[0], s[1]);
+      const bf16x8 dsf = pack_pair(dp[0], dp[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            img_tr_frag(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            img_tr_frag(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+    if (kj < p.Lk) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store4(dkb + (int64_t)kj * p.k_sl + dt * 16 + 4 * g, dk[dt], 1.0f);
+        store4(dvb + (int64_t)kj * p.v_sl + dt * 16 + 4 * g, dv[dt], 1.0f);
+      }
+    }
+  }
+}
+
+// ======================================================================= host
+constexpr int kMaxLds = 160 * 1024;
+
+int fill_params(const dvt_attn_desc* d, AttnParams& p, bool bwd, const char* name) {
+  DVT_REQUIRE(d, "%s: null descriptor", name);
+  DVT_REQUIRE(d->q && d->k && d->v && d->o && d->lse, "%s: null q/k/v/o/lse", name);
+  DVT_REQUIRE(d->B >= 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0 && d->dh > 0, "%s: bad sizes", name);
+  DVT_REQUIRE(d->B * d->H < (1ll << 31) && d->Lq < (1 << 24) && d->Lk < (1 << 24), "%s: sizes too large", name);
+  if (bwd) DVT_REQUIRE(d->d_o && d->dq && d->dk && d->dv, "%s: null gradient pointer", name);
+  p.q = d->q; p.k = d->k; p.v = d->v; p.o = d->o; p.out = d->o; p.d_o = d->d_o;
+  p.dq = d->dq; p.dk = d->dk; p.dv = d->dv; p.lse = d->lse; p.delta = nullptr;
+  p.B = (int)d->B; p.H = (int)d->H; p.Lq = (int)d->Lq; p.Lk = (int)d->Lk; p.dh = (int)d->dh;
+  p.q_sb = d->q_sb; p.q_sh = d->q_sh; p.q_sl = d->q_sl;
+  p.k_sb = d->k_sb; p.k_sh = d->k_sh; p.k_sl = d->k_sl;
+  p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_sl = d->v_sl;
+  p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_sl = d->o_sl;
+  p.scale = d->scale;
+  p.Lkp = (p.Lk + 31) & ~31;
+  p.Lqp = (p.Lq + 31) & ~31;
+  return DVT_OK;
+}
+
+bool strides_vec_ok(const dvt_attn_desc* d) {
+  const int64_t s[] = {d->q_sb, d->q_sh, d->q_sl, d->k_sb, d->k_sh, d->k_sl,
+                       d->v_sb, d->v_sh, d->v_sl, d->o_sb, d->o_sh, d->o_sl};
+  for (int64_t x : s)
+    if (x % 8) return false;
+  return true;
+}
+
+bool mfma_fwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
+  return d->dtype == DVT_BF16 && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
+         dvt_aligned16(d->k) && dvt_aligned16(d->v) && dvt_aligned16(d->o) &&
+         2 * p.Lkp * kRowBytes <= kMaxLds;
+}
+
+bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
+  return mfma_fwd_ok(d, p) && dvt_aligned16(d->d_o) && dvt_aligned16(d->dq) && dvt_aligned16(d->dk) &&
+         dvt_aligned16(d->dv) && 2 * p.Lqp * kRowBytes + 2 * p.Lqp * 4 <= kMaxLds;
+}
+
+// waves per block so that the tile count splits evenly over as few rounds as possible
+int pick_waves(int tiles) {
+  const int rounds = (tiles + 7) / 8;
+  int w = (tiles + rounds - 1) / rounds;
+  return w < 1 ? 1 : w;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* d) {
+  if (!d) return 0;
+  return (size_t)d->B * (size_t)d->H * (size_t)d->Lq * sizeof(float);
+}
+
+int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
+  AttnParams p;
+  int rc = fill_params(d, p, false, "dvt_attention_fwd");
+  if (rc) return rc;
+  if (p.B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (mfma_fwd_ok(d, p)) {
+    const size_t lds = (size_t)2 * p.Lkp * kRowBytes;
+    set_lds(attn_fwd_mfma_kernel, lds);
+    const int W = pick_waves((p.Lq + 15) / 16);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(p.B * p.H)), dim3(64 * W), lds, st, p);
+    DVT_LAUNCH_CHECK("dvt_attention_fwd(mfma)");
+    return DVT_OK;
+  }
+  const size_t lds = (size_t)4 * (p.dh + p.Lk) * sizeof(float);
+  if (lds > (size_t)kMaxLds) DVT_UNSUPPORTED("dvt_attention_fwd: Lk = %d, dh = %d exceed the LDS budget", p.Lk, p.dh);
+  const int64_t rows = (int64_t)p.B * p.H * p.Lq;
+  const dim3 grid((unsigned)dvt_cdiv(rows, 4)), block(256);
+  if (d->dtype == DVT_F32) {
+    set_lds(attn_fwd_generic_kernel<float>, lds);
+    hipLaunchKernelGGL((attn_fwd_generic_kernel<float>), grid, block, lds, st, p);
+  } else if (d->dtype == DVT_BF16) {
+    set_lds(attn_fwd_generic_kernel<bf16>, lds);
+    hipLaunchKernelGGL((attn_fwd_generic_kernel<bf16>), grid, block, lds, st, p);
+  } else {
+    DVT_UNSUPPORTED("dvt_attention_fwd: dtype %d not supported", d->dtype);
+  }
+  DVT_LAUNCH_CHECK("dvt_attention_fwd(generic)");
+  return DVT_OK;
+}
+
+int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
+  AttnParams p;
+  int rc = fill_params(d, p, true, "dvt_attention_bwd");
+  if (rc) return rc;
+  if (p.B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (mfma_bwd_ok(d, p)) {
+    const size_t lds_q = (size_t)2 * p.Lkp * kRowBytes;
+    const size_t lds_kv = (size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float);
+    set_lds(attn_bwd_dq_mfma_kernel, lds_q);
+    set_lds(attn_bwd_dkv_mfma_kernel, lds_kv);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((unsigned)(p.B * p.H)),
+                       dim3(64 * pick_waves((p.Lq + 15) / 16)), lds_q, st, p);
+    DVT_LAUNCH_CHECK("dvt_attention_bwd(dq)");
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((unsigned)(p.B * p.H)),
+                       dim3(64 * pick_waves((p.Lk + 15) / 16)), lds_kv, st, p);
+    DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
+    return DVT_OK;
+  }
+  DVT_REQUIRE(d->workspace, "dvt_attention_bwd: workspace (dvt_attention_bwd_workspace_bytes) required");
+  p.delta = (float*)d->workspace;
+  const size_t lds_q = (size_t)4 * (2 * p.dh + p.Lk) * sizeof(float);
+  const size_t lds_kv = (size_t)4 * (2 * p.dh + 2 * p.Lq) * sizeof(float);
+  if (lds_q > (size_t)kMaxLds || lds_kv > (size_t)kMaxLds)
+    DVT_UNSUPPORTED("dvt_attention_bwd: Lq = %d, Lk = %d, dh = %d exceed the LDS budget", p.Lq, p.Lk, p.dh);
+  const int64_t qrows = (int64_t)p.B * p.H * p.Lq, krows = (int64_t)p.B * p.H * p.Lk;
+  const dim3 block(256);
+#define DVT_ATTN_BWD_GENERIC(T)                                                                   \
+  do {                                                                                            \
+    set_lds(attn_bwd_dq_generic_kernel<T>, lds_q);                                                \
+    set_lds(attn_bwd_dkv_generic_kernel<T>, lds_kv);                                              \
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)dvt_cdiv(qrows, 4)), block, 0, st, p); \
+    hipLaunchKernelGGL((attn_bwd_dq_generic_kernel<T>), dim3((unsigned)dvt_cdiv(qrows, 4)), block, lds_q, st, p); \
+    hipLaunchKernelGGL((attn_bwd_dkv_generic_kernel<T>), dim3((unsigned)dvt_cdiv(krows, 4)), block, lds_kv, st, p); \
+  } while (0)
+  if (d->dtype == DVT_F32) DVT_ATTN_BWD_GENERIC(float);
+  else if (d->dtype == DVT_BF16) DVT_ATTN_BWD_GENERIC(bf16);
+  else DVT_UNSUPPORTED("dvt_attention_bwd: dtype %d not supported", d->dtype);
+#undef DVT_ATTN_BWD_GENERIC
+  DVT_LAUNCH_CHECK("dvt_attention_bwd(generic)");
+  return DVT_OK;
+}
+
+}  // extern "C"

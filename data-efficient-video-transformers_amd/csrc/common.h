@@ -1,0 +1,126 @@
+// common.h -- shared device/host helpers for libdvt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dvt_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define DVT_WAVE 64
+
+// ---------------------------------------------------------------- host: errors
+int dvt_fail(int code, const char* fmt, ...);
+int dvt_fail_hip(hipError_t e, const char* where);
+
+#define DVT_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) return dvt_fail(DVT_ERR_BAD_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define DVT_UNSUPPORTED(...) return dvt_fail(DVT_ERR_UNSUPPORTED, __VA_ARGS__)
+
+#define DVT_LAUNCH_CHECK(name)                          \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return dvt_fail_hip(e__, name); \
+  } while (0)
+
+static inline bool dvt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t dvt_dtype_size(int dt) { return dt == DVT_F32 ? 4 : 2; }
+static inline int64_t dvt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+int dvt_num_cus();
+
+// ---------------------------------------------------------------- device: scalar conversions
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 8 contiguous elements <-> 8 floats (16-byte accesses for bf16, 2x16 for f32).
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[8]) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&o)[8]);
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&o)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = o[i]; b[i] = o[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// ---------------------------------------------------------------- device: wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- device: activations
+// Exact-erf GELU evaluated with the Abramowitz-Stegun 7.1.26 rational form
+// (|erf error| <= 1.5e-7 absolute), sharing one exponential between the cdf and
+// the pdf: exp(-x^2/2) is both the tail factor of erf(x/sqrt2) and the Gaussian
+// density.  ~14 VALU ops instead of erff+expf (~45): the GEMM epilogues that
+// fuse GELU / GELU' stay MFMA-bound.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float E = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2)
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float half_erf = 0.5f - 0.5f * (p * t) * E;  // 0.5 * erf(|x|/sqrt2)
+  cdf = x >= 0.0f ? 0.5f + half_erf : 0.5f - half_erf;
+  pdf = 0.39894228040143267794f * E;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
+// d/dx [ x Phi(x) ] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
+}
+
+// Dispatch a templated launcher on the activation dtype.
+#define DVT_DISPATCH_DTYPE(dtype, T, ...)                                   \
+  do {                                                                      \
+    if ((dtype) == DVT_F32) { typedef float T; __VA_ARGS__; }               \
+    else if ((dtype) == DVT_BF16) { typedef bf16 T; __VA_ARGS__; }          \
+    else DVT_UNSUPPORTED("dtype %d not supported by this kernel", (int)(dtype)); \
+  } while (0)

@@ -1,0 +1,692 @@
+// elementwise.hip -- HBM-bound data-movement kernels of the clip path:
+// casts, residual add, patchify gather, token assembly (CLS + positional add),
+// CLS row gather, losses, AdamW.  All are streaming kernels: 16-byte accesses
+// per lane, grid-stride over at most 256 CUs x 8 blocks.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t work_items) {
+  int64_t blocks = dvt_cdiv(work_items, kBlock);
+  int64_t cap = (int64_t)dvt_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 4 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += smem[i];
+  return t;
+}
+
+// ------------------------------------------------------------------ cast / add / axpby
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float v[8];
+    load8<S>(src + i * 8, v);
+    store8<D>(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0) {  // tail (n % 8)
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < n) dst[t] = from_f32<D>(to_f32<S>(src[t]));
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                           int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float x[8], y[8];
+    load8<T>(a + i * 8, x);
+    load8<T>(b + i * 8, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    store8<T>(out + i * 8, x);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < n) out[t] = from_f32<T>(to_f32<T>(a[t]) + to_f32<T>(b[t]));
+  }
+}
+
+template <typename S>
+__global__ void axpby_kernel(const S* __restrict__ src, float alpha, float* __restrict__ dst,
+                             float beta, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float s = alpha * to_f32<S>(src[i]);
+    dst[i] = beta == 0.0f ? s : fmaf(beta, dst[i], s);
+  }
+}
+
+template <typename T, bool FWD>
+__global__ void act_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ out,
+                           int64_t n, int act) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = to_f32<T>(x[i]);
+    float r;
+    if (FWD) r = act == 1 ? gelu_erf_f(v) : fmaxf(v, 0.f);
+    else r = to_f32<T>(dy[i]) * (act == 1 ? gelu_erf_grad_f(v) : (v > 0.f ? 1.f : 0.f));
+    out[i] = from_f32<T>(r);
+  }
+}
+
+// ------------------------------------------------------------------ patchify
+// out[(f*nh + ph)*nw + pw, (p1*P + p2)*C + c] = x[f, c, ph*P + p1, pw*P + p2]
+// Work item = one patch row (frame, ph, p1, pw): C runs of P contiguous pixels in,
+// one run of P*C contiguous patch-vector elements out.  pw is the fastest index so
+// a wave reads 64 adjacent pixel runs (a contiguous span of the image row per channel).
+template <int P, int C, typename S, typename D, bool FWD>
+__global__ void patchify_vec_kernel(const S* __restrict__ x, D* __restrict__ out, S* __restrict__ dx,
+                                    const D* __restrict__ dout, int64_t frames, int H, int W) {
+  const int nh = H / P, nw = W / P;
+  const int64_t items = frames * nh * P * nw;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int64_t pd = (int64_t)P * P * C;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int pw = (int)(it % nw);
+    int64_t r = it / nw;
+    const int p1 = (int)(r % P);
+    r /= P;
+    const int ph = (int)(r % nh);
+    const int64_t f = r / nh;
+    const int64_t orow = (f * nh + ph) * nw + pw;
+    const int64_t ooff = orow * pd + (int64_t)p1 * P * C;
+    const int64_t xoff = ((f * C) * H + (int64_t)ph * P + p1) * W + (int64_t)pw * P;
+    float pix[C][P];
+    float vec[P * C];
+    if (FWD) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int q = 0; q < P / 8; ++q) {
+          float t[8];
+          load8<S>(x + xoff + (int64_t)c * H * W + q * 8, t);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pix[c][q * 8 + k] = t[k];
+        }
+#pragma unroll
+      for (int p2 = 0; p2 < P; ++p2)
+#pragma unroll
+        for (int c = 0; c < C; ++c) vec[p2 * C + c] = pix[c][p2];
+#pragma unroll
+      for (int q = 0; q < P * C / 8; ++q) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = vec[q * 8 + k];
+        store8<D>(out + ooff + q * 8, t);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < P * C / 8; ++q) {
+        float t[8];
+        load8<D>(dout + ooff + q * 8, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vec[q * 8 + k] = t[k];
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int q = 0; q < P / 8; ++q) {
+          float t[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = vec[(q * 8 + k) * C + c];
+          store8<S>(dx + xoff + (int64_t)c * H * W + q * 8, t);
+        }
+    }
+  }
+}
+
+// Any P, C, alignment: scalar accesses.
+template <typename S, typename D, bool FWD>
+__global__ void patchify_generic_kernel(const S* __restrict__ x, D* __restrict__ out,
+                                        S* __restrict__ dx, const D* __restrict__ dout,
+                                        int64_t frames, int C, int H, int W, int P) {
+  const int nh = H / P, nw = W / P;
+  const int64_t pd = (int64_t)P * P * C;
+  const int64_t total = frames * nh * nw * pd;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t e = i % pd;
+    const int64_t orow = i / pd;
+    const int c = (int)(e % C);
+    const int p2 = (int)((e / C) % P);
+    const int p1 = (int)(e / ((int64_t)C * P));
+    const int pw = (int)(orow % nw);
+    const int ph = (int)((orow / nw) % nh);
+    const int64_t f = orow / ((int64_t)nw * nh);
+    const int64_t xi = ((f * C + c) * H + (int64_t)ph * P + p1) * W + (int64_t)pw * P + p2;
+    if (FWD) out[i] = from_f32<D>(to_f32<S>(x[xi]));
+    else dx[xi] = from_f32<S>(to_f32<D>(dout[i]));
+  }
+}
+
+// ------------------------------------------------------------------ token assembly
+template <typename T>
+__global__ void tokens_fwd_kernel(const T* __restrict__ emb, const float* __restrict__ cls,
+                                  const float* __restrict__ pos, T* __restrict__ out, int64_t S,
+                                  int64_t Tn, int64_t n, int64_t d, int64_t pos_rows) {
+  const int64_t dv = d >> 3;
+  const int64_t items = S * (n + 1) * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3;
+    const int64_t row = it / dv;
+    const int64_t j = row % (n + 1);
+    const int64_t s = row / (n + 1);
+    float v[8], p[8];
+    load8<float>(pos + ((s % Tn) * pos_rows + j) * d + c, p);
+    if (j == 0) load8<float>(cls + c, v);
+    else load8<T>(emb + (s * n + (j - 1)) * d + c, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += p[k];
+    store8<T>(out + row * d + c, v);
+  }
+}
+
+template <typename T>
+__global__ void tokens_bwd_emb_kernel(const T* __restrict__ dout, T* __restrict__ demb, int64_t S,
+                                      int64_t n, int64_t d) {
+  const int64_t dv = d >> 3;
+  const int64_t items = S * n * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3;
+    const int64_t row = it / dv;  // = s*n + j
+    const int64_t j = row % n;
+    const int64_t s = row / n;
+    float v[8];
+    load8<T>(dout + (s * (n + 1) + j + 1) * d + c, v);
+    store8<T>(demb + row * d + c, v);
+  }
+}
+
+// dpos[t, j, :] (+)= sum_b dout[b*T + t, j, :]   (rows j > n get 0 when overwriting)
+template <typename T>
+__global__ void tokens_bwd_pos_kernel(const T* __restrict__ dout, float* __restrict__ dpos,
+                                      int64_t S, int64_t Tn, int64_t n, int64_t d, int64_t pos_rows,
+                                      int accumulate) {
+  const int64_t dv = d >> 3;
+  const int64_t items = Tn * pos_rows * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t B = S / Tn;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3;
+    const int64_t row = it / dv;
+    const int64_t j = row % pos_rows;
+    const int64_t t = row / pos_rows;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j <= n) {
+      for (int64_t b = 0; b < B; ++b) {
+        float v[8];
+        load8<T>(dout + ((b * Tn + t) * (n + 1) + j) * d + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+    }
+    float* o = dpos + row * d + c;
+    if (accumulate) {
+      float p[8];
+      load8<float>(o, p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += p[k];
+    }
+    store8<float>(o, acc);
+  }
+}
+
+// out[c] (+)= sum_{r < R} src[r * row_stride + c]; one block per 8-column chunk.
+template <typename T>
+__global__ void strided_rows_sum_kernel(const T* __restrict__ src, int64_t row_stride, int64_t R,
+                                        float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][kBlock / 64];
+  const int64_t c = (int64_t)blockIdx.x << 3;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = threadIdx.x; r < R; r += blockDim.x) {
+    float v[8];
+    load8<T>(src + r * row_stride + c, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float s = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float t = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) t += red[threadIdx.x][i];
+    float* o = out + c + threadIdx.x;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+// ------------------------------------------------------------------ CLS row gather
+template <typename T>
+__global__ void rows_gather_fwd_kernel(const T* __restrict__ src, int64_t src_row_stride,
+                                       const float* __restrict__ tok, T* __restrict__ out, int64_t B,
+                                       int64_t Tn, int64_t d, int lead) {
+  const int64_t dv = d >> 3;
+  const int64_t items = B * (Tn + lead) * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3;
+    const int64_t row = it / dv;
+    const int64_t j = row % (Tn + lead);
+    const int64_t b = row / (Tn + lead);
+    float v[8];
+    if (lead && j == 0) load8<float>(tok + c, v);
+    else load8<T>(src + (b * Tn + (j - lead)) * src_row_stride + c, v);
+    store8<T>(out + row * d + c, v);
+  }
+}
+
+template <typename T>
+__global__ void rows_gather_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dsrc,
+                                       int64_t src_row_stride, int64_t B, int64_t Tn, int64_t d,
+                                       int lead) {
+  const int64_t dv = d >> 3;
+  const int64_t items = B * Tn * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3;
+    const int64_t row = it / dv;  // b*T + t
+    const int64_t t = row % Tn;
+    const int64_t b = row / Tn;
+    float v[8];
+    load8<T>(dout + (b * (Tn + lead) + t + lead) * d + c, v);
+    store8<T>(dsrc + row * src_row_stride + c, v);
+  }
+}
+
+// ------------------------------------------------------------------ losses
+template <typename T>
+__global__ void bce_fwd_kernel(const T* __restrict__ z, const float* __restrict__ y,
+                               float* __restrict__ loss, int64_t n) {
+  __shared__ float red[kBlock / 64];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = to_f32<T>(z[i]);
+    acc += fmaxf(x, 0.f) - x * y[i] + log1pf(expf(-fabsf(x)));
+  }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = t / (float)n;
+}
+
+template <typename T>
+__global__ void bce_bwd_kernel(const T* __restrict__ z, const float* __restrict__ y,
+                               const float* __restrict__ gloss, T* __restrict__ dz, int64_t n) {
+  const float g = gloss[0] / (float)n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = to_f32<T>(z[i]);
+    const float s = 1.0f / (1.0f + expf(-x));
+    dz[i] = from_f32<T>(g * (s - y[i]));
+  }
+}
+
+// One wave per row: lse(student) - student[argmax teacher]; first max wins (torch.argmax).
+template <typename T, bool FWD>
+__global__ void ce_argmax_kernel(const T* __restrict__ st, const T* __restrict__ te,
+                                 const float* __restrict__ gloss, float* __restrict__ loss,
+                                 T* __restrict__ dst, int64_t rows, int64_t C) {
+  __shared__ float red[kBlock / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  float total = 0.f;
+  for (int64_t r = wave; r < rows; r += nw) {
+    const T* s = st + r * C;
+    const T* t = te + r * C;
+    float m = -INFINITY, tm = -INFINITY;
+    int64_t ti = C;
+    for (int64_t c = lane; c < C; c += 64) {
+      m = fmaxf(m, to_f32<T>(s[c]));
+      const float tv = to_f32<T>(t[c]);
+      if (tv > tm) { tm = tv; ti = c; }
+    }
+    m = wave_max(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(tm, o, 64);
+      const int64_t oi = __shfl_xor((long long)ti, o, 64);
+      if (om > tm || (om == tm && oi < ti)) { tm = om; ti = oi; }
+    }
+    float se = 0.f;
+    for (int64_t c = lane; c < C; c += 64) se += expf(to_f32<T>(s[c]) - m);
+    se = wave_sum(se);
+    if (FWD) {
+      if (lane == 0) total += m + logf(se) - to_f32<T>(s[ti]);
+    } else {
+      const float g = gloss[0] / (float)rows;
+      for (int64_t c = lane; c < C; c += 64) {
+        const float p = expf(to_f32<T>(s[c]) - m) / se;
+        dst[r * C + c] = from_f32<T>(g * (p - (c == ti ? 1.f : 0.f)));
+      }
+    }
+  }
+  if (FWD) {
+    const float t = block_sum(total, red);
+    if (threadIdx.x == 0) loss[0] = t / (float)rows;
+  }
+}
+
+// ------------------------------------------------------------------ AdamW
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                             float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                             float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+             dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && n >= 0, "dvt_cast: null pointer or negative size");
+  DVT_REQUIRE(dvt_aligned16(src) && dvt_aligned16(dst), "dvt_cast: buffers must be 16-byte aligned");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for((n >> 3) + 1);
+#define DVT_CAST_CASE(SD, S, DD, D)                                                        \
+  if (src_dtype == SD && dst_dtype == DD) {                                                \
+    hipLaunchKernelGGL((cast_kernel<S, D>), dim3(g), dim3(kBlock), 0, st, (const S*)src, (D*)dst, n); \
+    DVT_LAUNCH_CHECK("dvt_cast");                                                          \
+    return DVT_OK;                                                                         \
+  }
+  DVT_CAST_CASE(DVT_F32, float, DVT_BF16, bf16)
+  DVT_CAST_CASE(DVT_BF16, bf16, DVT_F32, float)
+  DVT_CAST_CASE(DVT_F32, float, DVT_F32, float)
+  DVT_CAST_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+#undef DVT_CAST_CASE
+  DVT_UNSUPPORTED("dvt_cast: dtype pair (%d -> %d) not supported", src_dtype, dst_dtype);
+}
+
+int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(a && b && out && n >= 0, "dvt_add: null pointer or negative size");
+  DVT_REQUIRE(dvt_aligned16(a) && dvt_aligned16(b) && dvt_aligned16(out),
+              "dvt_add: buffers must be 16-byte aligned");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for((n >> 3) + 1)), dim3(kBlock),
+                                        0, st, (const T*)a, (const T*)b, (T*)out, n));
+  DVT_LAUNCH_CHECK("dvt_add");
+  return DVT_OK;
+}
+
+int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && y && n >= 0 && (act == 1 || act == 2), "dvt_act_fwd: bad arguments");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((act_kernel<T, true>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                        (const T*)nullptr, (const T*)x, (T*)y, n, act));
+  DVT_LAUNCH_CHECK("dvt_act_fwd");
+  return DVT_OK;
+}
+
+int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
+                dvt_stream_t stream) {
+  DVT_REQUIRE(dy && x && dx && n >= 0 && (act == 1 || act == 2), "dvt_act_bwd: bad arguments");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((act_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                        (const T*)dy, (const T*)x, (T*)dx, n, act));
+  DVT_LAUNCH_CHECK("dvt_act_bwd");
+  return DVT_OK;
+}
+
+int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float beta, int64_t n,
+                  dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && n >= 0, "dvt_axpby_f32: null pointer or negative size");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(src_dtype, T,
+                     hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                        (const T*)src, alpha, dst, beta, n));
+  DVT_LAUNCH_CHECK("dvt_axpby_f32");
+  return DVT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <typename S, typename D, bool FWD>
+int patchify_dispatch(const void* x, void* out, void* dx, const void* dout, int64_t frames, int C,
+                      int H, int W, int P, hipStream_t st, const char* name) {
+  const int nh = H / P, nw = W / P;
+  const int64_t items = frames * nh * P * nw;
+  const void* pix = FWD ? x : (const void*)dx;
+  const void* vecp = FWD ? (const void*)out : dout;
+  const bool vec_ok = (W % 8 == 0) && (P % 8 == 0) && ((P * C) % 8 == 0) && dvt_aligned16(pix) &&
+                      dvt_aligned16(vecp) && ((int64_t)H * W % 8 == 0);
+  if (vec_ok && P == 16 && C == 3) {
+    hipLaunchKernelGGL((patchify_vec_kernel<16, 3, S, D, FWD>), dim3(grid_for(items)), dim3(kBlock),
+                       0, st, (const S*)x, (D*)out, (S*)dx, (const D*)dout, frames, H, W);
+  } else if (vec_ok && P == 8 && C == 3) {
+    hipLaunchKernelGGL((patchify_vec_kernel<8, 3, S, D, FWD>), dim3(grid_for(items)), dim3(kBlock),
+                       0, st, (const S*)x, (D*)out, (S*)dx, (const D*)dout, frames, H, W);
+  } else {
+    const int64_t total = frames * nh * nw * (int64_t)P * P * C;
+    hipLaunchKernelGGL((patchify_generic_kernel<S, D, FWD>), dim3(grid_for(total)), dim3(kBlock), 0,
+                       st, (const S*)x, (D*)out, (S*)dx, (const D*)dout, frames, C, H, W, P);
+  }
+  DVT_LAUNCH_CHECK(name);
+  return DVT_OK;
+}
+
+template <bool FWD>
+int patchify_entry(const void* pix, int pix_dtype, const void* vec, int vec_dtype, int64_t frames,
+                   int C, int H, int W, int P, dvt_stream_t stream, const char* name) {
+  DVT_REQUIRE(pix && vec, "%s: null pointer", name);
+  DVT_REQUIRE(frames >= 0 && C > 0 && H > 0 && W > 0 && P > 0, "%s: bad sizes", name);
+  DVT_REQUIRE(H % P == 0 && W % P == 0, "%s: image %dx%d not divisible by patch %d", name, H, W, P);
+  if (frames == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // pixel tensor: x (fwd, const) / dx (bwd, written); vector tensor: out (fwd) / dout (bwd)
+#define DVT_PATCH_CASE(PD, S, VD, D)                                                            \
+  if (pix_dtype == PD && vec_dtype == VD)                                                       \
+    return patchify_dispatch<S, D, FWD>(FWD ? pix : nullptr, FWD ? (void*)vec : nullptr,        \
+                                        FWD ? nullptr : (void*)pix, FWD ? nullptr : vec, frames, \
+                                        C, H, W, P, st, name);
+  DVT_PATCH_CASE(DVT_F32, float, DVT_F32, float)
+  DVT_PATCH_CASE(DVT_F32, float, DVT_BF16, bf16)
+  DVT_PATCH_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+  DVT_PATCH_CASE(DVT_BF16, bf16, DVT_F32, float)
+#undef DVT_PATCH_CASE
+  DVT_UNSUPPORTED("%s: dtype pair (%d, %d) not supported", name, pix_dtype, vec_dtype);
+}
+}  // namespace
+
+extern "C" {
+
+int dvt_patchify(const void* x, int x_dtype, void* out, int out_dtype, int64_t frames, int C, int H,
+                 int W, int P, dvt_stream_t stream) {
+  return patchify_entry<true>(x, x_dtype, out, out_dtype, frames, C, H, W, P, stream, "dvt_patchify");
+}
+
+int dvt_patchify_bwd(const void* dout, int dout_dtype, void* dx, int dx_dtype, int64_t frames, int C,
+                     int H, int W, int P, dvt_stream_t stream) {
+  return patchify_entry<false>(dx, dx_dtype, dout, dout_dtype, frames, C, H, W, P, stream,
+                               "dvt_patchify_bwd");
+}
+
+int dvt_tokens_assemble_fwd(const void* emb, const float* cls, const float* pos, void* out,
+                            int64_t S, int64_t T, int64_t n, int64_t d, int64_t pos_rows, int dtype,
+                            dvt_stream_t stream) {
+  DVT_REQUIRE(emb && cls && pos && out, "dvt_tokens_assemble_fwd: null pointer");
+  DVT_REQUIRE(S >= 0 && T > 0 && n >= 0 && d > 0 && S % T == 0, "dvt_tokens_assemble_fwd: bad sizes");
+  DVT_REQUIRE(pos_rows >= n + 1, "dvt_tokens_assemble_fwd: positional table has %lld rows < n+1 = %lld",
+              (long long)pos_rows, (long long)(n + 1));
+  DVT_REQUIRE(d % 8 == 0, "dvt_tokens_assemble_fwd: d = %lld must be a multiple of 8", (long long)d);
+  DVT_REQUIRE(dvt_aligned16(emb) && dvt_aligned16(cls) && dvt_aligned16(pos) && dvt_aligned16(out),
+              "dvt_tokens_assemble_fwd: buffers must be 16-byte aligned");
+  if (S == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t items = S * (n + 1) * (d >> 3);
+  DVT_DISPATCH_DTYPE(dtype, Tt,
+                     hipLaunchKernelGGL((tokens_fwd_kernel<Tt>), dim3(grid_for(items)), dim3(kBlock),
+                                        0, st, (const Tt*)emb, cls, pos, (Tt*)out, S, T, n, d,
+                                        pos_rows));
+  DVT_LAUNCH_CHECK("dvt_tokens_assemble_fwd");
+  return DVT_OK;
+}
+
+int dvt_tokens_assemble_bwd(const void* dout, void* demb, float* dcls, float* dpos, int64_t S,
+                            int64_t T, int64_t n, int64_t d, int64_t pos_rows, int dtype,
+                            int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(dout, "dvt_tokens_assemble_bwd: null dout");
+  DVT_REQUIRE(S > 0 && T > 0 && n >= 0 && d > 0 && S % T == 0, "dvt_tokens_assemble_bwd: bad sizes");
+  DVT_REQUIRE(pos_rows >= n + 1 && d % 8 == 0, "dvt_tokens_assemble_bwd: bad pos_rows / d");
+  DVT_REQUIRE(dvt_aligned16(dout) && dvt_aligned16(demb) && dvt_aligned16(dcls) && dvt_aligned16(dpos),
+              "dvt_tokens_assemble_bwd: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t dv = d >> 3;
+  DVT_DISPATCH_DTYPE(dtype, Tt, {
+    if (demb && n > 0)
+      hipLaunchKernelGGL((tokens_bwd_emb_kernel<Tt>), dim3(grid_for(S * n * dv)), dim3(kBlock), 0, st,
+                         (const Tt*)dout, (Tt*)demb, S, n, d);
+    if (dpos)
+      hipLaunchKernelGGL((tokens_bwd_pos_kernel<Tt>), dim3(grid_for(T * pos_rows * dv)), dim3(kBlock),
+                         0, st, (const Tt*)dout, dpos, S, T, n, d, pos_rows, accumulate);
+    if (dcls)
+      hipLaunchKernelGGL((strided_rows_sum_kernel<Tt>), dim3((unsigned)dv), dim3(kBlock), 0, st,
+                         (const Tt*)dout, (n + 1) * d, S, dcls, accumulate);
+  });
+  DVT_LAUNCH_CHECK("dvt_tokens_assemble_bwd");
+  return DVT_OK;
+}
+
+int dvt_rows_gather_fwd(const void* src, int64_t src_row_stride, const float* tok, void* out,
+                        int64_t B, int64_t T, int64_t d, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(src && out, "dvt_rows_gather_fwd: null pointer");
+  DVT_REQUIRE(B >= 0 && T >= 0 && d > 0 && d % 8 == 0 && src_row_stride % 8 == 0,
+              "dvt_rows_gather_fwd: bad sizes (d and row stride must be multiples of 8)");
+  DVT_REQUIRE(dvt_aligned16(src) && dvt_aligned16(out) && dvt_aligned16(tok),
+              "dvt_rows_gather_fwd: buffers must be 16-byte aligned");
+  if (B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int lead = tok ? 1 : 0;
+  const int64_t items = B * (T + lead) * (d >> 3);
+  DVT_DISPATCH_DTYPE(dtype, Tt,
+                     hipLaunchKernelGGL((rows_gather_fwd_kernel<Tt>), dim3(grid_for(items)),
+                                        dim3(kBlock), 0, st, (const Tt*)src, src_row_stride, tok,
+                                        (Tt*)out, B, T, d, lead));
+  DVT_LAUNCH_CHECK("dvt_rows_gather_fwd");
+  return DVT_OK;
+}
+
+int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, float* dtok, int64_t B,
+                        int64_t T, int64_t d, int dtype, int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(dout && dsrc, "dvt_rows_gather_bwd: null pointer");
+  DVT_REQUIRE(B > 0 && T >= 0 && d > 0 && d % 8 == 0 && src_row_stride % 8 == 0,
+              "dvt_rows_gather_bwd: bad sizes");
+  DVT_REQUIRE(dvt_aligned16(dout) && dvt_aligned16(dsrc) && dvt_aligned16(dtok),
+              "dvt_rows_gather_bwd: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int lead = dtok ? 1 : 0;
+  const int64_t dv = d >> 3;
+  DVT_DISPATCH_DTYPE(dtype, Tt, {
+    if (T > 0)
+      hipLaunchKernelGGL((rows_gather_bwd_kernel<Tt>), dim3(grid_for(B * T * dv)), dim3(kBlock), 0, st,
+                         (const Tt*)dout, (Tt*)dsrc, src_row_stride, B, T, d, lead);
+    if (dtok)
+      hipLaunchKernelGGL((strided_rows_sum_kernel<Tt>), dim3((unsigned)dv), dim3(kBlock), 0, st,
+                         (const Tt*)dout, (T + 1) * d, B, dtok, accumulate);
+  });
+  DVT_LAUNCH_CHECK("dvt_rows_gather_bwd");
+  return DVT_OK;
+}
+
+int dvt_bce_logits_fwd(const void* z, const float* target, float* loss, int64_t n, int dtype,
+                       dvt_stream_t stream) {
+  DVT_REQUIRE(z && target && loss && n > 0, "dvt_bce_logits_fwd: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((bce_fwd_kernel<T>), dim3(1), dim3(kBlock), 0, st,
+                                        (const T*)z, target, loss, n));
+  DVT_LAUNCH_CHECK("dvt_bce_logits_fwd");
+  return DVT_OK;
+}
+
+int dvt_bce_logits_bwd(const void* z, const float* target, const float* gloss, void* dz, int64_t n,
+                       int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(z && target && gloss && dz && n > 0, "dvt_bce_logits_bwd: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((bce_bwd_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                        (const T*)z, target, gloss, (T*)dz, n));
+  DVT_LAUNCH_CHECK("dvt_bce_logits_bwd");
+  return DVT_OK;
+}
+
+int dvt_ce_argmax_fwd(const void* student, const void* teacher, float* loss, int64_t rows, int64_t C,
+                      int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(student && teacher && loss && rows > 0 && C > 0, "dvt_ce_argmax_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((ce_argmax_kernel<T, true>), dim3(1), dim3(kBlock), 0, st,
+                                        (const T*)student, (const T*)teacher, (const float*)nullptr,
+                                        loss, (T*)nullptr, rows, C));
+  DVT_LAUNCH_CHECK("dvt_ce_argmax_fwd");
+  return DVT_OK;
+}
+
+int dvt_ce_argmax_bwd(const void* student, const void* teacher, const float* gloss, void* dstudent,
+                      int64_t rows, int64_t C, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(student && teacher && gloss && dstudent && rows > 0 && C > 0,
+              "dvt_ce_argmax_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((ce_argmax_kernel<T, false>), dim3(1), dim3(kBlock), 0, st,
+                                        (const T*)student, (const T*)teacher, gloss, (float*)nullptr,
+                                        (T*)dstudent, rows, C));
+  DVT_LAUNCH_CHECK("dvt_ce_argmax_bwd");
+  return DVT_OK;
+}
+
+int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   dvt_stream_t stream) {
+  DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1,
+              "dvt_adamw_step: bad arguments");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2));
+  DVT_LAUNCH_CHECK("dvt_adamw_step");
+  return DVT_OK;
+}
+
+}  // extern "C"

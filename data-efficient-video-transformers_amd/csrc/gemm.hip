@@ -1,0 +1,591 @@
+// gemm.hip -- the GEMM family behind every Linear on the clip path.
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) B(k,n) )
+//
+// bf16 fast path (gemm_mfma_kernel): 128x128x64 block tile, 4 waves (2x2, 64x64
+// each = 4x4 v_mfma_f32_16x16x32_bf16 accumulators), fp32 accumulate.
+//   * operands are staged HBM -> registers -> LDS (16-byte accesses), double
+//     buffered: the global loads of tile k+1 are issued before the MFMAs of
+//     tile k and written to the other LDS stage after them (one barrier / tile).
+//   * an operand whose reduction index is contiguous in memory ("k-major":
+//     activations x, weights W[N,K] in forward) is kept as [rows][64 k] with the
+//     16-byte chunk index XOR-swizzled by (row & 7) and read with ds_read_b128.
+//   * an operand whose reduction index is the row of the matrix ("mn-major":
+//     W in dgrad, dY and x in wgrad) is kept as [64 k][128 mn] and read through
+//     ds_read_b64_tr_b16 (hardware transpose); 32-byte units are XOR-swizzled by
+//     (k&3)|((k>>3)&1)<<2 so that each 32-lane half hits 8 distinct bank groups.
+//     No operand is ever transposed through HBM.
+//   * the MFMA is issued as D = Bfrag x Afrag (C^T orientation) so that a lane
+//     ends up with 4 consecutive n of one row m; the accumulators are staged
+//     through LDS as fp32 and leave as whole 256-byte row segments, with
+//     bias / GELU / GELU' / ReLU / residual applied on the way out.
+//   * split-K (wgrad: M,N small, K = tokens) writes fp32 slabs that a second
+//     kernel sums in a fixed order (bitwise reproducible, no atomics).
+// generic path (gemm_generic_kernel): any dtype / shape / alignment, fp32 FMA,
+// 64x64x16 tiles -- the fp32 parity mode and odd shapes (19-class head).
+#include "common.h"
+
+namespace {
+
+enum { BM = 128, BN = 128, BK = 64, NTHREADS = 256 };
+constexpr int kStageBytes = (BM * BK + BN * BK) * 2;   // 32 KiB
+constexpr int kCPad = BN + 4;                           // fp32 staging row stride (floats)
+constexpr int kSmemBytes = BM * kCPad * 4;              // 67,584 B >= 2 stages (65,536 B)
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int epilogue, out_f32, accumulate;
+  const float* bias;
+  const void* residual;
+  int64_t ldr;
+  void* aux;
+  int64_t ldaux;
+  float alpha;
+  int k_per_split;  // multiple of BK; == K rounded up when not splitting
+  float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
+  int tiles_n;
+};
+
+__device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> registers (4 x 16 B per thread per operand tile)
+template <bool KMAJOR>
+__device__ __forceinline__ void g2r(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim,
+                                    int k0, int k_lim, int tid, bf16x8 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NTHREADS * i;
+    int gk, gmn;
+    int64_t off;
+    if (KMAJOR) {
+      gmn = mn0 + (idx >> 3);
+      gk = k0 + ((idx & 7) << 3);
+      off = (int64_t)gmn * ld + gk;
+    } else {
+      gk = k0 + (idx >> 4);
+      gmn = mn0 + ((idx & 15) << 3);
+      off = (int64_t)gk * ld + gmn;
+    }
+    const bool ok = (gmn < mn_lim) && (gk < k_lim);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (ok ? off : 0));
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[i] = ok ? v : z;
+  }
+}
+
+// ---- registers -> LDS stage
+template <bool KMAJOR>
+__device__ __forceinline__ void r2s(char* tile, int tid, const bf16x8 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NTHREADS * i;
+    int off;
+    if (KMAJOR) {
+      const int row = idx >> 3, c = idx & 7;
+      off = row * (BK * 2) + ((c ^ (row & 7)) << 4);
+    } else {
+      const int k = idx >> 4, c = idx & 15;
+      off = k * (BM * 2) + ((((c >> 1) ^ swz_mn(k)) << 5) | ((c & 1) << 4));
+    }
+    *reinterpret_cast<bf16x8*>(tile + off) = r[i];
+  }
+}
+
+// ---- LDS -> MFMA fragment: lane (g = lane>>4, li = lane&15) gets
+//      element j <-> (index = base + li, k = kk*32 + 8g + j)
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int base, int kk, int g, int li) {
+  if (KMAJOR) {
+    const int row = base + li;
+    const int c = kk * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(tile + row * (BK * 2) + ((c ^ (row & 7)) << 4));
+  } else {
+    const int q = li >> 2, p = li & 3;
+    const int u = base >> 4;  // 32-byte unit of the 16-column block
+    bf16x8 out;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = kk * 32 + 8 * g + 4 * hf + q;
+      const char* a = tile + k * (BM * 2) + ((u ^ swz_mn(k)) << 5) + 8 * p;
+      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(a));
+      out[4 * hf + 0] = v[0];
+      out[4 * hf + 1] = v[1];
+      out[4 * hf + 2] = v[2];
+      out[4 * hf + 3] = v[3];
+    }
+    return out;
+  }
+}
+
+__device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float res, float aux_in,
+                                           float& aux_out) {
+  switch (epi) {
+    case DVT_EPI_GELU: {
+      const float pre = acc + bias;
+      aux_out = pre;
+      return gelu_erf_f(pre);
+    }
+    case DVT_EPI_RELU: return fmaxf(acc + bias, 0.f);
+    case DVT_EPI_RESIDUAL: return acc + bias + res;
+    case DVT_EPI_DGELU: return acc * gelu_erf_grad_f(aux_in);
+    case DVT_EPI_DRELU: return aux_in > 0.f ? acc : 0.f;
+    default: return acc + bias;
+  }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, li = lane & 15;
+
+  const int tile = blockIdx.x;
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x4 acc[4][4];  // [u: n sub-tile][t: m sub-tile]
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ra[4], rb[4];
+  if (nk > 0) {
+    g2r<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+    g2r<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+    r2s<A_KMAJOR>(smem, tid, ra);
+    r2s<B_KMAJOR>(smem + BM * BK * 2, tid, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sa = smem + (kt & 1) * kStageBytes;
+    const char* sb = sa + BM * BK * 2;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      g2r<A_KMAJOR>(p.A, p.lda, m0, p.M, k0, kend, tid, ra);
+      g2r<B_KMAJOR>(p.B, p.ldb, n0, p.N, k0, kend, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = lds_frag<A_KMAJOR>(sa, wm * 64 + t * 16, kk, g, li);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bfr[u] = lds_frag<B_KMAJOR>(sb, wn * 64 + u * 16, kk, g, li);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[u], af[t], acc[u][t], 0, 0, 0);
+    }
+    if (more) {
+      char* da = smem + ((kt + 1) & 1) * kStageBytes;
+      r2s<A_KMAJOR>(da, tid, ra);
+      r2s<B_KMAJOR>(da + BM * BK * 2, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulators -> LDS (fp32, padded rows): lane holds C[m = .. + li][n = .. + 4g + r]
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = wm * 64 + t * 16 + li;
+      const int n = wn * 64 + u * 16 + 4 * g;
+      *reinterpret_cast<f32x4*>(cs + m * kCPad + n) = acc[u][t] * p.alpha;
+    }
+  __syncthreads();
+
+  // ---- coalesced epilogue: 8 consecutive n per thread, 16 threads per row
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + NTHREADS * i;
+    const int row = idx >> 4, c = (idx & 15) << 3;
+    const int m = m0 + row, n = n0 + c;
+    if (m >= p.M || n >= p.N) continue;
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(cs + row * kCPad + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(cs + row * kCPad + c + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+    }
+    if (p.slab) {  // raw split-K partial
+      store8<float>(p.slab + ((int64_t)blockIdx.z * p.M + m) * p.N + n, v);
+      continue;
+    }
+    float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, res[8] = {0, 0, 0, 0, 0, 0, 0, 0},
+          aux[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
+    if (p.bias) load8<float>(p.bias + n, bias);
+    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, res);
+    if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
+      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, aux);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = epi_apply(p.epilogue, v[k], bias[k], res[k], aux[k], pre[k]);
+    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+    if (p.out_f32) {
+      float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+      if (p.accumulate) {
+        float old[8];
+        load8<float>(o, old);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += old[k];
+      }
+      store8<float>(o, v);
+    } else {
+      store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+// C (+)= sum_z slab[z]   (fixed order => reproducible)
+template <typename OutT>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                     OutT* __restrict__ C, int64_t ldc, int accumulate) {
+  const int64_t nvec = (int64_t)M * N / 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t MN = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t e = i * 8;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < splits; ++z) {
+      float v[8];
+      load8<float>(slab + (int64_t)z * MN + e, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    OutT* o = C + (int64_t)m * ldc + n;
+    if (accumulate) {
+      float old[8];
+      load8<OutT>(o, old);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += old[k];
+    }
+    store8<OutT>(o, acc);
+  }
+}
+
+// ---------------------------------------------------------------- generic path
+struct GenericParams {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int64_t sam, sak, sbk, sbn, ldc;
+  int epilogue, out_f32, accumulate;
+  const float* bias;
+  const void* residual;
+  int64_t ldr;
+  void* aux;
+  int64_t ldaux;
+  float alpha;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p) {
+  constexpr int TM = 64, TN = 64, TK = 16;
+  __shared__ float As[TK][TM + 1];
+  __shared__ float Bs[TK][TN + 1];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const T* A = (const T*)p.A;
+  const T* B = (const T*)p.B;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;  // 1024 elements per tile
+      {
+        // A tile: pick the faster-varying index to follow the contiguous dimension
+        int mm, kk;
+        if (p.sak == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+        const int gm = m0 + mm, gk = k0 + kk;
+        As[kk][mm] = (gm < p.M && gk < p.K) ? to_f32<T>(A[(int64_t)gm * p.sam + (int64_t)gk * p.sak]) : 0.f;
+      }
+      {
+        int nn, kk;
+        if (p.sbk == 1) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kk = idx >> 6; }
+        const int gn = n0 + nn, gk = k0 + kk;
+        Bs[kk][nn] = (gn < p.N && gk < p.K) ? to_f32<T>(B[(int64_t)gk * p.sbk + (int64_t)gn * p.sbn]) : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+      float res = 0.f, aux = 0.f, pre = 0.f;
+      if (p.epilogue == DVT_EPI_RESIDUAL) res = to_f32<T>(((const T*)p.residual)[(int64_t)m * p.ldr + n]);
+      if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
+        aux = to_f32<T>(((const T*)p.aux)[(int64_t)m * p.ldaux + n]);
+      float v = epi_apply(p.epilogue, acc[i][j] * p.alpha, bias, res, aux, pre);
+      if (p.epilogue == DVT_EPI_GELU && p.aux) ((T*)p.aux)[(int64_t)m * p.ldaux + n] = from_f32<T>(pre);
+      if (p.out_f32) {
+        float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+        *o = p.accumulate ? *o + v : v;
+      } else {
+        ((T*)p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- colsum (bias gradients)
+// partial[b][n] = sum over this block's row range; then a second pass sums partials.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx,
+                                                             int64_t M, int64_t N, int rows_per_block,
+                                                             float* __restrict__ partial) {
+  // thread handles 8 columns; blockDim.x = 256 threads = 32 column-chunks x 8 row lanes
+  __shared__ float red[8][32][8];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t c = ((int64_t)blockIdx.x * 32 + cl) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < N) {
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float v[8];
+      load8<T>(x + r * ldx + c, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl][cl][k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      t[k] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t[k] += red[r][cl][k];
+    }
+    store8<float>(partial + (int64_t)blockIdx.y * N + c, t);
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nparts, int64_t N,
+                                    float* __restrict__ out, int accumulate) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float t = 0.f;
+  for (int p = 0; p < nparts; ++p) t += partial[(int64_t)p * N + n];
+  out[n] = accumulate ? out[n] + t : t;
+}
+
+template <typename T>
+__global__ void colsum_generic_kernel(const T* __restrict__ x, int64_t ldx, int64_t M, int64_t N,
+                                      float* __restrict__ out, int accumulate) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float t = 0.f;
+  for (int64_t m = 0; m < M; ++m) t += to_f32<T>(x[m * ldx + n]);
+  out[n] = accumulate ? out[n] + t : t;
+}
+
+constexpr int kColsumParts = 256;
+
+// ---------------------------------------------------------------- host side
+bool mfma_eligible(const dvt_gemm_desc* d) {
+  if (d->in_dtype != DVT_BF16) return false;
+  if (!(d->out_dtype == DVT_BF16 || d->out_dtype == DVT_F32)) return false;
+  if (d->K % 8 || d->N % 8) return false;
+  if (d->lda % 8 || d->ldb % 8 || d->ldc % 8) return false;
+  if (!d->a_kmajor && d->M % 8) return false;
+  if (!dvt_aligned16(d->A) || !dvt_aligned16(d->B) || !dvt_aligned16(d->C)) return false;
+  if (d->bias && !dvt_aligned16(d->bias)) return false;
+  if (d->residual && (!dvt_aligned16(d->residual) || d->ldr % 8)) return false;
+  if (d->aux && (!dvt_aligned16(d->aux) || d->ldaux % 8)) return false;
+  if (d->M > (1 << 30) || d->N > (1 << 30) || d->K > (1 << 30)) return false;
+  return true;
+}
+
+int choose_split(const dvt_gemm_desc* d) {
+  if (d->epilogue != DVT_EPI_NONE || d->bias || d->alpha != 1.0f) return 1;
+  if (d->split_k > 1) return d->split_k;
+  if (d->split_k == 1) return 1;
+  const int64_t tiles = dvt_cdiv(d->M, BM) * dvt_cdiv(d->N, BN);
+  const int64_t cus = dvt_num_cus();
+  if (tiles >= cus || d->K < 2048) return 1;
+  int64_t s = dvt_cdiv(2 * cus, tiles);
+  const int64_t maxs = d->K / 512;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
+int check_desc(const dvt_gemm_desc* d) {
+  DVT_REQUIRE(d, "dvt_gemm: null descriptor");
+  DVT_REQUIRE(d->A && d->B && d->C, "dvt_gemm: null operand pointer");
+  DVT_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "dvt_gemm: negative dimension");
+  DVT_REQUIRE(d->in_dtype == DVT_F32 || d->in_dtype == DVT_BF16, "dvt_gemm: in_dtype %d unsupported",
+              d->in_dtype);
+  DVT_REQUIRE(d->out_dtype == d->in_dtype || d->out_dtype == DVT_F32,
+              "dvt_gemm: out_dtype must equal in_dtype or be f32");
+  DVT_REQUIRE(d->epilogue >= DVT_EPI_NONE && d->epilogue <= DVT_EPI_DRELU, "dvt_gemm: bad epilogue %d",
+              d->epilogue);
+  DVT_REQUIRE(!(d->accumulate && d->out_dtype != DVT_F32), "dvt_gemm: accumulate needs f32 output");
+  DVT_REQUIRE(d->epilogue != DVT_EPI_RESIDUAL || d->residual, "dvt_gemm: RESIDUAL epilogue without residual");
+  DVT_REQUIRE(!(d->epilogue == DVT_EPI_DGELU || d->epilogue == DVT_EPI_DRELU) || d->aux,
+              "dvt_gemm: DGELU/DRELU epilogue without aux");
+  const int64_t min_lda = d->a_kmajor ? d->K : d->M, min_ldb = d->b_kmajor ? d->K : d->N;
+  DVT_REQUIRE(d->lda >= min_lda && d->ldb >= min_ldb && d->ldc >= d->N, "dvt_gemm: leading dimension too small");
+  return DVT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
+  if (!d || !mfma_eligible(d)) return 0;
+  dvt_gemm_desc t = *d;
+  const int s = choose_split(&t);
+  return s > 1 ? (size_t)s * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
+}
+
+int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (d->M == 0 || d->N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+
+  if (mfma_eligible(d) && d->K > 0) {
+    int split = choose_split(d);
+    if (split > 1 && !d->workspace) split = 1;
+    GemmParams p;
+    p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+    p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
+    p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
+    p.alpha = d->alpha;
+    const int tiles_m = (int)dvt_cdiv(d->M, BM);
+    p.tiles_n = (int)dvt_cdiv(d->N, BN);
+    int kps = (int)dvt_cdiv(dvt_cdiv(d->K, split), BK) * BK;
+    split = (int)dvt_cdiv(d->K, kps);
+    p.k_per_split = kps;
+    p.slab = split > 1 ? (float*)d->workspace : nullptr;
+    const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(NTHREADS);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+      attr_set = true;
+    }
+    if (d->a_kmajor && d->b_kmajor)
+      hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, block, kSmemBytes, st, p);
+    else if (d->a_kmajor && !d->b_kmajor)
+      hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, block, kSmemBytes, st, p);
+    else if (!d->a_kmajor && d->b_kmajor)
+      hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, block, kSmemBytes, st, p);
+    else
+      hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, block, kSmemBytes, st, p);
+    DVT_LAUNCH_CHECK("dvt_gemm(mfma)");
+    if (split > 1) {
+      const int64_t nvec = d->M * d->N / 8;
+      int64_t blocks = dvt_cdiv(nvec, 256);
+      const int64_t cap = (int64_t)dvt_num_cus() * 8;
+      if (blocks > cap) blocks = cap;
+      if (p.out_f32)
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate);
+      else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const float*)p.slab, split, p.M, p.N, (bf16*)d->C, d->ldc, 0);
+      DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce)");
+    }
+    return DVT_OK;
+  }
+
+  GenericParams g;
+  g.A = d->A; g.B = d->B; g.C = d->C;
+  g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;
+  g.sam = d->a_kmajor ? d->lda : 1; g.sak = d->a_kmajor ? 1 : d->lda;
+  g.sbk = d->b_kmajor ? 1 : d->ldb; g.sbn = d->b_kmajor ? d->ldb : 1;
+  g.ldc = d->ldc; g.epilogue = d->epilogue; g.out_f32 = d->out_dtype == DVT_F32;
+  g.accumulate = d->accumulate; g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
+  g.aux = d->aux; g.ldaux = d->ldaux; g.alpha = d->alpha;
+  const dim3 grid((unsigned)dvt_cdiv(d->N, 64), (unsigned)dvt_cdiv(d->M, 64)), block(256);
+  if (d->in_dtype == DVT_F32) hipLaunchKernelGGL((gemm_generic_kernel<float>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_generic_kernel<bf16>), grid, block, 0, st, g);
+  DVT_LAUNCH_CHECK("dvt_gemm(generic)");
+  return DVT_OK;
+}
+
+size_t dvt_colsum_workspace_bytes(int64_t M, int64_t N) {
+  (void)M;
+  return (size_t)kColsumParts * (size_t)(N > 0 ? N : 0) * sizeof(float);
+}
+
+int dvt_colsum(const void* x, int64_t ldx, float* out, void* workspace, int64_t M, int64_t N,
+               int dtype, int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(x && out && M >= 0 && N > 0 && ldx >= N, "dvt_colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = workspace && N % 8 == 0 && ldx % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(workspace) && M >= 64;
+  if (vec) {
+    int parts = (int)(M / 64 < kColsumParts ? M / 64 : kColsumParts);
+    if (parts < 1) parts = 1;
+    const int rpb = (int)dvt_cdiv(M, parts);
+    parts = (int)dvt_cdiv(M, rpb);
+    const dim3 grid((unsigned)dvt_cdiv(N, 256), (unsigned)parts);
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st,
+                                                    (const T*)x, ldx, M, N, rpb, (float*)workspace));
+    DVT_LAUNCH_CHECK("dvt_colsum(partial)");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dvt_cdiv(N, 256)), dim3(256), 0, st,
+                       (const float*)workspace, parts, N, out, accumulate);
+    DVT_LAUNCH_CHECK("dvt_colsum(final)");
+    return DVT_OK;
+  }
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colsum_generic_kernel<T>), dim3((unsigned)dvt_cdiv(N, 256)),
+                                                  dim3(256), 0, st, (const T*)x, ldx, M, N, out, accumulate));
+  DVT_LAUNCH_CHECK("dvt_colsum(generic)");
+  return DVT_OK;
+}
+
+}  // extern "C"

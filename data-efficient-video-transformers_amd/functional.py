@@ -1,0 +1,515 @@
+"""torch.autograd.Function wrappers: the differentiable operators of the clip path.
+
+Forward and backward of every Function are sequences of HIP kernel launches
+through ``ops`` (the C ABI); torch contributes tensors, the autograd tape and
+nothing else.  Parameters are fp32 masters; GEMM operands are cast to the
+compute dtype (bf16 by default) inside the Functions and parameter gradients are
+produced directly in fp32 (the weight-gradient GEMM writes fp32).
+
+Block-level Functions (``attn_block``, ``mlp_block``) cover one residual branch
+``fn(LN(x)) + x`` each (src/models/vit.py:71-74) so that the fusions that cross
+operator boundaries live in one place: bias+GELU and bias+residual in the GEMM
+epilogues, GELU' in the dgrad epilogue, and the sum of the two gradient paths
+into ``x`` inside the LayerNorm backward kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _wc(w: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
+    """Compute-dtype copy of an fp32 master weight (identity in fp32 mode)."""
+    if w is None:
+        return None
+    w = w.detach()
+    if w.dtype == dtype:
+        return w.contiguous()
+    return ops.cast(w, dtype)
+
+
+def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.detach()
+    return t.contiguous() if t.dtype == torch.float32 else ops.cast(t, torch.float32)
+
+
+def _as(t: Tensor, dtype: torch.dtype) -> Tensor:
+    return t if t.dtype == dtype else ops.cast(t, dtype)
+
+
+# ---------------------------------------------------------------------------
+# Linear (+ optional fp32 output), used for patch embedding and heads
+# ---------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, out_f32):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        wc = _wc(w, x.dtype)
+        M, K = x2.shape
+        N = wc.shape[0]
+        out_dtype = torch.float32 if out_f32 else x.dtype
+        y = ops.gemm(x2, wc, M, N, K, a_kmajor=True, b_kmajor=True, lda=x2.stride(0), ldb=K,
+                     out_dtype=out_dtype, bias=_f32(b))
+        ctx.save_for_backward(x2, wc)
+        ctx.has_bias = b is not None
+        ctx.xshape = shp
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wc = ctx.saved_tensors
+        dy2 = _as(dy.reshape(-1, dy.shape[-1]).contiguous(), x2.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(dy2, wc).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2)
+        return dx, dw, db, None
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+    return _Linear.apply(x, w, b, out_f32)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(_as(dy, x.dtype), x, ctx.act), None
+
+
+def gelu(x: Tensor) -> Tensor:
+    return _Act.apply(x, ops.ACT_GELU)
+
+
+def relu(x: Tensor) -> Tensor:
+    return _Act.apply(x, ops.ACT_RELU)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    return _Add.apply(a, b)
+
+
+class _Cast(torch.autograd.Function):
+    """Differentiable dtype change of an activation (grad cast back)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return _as(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _as(dy.contiguous(), ctx.src), None
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        xc = x.contiguous()
+        g, bb = _f32(w), _f32(b)
+        y, mean, rstd = ops.layernorm_fwd(xc, g, bb, eps)
+        ctx.save_for_backward(xc, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_as(dy.contiguous(), xc.dtype), xc, g, mean, rstd)
+        return dx, dg, db, None
+
+
+def layernorm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+# ---------------------------------------------------------------------------
+# Patch embedding: patchify gather + Linear  (vit.py:89-92,110)
+# ---------------------------------------------------------------------------
+class _PatchEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, w, b, patch, dtype):
+        patches = ops.patchify(clip, patch, dtype)          # [frames*n, P*P*C]
+        wc = _wc(w, dtype)
+        emb = ops.linear_fwd(patches, wc, _f32(b))
+        ctx.save_for_backward(patches, wc)
+        ctx.clip_shape, ctx.clip_dtype, ctx.patch = tuple(clip.shape), clip.dtype, patch
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        patches, wc = ctx.saved_tensors
+        demb = demb.contiguous()
+        dclip = None
+        if ctx.needs_input_grad[0]:
+            dpatch = ops.linear_dgrad(demb, wc)
+            dclip = ops.patchify_bwd(dpatch, ctx.clip_shape, ctx.patch, ctx.clip_dtype)
+        dw = ops.linear_wgrad(demb, patches) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(demb) if ctx.needs_input_grad[2] else None
+        return dclip, dw, db, None, None
+
+
+def patch_embed(clip: Tensor, w: Tensor, b: Tensor, patch: int, dtype: torch.dtype) -> Tensor:
+    """clip [..., C, H, W] -> [frames * n, d] in ``dtype``."""
+    return _PatchEmbed.apply(clip, w, b, patch, dtype)
+
+
+# ---------------------------------------------------------------------------
+# Token assembly (CLS concat + learned positional add), vit.py:113-115
+# ---------------------------------------------------------------------------
+class _Tokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, cls, pos, S, T, n):
+        cls32 = _f32(cls).reshape(-1)
+        pos32 = _f32(pos)
+        pos32 = pos32.reshape(T, pos32.shape[-2], pos32.shape[-1])
+        ctx.T, ctx.pos_rows = T, pos32.shape[1]
+        ctx.cls_shape, ctx.pos_shape = tuple(cls.shape), tuple(pos.shape)
+        return ops.tokens_assemble_fwd(emb.contiguous(), cls32, pos32, S, T, n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        demb, dcls, dpos = ops.tokens_assemble_bwd(dout, ctx.T, ctx.pos_rows)
+        return demb, dcls.view(ctx.cls_shape), dpos.view(ctx.pos_shape), None, None, None
+
+
+def tokens_assemble(emb: Tensor, cls: Tensor, pos: Tensor, S: int, T: int, n: int) -> Tensor:
+    """emb [S*n, d], cls [1,1,d], pos [1,T,rows,d] -> [S, n+1, d]."""
+    return _Tokens.apply(emb, cls, pos, S, T, n)
+
+
+# ---------------------------------------------------------------------------
+# Final space LayerNorm on the CLS rows + temporal CLS concat (vit.py:75,120-123)
+# ---------------------------------------------------------------------------
+class _ClsNormConcat(torch.autograd.Function):
+    """x [B*T, N, d] -> LN(x)[:, 0] as [B, T, d] -> cat(token, .) -> [B, T+1, d].
+
+    LayerNorm is row-wise, so normalising only the rows that are read
+    (``x[:, 0]``, vit.py:120) gives the same values and gradients as the
+    reference's LayerNorm over all N rows followed by the slice.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, b, tok, B, T, eps):
+        S, N, d = x.shape
+        xc = x.contiguous()
+        g, bb = _f32(w), _f32(b)
+        rows = (S, 1, N * d, 0)
+        cls_rows, mean, rstd = ops.layernorm_fwd(xc, g, bb, eps, rows=rows)      # [S, d]
+        tok32 = _f32(tok).reshape(-1) if tok is not None else None
+        seq = ops.rows_gather_fwd(cls_rows, d, tok32, B, T, d)
+        ctx.save_for_backward(xc, g, mean, rstd)
+        ctx.dims = (B, T, S, N, d)
+        ctx.tok_shape = tuple(tok.shape) if tok is not None else None
+        return seq
+
+    @staticmethod
+    def backward(ctx, dseq):
+        xc, g, mean, rstd = ctx.saved_tensors
+        B, T, S, N, d = ctx.dims
+        dseq = _as(dseq.contiguous(), xc.dtype)
+        drows = torch.empty((S, d), dtype=xc.dtype, device=xc.device)
+        dtok = ops.rows_gather_bwd(dseq, drows, d, ctx.tok_shape is not None, B, T, d)
+        dx = torch.zeros_like(xc)   # rows other than CLS receive no gradient
+        _, dg, db = ops.layernorm_bwd(drows, xc, g, mean, rstd, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
+        if dtok is not None:
+            dtok = dtok.view(ctx.tok_shape)
+        return dx, dg, db, dtok, None, None, None
+
+
+def cls_norm_concat(x: Tensor, w: Tensor, b: Tensor, tok: Optional[Tensor], B: int, T: int,
+                    eps: float = 1e-5) -> Tensor:
+    return _ClsNormConcat.apply(x, w, b, tok, B, T, eps)
+
+
+class _RowsSelect(torch.autograd.Function):
+    """x [B, L, d] -> x[:, 0] (pool == 'cls', vit.py:126) without a torch kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Ln, d = x.shape
+        xc = x.contiguous()
+        ctx.shape = (B, Ln, d)
+        return ops.rows_gather_fwd(xc, Ln * d, None, B, 1, d).view(B, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Ln, d = ctx.shape
+        dx = torch.zeros((B, Ln, d), dtype=dy.dtype, device=dy.device)
+        ops.rows_gather_bwd(dy.contiguous().view(B, 1, d), dx, Ln * d, False, B, 1, d)
+        return dx
+
+
+def select_first_row(x: Tensor) -> Tensor:
+    return _RowsSelect.apply(x)
+
+
+# ---------------------------------------------------------------------------
+# Attention core on separate q/k/v (cross-modal form; MHA)
+# ---------------------------------------------------------------------------
+class _AttentionCore(torch.autograd.Function):
+    """q [B,H,Lq,dh], k/v [B,H,Lk,dh] (arbitrary strides, dh contiguous) ->
+    o [B,H,Lq,dh] laid out as [B, Lq, H, dh] in memory ('b n (h d)', vit.py:56)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        B, H, Lq, dh = q.shape
+        o_mem = torch.empty((B, Lq, H, dh), dtype=q.dtype, device=q.device)
+        o = o_mem.permute(0, 2, 1, 3)
+        lse = ops.attention_fwd(q, k, v, o, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, H, Lq, dh = q.shape
+        Lk = k.shape[2]
+        do_mem = torch.empty((B, Lq, H, dh), dtype=q.dtype, device=q.device)
+        do_v = do_mem.permute(0, 2, 1, 3)
+        if do.stride() == o.stride() and do.dtype == q.dtype:
+            do_v = do
+        else:
+            # re-layout through the cast kernel (contiguous copy in o's memory order)
+            do_c = _as(do.permute(0, 2, 1, 3).contiguous(), q.dtype)
+            do_v = do_c.permute(0, 2, 1, 3)
+        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device)
+        dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device)
+        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
+        ops.attention_bwd(q, k, v, o, lse, do_v, dq, dk, dv, ctx.scale)
+        return dq, dk, dv, None
+
+
+def attention_core(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
+    return _AttentionCore.apply(q, k, v, scale)
+
+
+# ---------------------------------------------------------------------------
+# Residual branches of the pre-norm Transformer (vit.py:30-75)
+# ---------------------------------------------------------------------------
+class _AttnBlock(torch.autograd.Function):
+    """y = [x +] to_out(attention(to_qkv([LN](x))))   -- ``PreNorm(Attention)`` + residual.
+
+    to_qkv has no bias (vit.py:39); q,k,v are the three chunks of the last dim and
+    heads are the outer factor of each chunk (vit.py:48-49); to_out is skipped when
+    ``w_out is None`` (heads == 1 and dim_head == dim, vit.py:34,41-44).
+    """
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps):
+        shp = x.shape
+        d = shp[-1]
+        S, N = (shp[0], shp[1]) if x.dim() == 3 else (1, shp[0])
+        x2 = x.reshape(-1, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        T = x.dtype
+        if prenorm:
+            g, bb = _f32(ln_w), _f32(ln_b)
+            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+        else:
+            g = mean = rstd = None
+            xn = x2
+        wq = _wc(w_qkv, T)
+        inner = wq.shape[0] // 3
+        dh = inner // heads
+        qkv = ops.linear_fwd(xn, wq)                                   # [M, 3*inner]
+        qkv5 = qkv.view(S, N, 3, heads, dh)
+        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # [S,H,N,dh] views
+        o_mem = torch.empty((S, N, heads, dh), dtype=T, device=x.device)
+        lse = ops.attention_fwd(q, k, v, o_mem.permute(0, 2, 1, 3), dh ** -0.5)
+        o2 = o_mem.view(M, inner)
+        if w_out is not None:
+            wo = _wc(w_out, T)
+            if residual:
+                y = ops.linear_fwd(o2, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2)
+            else:
+                y = ops.linear_fwd(o2, wo, _f32(b_out))
+        else:
+            wo = None
+            y = ops.add(o2, x2) if residual else o2
+        ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, wq, wo, qkv, o_mem, lse)
+        ctx.cfg = (S, N, heads, dh, inner, prenorm, residual, w_out is not None, b_out is not None)
+        ctx.xshape = shp
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd, xn, wq, wo, qkv, o_mem, lse = ctx.saved_tensors
+        S, N, heads, dh, inner, prenorm, residual, has_out, has_bias = ctx.cfg
+        M = x2.shape[0]
+        T = x2.dtype
+        if xn is None:
+            xn = x2
+        dy2 = _as(dy.reshape(M, -1).contiguous(), T)
+        dwo = dbo = None
+        if has_out:
+            do2 = ops.linear_dgrad(dy2, wo)                            # [M, inner]
+            dwo = ops.linear_wgrad(dy2, o_mem.view(M, inner))
+            if has_bias:
+                dbo = ops.colsum(dy2)
+        else:
+            do2 = dy2
+        qkv5 = qkv.view(S, N, 3, heads, dh)
+        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(S, N, 3, heads, dh)
+        dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ops.attention_bwd(q, k, v, o_mem.permute(0, 2, 1, 3), lse,
+                          do2.view(S, N, heads, dh).permute(0, 2, 1, 3), dq, dk, dv, dh ** -0.5)
+        dwq = ops.linear_wgrad(dqkv, xn)
+        dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
+        dg = db = None
+        if prenorm:
+            dx, dg, db = ops.layernorm_bwd(dxn, x2, g, mean, rstd, dx_add=dy2 if residual else None)
+        else:
+            dx = ops.add(dxn, dy2) if residual else dxn
+        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None
+
+
+def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, residual=True, eps=1e-5):
+    return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps)
+
+
+class _MlpBlock(torch.autograd.Function):
+    """y = [x +] W2 act(W1 [LN](x) + b1) + b2   -- ``PreNorm(FeedForward)`` + residual
+    (vit.py:17-28,73-74).  act: 'gelu' (exact erf) or 'relu'."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps):
+        shp = x.shape
+        d = shp[-1]
+        x2 = x.reshape(-1, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x.dtype
+        if prenorm:
+            g, bb = _f32(ln_w), _f32(ln_b)
+            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+        else:
+            g = mean = rstd = None
+            xn = x2
+        w1c, w2c = _wc(w1, T), _wc(w2, T)
+        M = x2.shape[0]
+        if act == "gelu":
+            u = torch.empty((M, w1c.shape[0]), dtype=T, device=x.device)    # pre-activation
+            h = ops.linear_fwd(xn, w1c, _f32(b1), epilogue=L.EPI_GELU, aux=u)
+        else:
+            u = None
+            h = ops.linear_fwd(xn, w1c, _f32(b1), epilogue=L.EPI_RELU)
+        if residual:
+            y = ops.linear_fwd(h, w2c, _f32(b2), epilogue=L.EPI_RESIDUAL, residual=x2)
+        else:
+            y = ops.linear_fwd(h, w2c, _f32(b2))
+        ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, w1c, w2c, u, h)
+        ctx.cfg = (act, prenorm, residual, b1 is not None, b2 is not None)
+        ctx.xshape = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd, xn, w1c, w2c, u, h = ctx.saved_tensors
+        act, prenorm, residual, has_b1, has_b2 = ctx.cfg
+        T = x2.dtype
+        if xn is None:
+            xn = x2
+        dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
+        dw2 = ops.linear_wgrad(dy2, h)
+        db2 = ops.colsum(dy2) if has_b2 else None
+        if act == "gelu":
+            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u)
+        else:
+            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h)
+        dw1 = ops.linear_wgrad(du, xn)
+        db1 = ops.colsum(du) if has_b1 else None
+        dxn = ops.linear_dgrad(du, w1c)
+        dg = db = None
+        if prenorm:
+            dx, dg, db = ops.layernorm_bwd(dxn, x2, g, mean, rstd, dx_add=dy2 if residual else None)
+        else:
+            dx = ops.add(dxn, dy2) if residual else dxn
+        return dx.view(ctx.xshape), dg, db, dw1, db1, dw2, db2, None, None, None, None
+
+
+def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, *, act="gelu", prenorm=True, residual=True, eps=1e-5):
+    return _MlpBlock.apply(x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps)
+
+
+# ---------------------------------------------------------------------------
+# Losses (frame_transformer.py:89-90,246-273)
+# ---------------------------------------------------------------------------
+class _BceLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, target):
+        zc = z.contiguous()
+        t32 = _f32(target)
+        ctx.save_for_backward(zc, t32)
+        return ops.bce_logits_fwd(zc, t32).view(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        zc, t32 = ctx.saved_tensors
+        g = _f32(gloss).reshape(1)
+        return ops.bce_logits_bwd(zc, t32, g), None
+
+
+def bce_with_logits(z: Tensor, target: Tensor) -> Tensor:
+    """nn.BCEWithLogitsLoss() (mean)."""
+    return _BceLogits.apply(z, target)
+
+
+class _CeArgmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher):
+        s = student.contiguous()
+        t = _as(teacher.detach().contiguous(), s.dtype)
+        ctx.save_for_backward(s, t)
+        return ops.ce_argmax_fwd(s, t).view(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        s, t = ctx.saved_tensors
+        return ops.ce_argmax_bwd(s, t, _f32(gloss).reshape(1)), None
+
+
+def cross_entropy_argmax(student: Tensor, teacher: Tensor) -> Tensor:
+    """CrossEntropyLoss(student, argmax(teacher, -1)) -- the hard-label distillation term."""
+    return _CeArgmax.apply(student, teacher)

@@ -1,0 +1,198 @@
+"""Drop-in mirror of the reference's ``src/models/vit.py`` on MI355X kernels.
+
+Same class names, constructor signatures, ``forward`` signatures, submodule
+layout and therefore the same ``state_dict`` keys as the reference
+(``pos_embedding, space_token, temporal_token, to_patch_embedding.1.*,
+{space,temporal}_transformer.layers.{i}.{0,1}.{norm,fn...}``, ``mlp_head.{0,1}.*``;
+reference: src/models/vit.py:8-128), so reference checkpoints load unchanged.
+``nn.Linear`` / ``nn.LayerNorm`` instances are parameter containers only: every
+forward/backward runs through the HIP kernels of libdvt_hip.so (functional.py);
+there is no torch arithmetic and no CPU path.
+
+Build-side additions (keyword-only, defaults keep reference behaviour):
+``compute_dtype`` -- activation / GEMM dtype (torch.bfloat16 default, torch.float32
+for the fp32 parity mode).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import functional as F
+
+
+def _no_dropout(p: float, training: bool, where: str) -> None:
+    if p > 0.0 and training:
+        raise NotImplementedError(
+            f"{where}: dropout p={p} in training mode has no HIP kernel yet; use p=0 (the "
+            "reference's ViViT default, vit.py:80-81) or eval()")
+
+
+class Patchify(nn.Module):
+    """Position 0 of ``to_patch_embedding`` (the reference's einops ``Rearrange``,
+    vit.py:90).  Parameter-free; the gather itself is fused into ``F.patch_embed``."""
+
+    def __init__(self, patch_size: int):
+        super().__init__()
+        self.patch_size = patch_size
+
+    def forward(self, x):  # only reached when used stand-alone
+        from .. import ops
+        b, t = x.shape[0], x.shape[1]
+        out = ops.patchify(x, self.patch_size, x.dtype)
+        return out.view(b, t, -1, out.shape[-1])
+
+
+class GELU(nn.Module):
+    """Exact-erf GELU (vit.py:22); fused into the GEMM epilogue inside FeedForward."""
+
+    def forward(self, x):
+        return F.gelu(x)
+
+
+class PreNorm(nn.Module):
+    """vit.py:8-14."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        if isinstance(self.fn, (Attention, FeedForward)) and not kwargs:
+            return self.fn(x, _norm=self.norm)
+        return self.fn(F.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
+
+
+class FeedForward(nn.Module):
+    """vit.py:17-28: Linear(dim, hidden) - GELU - Dropout - Linear(hidden, dim) - Dropout."""
+
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Linear(dim, hidden_dim),
+            GELU(),
+            nn.Dropout(dropout),
+            nn.Linear(hidden_dim, dim),
+            nn.Dropout(dropout),
+        )
+        self.dropout_p = dropout
+
+    def forward(self, x, _norm=None, _residual=False):
+        _no_dropout(self.dropout_p, self.training, "FeedForward")
+        l1, l2 = self.net[0], self.net[3]
+        return F.mlp_block(x, _norm.weight if _norm is not None else None,
+                           _norm.bias if _norm is not None else None,
+                           l1.weight, l1.bias, l2.weight, l2.bias, act="gelu",
+                           prenorm=_norm is not None, residual=_residual,
+                           eps=_norm.eps if _norm is not None else 1e-5)
+
+
+class Attention(nn.Module):
+    """vit.py:30-58."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout),
+        ) if project_out else nn.Identity()
+        self.project_out = project_out
+        self.dropout_p = dropout
+
+    def forward(self, x, _norm=None, _residual=False):
+        _no_dropout(self.dropout_p, self.training, "Attention")
+        w_out = self.to_out[0].weight if self.project_out else None
+        b_out = self.to_out[0].bias if self.project_out else None
+        return F.attn_block(x, _norm.weight if _norm is not None else None,
+                            _norm.bias if _norm is not None else None,
+                            self.to_qkv.weight, w_out, b_out, self.heads,
+                            prenorm=_norm is not None, residual=_residual,
+                            eps=_norm.eps if _norm is not None else 1e-5)
+
+
+class Transformer(nn.Module):
+    """vit.py:60-75: depth x [x = attn(LN x) + x; x = ff(LN x) + x], final LayerNorm."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.norm = nn.LayerNorm(dim)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout)),
+            ]))
+
+    def forward_layers(self, x):
+        """All residual blocks, without the final norm."""
+        for attn, ff in self.layers:
+            x = attn.fn(x, _norm=attn.norm, _residual=True)
+            x = ff.fn(x, _norm=ff.norm, _residual=True)
+        return x
+
+    def forward(self, x):
+        x = self.forward_layers(x)
+        return F.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class ViViT(nn.Module):
+    """vit.py:79-128.  ``forward(x[b, t, c, H, W]) -> [b, num_classes]`` (fp32 logits)."""
+
+    def __init__(self, image_size, patch_size, num_classes, num_frames, dim=192, depth=4, heads=3,
+                 pool='cls', in_channels=3, dim_head=64, dropout=0., emb_dropout=0., scale_dim=4, *,
+                 compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
+        num_patches = (image_size // patch_size) ** 2
+        patch_dim = in_channels * patch_size ** 2
+        self.to_patch_embedding = nn.Sequential(
+            Patchify(patch_size),
+            nn.Linear(patch_dim, dim),
+        )
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_frames, num_patches + 1, dim))
+        self.space_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.space_transformer = Transformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.temporal_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.temporal_transformer = Transformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.dropout = nn.Dropout(emb_dropout)
+        self.pool = pool
+        self.mlp_head = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, num_classes),
+        )
+        self.patch_size = patch_size
+        self.num_patches = num_patches
+        self.num_frames = num_frames
+        self.emb_dropout_p = emb_dropout
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):
+        _no_dropout(self.emb_dropout_p, self.training, "ViViT(emb_dropout)")
+        if x.dim() != 5:
+            raise ValueError("ViViT expects a clip tensor [b, t, c, H, W]")
+        b, t = x.shape[0], x.shape[1]
+        if t != self.num_frames:
+            raise ValueError(f"clip has {t} frames but pos_embedding was built for {self.num_frames} "
+                             "(vit.py:94,115 broadcast)")
+        T = self.compute_dtype
+        n = (x.shape[3] // self.patch_size) * (x.shape[4] // self.patch_size)
+        pe = self.to_patch_embedding[1]
+        emb = F.patch_embed(x, pe.weight, pe.bias, self.patch_size, T)              # vit.py:110
+        tok = F.tokens_assemble(emb, self.space_token, self.pos_embedding, b * t, t, n)   # :113-115
+        s = self.space_transformer.forward_layers(tok)                              # :118-119
+        sn = self.space_transformer.norm
+        seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)  # :119-123
+        z = self.temporal_transformer(seq)                                          # :125
+        if self.pool == 'mean':
+            raise NotImplementedError("pool='mean' (vit.py:126) has no HIP kernel yet; use pool='cls'")
+        pooled = F.select_first_row(z)                                              # :126
+        hn, hl = self.mlp_head[0], self.mlp_head[1]
+        h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)
+        return F.linear(h, hl.weight, hl.bias, out_f32=True)                        # :128

@@ -1,0 +1,399 @@
+"""Raw (autograd-free) Python wrappers over the C ABI.
+
+Every function launches hand-written HIP kernels from libdvt_hip.so on the
+current torch stream; torch is used only to own device memory.  Nothing here
+falls back to torch arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def dt(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"dtype {t.dtype} is not supported by libdvt_hip (float32 / bfloat16)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libdvt_hip operators need tensors on the GPU (HIP device); "
+                               "there is no CPU path")
+
+
+_ws = {}
+
+
+def workspace(nbytes: int, device, slot: str = "main") -> Optional[Tensor]:
+    """Grow-only scratch buffer per (device, slot).  Kernels on one stream run in
+    order, so consecutive operators may share it."""
+    if nbytes <= 0:
+        return None
+    key = (str(device), slot)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ elementwise
+def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
+    _need_cuda(src)
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.check(L.load().dvt_cast(src.data_ptr(), dt(src), out.data_ptr(), _DT[dtype], src.numel(), _stream()),
+            "dvt_cast")
+    return out
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    _need_cuda(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    a = a.contiguous(); b = b.contiguous()
+    out = torch.empty_like(a)
+    L.check(L.load().dvt_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dt(a), _stream()), "dvt_add")
+    return out
+
+
+def axpby_f32_(dst: Tensor, src: Tensor, alpha: float = 1.0, beta: float = 1.0) -> Tensor:
+    """dst(f32) = beta*dst + alpha*src."""
+    _need_cuda(dst, src)
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    assert dst.numel() == src.numel()
+    L.check(L.load().dvt_axpby_f32(src.data_ptr(), dt(src), alpha, dst.data_ptr(), beta, dst.numel(), _stream()),
+            "dvt_axpby_f32")
+    return dst
+
+
+ACT_GELU, ACT_RELU = 1, 2
+
+
+def act_fwd(x: Tensor, act: int) -> Tensor:
+    _need_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().dvt_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, dt(x), _stream()), "dvt_act_fwd")
+    return y
+
+
+def act_bwd(dy: Tensor, x: Tensor, act: int) -> Tensor:
+    _need_cuda(dy, x)
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    L.check(L.load().dvt_act_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), act, dt(x), _stream()),
+            "dvt_act_bwd")
+    return dx
+
+
+def patchify(x: Tensor, patch: int, out_dtype: torch.dtype) -> Tensor:
+    """[..., C, H, W] -> [frames * n, P*P*C]  (vit.py:90 ordering)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    Cc, H, W = x.shape[-3:]
+    frames = x.numel() // (Cc * H * W)
+    n = (H // patch) * (W // patch)
+    out = torch.empty((frames * n, patch * patch * Cc), dtype=out_dtype, device=x.device)
+    L.check(L.load().dvt_patchify(x.data_ptr(), dt(x), out.data_ptr(), _DT[out_dtype], frames, Cc, H, W, patch,
+                                  _stream()), "dvt_patchify")
+    return out
+
+
+def patchify_bwd(dout: Tensor, shape, patch: int, dx_dtype: torch.dtype) -> Tensor:
+    _need_cuda(dout)
+    dout = dout.contiguous()
+    Cc, H, W = shape[-3:]
+    frames = 1
+    for s in shape[:-3]:
+        frames *= s
+    dx = torch.empty(tuple(shape), dtype=dx_dtype, device=dout.device)
+    L.check(L.load().dvt_patchify_bwd(dout.data_ptr(), dt(dout), dx.data_ptr(), _DT[dx_dtype], frames, Cc, H, W,
+                                      patch, _stream()), "dvt_patchify_bwd")
+    return dx
+
+
+def tokens_assemble_fwd(emb: Tensor, cls: Tensor, pos: Tensor, S: int, T: int, n: int) -> Tensor:
+    """emb [S*n, d]; cls [d] f32; pos [T, rows>=n+1, d] f32 -> [S, n+1, d]."""
+    _need_cuda(emb, cls, pos)
+    d = emb.shape[-1]
+    assert emb.is_contiguous() and cls.is_contiguous() and pos.is_contiguous()
+    assert cls.dtype == torch.float32 and pos.dtype == torch.float32
+    out = torch.empty((S, n + 1, d), dtype=emb.dtype, device=emb.device)
+    L.check(L.load().dvt_tokens_assemble_fwd(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), S, T,
+                                             n, d, pos.shape[-2], dt(emb), _stream()), "dvt_tokens_assemble_fwd")
+    return out
+
+
+def tokens_assemble_bwd(dout: Tensor, T: int, pos_rows: int) -> Tuple[Tensor, Tensor, Tensor]:
+    _need_cuda(dout)
+    dout = dout.contiguous()
+    S, n1, d = dout.shape
+    n = n1 - 1
+    demb = torch.empty((S * n, d), dtype=dout.dtype, device=dout.device)
+    dcls = torch.empty((d,), dtype=torch.float32, device=dout.device)
+    dpos = torch.empty((T, pos_rows, d), dtype=torch.float32, device=dout.device)
+    L.check(L.load().dvt_tokens_assemble_bwd(dout.data_ptr(), demb.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), S,
+                                             T, n, d, pos_rows, dt(dout), 0, _stream()), "dvt_tokens_assemble_bwd")
+    return demb, dcls, dpos
+
+
+def rows_gather_fwd(src: Tensor, row_stride: int, tok: Optional[Tensor], B: int, T: int, d: int) -> Tensor:
+    _need_cuda(src, tok)
+    lead = 0 if tok is None else 1
+    out = torch.empty((B, T + lead, d), dtype=src.dtype, device=src.device)
+    L.check(L.load().dvt_rows_gather_fwd(src.data_ptr(), row_stride, _p(tok), out.data_ptr(), B, T, d, dt(src),
+                                         _stream()), "dvt_rows_gather_fwd")
+    return out
+
+
+def rows_gather_bwd(dout: Tensor, dsrc: Tensor, row_stride: int, want_tok: bool, B: int, T: int,
+                    d: int) -> Optional[Tensor]:
+    """Scatters dout rows into ``dsrc`` (pre-zeroed by the caller where needed)."""
+    _need_cuda(dout, dsrc)
+    dout = dout.contiguous()
+    dtok = torch.empty((d,), dtype=torch.float32, device=dout.device) if want_tok else None
+    L.check(L.load().dvt_rows_gather_bwd(dout.data_ptr(), dsrc.data_ptr(), row_stride, _p(dtok), B, T, d, dt(dout),
+                                         0, _stream()), "dvt_rows_gather_bwd")
+    return dtok
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, *, rows=None,
+                  out: Optional[Tensor] = None, out_rows=None) -> Tuple[Tensor, Tensor, Tensor]:
+    """Dense (rows is None): x [..., d] contiguous -> y like x.
+    Strided: rows = (n0, n1, xs0, xs1) selects row (i0,i1) of ``x`` at element
+    i0*xs0 + i1*xs1; the output row goes to ``out`` at i0*ys0 + i1*ys1 with
+    out_rows = (ys0, ys1) (default: a dense [n0*n1, d] tensor)."""
+    _need_cuda(x, gamma, beta)
+    d = x.shape[-1]
+    if rows is None:
+        assert x.is_contiguous()
+        n0, n1, xs0, xs1 = x.numel() // d, 1, d, 0
+        if out is None:
+            out = torch.empty_like(x)
+        ys0, ys1 = d, 0
+    else:
+        n0, n1, xs0, xs1 = rows
+        if out is None:
+            out = torch.empty((n0 * n1, d), dtype=x.dtype, device=x.device)
+        ys0, ys1 = out_rows if out_rows is not None else (n1 * d, d)
+    nrows = n0 * n1
+    mean = torch.empty((nrows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((nrows,), dtype=torch.float32, device=x.device)
+    L.check(L.load().dvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1, eps,
+                                       dt(x), _stream()), "dvt_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *,
+                  dx_add: Optional[Tensor] = None, rows=None, dy_rows=None,
+                  dx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    _need_cuda(dy, x, gamma, mean, rstd, dx_add)
+    d = x.shape[-1]
+    if rows is None:
+        assert x.is_contiguous() and dy.is_contiguous()
+        n0, n1, xs0, xs1 = x.numel() // d, 1, d, 0
+        ys0, ys1 = d, 0
+    else:
+        n0, n1, xs0, xs1 = rows
+        ys0, ys1 = dy_rows if dy_rows is not None else (d * n1, d)
+    if dx is None:
+        dx = torch.empty_like(x)
+    dg = torch.empty((d,), dtype=torch.float32, device=x.device)
+    db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
+    L.check(lib.dvt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                  _p(dx_add), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d,
+                                  xs0, xs1, ys0, ys1, dt(x), 0, _stream()), "dvt_layernorm_bwd")
+    return dx, dg, db
+
+
+# ------------------------------------------------------------------ GEMM family
+def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmajor: bool,
+         lda: int, ldb: int, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+         aux: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0,
+         split_k: int = 0) -> Tensor:
+    _need_cuda(A, B, bias, residual, aux)
+    assert A.dtype == B.dtype
+    if out_dtype is None:
+        out_dtype = A.dtype
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    assert out.dtype == out_dtype and out.stride(-1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, out.stride(0) if out.dim() == 2 else N
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype, d.out_dtype = dt(A), _DT[out_dtype]
+    d.epilogue, d.accumulate = epilogue, int(accumulate)
+    d.bias = _p(bias)
+    d.residual = _p(residual)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.aux = _p(aux)
+    d.ldaux = aux.stride(0) if aux is not None else 0
+    d.alpha = alpha
+    d.split_k = split_k
+    lib = L.load()
+    ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device)
+    d.workspace = _p(ws)
+    L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
+    return out
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, epilogue: int = L.EPI_NONE,
+               residual: Optional[Tensor] = None, aux: Optional[Tensor] = None) -> Tensor:
+    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias)."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.is_contiguous()
+    return gemm(x, w, M, N, K, a_kmajor=True, b_kmajor=True, lda=x.stride(0), ldb=K, epilogue=epilogue,
+                bias=bias, residual=residual, aux=aux)
+
+
+def linear_dgrad(dy: Tensor, w: Tensor, *, epilogue: int = L.EPI_NONE, aux: Optional[Tensor] = None) -> Tensor:
+    """dx[M,K] = epi(dy[M,N] @ w[N,K])   (epilogue DGELU / DRELU multiplies by act'(aux))."""
+    M, N = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == N and dy.stride(1) == 1 and w.is_contiguous()
+    return gemm(dy, w, M, K, N, a_kmajor=True, b_kmajor=False, lda=dy.stride(0), ldb=K, epilogue=epilogue,
+                aux=aux)
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K]."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
+    return gemm(dy, x, N, K, M, a_kmajor=False, b_kmajor=False, lda=dy.stride(0), ldb=x.stride(0), out=out,
+                out_dtype=torch.float32, accumulate=accumulate)
+
+
+def colsum(x: Tensor) -> Tensor:
+    """f32 [N] = sum over rows of x[M,N] (bias gradients)."""
+    _need_cuda(x)
+    M, N = x.shape
+    assert x.stride(1) == 1
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    ws = workspace(lib.dvt_colsum_workspace_bytes(M, N), x.device)
+    L.check(lib.dvt_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), _p(ws), M, N, dt(x), 0, _stream()),
+            "dvt_colsum")
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def _attn_desc(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, scale: float) -> L.AttnDesc:
+    """q,k,v,o are 4-D views [B, H, L, dh] with unit stride in the last dim."""
+    for t in (q, k, v, o):
+        assert t.dim() == 4 and t.stride(3) == 1, "attention operands must be [B,H,L,dh] views, dh contiguous"
+    B, H, Lq, dh = q.shape
+    Lk = k.shape[2]
+    assert k.shape == (B, H, Lk, dh) and v.shape == (B, H, Lk, dh) and o.shape == (B, H, Lq, dh)
+    d = L.AttnDesc()
+    d.q, d.k, d.v, d.o, d.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    d.B, d.H, d.Lq, d.Lk, d.dh = B, H, Lq, Lk, dh
+    d.q_sb, d.q_sh, d.q_sl = q.stride(0), q.stride(1), q.stride(2)
+    d.k_sb, d.k_sh, d.k_sl = k.stride(0), k.stride(1), k.stride(2)
+    d.v_sb, d.v_sh, d.v_sl = v.stride(0), v.stride(1), v.stride(2)
+    d.o_sb, d.o_sh, d.o_sl = o.stride(0), o.stride(1), o.stride(2)
+    d.scale = scale
+    d.dtype = dt(q)
+    return d
+
+
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float) -> Tensor:
+    """Writes o (a [B,H,Lq,dh] view of caller-owned memory); returns lse [B,H,Lq] f32."""
+    _need_cuda(q, k, v, o)
+    B, H, Lq, _ = q.shape
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, lse, scale)
+    L.check(L.load().dvt_attention_fwd(C.byref(d), _stream()), "dvt_attention_fwd")
+    return lse
+
+
+def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: Tensor, dq: Tensor,
+                  dk: Tensor, dv: Tensor, scale: float) -> None:
+    """do must share o's strides; dq/dk/dv must share q/k/v's strides (views of
+    caller-owned memory, fully overwritten)."""
+    _need_cuda(q, k, v, o, do, dq, dk, dv)
+    assert do.stride() == o.stride() and dq.stride() == q.stride()
+    assert dk.stride() == k.stride() and dv.stride() == v.stride()
+    d = _attn_desc(q, k, v, o, lse, scale)
+    d.d_o, d.dq, d.dk, d.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    lib = L.load()
+    ws = workspace(lib.dvt_attention_bwd_workspace_bytes(C.byref(d)), q.device)
+    d.workspace = _p(ws)
+    L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
+
+
+# ------------------------------------------------------------------ losses / optimizer
+def bce_logits_fwd(z: Tensor, target: Tensor) -> Tensor:
+    _need_cuda(z, target)
+    assert z.is_contiguous() and target.is_contiguous() and target.dtype == torch.float32
+    loss = torch.empty((1,), dtype=torch.float32, device=z.device)
+    L.check(L.load().dvt_bce_logits_fwd(z.data_ptr(), target.data_ptr(), loss.data_ptr(), z.numel(), dt(z),
+                                        _stream()), "dvt_bce_logits_fwd")
+    return loss
+
+
+def bce_logits_bwd(z: Tensor, target: Tensor, gloss: Tensor) -> Tensor:
+    _need_cuda(z, target, gloss)
+    dz = torch.empty_like(z)
+    L.check(L.load().dvt_bce_logits_bwd(z.data_ptr(), target.data_ptr(), gloss.data_ptr(), dz.data_ptr(), z.numel(),
+                                        dt(z), _stream()), "dvt_bce_logits_bwd")
+    return dz
+
+
+def ce_argmax_fwd(student: Tensor, teacher: Tensor) -> Tensor:
+    _need_cuda(student, teacher)
+    assert student.is_contiguous() and teacher.is_contiguous() and student.dtype == teacher.dtype
+    rows, Cn = student.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=student.device)
+    L.check(L.load().dvt_ce_argmax_fwd(student.data_ptr(), teacher.data_ptr(), loss.data_ptr(), rows, Cn,
+                                       dt(student), _stream()), "dvt_ce_argmax_fwd")
+    return loss
+
+
+def ce_argmax_bwd(student: Tensor, teacher: Tensor, gloss: Tensor) -> Tensor:
+    rows, Cn = student.shape
+    ds = torch.empty_like(student)
+    L.check(L.load().dvt_ce_argmax_bwd(student.data_ptr(), teacher.data_ptr(), gloss.data_ptr(), ds.data_ptr(), rows,
+                                       Cn, dt(student), _stream()), "dvt_ce_argmax_bwd")
+    return ds
+
+
+def adamw_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, *, lr: float, beta1: float,
+                beta2: float, eps: float, weight_decay: float, step: int) -> None:
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    L.check(L.load().dvt_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                    param.numel(), lr, beta1, beta2, eps, weight_decay, step, _stream()),
+            "dvt_adamw_step")

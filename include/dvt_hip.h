@@ -1,0 +1,237 @@
+/*
+ * dvt_hip.h -- C ABI of libdvt_hip.so: the MI355X (gfx950) kernels behind the
+ * video-clip forward/backward hot path of data-efficient-video-transformers.
+ *
+ * The reference has no native layer: every entry point below replaces a
+ * third-party PyTorch operator at the reference call site cited next to it
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - Plain C: raw device pointers, int64 sizes / element strides, enums as int.
+ *   - Every function is asynchronous on `stream` (a hipStream_t passed as
+ *     void*; NULL = the legacy default stream), never synchronises, never
+ *     allocates or retains memory: the caller owns all buffers and workspaces.
+ *   - Return value: 0 (DVT_OK) or a negative dvt_status; the message for the
+ *     last failure on the calling thread is dvt_last_error().  No C++
+ *     exception crosses the boundary.
+ *   - Activations are `dtype` (DVT_BF16 or DVT_F32 ...); LayerNorm scale/shift,
+ *     biases, positional tables, statistics and all parameter gradients are
+ *     float32.  Accumulation is always float32.
+ *   - Matrices are row-major with the last dimension contiguous unless an
+ *     element stride says otherwise.
+ */
+#ifndef DVT_HIP_H
+#define DVT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVT_ABI_VERSION 1
+
+typedef void* dvt_stream_t; /* hipStream_t */
+
+enum dvt_dtype { DVT_F32 = 0, DVT_BF16 = 1, DVT_F16 = 2 };
+
+enum dvt_status {
+  DVT_OK = 0,
+  DVT_ERR_BAD_ARG = -1,     /* null pointer, negative size, misaligned buffer ... */
+  DVT_ERR_UNSUPPORTED = -2, /* shape / dtype this build has no kernel for */
+  DVT_ERR_HIP = -3          /* a HIP runtime call or launch failed */
+};
+
+int dvt_version(void);
+const char* dvt_last_error(void);
+/* Fills compute-unit count, LDS bytes per CU and the gcnArchName of the
+ * current device. */
+int dvt_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------- casts / adds
+ * dst[i] = (dst_dtype) src[i].  Replaces tensor.to(dtype) on the path (bf16
+ * compute copies of the fp32 master weights, clip tensors). */
+int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+             dvt_stream_t stream);
+/* out = a + b (residual adds `attn(x) + x`, `ff(x) + x`: src/models/vit.py:73-74
+ * when the producing GEMM is not the one fusing it). */
+int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_stream_t stream);
+/* dst(f32)[i] = beta * dst[i] + alpha * src[i]  (gradient accumulation). */
+int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float beta, int64_t n,
+                  dvt_stream_t stream);
+
+/* Stand-alone activations (the 3-layer GELU head, src/models/frame_transformer.py:106,
+ * where no GEMM epilogue is worth fusing into).  act: 1 = GELU(erf), 2 = ReLU.
+ * fwd: y = act(x);  bwd: dx = dy * act'(x). */
+int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_stream_t stream);
+int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
+                dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- patchify
+ * Rearrange 'b t c (h p1) (w p2) -> b t (h w) (p1 p2 c)'  (src/models/vit.py:90).
+ * x: [frames, C, H, W] in x_dtype; out: [frames * (H/P) * (W/P), P*P*C] in
+ * out_dtype (patch-vector index = (p1*P + p2)*C + c). */
+int dvt_patchify(const void* x, int x_dtype, void* out, int out_dtype, int64_t frames, int C,
+                 int H, int W, int P, dvt_stream_t stream);
+/* Adjoint of dvt_patchify (scatter back to pixel layout): needed when the clip
+ * itself carries a gradient (learnable pixel-space CLS clip,
+ * src/models/frame_transformer.py:105,195). */
+int dvt_patchify_bwd(const void* dout, int dout_dtype, void* dx, int dx_dtype, int64_t frames,
+                     int C, int H, int W, int P, dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- token assembly
+ * ViViT.forward token plumbing, src/models/vit.py:113-115:
+ *   out[s, 0, :]   = cls[:]            + pos[s % T, 0, :]
+ *   out[s, 1+j, :] = emb[s*n + j, :]   + pos[s % T, 1+j, :]
+ * emb: [S*n, d] dtype; cls: [d] f32; pos: [T, pos_rows, d] f32 (pos_rows >= n+1);
+ * out: [S, n+1, d] dtype.  */
+int dvt_tokens_assemble_fwd(const void* emb, const float* cls, const float* pos, void* out,
+                            int64_t S, int64_t T, int64_t n, int64_t d, int64_t pos_rows,
+                            int dtype, dvt_stream_t stream);
+/* demb = dout[:, 1:, :]; dcls (+)= sum_s dout[s,0,:]; dpos[t,j,:] (+)= sum_{s%T==t} dout[s,j,:].
+ * `accumulate` != 0 adds into dcls/dpos instead of overwriting. */
+int dvt_tokens_assemble_bwd(const void* dout, void* demb, float* dcls, float* dpos, int64_t S,
+                            int64_t T, int64_t n, int64_t d, int64_t pos_rows, int dtype,
+                            int accumulate, dvt_stream_t stream);
+
+/* Row gather with an optional leading token (vit.py:120-123, x[:, 0] then
+ * cat(temporal_token, .)):  out[b, 0, :] = tok (if tok != NULL, then lead = 1)
+ * out[b, lead + t, :] = src[(b*T + t) * src_row_stride : + d].  */
+int dvt_rows_gather_fwd(const void* src, int64_t src_row_stride, const float* tok, void* out,
+                        int64_t B, int64_t T, int64_t d, int dtype, dvt_stream_t stream);
+/* dsrc rows (same addressing) = dout[b, lead+t, :]; dtok (+)= sum_b dout[b,0,:].
+ * Rows of dsrc that are not gathered are NOT touched (caller zero-fills). */
+int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, float* dtok,
+                        int64_t B, int64_t T, int64_t d, int dtype, int accumulate,
+                        dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- LayerNorm
+ * nn.LayerNorm(d), eps 1e-5, affine: src/models/vit.py:11,64,105;
+ * src/models/frame_transformer.py:117; torch TransformerEncoderLayer norm1/2.
+ * Rows are indexed (i0, i1), i0 < n0, i1 < n1; row (i0,i1) of x starts at element
+ * i0*xs0 + i1*xs1, of y at i0*ys0 + i1*ys1 (dense: n0 = rows, n1 = 1, xs0 = ys0 = d).
+ * mean/rstd: [n0*n1] f32, written by fwd, read by bwd. */
+int dvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1,
+                      int64_t ys0, int64_t ys1, float eps, int dtype, dvt_stream_t stream);
+size_t dvt_layernorm_bwd_workspace_bytes(int64_t d);
+/* dy uses the y strides; x, dx and dx_add use the x strides.  dx = LN'(dy) (+ dx_add
+ * when dx_add != NULL: the residual-branch gradient of `fn(LN(x)) + x`, vit.py:73-74,
+ * so that the two gradient paths into x are summed inside this kernel).
+ * dgamma/dbeta: [d] f32, overwritten (accumulate == 0) or added to.  workspace: at
+ * least dvt_layernorm_bwd_workspace_bytes(d) bytes of device memory. */
+int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dx_add, void* dx, float* dgamma,
+                      float* dbeta, void* workspace,
+                      int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
+                      int64_t ys1, int dtype, int accumulate, dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- GEMM family
+ * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).  One kernel family serves
+ *   forward  Linear        y = x W^T          (A k-major, B = W[N,K] k-major)
+ *   dgrad                  dx = dy W          (A k-major, B = W[K=N_out, N=K_in] mn-major)
+ *   wgrad                  dW = dy^T x        (A, B mn-major; reduction over rows)
+ * and so replaces nn.Linear at src/models/vit.py:20-25,39-43,91,106 and inside
+ * torch's TransformerEncoderLayer (frame_transformer.py:41-44).
+ *   a_kmajor: element (m,k) at A[m*lda + k]  else at A[k*lda + m]
+ *   b_kmajor: element (k,n) at B[n*ldb + k]  else at B[k*ldb + n]
+ */
+enum dvt_epilogue {
+  DVT_EPI_NONE = 0,          /* C = acc (+ bias) */
+  DVT_EPI_GELU = 1,          /* aux = acc + bias (pre-activation, if aux != NULL); C = gelu_erf(aux) */
+  DVT_EPI_RELU = 2,          /* C = relu(acc + bias) */
+  DVT_EPI_RESIDUAL = 3,      /* C = acc + bias + residual */
+  DVT_EPI_DGELU = 4,         /* C = acc * gelu'(aux)   (aux = saved pre-activation) */
+  DVT_EPI_DRELU = 5          /* C = acc * (aux > 0)    (aux = saved post-activation) */
+};
+
+typedef struct dvt_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int32_t a_kmajor, b_kmajor;
+  int32_t in_dtype;     /* dtype of A, B, residual, aux */
+  int32_t out_dtype;    /* dtype of C: in_dtype, or DVT_F32 (weight gradients) */
+  int32_t epilogue;     /* enum dvt_epilogue */
+  int32_t accumulate;   /* out_dtype == DVT_F32 only: C += result instead of C = result */
+  const float* bias;    /* [N] f32 or NULL */
+  const void* residual; /* [M, ldr] or NULL */
+  int64_t ldr;
+  void* aux;            /* [M, ldaux] or NULL */
+  int64_t ldaux;
+  float alpha;          /* result scale applied to acc before the epilogue (1.0f default) */
+  int32_t split_k;      /* 0 = library chooses; >1 forces that many K slices */
+  void* workspace;      /* >= dvt_gemm_workspace_bytes(desc) bytes (may be NULL if that is 0) */
+} dvt_gemm_desc;
+
+size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* desc);
+int dvt_gemm(const dvt_gemm_desc* desc, dvt_stream_t stream);
+
+/* out[n] (+)= sum_m x[m*ldx + n]  -- bias gradients. workspace >=
+ * dvt_colsum_workspace_bytes(M, N). */
+size_t dvt_colsum_workspace_bytes(int64_t M, int64_t N);
+int dvt_colsum(const void* x, int64_t ldx, float* out, void* workspace, int64_t M, int64_t N,
+               int dtype, int accumulate, dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- attention
+ * o = softmax(q k^T * scale) v per (batch, head): src/models/vit.py:51-55, and
+ * the core of nn.MultiheadAttention inside TransformerEncoderLayer
+ * (frame_transformer.py:41-44).  Lq != Lk gives the cross-modal form
+ * (frame_transformer.py:225-226 joint video/image tokens; BASELINE config 4).
+ * Element (b, h, l, e) of q sits at q[b*q_sb + h*q_sh + l*q_sl + e]; likewise
+ * k, v, o.  do/dq/dk/dv reuse the strides of o/q/k/v.  lse: [B, H, Lq] f32
+ * (log-sum-exp of the scaled scores), written by fwd and read by bwd.
+ * Scores are never materialised in HBM. */
+typedef struct dvt_attn_desc {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const void* d_o; /* bwd only */
+  void* dq;        /* bwd only */
+  void* dk;
+  void* dv;
+  int64_t B, H, Lq, Lk, dh;
+  int64_t q_sb, q_sh, q_sl;
+  int64_t k_sb, k_sh, k_sl;
+  int64_t v_sb, v_sh, v_sl;
+  int64_t o_sb, o_sh, o_sl;
+  float scale;
+  int32_t dtype;
+  void* workspace; /* bwd only: >= dvt_attention_bwd_workspace_bytes(desc) bytes (may be NULL if 0) */
+} dvt_attn_desc;
+
+size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);
+int dvt_attention_fwd(const dvt_attn_desc* desc, dvt_stream_t stream);
+int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- losses
+ * nn.BCEWithLogitsLoss() (mean): src/models/frame_transformer.py:89,263,268,273.
+ * z: [n] dtype, target: [n] f32, loss: [1] f32. */
+int dvt_bce_logits_fwd(const void* z, const float* target, float* loss, int64_t n, int dtype,
+                       dvt_stream_t stream);
+/* dz = gscale * (sigmoid(z) - target) / n */
+int dvt_bce_logits_bwd(const void* z, const float* target, const float* gloss, void* dz,
+                       int64_t n, int dtype, dvt_stream_t stream);
+/* Hard-label distillation CE(student, argmax(teacher)), mean over rows:
+ * src/models/frame_transformer.py:90,250.  student/teacher: [rows, C]. */
+int dvt_ce_argmax_fwd(const void* student, const void* teacher, float* loss, int64_t rows,
+                      int64_t C, int dtype, dvt_stream_t stream);
+int dvt_ce_argmax_bwd(const void* student, const void* teacher, const float* gloss, void* dstudent,
+                      int64_t rows, int64_t C, int dtype, dvt_stream_t stream);
+
+/* ---------------------------------------------------------------- optimizer
+ * torch.optim.AdamW step over a flat fp32 buffer (frame_transformer.py:127-129). */
+int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   dvt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVT_HIP_H */

@@ -1,0 +1,339 @@
+"""Per-operator parity: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Tolerances: fp32 mode rel-L2 <= 1e-4 (north_star bound 1e-3; observed ~1e-6);
+bf16 mode rel-L2 <= 1e-2 against the oracle evaluated on the same bf16-rounded
+inputs (BASELINE.md section 2 protocol).  Integer/byte work (patchify gather,
+casts) is bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_path as O
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_TOL = 1e-2
+
+
+@pytest.fixture(scope="module")
+def dvt():
+    import dvt_amd
+    dvt_amd._lib.load()
+    return dvt_amd
+
+
+def _tol(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+def _rnd(shape, dtype, gen, scale=1.0):
+    """Random tensor already rounded to ``dtype``; returns (device tensor, cpu fp32 copy)."""
+    x = (torch.randn(shape, generator=gen) * scale).to(dtype)
+    return x.cuda(), x.float()
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ------------------------------------------------------------------ elementwise
+def test_cast_add_exact(dvt, device):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1003, generator=g)
+    xb = dvt.ops.cast(x.cuda(), torch.bfloat16)
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(dvt.ops.cast(xb, torch.float32).cpu(), x.to(torch.bfloat16).float())
+    a, b = torch.randn(4, 999, generator=g), torch.randn(4, 999, generator=g)
+    assert torch.equal(dvt.ops.add(a.cuda(), b.cuda()).cpu(), a + b)
+
+
+@pytest.mark.parametrize("P,H,W", [(16, 64, 64), (8, 32, 32), (4, 8, 12), (16, 224, 224)])
+def test_patchify_bit_exact(dvt, device, P, H, W):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 3, H, W, generator=g)
+    ref = O.patchify(x, P).reshape(-1, P * P * 3)
+    out = dvt.ops.patchify(x.cuda(), P, torch.float32)
+    assert torch.equal(out.cpu(), ref)
+    outb = dvt.ops.patchify(x.cuda(), P, torch.bfloat16)
+    assert torch.equal(outb.cpu(), ref.to(torch.bfloat16))
+    back = dvt.ops.patchify_bwd(out, x.shape, P, torch.float32)
+    assert torch.equal(back.cpu(), x)          # adjoint of a permutation = inverse
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tokens_assemble(dvt, device, dtype):
+    g = torch.Generator().manual_seed(3)
+    B, T, n, d = 2, 3, 5, 64
+    S = B * T
+    emb_d, emb = _rnd((S * n, d), dtype, g)
+    cls = torch.randn(1, 1, d, generator=g)
+    pos = torch.randn(1, T, n + 1, d, generator=g)
+    embr, clsr, posr = (t.clone().requires_grad_(True) for t in (emb, cls, pos))
+    ref = torch.cat((clsr.reshape(1, 1, d).expand(S, 1, d), embr.reshape(S, n, d)), 1) \
+        + posr[0].repeat(B, 1, 1)
+    e_d = emb_d.clone().requires_grad_(True)
+    c_d = cls.cuda().requires_grad_(True)
+    p_d = pos.cuda().requires_grad_(True)
+    out = dvt.functional.tokens_assemble(e_d, c_d, p_d, S, T, n)
+    assert rel_l2(out, ref) < _tol(dtype)
+    gy_d, gy = _rnd(out.shape, dtype, g)
+    ref.backward(gy)
+    out.backward(gy_d)
+    assert rel_l2(e_d.grad, embr.grad) < _tol(dtype)
+    assert rel_l2(c_d.grad, clsr.grad) < 1e-5
+    assert rel_l2(p_d.grad, posr.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(7, 64), (130, 128), (1030, 512), (28, 896), (9, 2048)])
+def test_layernorm(dvt, device, dtype, rows, d):
+    g = torch.Generator().manual_seed(4)
+    x_d, x = _rnd((rows, d), dtype, g, 2.0)
+    w = 1 + 0.2 * torch.randn(d, generator=g)
+    b = 0.3 * torch.randn(d, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = O.layernorm(xr, wr, br)
+    xd = x_d.clone().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = dvt.functional.layernorm(xd, wd, bd)
+    assert rel_l2(out, ref) < _tol(dtype)
+    gy_d, gy = _rnd((rows, d), dtype, g)
+    ref.backward(gy)
+    out.backward(gy_d)
+    assert rel_l2(xd.grad, xr.grad) < _tol(dtype)
+    assert rel_l2(wd.grad, wr.grad) < 5e-5 if dtype == torch.float32 else rel_l2(wd.grad, wr.grad) < BF16_TOL
+    assert rel_l2(bd.grad, br.grad) < 5e-5
+
+
+def test_layernorm_strided_rows_and_fused_residual_grad(dvt, device):
+    g = torch.Generator().manual_seed(5)
+    S, N, d = 6, 5, 64
+    x_d, x = _rnd((S, N, d), torch.float32, g)
+    w, b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    y, mean, rstd = dvt.ops.layernorm_fwd(x_d, w.cuda(), b.cuda(), 1e-5, rows=(S, 1, N * d, 0))
+    assert rel_l2(y, O.layernorm(x[:, 0], w, b)) < F32_TOL
+    # dx = LN'(dy) + dx_add in one kernel
+    x2 = x.reshape(-1, d).clone().requires_grad_(True)
+    ref = O.layernorm(x2, w, b)
+    gy_d, gy = _rnd((S * N, d), torch.float32, g)
+    add_d, add = _rnd((S * N, d), torch.float32, g)
+    ref.backward(gy)
+    yy, m2, r2 = dvt.ops.layernorm_fwd(x_d.view(-1, d), w.cuda(), b.cuda())
+    dx, dg, db = dvt.ops.layernorm_bwd(gy_d, x_d.view(-1, d), w.cuda(), m2, r2, dx_add=add_d)
+    assert rel_l2(dx, x2.grad + add) < F32_TOL
+
+
+# ------------------------------------------------------------------ GEMM family
+GEMM_SHAPES = [
+    (64, 64, 64), (128, 128, 128), (200, 136, 72), (130, 264, 200), (1000, 256, 512),
+    (8, 19, 512),        # 19-class head: generic path
+    (136, 384, 128),     # C1-like token count (not a multiple of 64 rows)
+    (257, 128, 1024),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_linear_fwd_dgrad_wgrad(dvt, device, dtype, M, N, K):
+    g = torch.Generator().manual_seed(6)
+    s = 1.0 / math.sqrt(K)
+    x_d, x = _rnd((M, K), dtype, g)
+    w_d, w = _rnd((N, K), dtype, g, s)
+    bias = torch.randn(N, generator=g)
+    y = dvt.ops.linear_fwd(x_d, w_d, bias.cuda())
+    assert rel_l2(y, x @ w.t() + bias) < _tol(dtype)
+    dy_d, dy = _rnd((M, N), dtype, g)
+    dx = dvt.ops.linear_dgrad(dy_d, w_d)
+    assert rel_l2(dx, dy @ w) < _tol(dtype)
+    dw = dvt.ops.linear_wgrad(dy_d, x_d)
+    assert dw.dtype == torch.float32
+    assert rel_l2(dw, dy.t() @ x) < _tol(dtype)
+    db = dvt.ops.colsum(dy_d)
+    assert rel_l2(db, dy.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dvt, device, dtype):
+    L = dvt._lib
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 260, 136, 192
+    x_d, x = _rnd((M, K), dtype, g)
+    w_d, w = _rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias = 0.5 * torch.randn(N, generator=g)
+    res_d, res = _rnd((M, N), dtype, g)
+    pre = x @ w.t() + bias
+    tol = _tol(dtype)
+    # GELU with saved pre-activation
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    h = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_GELU, aux=aux)
+    assert rel_l2(aux, pre) < tol
+    assert rel_l2(h, O.gelu_erf(pre)) < tol
+    # ReLU
+    r = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RELU)
+    assert rel_l2(r, torch.relu(pre)) < tol
+    # residual
+    y = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d)
+    assert rel_l2(y, pre + res) < tol
+    # dgrad with GELU' / ReLU' epilogue: du = (dy @ W2) * act'(u)
+    u_d, u = _rnd((M, K), dtype, g)
+    dy_d, dy = _rnd((M, N), dtype, g)
+    uu = u.clone().requires_grad_(True)
+    O.gelu_erf(uu).backward(dy @ w)
+    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d)
+    assert rel_l2(du, uu.grad) < tol
+    hpos = torch.relu(u)
+    dr = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DRELU, aux=dvt.ops.cast(hpos.cuda(), dtype))
+    assert rel_l2(dr, (dy @ w) * (hpos > 0)) < tol
+
+
+def test_wgrad_split_k_reproducible(dvt, device):
+    """Token-count reduction (K = rows) with few output tiles -> split-K slabs."""
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 8192, 128, 256          # dW[N,K] = dy[M,N]^T x[M,K]
+    dy_d, dy = _rnd((M, N), torch.bfloat16, g)
+    x_d, x = _rnd((M, K), torch.bfloat16, g)
+    a = dvt.ops.linear_wgrad(dy_d, x_d)
+    b = dvt.ops.linear_wgrad(dy_d, x_d)
+    assert torch.equal(a, b)                       # fixed summation order
+    assert rel_l2(a, dy.t() @ x) < BF16_TOL
+    acc = torch.ones((N, K), device="cuda")
+    dvt.ops.linear_wgrad(dy_d, x_d, out=acc, accumulate=True)
+    assert rel_l2(acc, dy.t() @ x + 1) < BF16_TOL
+
+
+def test_gemm_rejects_bad_arguments(dvt, device):
+    x = torch.randn(4, 8, device="cuda")
+    w = torch.randn(6, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="RESIDUAL"):
+        dvt.ops.linear_fwd(x, w, None, epilogue=dvt._lib.EPI_RESIDUAL)
+    with pytest.raises(RuntimeError, match="GPU"):
+        dvt.ops.linear_fwd(x.cpu(), w.cpu())
+
+
+# ------------------------------------------------------------------ attention
+ATTN_CASES = [
+    # B, H, Lq, Lk, dh
+    (2, 2, 17, 17, 64), (2, 3, 33, 33, 64), (1, 2, 197, 197, 64), (2, 2, 5, 40, 64),
+    (1, 1, 64, 64, 64), (2, 2, 14, 14, 32), (1, 2, 15, 14, 448), (1, 4, 14, 15, 224),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", ATTN_CASES)
+def test_attention_core(dvt, device, dtype, B, H, Lq, Lk, dh):
+    g = torch.Generator().manual_seed(9)
+    q_d, q = _rnd((B, H, Lq, dh), dtype, g)
+    k_d, k = _rnd((B, H, Lk, dh), dtype, g)
+    v_d, v = _rnd((B, H, Lk, dh), dtype, g)
+    scale = dh ** -0.5
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = O.attention_core(qr, kr, vr, scale)
+    qd, kd, vd = (t.clone().requires_grad_(True) for t in (q_d, k_d, v_d))
+    out = dvt.functional.attention_core(qd, kd, vd, scale)
+    tol = _tol(dtype)
+    assert rel_l2(out, ref) < tol
+    go_d, go = _rnd((B, H, Lq, dh), dtype, g)
+    ref.backward(go)
+    out.backward(go_d)
+    assert rel_l2(qd.grad, qr.grad) < 2 * tol
+    assert rel_l2(kd.grad, kr.grad) < 2 * tol
+    assert rel_l2(vd.grad, vr.grad) < 2 * tol
+
+
+def test_attention_softmax_spike(dvt, device):
+    """Online-softmax rescale path: one key dominates late in the sequence."""
+    g = torch.Generator().manual_seed(10)
+    B, H, L, dh = 1, 1, 96, 64
+    q = torch.randn(B, H, L, dh, generator=g)
+    k = torch.randn(B, H, L, dh, generator=g)
+    v = torch.randn(B, H, L, dh, generator=g)
+    k[0, 0, 70] = 6.0 * q[0, 0, 3]       # spikes row 3 at key 70 (third 32-key step)
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    ref = O.attention_core(qb.float(), kb.float(), vb.float(), dh ** -0.5)
+    out = dvt.functional.attention_core(qb.cuda(), kb.cuda(), vb.cuda(), dh ** -0.5)
+    assert rel_l2(out, ref) < BF16_TOL
+    assert torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------ fused residual blocks
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dim,heads,dh,N", [(64, 2, 32, 10), (128, 2, 64, 17), (64, 1, 64, 9)])
+def test_attn_and_mlp_blocks(dvt, device, dtype, dim, heads, dh, N):
+    g = torch.Generator().manual_seed(11)
+    S = 3
+    inner = heads * dh
+    project = not (heads == 1 and dh == dim)
+    x_d, x = _rnd((S, N, dim), dtype, g)
+    P = {
+        "ln_w": 1 + 0.1 * torch.randn(dim, generator=g), "ln_b": 0.1 * torch.randn(dim, generator=g),
+        "wqkv": torch.randn(3 * inner, dim, generator=g) / math.sqrt(dim),
+        "wout": torch.randn(dim, inner, generator=g) / math.sqrt(inner) if project else None,
+        "bout": 0.1 * torch.randn(dim, generator=g) if project else None,
+        "w1": torch.randn(4 * dim, dim, generator=g) / math.sqrt(dim), "b1": 0.1 * torch.randn(4 * dim, generator=g),
+        "w2": torch.randn(dim, 4 * dim, generator=g) / math.sqrt(4 * dim), "b2": 0.1 * torch.randn(dim, generator=g),
+    }
+    rd = lambda t: None if t is None else t.to(dtype).float()      # weights as the kernels see them
+    R = {k: (None if v is None else (rd(v) if v.dim() == 2 else v).clone().requires_grad_(True)) for k, v in P.items()}
+    D = {k: (None if v is None else v.cuda().requires_grad_(True)) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    xd = x_d.clone().requires_grad_(True)
+    F = dvt.functional
+    ref_a = O.self_attention(O.layernorm(xr, R["ln_w"], R["ln_b"]), R["wqkv"], R["wout"], R["bout"], heads) + xr
+    out_a = F.attn_block(xd, D["ln_w"], D["ln_b"], D["wqkv"], D["wout"], D["bout"], heads)
+    tol = _tol(dtype)
+    assert rel_l2(out_a, ref_a) < tol
+    ref_m = O.feedforward(O.layernorm(ref_a, R["ln_w"], R["ln_b"]), R["w1"], R["b1"], R["w2"], R["b2"]) + ref_a
+    out_m = F.mlp_block(out_a, D["ln_w"], D["ln_b"], D["w1"], D["b1"], D["w2"], D["b2"])
+    assert rel_l2(out_m, ref_m) < 2 * tol
+    gy_d, gy = _rnd(out_m.shape, dtype, g)
+    ref_m.backward(gy)
+    out_m.backward(gy_d)
+    assert rel_l2(xd.grad, xr.grad) < 3 * tol
+    for k in P:
+        if P[k] is not None:
+            assert rel_l2(D[k].grad, R[k].grad) < 3 * tol, k
+
+
+# ------------------------------------------------------------------ losses / optimizer
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_losses(dvt, device, dtype):
+    g = torch.Generator().manual_seed(12)
+    z_d, z = _rnd((8, 19), dtype, g, 2.0)
+    y = (torch.rand(8, 19, generator=g) < 0.2).float()
+    zr = z.clone().requires_grad_(True)
+    ref = O.bce_with_logits(zr, y)
+    zd = z_d.clone().requires_grad_(True)
+    out = dvt.functional.bce_with_logits(zd, y.cuda())
+    assert abs(float(out) - float(ref)) < 1e-5
+    ref.backward()
+    out.backward()
+    assert rel_l2(zd.grad, zr.grad) < _tol(dtype)
+    t_d, t = _rnd((8, 19), dtype, g)
+    zr2 = z.clone().requires_grad_(True)
+    ref2 = O.cross_entropy_hard(zr2, t)
+    zd2 = z_d.clone().requires_grad_(True)
+    out2 = dvt.functional.cross_entropy_argmax(zd2, t_d)
+    assert abs(float(out2) - float(ref2)) < 1e-5
+    ref2.backward()
+    out2.backward()
+    assert rel_l2(zd2.grad, zr2.grad) < _tol(dtype)
+
+
+def test_adamw_matches_torch(dvt, device):
+    g = torch.Generator().manual_seed(13)
+    p = torch.randn(1000, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=5e-3, weight_decay=0.09)      # frame_transformer.py:127-129
+    pd, m, v = p.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        dvt.ops.adamw_step_(pd, gr.cuda(), m, v, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.09,
+                            step=step)
+    assert rel_l2(pd, pr) < 1e-6
