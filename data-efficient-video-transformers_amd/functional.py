@@ -41,6 +41,11 @@ def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
     return t.contiguous() if t.dtype == torch.float32 else ops.cast(t, torch.float32)
 
 
+def _same_layout(a: Tensor, b: Tensor) -> bool:
+    """Equal shapes and equal strides on every dimension of extent > 1."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 def _as(t: Tensor, dtype: torch.dtype) -> Tensor:
     return t if t.dtype == dtype else ops.cast(t, dtype)
 
@@ -302,14 +307,12 @@ class _AttentionCore(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         B, H, Lq, dh = q.shape
         Lk = k.shape[2]
-        do_mem = torch.empty((B, Lq, H, dh), dtype=q.dtype, device=q.device)
-        do_v = do_mem.permute(0, 2, 1, 3)
-        if do.stride() == o.stride() and do.dtype == q.dtype:
-            do_v = do
+        if _same_layout(do, o) and do.dtype == q.dtype:
+            do_v = do.as_strided(o.shape, o.stride())
         else:
-            # re-layout through the cast kernel (contiguous copy in o's memory order)
+            # re-layout into o's memory order ([B, Lq, H, dh]) before the kernel
             do_c = _as(do.permute(0, 2, 1, 3).contiguous(), q.dtype)
-            do_v = do_c.permute(0, 2, 1, 3)
+            do_v = do_c.permute(0, 2, 1, 3).as_strided(o.shape, o.stride())
         dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device)
         dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device)
         dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)

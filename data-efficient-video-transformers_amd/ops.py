@@ -343,8 +343,9 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: T
     """do must share o's strides; dq/dk/dv must share q/k/v's strides (views of
     caller-owned memory, fully overwritten)."""
     _need_cuda(q, k, v, o, do, dq, dk, dv)
-    assert do.stride() == o.stride() and dq.stride() == q.stride()
-    assert dk.stride() == k.stride() and dv.stride() == v.stride()
+    for a, b in ((do, o), (dq, q), (dk, k), (dv, v)):
+        assert a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1), \
+            "gradient views must share the layout of their primal"
     d = _attn_desc(q, k, v, o, lse, scale)
     d.d_o, d.dq, d.dk, d.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     lib = L.load()
