@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec, forward + backward (+ gradient all-reduce under DP
+and the fused AdamW step), ViViT metric shape of BASELINE.json
+(B=8 per GPU, T=32, 3x224x224, bf16, d=512, 4+4 layers, 8 heads), synthetic data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel family (the MFMA GEMM, forward layout) measured live with
+                HIP events on the launch stream inside the timed steps: algorithmic
+                FLOPs of its launches / their summed duration, vs the dense bf16 MFMA peak.
+  cpu_baseline  the CPU oracle (the reference's arithmetic restated, pinned to the
+                reference by tests/golden) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch):
+    """2 flop/MAC, forward; backward = 2x forward."""
+    inner = heads * dh
+
+    def layer(tokens_per_seq, seqs):
+        m = tokens_per_seq * seqs
+        qkv = 2 * m * d * 3 * inner
+        qk = 2 * seqs * heads * tokens_per_seq ** 2 * dh
+        pv = qk
+        proj = 2 * m * inner * d
+        ff = 4 * m * d * 4 * d
+        return qkv + qk + pv + proj + ff
+
+    fwd = 2 * T * n_patch * patch_dim * d + depth * layer(n_tok, T) + depth * layer(T + 1, 1)
+    return fwd, 3 * fwd
+
+
+class EventProfiler:
+    """HIP-event pairs around tagged launches on the current (launch) stream."""
+
+    def __init__(self):
+        self.open = {}
+        self.records = {}
+
+    def begin(self, key, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.open[key] = (e0, flops)
+
+    def end(self, key):
+        e0, flops = self.open.pop(key)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1, flops))
+
+    def summary(self):
+        out = {}
+        for key, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[key] = (ms, fl, len(recs))
+        return out
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """Oracle fwd+bwd on host cores, bounded sample of the same workload."""
+    from oracle import clip_path as O
+    torch.manual_seed(1130)
+    from dvt_amd.models.vit import ViViT
+    net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
+                heads=cfg["heads"], dim_head=cfg["dh"])
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    bs = 1
+    x = torch.randn(bs, cfg["T"], 3, cfg["image"], cfg["image"])
+    y = (torch.rand(bs, cfg["classes"]) < 0.2).float()
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    O.vivit_step_fwd_bwd(x, y, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])   # warm-up
+    warm = time.perf_counter() - t0
+    steps = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.vivit_step_fwd_bwd(x, y, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(bs / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (pure-torch fp32 restatement) fwd+bwd on {bs} clip of the metric shape "
+                      f"(T={cfg['T']}, {cfg['image']}^2, d={cfg['d']}), 1 warm-up + {steps} timed steps, "
+                      f"{dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import dvt_amd
+    from dvt_amd import functional as F
+    from dvt_amd import ops
+    from dvt_amd.dp import FlatParameters
+    from dvt_amd.models.vit import ViViT
+
+    cfg = dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64)
+    torch.manual_seed(1130)                                       # src/main.py:25
+    net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
+                heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=torch.bfloat16).cuda()
+    flat = FlatParameters(net, bucket_mb=args.bucket_mb)
+    flat.broadcast_parameters(0)
+    flat.sync_compute_copy()
+
+    gen = torch.Generator().manual_seed(1130 + rank)
+    B = args.batch
+    x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(torch.bfloat16).cuda()
+    y = (torch.rand(B, cfg["classes"], generator=gen) < 0.2).float()
+    y[:, 0] = 1.0
+    y = y.cuda()
+    gloss = torch.full((), flat.loss_scale, device="cuda")
+
+    def step():
+        flat.zero_grad()
+        logits = net(x)
+        loss = F.bce_with_logits(logits, y)
+        loss.backward(gloss)
+        flat.finish_backward()
+        flat.adamw_step(lr=5e-6, weight_decay=0.09)              # config.yaml:3,12
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
+    #      event records do not perturb the headline timing)
+    roof = None
+    if not args.no_roofline:
+        prof = EventProfiler()
+        ops.set_profiler(prof)
+        nprof = max(1, min(3, args.steps))
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
+        summ = prof.summary()
+        fam = {}
+        for (tag, ak, bk, M, N, K), (ms, fl, cnt) in summ.items():
+            if M * N * K < (1 << 30):      # launch-bound temporal/head GEMMs: not this kernel's regime
+                continue
+            f = fam.setdefault((ak, bk), [0.0, 0.0, 0])
+            f[0] += ms; f[1] += fl; f[2] += cnt
+        names = {(1, 1): "gemm_mfma_kernel<k-major,k-major> (forward Linear)",
+                 (1, 0): "gemm_mfma_kernel<k-major,mn-major> (dgrad)",
+                 (0, 0): "gemm_mfma_kernel<mn-major,mn-major> (wgrad, split-K incl. reduce)"}
+        if fam:
+            dom = max(fam, key=lambda k: fam[k][0])
+            ms, fl, cnt = fam[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(ach, 1),
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
+                    "families": {names.get(k, str(k)): {"ms_per_step": round(v[0] / nprof, 3),
+                                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                                 for k, v in fam.items()}}
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        clips = B * world * args.steps / elapsed
+        n_tok = (cfg["image"] // cfg["patch"]) ** 2 + 1
+        fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
+                                              3 * cfg["patch"] ** 2, n_tok - 1)
+        out = {
+            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16",
+            "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViViT metric shape (SURVEY 8 'M'; BASELINE configs[2]/[3] transformer): "
+                                   "B=8/GPU, T=32, 3x224x224, patch 16, d=512, depth 4+4, heads 8, dim_head 64; "
+                                   "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
+            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1),
+            "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "final_loss": round(final_loss, 5),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""Flat parameter / gradient storage and data-parallel gradient exchange.
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).
+The clips of the global batch are independent through the whole forward
+(SURVEY section 8e), so data parallelism needs exactly one exchange: the sum of
+the parameter gradients.  The reference itself is single-GPU
+(``pl.Trainer(gpus=1)``, src/main.py:87); this module is the new MI355X-side
+functionality north_star asks for.
+
+Design (MI355X-first, not a DDP clone):
+  * all fp32 master parameters live in ONE flat HBM buffer, all gradients in a
+    second one; ``param.data`` / ``param.grad`` are views.  The backward kernels
+    write weight gradients straight into their slice (``GradSink``): no per-
+    parameter gradient tensors, no flatten/copy, no torch accumulate kernels.
+  * buckets are contiguous ranges of the gradient buffer, formed in reverse
+    registration order (the order in which backward completes them).  When the
+    last gradient of a bucket has been written, its all-reduce is enqueued
+    asynchronously; RCCL runs it on its own stream, overlapped with the rest of
+    backward.  xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce is
+    bound by one link, so buckets are large (default 32 MiB: ~2 buckets for the
+    115 MB of fp32 gradients of the d=512 model) to amortise latency.
+  * averaging is folded into the loss gradient (1/world), so the collective is a
+    plain sum and no extra pass over the gradients exists.
+  * the optimizer step is one fused AdamW launch over the flat buffers, followed
+    by one cast launch that refreshes the bf16 compute copy of all weights.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+_ALIGN = 64  # elements: every parameter slice starts 256-byte aligned
+
+
+class GradSink:
+    """Destination of one parameter's gradient inside the flat gradient buffer."""
+
+    __slots__ = ("buf", "fresh", "bucket", "owner", "index")
+
+    def __init__(self, buf: torch.Tensor, bucket: int, owner: "FlatParameters", index: int):
+        self.buf = buf          # view shaped like the parameter
+        self.fresh = True       # True until first written in the current step
+        self.bucket = bucket
+        self.owner = owner
+        self.index = index
+
+    def mark_written(self) -> None:
+        if self.fresh:
+            self.fresh = False
+            self.owner._on_first_write(self)
+
+
+def sink_of(p) -> Optional[GradSink]:
+    return getattr(p, "_dvt_sink", None)
+
+
+class FlatParameters:
+    def __init__(self, module: torch.nn.Module, *, bucket_mb: float = 32.0,
+                 process_group: Optional[dist.ProcessGroup] = None,
+                 compute_dtype: Optional[torch.dtype] = torch.bfloat16):
+        seen, params = set(), []
+        for p in module.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        dev = params[0].device   # CPU tensors are accepted for the exchange logic only (gloo tests);
+        # the fused optimizer / compute-copy kernels need the GPU and raise otherwise.
+        self.params: List[torch.nn.Parameter] = params
+        self.offsets, total = [], 0
+        for p in params:
+            self.offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = total
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.compute_dtype = compute_dtype
+        self.compute = (torch.zeros(total, dtype=compute_dtype, device=dev)
+                        if compute_dtype not in (None, torch.float32) and dev.type == "cuda" else None)
+        self.compute_valid = False
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+
+        # buckets: walk parameters in reverse registration order
+        bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.bucket_ranges: List[List[int]] = []      # [lo, hi) element ranges
+        bucket_of = [0] * len(params)
+        hi = total
+        for i in range(len(params) - 1, -1, -1):
+            lo = self.offsets[i]
+            bucket_of[i] = len(self.bucket_ranges)
+            if hi - lo >= bucket_elems or i == 0:
+                self.bucket_ranges.append([lo, hi])
+                hi = lo
+        self.bucket_size = [0] * len(self.bucket_ranges)
+        self.sinks: List[GradSink] = []
+        for i, p in enumerate(params):
+            n, off = p.numel(), self.offsets[i]
+            dview = self.data[off:off + n].view(p.shape)
+            dview.copy_(p.data)                 # one-time setup copy
+            p.data = dview
+            gview = self.grad[off:off + n].view(p.shape)
+            p.grad = gview
+            s = GradSink(gview, bucket_of[i], self, i)
+            p._dvt_sink = s
+            if self.compute is not None:
+                p._dvt_compute = self.compute[off:off + n].view(p.shape)
+            self.sinks.append(s)
+            self.bucket_size[bucket_of[i]] += 1
+        self._pending = list(self.bucket_size)
+        self._handles = []
+        self._launched = [False] * len(self.bucket_ranges)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ compute copy
+    def sync_compute_copy(self) -> None:
+        """One cast launch: fp32 masters -> bf16 copy used by the GEMMs."""
+        if self.compute is not None:
+            from . import _lib as L
+            L.check(L.load().dvt_cast(self.data.data_ptr(), L.F32, self.compute.data_ptr(),
+                                      ops._DT[self.compute_dtype], self.total, ops._stream()), "dvt_cast")
+            self.compute_valid = True
+
+    def invalidate_compute_copy(self) -> None:
+        self.compute_valid = False
+
+    # ------------------------------------------------------------------ per-step protocol
+    def zero_grad(self) -> None:
+        """Marks every sink fresh (first write overwrites): no memset pass."""
+        for s in self.sinks:
+            s.fresh = True
+        self._pending = list(self.bucket_size)
+        self._launched = [False] * len(self.bucket_ranges)
+        self._handles = []
+
+    def _launch_bucket(self, b: int) -> None:
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        if self.world > 1:
+            lo, hi = self.bucket_ranges[b]
+            self._handles.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+
+    def _on_first_write(self, sink: GradSink) -> None:
+        b = sink.bucket
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch_bucket(b)
+
+    def finish_backward(self) -> None:
+        """Call after loss.backward(): zero gradients nobody wrote, flush remaining
+        buckets, wait for the collectives (on the compute stream, not the host)."""
+        for s in self.sinks:
+            if s.fresh:
+                s.buf.zero_()   # memset of a slice nobody wrote this step (rare)
+                s.fresh = False
+        for b in range(len(self.bucket_ranges)):
+            self._launch_bucket(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    @property
+    def loss_scale(self) -> float:
+        """Multiply the loss (or its gradient) by this so that the summed gradients
+        are the global-batch mean."""
+        return 1.0 / self.world
+
+    # ------------------------------------------------------------------ optimizer
+    def adamw_step(self, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """torch.optim.AdamW semantics (frame_transformer.py:127-129) in one launch."""
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.data)
+            self.exp_avg_sq = torch.zeros_like(self.data)
+        self.step_count += 1
+        ops.adamw_step_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr=lr, beta1=betas[0],
+                        beta2=betas[1], eps=eps, weight_decay=weight_decay, step=self.step_count)
+        self.sync_compute_copy()
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world > 1:
+            dist.broadcast(self.data, src=src, group=self.group)
+        self.invalidate_compute_copy()

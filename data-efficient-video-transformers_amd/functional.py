@@ -25,13 +25,52 @@ Tensor = torch.Tensor
 
 
 def _wc(w: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
-    """Compute-dtype copy of an fp32 master weight (identity in fp32 mode)."""
+    """Compute-dtype copy of an fp32 master weight (identity in fp32 mode).  When the
+    parameter lives in a ``dp.FlatParameters`` buffer whose bf16 mirror is current,
+    that mirror is used (one cast launch per step for all weights instead of one
+    per layer)."""
     if w is None:
         return None
+    c = getattr(w, "_dvt_compute", None)
+    if c is not None and c.dtype == dtype and w._dvt_sink.owner.compute_valid:
+        return c
     w = w.detach()
     if w.dtype == dtype:
         return w.contiguous()
     return ops.cast(w, dtype)
+
+
+def _sink(p):
+    """Gradient sink of a parameter managed by ``dp.FlatParameters`` (else None)."""
+    return None if p is None else getattr(p, "_dvt_sink", None)
+
+
+def _emit_wgrad(sink, dy2: Tensor, x2: Tensor):
+    """dW = dy^T x, written into the sink (returns None) or returned as a new tensor."""
+    if sink is None:
+        return ops.linear_wgrad(dy2, x2)
+    ops.linear_wgrad(dy2, x2, out=sink.buf.view(dy2.shape[1], x2.shape[1]), accumulate=not sink.fresh)
+    sink.mark_written()
+    return None
+
+
+def _emit_colsum(sink, dy2: Tensor):
+    if sink is None:
+        return ops.colsum(dy2)
+    ops.colsum(dy2, out=sink.buf.view(-1), accumulate=not sink.fresh)
+    sink.mark_written()
+    return None
+
+
+def _ln_bwd(dy, x, g, mean, rstd, sg, sb, **kw):
+    """LayerNorm backward with optional sinks for dgamma / dbeta."""
+    if sg is None or sb is None:
+        return ops.layernorm_bwd(dy, x, g, mean, rstd, **kw)
+    dx, _, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dg=sg.buf.view(-1), db=sb.buf.view(-1),
+                                 accumulate=not sg.fresh, **kw)
+    sg.mark_written()
+    sb.mark_written()
+    return dx, None, None
 
 
 def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -69,6 +108,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, wc)
         ctx.has_bias = b is not None
         ctx.xshape = shp
+        ctx.sinks = (_sink(w), _sink(b))
         return y.view(*shp[:-1], N)
 
     @staticmethod
@@ -79,9 +119,9 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, wc).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy2, x2)
+            dw = _emit_wgrad(ctx.sinks[0], dy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)
+            db = _emit_colsum(ctx.sinks[1], dy2)
         return dx, dw, db, None
 
 
@@ -151,12 +191,13 @@ class _LayerNorm(torch.autograd.Function):
         g, bb = _f32(w), _f32(b)
         y, mean, rstd = ops.layernorm_fwd(xc, g, bb, eps)
         ctx.save_for_backward(xc, g, mean, rstd)
+        ctx.sinks = (_sink(w), _sink(b))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, g, mean, rstd = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(_as(dy.contiguous(), xc.dtype), xc, g, mean, rstd)
+        dx, dg, db = _ln_bwd(_as(dy.contiguous(), xc.dtype), xc, g, mean, rstd, *ctx.sinks)
         return dx, dg, db, None
 
 
@@ -175,6 +216,7 @@ class _PatchEmbed(torch.autograd.Function):
         emb = ops.linear_fwd(patches, wc, _f32(b))
         ctx.save_for_backward(patches, wc)
         ctx.clip_shape, ctx.clip_dtype, ctx.patch = tuple(clip.shape), clip.dtype, patch
+        ctx.sinks = (_sink(w), _sink(b))
         return emb
 
     @staticmethod
@@ -185,8 +227,8 @@ class _PatchEmbed(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dpatch = ops.linear_dgrad(demb, wc)
             dclip = ops.patchify_bwd(dpatch, ctx.clip_shape, ctx.patch, ctx.clip_dtype)
-        dw = ops.linear_wgrad(demb, patches) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(demb) if ctx.needs_input_grad[2] else None
+        dw = _emit_wgrad(ctx.sinks[0], demb, patches) if ctx.needs_input_grad[1] else None
+        db = _emit_colsum(ctx.sinks[1], demb) if ctx.needs_input_grad[2] else None
         return dclip, dw, db, None, None
 
 
@@ -206,10 +248,19 @@ class _Tokens(torch.autograd.Function):
         pos32 = pos32.reshape(T, pos32.shape[-2], pos32.shape[-1])
         ctx.T, ctx.pos_rows = T, pos32.shape[1]
         ctx.cls_shape, ctx.pos_shape = tuple(cls.shape), tuple(pos.shape)
+        ctx.sinks = (_sink(cls), _sink(pos))
         return ops.tokens_assemble_fwd(emb.contiguous(), cls32, pos32, S, T, n)
 
     @staticmethod
     def backward(ctx, dout):
+        sc, sp = ctx.sinks
+        if sc is not None and sp is not None:
+            demb, _, _ = ops.tokens_assemble_bwd(dout, ctx.T, ctx.pos_rows, dcls=sc.buf.view(-1),
+                                                 dpos=sp.buf.view(ctx.T, ctx.pos_rows, -1),
+                                                 accumulate=not sc.fresh)
+            sc.mark_written()
+            sp.mark_written()
+            return demb, None, None, None, None, None
         demb, dcls, dpos = ops.tokens_assemble_bwd(dout, ctx.T, ctx.pos_rows)
         return demb, dcls.view(ctx.cls_shape), dpos.view(ctx.pos_shape), None, None, None
 
@@ -242,6 +293,7 @@ class _ClsNormConcat(torch.autograd.Function):
         ctx.save_for_backward(xc, g, mean, rstd)
         ctx.dims = (B, T, S, N, d)
         ctx.tok_shape = tuple(tok.shape) if tok is not None else None
+        ctx.sinks = (_sink(w), _sink(b), _sink(tok))
         return seq
 
     @staticmethod
@@ -250,9 +302,15 @@ class _ClsNormConcat(torch.autograd.Function):
         B, T, S, N, d = ctx.dims
         dseq = _as(dseq.contiguous(), xc.dtype)
         drows = torch.empty((S, d), dtype=xc.dtype, device=xc.device)
-        dtok = ops.rows_gather_bwd(dseq, drows, d, ctx.tok_shape is not None, B, T, d)
+        sg, sb, st = ctx.sinks
+        if st is not None:
+            ops.rows_gather_bwd(dseq, drows, d, True, B, T, d, dtok=st.buf.view(-1), accumulate=not st.fresh)
+            st.mark_written()
+            dtok = None
+        else:
+            dtok = ops.rows_gather_bwd(dseq, drows, d, ctx.tok_shape is not None, B, T, d)
         dx = torch.zeros_like(xc)   # rows other than CLS receive no gradient
-        _, dg, db = ops.layernorm_bwd(drows, xc, g, mean, rstd, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
+        _, dg, db = _ln_bwd(drows, xc, g, mean, rstd, sg, sb, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
         if dtok is not None:
             dtok = dtok.view(ctx.tok_shape)
         return dx, dg, db, dtok, None, None, None
@@ -372,6 +430,7 @@ class _AttnBlock(torch.autograd.Function):
         ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, wq, wo, qkv, o_mem, lse)
         ctx.cfg = (S, N, heads, dh, inner, prenorm, residual, w_out is not None, b_out is not None)
         ctx.xshape = shp
+        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
         return y.view(*shp[:-1], y.shape[-1])
 
     @staticmethod
@@ -386,9 +445,9 @@ class _AttnBlock(torch.autograd.Function):
         dwo = dbo = None
         if has_out:
             do2 = ops.linear_dgrad(dy2, wo)                            # [M, inner]
-            dwo = ops.linear_wgrad(dy2, o_mem.view(M, inner))
+            dwo = _emit_wgrad(ctx.sinks[3], dy2, o_mem.view(M, inner))
             if has_bias:
-                dbo = ops.colsum(dy2)
+                dbo = _emit_colsum(ctx.sinks[4], dy2)
         else:
             do2 = dy2
         qkv5 = qkv.view(S, N, 3, heads, dh)
@@ -398,11 +457,12 @@ class _AttnBlock(torch.autograd.Function):
         dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         ops.attention_bwd(q, k, v, o_mem.permute(0, 2, 1, 3), lse,
                           do2.view(S, N, heads, dh).permute(0, 2, 1, 3), dq, dk, dv, dh ** -0.5)
-        dwq = ops.linear_wgrad(dqkv, xn)
+        dwq = _emit_wgrad(ctx.sinks[2], dqkv, xn)
         dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
         dg = db = None
         if prenorm:
-            dx, dg, db = ops.layernorm_bwd(dxn, x2, g, mean, rstd, dx_add=dy2 if residual else None)
+            dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, ctx.sinks[0], ctx.sinks[1],
+                                 dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
         return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None
@@ -445,6 +505,7 @@ class _MlpBlock(torch.autograd.Function):
         ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, w1c, w2c, u, h)
         ctx.cfg = (act, prenorm, residual, b1 is not None, b2 is not None)
         ctx.xshape = shp
+        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w1, b1, w2, b2))
         return y.view(shp)
 
     @staticmethod
@@ -455,18 +516,19 @@ class _MlpBlock(torch.autograd.Function):
         if xn is None:
             xn = x2
         dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
-        dw2 = ops.linear_wgrad(dy2, h)
-        db2 = ops.colsum(dy2) if has_b2 else None
+        sk = ctx.sinks
+        dw2 = _emit_wgrad(sk[4], dy2, h)
+        db2 = _emit_colsum(sk[5], dy2) if has_b2 else None
         if act == "gelu":
             du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u)
         else:
             du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h)
-        dw1 = ops.linear_wgrad(du, xn)
-        db1 = ops.colsum(du) if has_b1 else None
+        dw1 = _emit_wgrad(sk[2], du, xn)
+        db1 = _emit_colsum(sk[3], du) if has_b1 else None
         dxn = ops.linear_dgrad(du, w1c)
         dg = db = None
         if prenorm:
-            dx, dg, db = ops.layernorm_bwd(dxn, x2, g, mean, rstd, dx_add=dy2 if residual else None)
+            dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, sk[0], sk[1], dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
         return dx.view(ctx.xshape), dg, db, dw1, db1, dw2, db2, None, None, None, None

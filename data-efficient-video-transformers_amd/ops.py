@@ -43,6 +43,16 @@ def _need_cuda(*ts: Optional[Tensor]) -> None:
 
 _ws = {}
 
+# Optional live profiler (bench.py): an object with begin(key, flops) / end(key) that
+# records HIP events on the current stream around selected launches.
+_profiler = None
+
+
+def set_profiler(p) -> None:
+    global _profiler
+    _profiler = p
+
+
 
 def workspace(nbytes: int, device, slot: str = "main") -> Optional[Tensor]:
     """Grow-only scratch buffer per (device, slot).  Kernels on one stream run in
@@ -144,16 +154,24 @@ def tokens_assemble_fwd(emb: Tensor, cls: Tensor, pos: Tensor, S: int, T: int, n
     return out
 
 
-def tokens_assemble_bwd(dout: Tensor, T: int, pos_rows: int) -> Tuple[Tensor, Tensor, Tensor]:
+def tokens_assemble_bwd(dout: Tensor, T: int, pos_rows: int, *, dcls: Optional[Tensor] = None,
+                        dpos: Optional[Tensor] = None, accumulate: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """dcls / dpos may be caller-owned fp32 destinations (gradient sinks)."""
     _need_cuda(dout)
     dout = dout.contiguous()
     S, n1, d = dout.shape
     n = n1 - 1
     demb = torch.empty((S * n, d), dtype=dout.dtype, device=dout.device)
-    dcls = torch.empty((d,), dtype=torch.float32, device=dout.device)
-    dpos = torch.empty((T, pos_rows, d), dtype=torch.float32, device=dout.device)
+    if dcls is None:
+        assert not accumulate
+        dcls = torch.empty((d,), dtype=torch.float32, device=dout.device)
+    if dpos is None:
+        assert not accumulate
+        dpos = torch.empty((T, pos_rows, d), dtype=torch.float32, device=dout.device)
+    assert dcls.is_contiguous() and dpos.is_contiguous() and dcls.numel() == d and dpos.numel() == T * pos_rows * d
     L.check(L.load().dvt_tokens_assemble_bwd(dout.data_ptr(), demb.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), S,
-                                             T, n, d, pos_rows, dt(dout), 0, _stream()), "dvt_tokens_assemble_bwd")
+                                             T, n, d, pos_rows, dt(dout), int(accumulate), _stream()),
+            "dvt_tokens_assemble_bwd")
     return demb, dcls, dpos
 
 
@@ -167,13 +185,17 @@ def rows_gather_fwd(src: Tensor, row_stride: int, tok: Optional[Tensor], B: int,
 
 
 def rows_gather_bwd(dout: Tensor, dsrc: Tensor, row_stride: int, want_tok: bool, B: int, T: int,
-                    d: int) -> Optional[Tensor]:
+                    d: int, *, dtok: Optional[Tensor] = None, accumulate: bool = False) -> Optional[Tensor]:
     """Scatters dout rows into ``dsrc`` (pre-zeroed by the caller where needed)."""
     _need_cuda(dout, dsrc)
     dout = dout.contiguous()
-    dtok = torch.empty((d,), dtype=torch.float32, device=dout.device) if want_tok else None
+    if want_tok and dtok is None:
+        assert not accumulate
+        dtok = torch.empty((d,), dtype=torch.float32, device=dout.device)
+    if not want_tok:
+        dtok = None
     L.check(L.load().dvt_rows_gather_bwd(dout.data_ptr(), dsrc.data_ptr(), row_stride, _p(dtok), B, T, d, dt(dout),
-                                         0, _stream()), "dvt_rows_gather_bwd")
+                                         int(accumulate), _stream()), "dvt_rows_gather_bwd")
     return dtok
 
 
@@ -208,7 +230,8 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, *, 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *,
                   dx_add: Optional[Tensor] = None, rows=None, dy_rows=None,
-                  dx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                  dx: Optional[Tensor] = None, dg: Optional[Tensor] = None, db: Optional[Tensor] = None,
+                  accumulate: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     _need_cuda(dy, x, gamma, mean, rstd, dx_add)
     d = x.shape[-1]
     if rows is None:
@@ -220,13 +243,15 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
         ys0, ys1 = dy_rows if dy_rows is not None else (d * n1, d)
     if dx is None:
         dx = torch.empty_like(x)
-    dg = torch.empty((d,), dtype=torch.float32, device=x.device)
-    db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    if dg is None or db is None:
+        assert not accumulate and dg is None and db is None
+        dg = torch.empty((d,), dtype=torch.float32, device=x.device)
+        db = torch.empty((d,), dtype=torch.float32, device=x.device)
     lib = L.load()
     ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
     L.check(lib.dvt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                   _p(dx_add), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d,
-                                  xs0, xs1, ys0, ys1, dt(x), 0, _stream()), "dvt_layernorm_bwd")
+                                  xs0, xs1, ys0, ys1, dt(x), int(accumulate), _stream()), "dvt_layernorm_bwd")
     return dx, dg, db
 
 
@@ -263,6 +288,13 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
     lib = L.load()
     ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device)
     d.workspace = _p(ws)
+    prof = _profiler
+    if prof is not None:
+        key = ("gemm", int(a_kmajor), int(b_kmajor), M, N, K)
+        prof.begin(key, 2.0 * M * N * K)
+        L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
+        prof.end(key)
+        return out
     L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
     return out
 
@@ -295,16 +327,19 @@ def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumul
                 out_dtype=torch.float32, accumulate=accumulate)
 
 
-def colsum(x: Tensor) -> Tensor:
+def colsum(x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """f32 [N] = sum over rows of x[M,N] (bias gradients)."""
     _need_cuda(x)
     M, N = x.shape
     assert x.stride(1) == 1
-    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.numel() == N and out.is_contiguous()
     lib = L.load()
     ws = workspace(lib.dvt_colsum_workspace_bytes(M, N), x.device)
-    L.check(lib.dvt_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), _p(ws), M, N, dt(x), 0, _stream()),
-            "dvt_colsum")
+    L.check(lib.dvt_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), _p(ws), M, N, dt(x), int(accumulate),
+                           _stream()), "dvt_colsum")
     return out
 
 
