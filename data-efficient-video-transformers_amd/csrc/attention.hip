@@ -26,7 +26,10 @@ namespace {
 
 // LDS hand-off between lanes of ONE wave (its LDS operations complete in order).
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // LDS operations of one wave complete in order; only the compiler must not reorder
+  // across this point.  (A wavefront-scope fence would also emit s_waitcnt vmcnt(0)
+  // and serialise the wave behind its outstanding global stores.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -24,6 +24,8 @@
 // generic path (gemm_generic_kernel): any dtype / shape / alignment, fp32 FMA,
 // 64x64x16 tiles -- the fp32 parity mode and odd shapes (19-class head).
 #include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,26 +33,6 @@ enum { BM = 128, BN = 128, BK = 64, NTHREADS = 256 };
 constexpr int kStageBytes = (BM * BK + BN * BK) * 2;   // 32 KiB
 constexpr int kCPad = BN + 4;                           // fp32 staging row stride (floats)
 constexpr int kSmemBytes = BM * kCPad * 4;              // 67,584 B >= 2 stages (65,536 B)
-
-struct GemmParams {
-  const bf16* A;
-  const bf16* B;
-  void* C;
-  int M, N, K;
-  int64_t lda, ldb, ldc;
-  int epilogue, out_f32, accumulate;
-  const float* bias;
-  const void* residual;
-  int64_t ldr;
-  void* aux;
-  int64_t ldaux;
-  float alpha;
-  int k_per_split;  // multiple of BK; == K rounded up when not splitting
-  float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
-  int tiles_n;
-};
-
-__device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 // ---- global -> registers (4 x 16 B per thread per operand tile)
 template <bool KMAJOR>
@@ -119,22 +101,6 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int base, int kk, i
       out[4 * hf + 3] = v[3];
     }
     return out;
-  }
-}
-
-__device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float res, float aux_in,
-                                           float& aux_out) {
-  switch (epi) {
-    case DVT_EPI_GELU: {
-      const float pre = acc + bias;
-      aux_out = pre;
-      return gelu_erf_f(pre);
-    }
-    case DVT_EPI_RELU: return fmaxf(acc + bias, 0.f);
-    case DVT_EPI_RESIDUAL: return acc + bias + res;
-    case DVT_EPI_DGELU: return acc * gelu_erf_grad_f(aux_in);
-    case DVT_EPI_DRELU: return aux_in > 0.f ? acc : 0.f;
-    default: return acc + bias;
   }
 }
 
@@ -210,12 +176,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
     }
   __syncthreads();
 
-  // ---- coalesced epilogue: 8 consecutive n per thread, 16 threads per row
-#pragma unroll
+  // ---- coalesced epilogue: 8 consecutive n per thread, 16 threads per row.  A real loop
+  //      (not unrolled): the epilogue code exists once and stays I-cache resident.
+  const int c = (tid & 15) << 3;
+  const int n = n0 + c;
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.bias && n < p.N && !p.slab) load8<float>(p.bias + n, bias);
+#pragma unroll 1
   for (int i = 0; i < 8; ++i) {
-    const int idx = tid + NTHREADS * i;
-    const int row = idx >> 4, c = (idx & 15) << 3;
-    const int m = m0 + row, n = n0 + c;
+    const int row = (tid >> 4) + 16 * i;
+    const int m = m0 + row;
     if (m >= p.M || n >= p.N) continue;
     float v[8];
     {
@@ -228,14 +198,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
       store8<float>(p.slab + ((int64_t)blockIdx.z * p.M + m) * p.N + n, v);
       continue;
     }
-    float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, res[8] = {0, 0, 0, 0, 0, 0, 0, 0},
-          aux[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
-    if (p.bias) load8<float>(p.bias + n, bias);
-    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, res);
+    float ld[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
+    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, ld);
     if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
-      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, aux);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = epi_apply(p.epilogue, v[k], bias[k], res[k], aux[k], pre[k]);
+      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, ld);
+    epi_apply8(p.epilogue, v, bias, ld, pre);
     if (p.epilogue == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
     if (p.out_f32) {
       float* o = (float*)p.C + (int64_t)m * p.ldc + n;
@@ -407,13 +374,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nparts, int64_t N,
-                                    float* __restrict__ out, int accumulate) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float t = 0.f;
-  for (int p = 0; p < nparts; ++p) t += partial[(int64_t)p * N + n];
-  out[n] = accumulate ? out[n] + t : t;
+// out[n] (+)= sum_p partial[p][n]; block = 32 columns x 8 part-lanes.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts,
+                                                           int64_t N, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int64_t n = (int64_t)blockIdx.x * 32 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) {
+    int p = pl;
+    for (; p + 8 < nparts; p += 16) {
+      a0 += partial[(int64_t)p * N + n];
+      a1 += partial[(int64_t)(p + 8) * N + n];
+    }
+    for (; p < nparts; p += 8) a0 += partial[(int64_t)p * N + n];
+  }
+  red[pl][cl] = a0 + a1;
+  __syncthreads();
+  if (pl == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    out[n] = accumulate ? out[n] + t : t;
+  }
 }
 
 template <typename T>
@@ -426,7 +410,7 @@ __global__ void colsum_generic_kernel(const T* __restrict__ x, int64_t ldx, int6
   out[n] = accumulate ? out[n] + t : t;
 }
 
-constexpr int kColsumParts = 256;
+constexpr int kColsumParts = 128;
 
 // ---------------------------------------------------------------- host side
 bool mfma_eligible(const dvt_gemm_desc* d) {
@@ -443,18 +427,72 @@ bool mfma_eligible(const dvt_gemm_desc* d) {
   return true;
 }
 
-int choose_split(const dvt_gemm_desc* d) {
-  if (d->epilogue != DVT_EPI_NONE || d->bias || d->alpha != 1.0f) return 1;
-  if (d->split_k > 1) return d->split_k;
-  if (d->split_k == 1) return 1;
-  const int64_t tiles = dvt_cdiv(d->M, BM) * dvt_cdiv(d->N, BN);
+struct GemmPlan {
+  bool use256;
+  int cfg;   // LDS-DMA kernel configuration (gemm256.hip)
+  int split;
+  int kps;   // K per split (multiple of 64)
+};
+
+// Tile size and split-K factor.  Split-K only for the plain epilogue (weight
+// gradients: few output tiles, K = number of tokens).
+GemmPlan plan_gemm(const dvt_gemm_desc* d) {
+  GemmPlan pl;
+  const bool can_split = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
   const int64_t cus = dvt_num_cus();
-  if (tiles >= cus || d->K < 2048) return 1;
-  int64_t s = dvt_cdiv(2 * cus, tiles);
-  const int64_t maxs = d->K / 512;
-  if (s > maxs) s = maxs;
-  if (s > 64) s = 64;
-  return s < 1 ? 1 : (int)s;
+  static const bool allow256 = [] {
+    const char* e = getenv("DVT_GEMM256");
+    return !(e && e[0] == '0');
+  }();
+  // --- 256x256 LDS-DMA kernel
+  if (allow256 && d->K % 64 == 0) {
+    const int64_t t256 = dvt_cdiv(d->M, 256) * dvt_cdiv(d->N, 256);
+    int64_t s = 1;
+    if (d->split_k > 0) s = d->split_k;
+    else if (can_split && t256 < (cus * 3) / 4) {
+      s = dvt_cdiv(cus, t256);
+      const int64_t maxs = d->K / 1024;
+      if (s > maxs) s = maxs;
+      if (s > 32) s = 32;
+      if (s < 1) s = 1;
+    }
+    if (!can_split) s = 1;
+    const int64_t kps = dvt_cdiv(dvt_cdiv(d->K, s), 64) * 64;
+    s = dvt_cdiv(d->K, kps);
+    if (t256 * s >= 96) {
+      pl.use256 = true;
+      pl.split = (int)s;
+      pl.kps = (int)kps;
+      // short K: the epilogue burst is a large share of a tile's life -> two workgroups per CU
+      static const int force_cfg = [] {
+        const char* e = getenv("DVT_GEMM_CFG");
+        return e ? atoi(e) : -1;
+      }();
+      pl.cfg = force_cfg >= 0 ? force_cfg : 0;   // cfg 1 (2 workgroups / CU) measured slower or equal on every metric shape
+      return pl;
+    }
+  }
+  // --- 128x128 register-staged kernel
+  int64_t s = 1;
+  if (can_split) {
+    if (d->split_k > 1) s = d->split_k;
+    else if (d->split_k == 0) {
+      const int64_t tiles = dvt_cdiv(d->M, BM) * dvt_cdiv(d->N, BN);
+      if (tiles < cus && d->K >= 2048) {
+        s = dvt_cdiv(2 * cus, tiles);
+        const int64_t maxs = d->K / 512;
+        if (s > maxs) s = maxs;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+      }
+    }
+  }
+  const int64_t kps = dvt_cdiv(dvt_cdiv(d->K, s), BK) * BK;
+  pl.use256 = false;
+  pl.cfg = 0;
+  pl.split = (int)dvt_cdiv(d->K, kps);
+  pl.kps = (int)kps;
+  return pl;
 }
 
 int check_desc(const dvt_gemm_desc* d) {
@@ -481,10 +519,9 @@ int check_desc(const dvt_gemm_desc* d) {
 extern "C" {
 
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
-  if (!d || !mfma_eligible(d)) return 0;
-  dvt_gemm_desc t = *d;
-  const int s = choose_split(&t);
-  return s > 1 ? (size_t)s * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
+  if (!d || !mfma_eligible(d) || d->K <= 0) return 0;
+  const GemmPlan pl = plan_gemm(d);
+  return pl.split > 1 ? (size_t)pl.split * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
 }
 
 int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
@@ -494,8 +531,13 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
 
   if (mfma_eligible(d) && d->K > 0) {
-    int split = choose_split(d);
-    if (split > 1 && !d->workspace) split = 1;
+    GemmPlan pl = plan_gemm(d);
+    if (pl.split > 1 && !d->workspace) {   // no scratch: fall back to an unsplit 128x128 launch
+      pl.use256 = false;
+      pl.split = 1;
+      pl.kps = (int)(dvt_cdiv(d->K, BK) * BK);
+    }
+    int split = pl.split;
     GemmParams p;
     p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
     p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
@@ -503,12 +545,17 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
     p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
     p.alpha = d->alpha;
+    p.k_per_split = pl.kps;
+    p.slab = split > 1 ? (float*)d->workspace : nullptr;
+    p.tiles_n = 0;
+    if (pl.use256) {
+      rc = dvt_gemm_dma_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, split, pl.cfg, st);
+      if (rc < 0) return rc;
+      if (rc == 1) pl.use256 = false;   // no instantiation for this combination
+    }
+    if (!pl.use256) {
     const int tiles_m = (int)dvt_cdiv(d->M, BM);
     p.tiles_n = (int)dvt_cdiv(d->N, BN);
-    int kps = (int)dvt_cdiv(dvt_cdiv(d->K, split), BK) * BK;
-    split = (int)dvt_cdiv(d->K, kps);
-    p.k_per_split = kps;
-    p.slab = split > 1 ? (float*)d->workspace : nullptr;
     const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(NTHREADS);
     static bool attr_set = false;
     if (!attr_set) {
@@ -527,6 +574,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     else
       hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, block, kSmemBytes, st, p);
     DVT_LAUNCH_CHECK("dvt_gemm(mfma)");
+    }
     if (split > 1) {
       const int64_t nvec = d->M * d->N / 8;
       int64_t blocks = dvt_cdiv(nvec, 256);
@@ -577,7 +625,7 @@ int dvt_colsum(const void* x, int64_t ldx, float* out, void* workspace, int64_t 
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st,
                                                     (const T*)x, ldx, M, N, rpb, (float*)workspace));
     DVT_LAUNCH_CHECK("dvt_colsum(partial)");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dvt_cdiv(N, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dvt_cdiv(N, 32)), dim3(256), 0, st,
                        (const float*)workspace, parts, N, out, accumulate);
     DVT_LAUNCH_CHECK("dvt_colsum(final)");
     return DVT_OK;

@@ -1,0 +1,348 @@
+// gemm256.hip -- 256x256x64 bf16 MFMA GEMM with LDS-DMA staging (large shapes).
+//
+// One workgroup = 8 waves (2 x 4), one 256x256 output tile, fp32 accumulate:
+//   * both operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB
+//     per wave-instruction, no VGPR staging); LDS is lane-linear for the DMA, so
+//     the bank-conflict swizzles are applied on the per-lane SOURCE address and
+//     again on the fragment read (both are the same XOR involution);
+//   * two 64 KiB stages: the DMA of k-tile t+1 is in flight during all 64 MFMAs
+//     per wave of k-tile t; counted s_waitcnt vmcnt(8) + raw s_barrier (never
+//     vmcnt(0) inside the loop);
+//   * each wave owns 128 x 64 of the tile (8 x 4 accumulators of
+//     v_mfma_f32_16x16x32_bf16); k-major operands are read with ds_read_b128,
+//     mn-major operands (dgrad's W, wgrad's dY and x) with ds_read_b64_tr_b16;
+//   * epilogue: every wave stages its own accumulators through a private LDS
+//     region (no workgroup barrier) and stores whole 128-byte row segments with
+//     bias / GELU / GELU' / ReLU / residual fused;
+//   * split-K over blockIdx.z writes fp32 slabs (summed by splitk_reduce_kernel).
+// Requirements (else gemm.hip's 128x128 register-staged kernel is used):
+//   K and every split a multiple of 64, all leading dimensions multiples of 8.
+#include "gemm_common.h"
+
+#ifndef DVT_ABL
+#define DVT_ABL 0   // dev ablations (tools/gemm_bench.hip); 0 = product kernel
+#endif
+
+namespace {
+
+// Two configurations of one kernel:
+//   CFG 0  256x256 tile, BK=64, 2 LDS stages (128 KiB), 8 waves (2x4): 1 workgroup / CU.
+//          Highest arithmetic intensity per L2 byte; used when K is long enough that the
+//          un-overlapped epilogue burst does not matter.
+//   CFG 1  256x128 tile, BK=32, 3 LDS stages (72 KiB), 4 waves (2x2): 2 workgroups / CU,
+//          so one workgroup's epilogue (stores) overlaps the other's main loop.  Used for
+//          the short-K, write-heavy Linear layers of the d=512 model (K = 512).
+template <int CFG> struct Cfg;
+template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
+template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
+
+constexpr int kEpiStride = 64 + 4;               // floats per staged row
+constexpr int kEpiBytes = 32 * kEpiStride * 4;   // 8,704 B per wave
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 16-byte-chunk swizzle of a k-major image row (XOR involution, also used on the read side)
+template <int TK> __device__ __forceinline__ int swz_k(int row) { return TK == 64 ? (row & 7) : ((row >> 1) & 3); }
+
+// DMA one operand tile into LDS in 1 KiB pieces (one wave-instruction each).
+//   k-major : image [ROWS][TK],  row = TK*2 bytes
+//   mn-major: image [TK][ROWS],  row = ROWS*2 bytes, 32-byte units XOR-swizzled by swz_mn(k)
+template <bool KMAJOR, int ROWS, int TK, int NW>
+__device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim,
+                                         int k0, char* tile, int wid, int lane) {
+  constexpr int PIECES = ROWS * TK * 2 / 1024;
+  constexpr int PPW = PIECES / NW;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wid * PPW + i;
+    const bf16* src;
+    if (KMAJOR) {
+      constexpr int CPR = TK / 8;               // 16-byte chunks per row
+      constexpr int RPP = 64 / CPR;             // rows per piece
+      const int row = piece * RPP + lane / CPR;
+      const int c = (lane % CPR) ^ swz_k<TK>(row);
+      int grow = mn0 + row;
+      grow = grow < mn_lim ? grow : mn_lim - 1;
+      src = base + (int64_t)grow * ld + k0 + c * 8;
+    } else {
+      constexpr int CPR = ROWS / 8;
+      constexpr int RPP = 64 / CPR;
+      const int k = piece * RPP + lane / CPR;
+      const int cp = lane % CPR;
+      const int c = ((((cp >> 1) ^ swz_mn(k)) << 1) | (cp & 1));
+      int gmn = mn0 + c * 8;
+      gmn = gmn < mn_lim ? gmn : mn_lim - 8;
+      src = base + (int64_t)(k0 + k) * ld + gmn;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+// MFMA operand fragment of 16 rows (k-major) / 16 columns (mn-major) starting at `base`,
+// k-step kk (32 k each): lane (g, li) gets element j <-> (base + li, kk*32 + 8g + j).
+template <bool KMAJOR, int ROWS, int TK>
+__device__ __forceinline__ bf16x8 frag(const char* tile, int base, int kk, int g, int li) {
+  if (KMAJOR) {
+    const int row = base + li;
+    const int c = kk * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(tile + row * (TK * 2) + ((c ^ swz_k<TK>(row)) << 4));
+  } else {
+    const int q = li >> 2, pp = li & 3;
+    const int u = base >> 4;
+    bf16x8 out;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = kk * 32 + 8 * g + 4 * hf + q;
+      const char* a = tile + k * (ROWS * 2) + ((u ^ swz_mn(k)) << 5) + 8 * pp;
+      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+      out[4 * hf + 0] = v[0];
+      out[4 * hf + 1] = v[1];
+      out[4 * hf + 2] = v[2];
+      out[4 * hf + 3] = v[3];
+    }
+    return out;
+  }
+}
+
+__device__ __forceinline__ bool v_dummy(const GemmParams& p) { return p.M < 0; }  // ablation 3: never true
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave complete in order; only the compiler must not reorder
+  // across this point.  (A wavefront-scope fence would also emit s_waitcnt vmcnt(0)
+  // and serialise the wave behind its outstanding global stores.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// OUT: 0 = C in bf16 with the fused epilogue EPI, 1 = C in fp32 (optionally accumulated),
+//      2 = raw fp32 split-K slab.  EPI and OUT are compile-time so that the unrolled
+//      epilogue stays a few hundred instructions (a runtime switch replicated over the
+//      4 x 4 unrolled passes was ~19k ISA lines per kernel and thrashed the I-cache).
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
+
+template <bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT>
+__global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const GemmParams p) {
+  typedef Cfg<CFG> C;
+  constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
+  constexpr int kATile = TM * TK * 2, kBTile = TN * TK * 2, kStage = kATile + kBTile;
+  constexpr int kPPT = (kATile + kBTile) / 1024 / NW;   // DMA instructions per thread per k-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;      // every wave owns 128 x 64
+  const int g = lane >> 4, li = lane & 15;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give
+  // each XCD a contiguous run of tiles so that consecutive n-tiles of one A row-panel
+  // hit the same L2.  Bijective for any tile count.
+  const int ntiles = gridDim.x;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int m0 = (tile / p.tiles_n) * TM;
+  const int n0 = (tile % p.tiles_n) * TN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (DVT_ABL == 5 || DVT_ABL == 6) ? 0 : (kend - kbeg) / TK;   // ablations 5/6: epilogue only
+
+  f32x4 acc[4][8];  // [u: n sub-tile][t: m sub-tile]
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: NSTG-1 k-tiles in flight
+#pragma unroll
+  for (int s = 0; s < NSTG - 1; ++s)
+    if (s < nk) {
+      dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
+    }
+  int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
+  for (int kt = 0; kt < nk; ++kt) {
+    // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
+    if (NSTG == 3 && kt + 1 < nk) wait_vm<kPPT>();
+    else wait_vm<0>();
+    // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
+    //     stage that the DMA below overwrites (it was consumed in iteration kt-1)
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
+      const int k0 = kbeg + (kt + NSTG - 1) * TK;
+      dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
+    }
+    const char* sa = smem + st_cur * kStage;
+    const char* sb = sa + kATile;
+#pragma unroll
+    for (int kk = 0; kk < (DVT_ABL == 1 ? 0 : TK / 32); ++kk) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bfr[u] = frag<B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = frag<A_KMAJOR, TM, TK>(sa, wm * 128 + (th * 4 + t) * 16, kk, g, li);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[u][th * 4 + t] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[u], af[t], acc[u][th * 4 + t], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    st_cur = st_cur + 1 == NSTG ? 0 : st_cur + 1;
+    st_nxt = st_nxt + 1 == NSTG ? 0 : st_nxt + 1;
+  }
+  __builtin_amdgcn_s_barrier();                // all LDS reads done before the staging overlay
+
+  // ---- epilogue: per-wave staging region, 4 passes of 32 rows x 64 cols.
+  // vmcnt counts loads and stores together in issue order, so a load issued after a
+  // store cannot be consumed before that store has retired.  Hence: the bias is
+  // loaded once, and the residual / aux rows of pass ps+1 are requested BEFORE the
+  // stores of pass ps (the compiler then waits with a counted vmcnt, not vmcnt(0)).
+  float* es = reinterpret_cast<float*>(smem + wid * kEpiBytes);
+  const int wrow0 = m0 + wm * 128, wcol0 = n0 + wn * 64;
+  const int c = (lane & 7) << 3;
+  const int n = wcol0 + c;
+  const bool n_ok = n < p.N;
+  constexpr bool kNeedLd = OUT == OUT_BF16 && (EPI == DVT_EPI_RESIDUAL || EPI == DVT_EPI_DGELU || EPI == DVT_EPI_DRELU);
+  const bf16* ldp = EPI == DVT_EPI_RESIDUAL ? (const bf16*)p.residual : (const bf16*)p.aux;
+  const int64_t ldl = EPI == DVT_EPI_RESIDUAL ? p.ldr : p.ldaux;
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (OUT != OUT_SLAB && p.bias && n_ok) load8<float>(p.bias + n, bias);
+  bf16x8 nxt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    const int m = wrow0 + (lane >> 3) + 8 * j;
+    if (kNeedLd && n_ok && m < p.M) nxt[j] = *reinterpret_cast<const bf16x8*>(ldp + (int64_t)m * ldl + n);
+  }
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<f32x4*>(es + (tt * 16 + li) * kEpiStride + u * 16 + 4 * g) =
+            acc[u][ps * 2 + tt] * p.alpha;
+    wave_lds_fence();
+    float v[4][8];
+    bf16x8 cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lane >> 3) + 8 * j;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(es + row * kEpiStride + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(es + row * kEpiStride + c + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[j][k] = a[k]; v[j][4 + k] = b[k]; }
+      cur[j] = nxt[j];
+    }
+    if (kNeedLd && ps + 1 < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = wrow0 + (ps + 1) * 32 + (lane >> 3) + 8 * j;
+        if (n_ok && m < p.M) nxt[j] = *reinterpret_cast<const bf16x8*>(ldp + (int64_t)m * ldl + n);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
+      if (m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
+        if (OUT == OUT_SLAB) {
+          store8<float>(p.slab + ((int64_t)blockIdx.z * p.M + m) * p.N + n, v[j]);
+        } else if (OUT == OUT_F32) {
+          float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[j][k] += bias[k];
+          if (p.accumulate) {
+            float old[8];
+            load8<float>(o, old);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j][k] += old[k];
+          }
+          store8<float>(o, v[j]);
+        } else {
+          float pre[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float ld = (float)cur[j][k];
+            v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
+          }
+          if (EPI == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+          if (DVT_ABL == 6) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(v[j][k]));
+          } else {
+            store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v[j]);
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// ---------------------------------------------------------------- host side
+template <bool AK, bool BK, int CFG, int EPI, int OUT>
+int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<AK, BK, CFG, EPI, OUT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<AK, BK, CFG, EPI, OUT>), grid, block, smem_bytes, st, p);
+  DVT_LAUNCH_CHECK("dvt_gemm(dma)");
+  return DVT_OK;
+}
+
+template <int CFG>
+int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t st) {
+  typedef Cfg<CFG> C;
+  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  static_assert(kSmem >= C::NW * kEpiBytes, "epilogue staging must fit in the stage buffers");
+  GemmParams p = pin;
+  const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
+  p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
+  const int e = p.epilogue;
+  if (p.slab) {
+    if (!ak && !bk) return launch_one<false, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+    if (ak && bk) return launch_one<true, true, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+    if (ak && !bk) return launch_one<true, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+  } else if (p.out_f32) {
+    if (!ak && !bk && e == DVT_EPI_NONE) return launch_one<false, false, CFG, DVT_EPI_NONE, OUT_F32>(p, grid, block, kSmem, st);
+  } else if (ak && bk) {
+    if (e == DVT_EPI_NONE) return launch_one<true, true, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_GELU) return launch_one<true, true, CFG, DVT_EPI_GELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_RELU) return launch_one<true, true, CFG, DVT_EPI_RELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_RESIDUAL) return launch_one<true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16>(p, grid, block, kSmem, st);
+  } else if (ak && !bk) {
+    if (e == DVT_EPI_NONE) return launch_one<true, false, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_DGELU) return launch_one<true, false, CFG, DVT_EPI_DGELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_DRELU) return launch_one<true, false, CFG, DVT_EPI_DRELU, OUT_BF16>(p, grid, block, kSmem, st);
+  }
+  return 1;   // combination not instantiated: caller falls back to the 128x128 kernel
+}
+
+}  // namespace
+
+// Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
+// combination has no LDS-DMA instantiation.
+int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
+  return cfg == 0 ? launch_cfg<0>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<1>(p, a_kmajor, b_kmajor, split, st);
+}

@@ -1,0 +1,74 @@
+// gemm_common.h -- parameter block and epilogue shared by the GEMM kernels.
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int epilogue, out_f32, accumulate;
+  const float* bias;
+  const void* residual;
+  int64_t ldr;
+  void* aux;
+  int64_t ldaux;
+  float alpha;
+  int k_per_split;  // multiple of BK; == K rounded up when not splitting
+  float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
+  int tiles_n;
+};
+
+__device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float res, float aux_in,
+                                           float& aux_out) {
+  switch (epi) {
+    case DVT_EPI_GELU: {
+      const float pre = acc + bias;
+      aux_out = pre;
+      return gelu_erf_f(pre);
+    }
+    case DVT_EPI_RELU: return fmaxf(acc + bias, 0.f);
+    case DVT_EPI_RESIDUAL: return acc + bias + res;
+    case DVT_EPI_DGELU: return acc * gelu_erf_grad_f(aux_in);
+    case DVT_EPI_DRELU: return aux_in > 0.f ? acc : 0.f;
+    default: return acc + bias;
+  }
+}
+
+
+// 8 consecutive outputs at once, the switch hoisted out of the element loop.
+__device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (&bias)[8],
+                                           const float (&ld)[8], float (&pre)[8]) {
+  switch (epi) {
+    case DVT_EPI_GELU:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { pre[k] = v[k] + bias[k]; v[k] = gelu_erf_f(pre[k]); }
+      break;
+    case DVT_EPI_RELU:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bias[k], 0.f);
+      break;
+    case DVT_EPI_RESIDUAL:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] + bias[k] + ld[k];
+      break;
+    case DVT_EPI_DGELU:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= gelu_erf_grad_f(ld[k]);
+      break;
+    case DVT_EPI_DRELU:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ld[k] > 0.f ? v[k] : 0.f;
+      break;
+    default:
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += bias[k];
+  }
+}
+
+// LDS-DMA kernels (gemm256.hip).  cfg 0: 256x256x64, 1 workgroup / CU;  cfg 1: 256x128x32,
+// 2 workgroups / CU.  K (and each K split) must be a multiple of 64.
+int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st);

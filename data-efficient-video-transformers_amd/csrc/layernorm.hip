@@ -169,22 +169,35 @@ __global__ __launch_bounds__(kLnBlock) void ln_bwd_kernel(
   for (int c = threadIdx.x; c < 2 * d; c += kLnBlock) out[c] = lds[c];
 }
 
-// out[c] (+)= sum_p partial[p][c]   for c in [0, 2d): dgamma then dbeta
+// out[c] (+)= sum_p partial[p][c]   for c in [0, 2d): dgamma then dbeta.
+// Block = 32 columns x 8 part-lanes; each thread sums nparts/8 partials (4 loads in
+// flight), then an LDS tree over the 8 part-lanes.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial,
                                                             int nparts, int d,
                                                             float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta,
                                                             int accumulate) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  float acc = 0.f;
-  if (c < 2 * d)
-    for (int p = w; p < nparts; p += 4) acc += partial[(int64_t)p * 2 * d + c];
-  red[w][lane] = acc;
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int64_t ld = 2 * (int64_t)d;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < 2 * d) {
+    int p = pl;
+    for (; p + 24 < nparts; p += 32) {
+      a0 += partial[(int64_t)p * ld + c];
+      a1 += partial[(int64_t)(p + 8) * ld + c];
+      a2 += partial[(int64_t)(p + 16) * ld + c];
+      a3 += partial[(int64_t)(p + 24) * ld + c];
+    }
+    for (; p < nparts; p += 8) a0 += partial[(int64_t)p * ld + c];
+  }
+  red[pl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0 && c < 2 * d) {
-    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (pl == 0 && c < 2 * d) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
     float* o = c < d ? dgamma + c : dbeta + (c - d);
     *o = accumulate ? *o + t : t;
   }
@@ -263,7 +276,7 @@ int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
       (ln_bwd_kernel<T, VPL>), dim3((unsigned)blocks), dim3(kLnBlock), lds, st, (const T*)dy,
       (const T*)x, gamma, mean, rstd, (const T*)dx_add, (T*)dx, partial, rows, n1, (int)d, xs0, xs1, ys0, ys1)));
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)dvt_cdiv(2 * d, 64)), dim3(256), 0, st,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)dvt_cdiv(2 * d, 32)), dim3(256), 0, st,
                      (const float*)partial, (int)blocks, (int)d, dgamma, dbeta, accumulate);
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd(reduce)");
   return DVT_OK;

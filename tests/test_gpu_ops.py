@@ -191,6 +191,43 @@ def test_gemm_epilogues(dvt, device, dtype):
     assert rel_l2(dr, (dy @ w) * (hpos > 0)) < tol
 
 
+def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device):
+    """Shapes large enough for the 256x256 LDS-DMA kernel (>= 96 tiles), with ragged
+    M (6208 = 24.25 tiles) and N edges, all three operand layouts, split-K and every
+    fused epilogue."""
+    L = dvt._lib
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 6208, 1024, 1024
+    x_d, x = _rnd((M, K), torch.bfloat16, g)
+    w_d, w = _rnd((N, K), torch.bfloat16, g, 1 / math.sqrt(K))
+    bias = 0.5 * torch.randn(N, generator=g)
+    pre = x @ w.t() + bias
+    y = dvt.ops.linear_fwd(x_d, w_d, bias.cuda())
+    assert rel_l2(y, pre) < BF16_TOL
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    h = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_GELU, aux=aux)
+    assert rel_l2(aux, pre) < BF16_TOL and rel_l2(h, O.gelu_erf(pre)) < BF16_TOL
+    res_d, res = _rnd((M, N), torch.bfloat16, g)
+    yr = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d)
+    assert rel_l2(yr, pre + res) < BF16_TOL
+    dy_d, dy = _rnd((M, N), torch.bfloat16, g)
+    dx = dvt.ops.linear_dgrad(dy_d, w_d)                      # k-major x mn-major
+    assert rel_l2(dx, dy @ w) < BF16_TOL
+    u_d, u = _rnd((M, K), torch.bfloat16, g)
+    uu = u.clone().requires_grad_(True)
+    O.gelu_erf(uu).backward(dy @ w)
+    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d)
+    assert rel_l2(du, uu.grad) < BF16_TOL
+    dw = dvt.ops.linear_wgrad(dy_d, x_d)                      # mn-major x mn-major, split-K
+    assert rel_l2(dw, dy.t() @ x) < BF16_TOL
+    assert torch.equal(dw, dvt.ops.linear_wgrad(dy_d, x_d))
+    # ragged N (1000 = 3.9 tiles) and a narrower K
+    w2_d, w2 = _rnd((1000, 192), torch.bfloat16, g, 0.1)
+    x2_d, x2 = _rnd((M, 192), torch.bfloat16, g)
+    y2 = dvt.ops.linear_fwd(x2_d, w2_d)
+    assert rel_l2(y2, x2 @ w2.t()) < BF16_TOL
+
+
 def test_wgrad_split_k_reproducible(dvt, device):
     """Token-count reduction (K = rows) with few output tiles -> split-K slabs."""
     g = torch.Generator().manual_seed(8)
