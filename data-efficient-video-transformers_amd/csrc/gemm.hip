@@ -247,6 +247,46 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
   }
 }
 
+// Split-K reduce with the fused epilogue (bias / activation / residual), bf16 output:
+// lets small-M GEMMs (the 33-token temporal encoder, M = 264) spread their K loop over
+// many workgroups instead of running one latency-bound loop per tile.
+__global__ void splitk_reduce_epi_kernel(const float* __restrict__ slab, int splits, const GemmParams p) {
+  const int64_t nvec = (int64_t)p.M * p.N / 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t MN = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t e = i * 8;
+    const int m = (int)(e / p.N), n = (int)(e % p.N);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < splits; ++z) {
+      float t[8];
+      load8<float>(slab + (int64_t)z * MN + e, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ld[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
+    if (p.bias) load8<float>(p.bias + n, bias);
+    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, ld);
+    if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
+      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, ld);
+    // (the slabs already carry alpha)
+    epi_apply8(p.epilogue, v, bias, ld, pre);
+    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+    if (p.out_f32) {
+      float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+      if (p.accumulate) {
+        float old[8];
+        load8<float>(o, old);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += old[k];
+      }
+      store8<float>(o, v);
+    } else {
+      store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- generic path
 struct GenericParams {
   const void* A;
@@ -438,7 +478,8 @@ struct GemmPlan {
 // gradients: few output tiles, K = number of tokens).
 GemmPlan plan_gemm(const dvt_gemm_desc* d) {
   GemmPlan pl;
-  const bool can_split = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
+  const bool plain = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
+  const bool can_split = plain;   // LDS-DMA path: slabs are summed without an epilogue
   const int64_t cus = dvt_num_cus();
   static const bool allow256 = [] {
     const char* e = getenv("DVT_GEMM256");
@@ -453,7 +494,7 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       s = dvt_cdiv(cus, t256);
       const int64_t maxs = d->K / 1024;
       if (s > maxs) s = maxs;
-      if (s > 32) s = 32;
+      if (s > 64) s = 64;
       if (s < 1) s = 1;
     }
     if (!can_split) s = 1;
@@ -473,18 +514,17 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
     }
   }
   // --- 128x128 register-staged kernel
+  // Any epilogue may be split here: splitk_reduce_epi_kernel applies it after the sum.
   int64_t s = 1;
-  if (can_split) {
-    if (d->split_k > 1) s = d->split_k;
-    else if (d->split_k == 0) {
-      const int64_t tiles = dvt_cdiv(d->M, BM) * dvt_cdiv(d->N, BN);
-      if (tiles < cus && d->K >= 2048) {
-        s = dvt_cdiv(2 * cus, tiles);
-        const int64_t maxs = d->K / 512;
-        if (s > maxs) s = maxs;
-        if (s > 64) s = 64;
-        if (s < 1) s = 1;
-      }
+  if (d->split_k > 1) s = d->split_k;
+  else if (d->split_k == 0) {
+    const int64_t tiles = dvt_cdiv(d->M, BM) * dvt_cdiv(d->N, BN);
+    if (tiles < cus && d->K >= 256) {
+      s = dvt_cdiv(cus, tiles);
+      const int64_t maxs = d->K / 128;     // at least two 64-wide k-tiles per slice
+      if (s > maxs) s = maxs;
+      if (s > 32) s = 32;
+      if (s < 1) s = 1;
     }
   }
   const int64_t kps = dvt_cdiv(dvt_cdiv(d->K, s), BK) * BK;
@@ -580,7 +620,11 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
       int64_t blocks = dvt_cdiv(nvec, 256);
       const int64_t cap = (int64_t)dvt_num_cus() * 8;
       if (blocks > cap) blocks = cap;
-      if (p.out_f32)
+      const bool plain = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
+      if (!plain)
+        hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const float*)p.slab, split, p);
+      else if (p.out_f32)
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate);
       else

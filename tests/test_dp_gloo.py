@@ -1,0 +1,118 @@
+"""Data-parallel gradient exchange on CPU (gloo, world_size 2).
+
+The GPU kernels cannot run here, so each rank computes the gradients of its half of
+the batch with the CPU oracle and hands them to ``dp.FlatParameters`` through the
+same GradSink protocol the HIP backward uses (first write overwrites, buckets fire
+when complete, sum all-reduce, 1/world folded into the loss).  The all-reduced flat
+gradient must equal the single-process full-batch gradient.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import clip_path as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    from dvt_amd.models.vit import ViViT
+    torch.manual_seed(1130)
+    return ViViT(32, 8, 19, 3, dim=64, depth=1, heads=2, dim_head=32, compute_dtype=torch.float32)
+
+
+def _data():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 3, 32, 32, generator=g)
+    y = (torch.rand(4, 19, generator=g) < 0.3).float()
+    return x, y
+
+
+def _oracle_grads(net, x, y, scale):
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.named_parameters()}
+    logits = O.vivit_forward(x, P, patch=8, depth=1, heads=2)
+    (O.bce_with_logits(logits, y) * scale).backward()
+    return {k: v.grad for k, v in P.items()}
+
+
+def _worker(rank, world, port, bucket_mb, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvt_amd.dp import FlatParameters
+    net = _model()
+    if rank == 1:                      # ranks start from different weights: broadcast must fix it
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    flat = FlatParameters(net, bucket_mb=bucket_mb, compute_dtype=None)
+    flat.broadcast_parameters(0)
+    x, y = _data()
+    xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+    for step in range(2):              # second step: stale gradients must be overwritten
+        flat.zero_grad()
+        grads = _oracle_grads(net, xs, ys, flat.loss_scale)
+        names = [k for k, _ in net.named_parameters()]
+        for k in reversed(names):      # backward order
+            p = dict(net.named_parameters())[k]
+            s = p._dvt_sink
+            if k == "temporal_token" and step == 0:
+                continue               # a parameter nobody writes: finish_backward zero-fills it
+            if s.fresh:
+                s.buf.copy_(grads[k])
+            else:
+                s.buf.add_(grads[k])
+            s.mark_written()
+        flat.finish_backward()
+    if rank == 0:
+        torch.save({"grad": flat.grad.clone(), "data": flat.data.clone(), "nb": len(flat.bucket_ranges),
+                    "names": names, "offsets": flat.offsets}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mb", [32.0, 0.05])
+def test_two_rank_allreduce_equals_full_batch(tmp_path, bucket_mb):
+    import dvt_amd  # noqa: F401  (registers the package alias before spawn pickles the worker)
+    port = _free_port()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, bucket_mb, out), nprocs=2, join=True)
+    res = torch.load(out)
+    net = _model()
+    x, y = _data()
+    ref = _oracle_grads(net, x, y, 1.0)                 # single process, full batch of 4
+    params = dict(net.named_parameters())
+    assert res["nb"] >= (1 if bucket_mb > 1 else 3)
+    for k, off in zip(res["names"], res["offsets"]):
+        n = params[k].numel()
+        got = res["grad"][off:off + n].view(params[k].shape)
+        assert torch.allclose(got, ref[k], rtol=1e-4, atol=1e-6), k
+        # broadcast made rank 1's (perturbed) weights equal rank 0's
+        assert torch.equal(res["data"][off:off + n].view(params[k].shape), params[k].detach())
+
+
+def test_bucket_layout_covers_every_parameter_once():
+    from dvt_amd.dp import FlatParameters
+    net = _model()
+    flat = FlatParameters(net, bucket_mb=0.02, compute_dtype=None)
+    covered = np.zeros(flat.total, dtype=np.int32)
+    for lo, hi in flat.bucket_ranges:
+        covered[lo:hi] += 1
+    assert (covered == 1).all()
+    assert sum(flat.bucket_size) == len(flat.params)
+    # parameters are views of the flat buffers
+    p0 = flat.params[0]
+    assert p0.data.data_ptr() == flat.data.data_ptr() and p0.grad.data_ptr() == flat.grad.data_ptr()
+    # buckets are formed from the END of the buffer (backward completion order)
+    assert flat.bucket_ranges[0][1] == flat.total and flat.bucket_ranges[-1][0] == 0

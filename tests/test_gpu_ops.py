@@ -158,10 +158,11 @@ def test_linear_fwd_dgrad_wgrad(dvt, device, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_epilogues(dvt, device, dtype):
+@pytest.mark.parametrize("K", [192, 1024])      # 1024: split-K with the epilogue applied in the reduce
+def test_gemm_epilogues(dvt, device, dtype, K):
     L = dvt._lib
     g = torch.Generator().manual_seed(7)
-    M, N, K = 260, 136, 192
+    M, N = 260, 136
     x_d, x = _rnd((M, K), dtype, g)
     w_d, w = _rnd((N, K), dtype, g, 1 / math.sqrt(K))
     bias = 0.5 * torch.randn(N, generator=g)
