@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
+                    "replaying one captured hipGraph per step (single-GPU only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,14 +159,27 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Single GPU: the whole step (fwd + loss + bwd + AdamW + weight cast) is captured once as a
+    # hipGraph and replayed.  Multi GPU: eager launches, so that the bucketed RCCL all-reduces
+    # stay ordinary asynchronous collectives overlapped with backward.
+    use_graph = world == 1 and not args.no_graph
+    run = step
+    if use_graph:
+        from dvt_amd.graph import capture_step
+        replay, static_loss = capture_step(step, warmup=2)
+
+        def run():
+            replay()
+            return static_loss
+
     for _ in range(args.warmup):
-        step()
+        run()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -173,7 +188,7 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
@@ -222,6 +237,7 @@ def main():
                                    "B=8/GPU, T=32, 3x224x224, patch 16, d=512, depth 4+4, heads 8, dim_head 64; "
                                    "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
+            "launch": "hipGraph replay" if use_graph else "eager",
             "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1),
             "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "final_loss": round(final_loss, 5),

@@ -479,6 +479,27 @@ int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float
 }  // extern "C"
 
 namespace {
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                 float b1, float b2, float eps, float wd,
+                                 const int64_t* __restrict__ step_dev) {
+  const float t = (float)(step_dev[0] + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+    pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+__global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
+
 template <typename S, typename D, bool FWD>
 int patchify_dispatch(const void* x, void* out, void* dx, const void* dout, int64_t frames, int C,
                       int H, int W, int P, hipStream_t st, const char* name) {
@@ -686,6 +707,19 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                      exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2));
   DVT_LAUNCH_CHECK("dvt_adamw_step");
+  return DVT_OK;
+}
+
+int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t* step_dev, dvt_stream_t stream) {
+  DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && n >= 0, "dvt_adamw_step_dev: bad arguments");
+  if (n == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev);
+  hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  DVT_LAUNCH_CHECK("dvt_adamw_step_dev");
   return DVT_OK;
 }
 

@@ -178,12 +178,17 @@ class FlatParameters:
     def adamw_step(self, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
         """torch.optim.AdamW semantics (frame_transformer.py:127-129) in one launch."""
         if self.exp_avg is None:
-            self.exp_avg = torch.zeros_like(self.data)
-            self.exp_avg_sq = torch.zeros_like(self.data)
+            self.init_optimizer_state()
         self.step_count += 1
-        ops.adamw_step_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr=lr, beta1=betas[0],
-                        beta2=betas[1], eps=eps, weight_decay=weight_decay, step=self.step_count)
+        # step counter lives on the device so the launch can be captured in a hipGraph
+        ops.adamw_step_dev_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
+                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.sync_compute_copy()
+
+    def init_optimizer_state(self) -> None:
+        self.exp_avg = torch.zeros_like(self.data)
+        self.exp_avg_sq = torch.zeros_like(self.data)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.data.device)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:

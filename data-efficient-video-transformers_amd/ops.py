@@ -433,3 +433,15 @@ def adamw_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
     L.check(L.load().dvt_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                     param.numel(), lr, beta1, beta2, eps, weight_decay, step, _stream()),
             "dvt_adamw_step")
+
+
+def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev: Tensor, *,
+                    lr: float, beta1: float, beta2: float, eps: float, weight_decay: float) -> None:
+    """AdamW with the step counter on the device (hipGraph-capturable)."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert step_dev.dtype == torch.int64 and step_dev.numel() == 1
+    L.check(L.load().dvt_adamw_step_dev(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                        exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps,
+                                        weight_decay, step_dev.data_ptr(), _stream()), "dvt_adamw_step_dev")

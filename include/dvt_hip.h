@@ -230,6 +230,12 @@ int dvt_ce_argmax_bwd(const void* student, const void* teacher, const float* glo
 int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    dvt_stream_t stream);
+/* Same update with the step counter in device memory (*step_dev is the number of steps
+ * already taken; it is incremented by the call), so that the launch can be captured in
+ * a hipGraph and replayed. */
+int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t* step_dev, dvt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -375,3 +375,12 @@ def test_adamw_matches_torch(dvt, device):
         dvt.ops.adamw_step_(pd, gr.cuda(), m, v, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.09,
                             step=step)
     assert rel_l2(pd, pr) < 1e-6
+    # device-side step counter variant (hipGraph-capturable)
+    p2, m2, v2 = p.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    sd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    g2 = torch.Generator().manual_seed(13)
+    torch.randn(1000, generator=g2)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g2)
+        dvt.ops.adamw_step_dev_(p2, gr.cuda(), m2, v2, sd, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.09)
+    assert int(sd) == 3 and rel_l2(p2, pr) < 1e-6
