@@ -57,6 +57,10 @@ SIGNATURES = {
     "dvt_device_info": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int]),
     "dvt_cast": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_p]),
     "dvt_add": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_add_rowtable": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_copy2d": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_rows_sum": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_p]),
+    "dvt_permute_021": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_axpby_f32": (c_int, [c_p, c_int, c_f, c_p, c_f, c_i64, c_p]),
     "dvt_act_fwd": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p]),
     "dvt_act_bwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_p]),
@@ -66,6 +70,8 @@ SIGNATURES = {
     "dvt_tokens_assemble_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_rows_gather_fwd": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_rows_gather_bwd": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_mean_rows_fwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_mean_rows_bwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                   c_i64, c_f, c_int, c_p]),
     "dvt_layernorm_bwd_workspace_bytes": (C.c_size_t, [c_i64]),

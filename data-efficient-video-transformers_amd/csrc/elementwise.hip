@@ -62,6 +62,58 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
   }
 }
 
+template <typename T>
+__global__ void add_rowtable_kernel(const T* __restrict__ x, const float* __restrict__ table,
+                                    T* __restrict__ out, int64_t rows, int64_t d, int64_t rpe) {
+  const int64_t dv = d >> 3;
+  const int64_t items = rows * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const int64_t c = (it % dv) << 3, r = it / dv;
+    float v[8], t[8];
+    load8<T>(x + r * d + c, v);
+    load8<float>(table + (r / rpe) * d + c, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += t[k];
+    store8<T>(out + r * d + c, v);
+  }
+}
+
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t rows, int64_t cols,
+                              int64_t src_ld, int64_t dst_ld, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t cv = cols >> 3;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += stride) {
+      const int64_t c = (it % cv) << 3, r = it / cv;
+      float v[8];
+      load8<T>(src + r * src_ld + c, v);
+      store8<T>(dst + r * dst_ld + c, v);
+    }
+  } else {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cols; it += stride) {
+      const int64_t c = it % cols, r = it / cols;
+      dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+  }
+}
+
+template <typename T>
+__global__ void permute021_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t A, int64_t B,
+                                  int64_t Cc) {
+  const int64_t cv = Cc >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < A * B * cv; it += stride) {
+    const int64_t c = (it % cv) << 3;
+    const int64_t ab = it / cv;           // destination row index (b, a)
+    const int64_t a = ab % A, b = ab / A;
+    float v[8];
+    load8<T>(src + (a * B + b) * Cc + c, v);
+    store8<T>(dst + ab * Cc + c, v);
+  }
+}
+
 template <typename S>
 __global__ void axpby_kernel(const S* __restrict__ src, float alpha, float* __restrict__ dst,
                              float beta, int64_t n) {
@@ -314,6 +366,39 @@ __global__ void rows_gather_bwd_kernel(const T* __restrict__ dout, T* __restrict
   }
 }
 
+// ------------------------------------------------------------------ mean over rows
+template <typename T, bool FWD>
+__global__ void mean_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B, int64_t Ln,
+                                 int64_t d) {
+  const int64_t dv = d >> 3;
+  const float inv = 1.0f / (float)Ln;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (FWD) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < B * dv; it += stride) {
+      const int64_t c = (it % dv) << 3, b = it / dv;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int64_t j = 0; j < Ln; ++j) {
+        float v[8];
+        load8<T>(src + (b * Ln + j) * d + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] *= inv;
+      store8<T>(dst + b * d + c, acc);
+    }
+  } else {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < B * Ln * dv; it += stride) {
+      const int64_t c = (it % dv) << 3, row = it / dv, b = row / Ln;
+      float v[8];
+      load8<T>(src + b * d + c, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= inv;
+      store8<T>(dst + row * d + c, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ losses
 template <typename T>
 __global__ void bce_fwd_kernel(const T* __restrict__ z, const float* __restrict__ y,
@@ -461,6 +546,59 @@ int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int
                      hipLaunchKernelGGL((act_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0, st,
                                         (const T*)dy, (const T*)x, (T*)dx, n, act));
   DVT_LAUNCH_CHECK("dvt_act_bwd");
+  return DVT_OK;
+}
+
+int dvt_add_rowtable(const void* x, const float* table, void* out, int64_t rows, int64_t d,
+                     int64_t rows_per_entry, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && table && out && rows >= 0 && d > 0 && rows_per_entry > 0, "dvt_add_rowtable: bad arguments");
+  DVT_REQUIRE(d % 8 == 0, "dvt_add_rowtable: d must be a multiple of 8");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(table) && dvt_aligned16(out), "dvt_add_rowtable: misaligned buffer");
+  if (rows == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((add_rowtable_kernel<T>), dim3(grid_for(rows * (d >> 3))), dim3(kBlock),
+                                        0, st, (const T*)x, table, (T*)out, rows, d, rows_per_entry));
+  DVT_LAUNCH_CHECK("dvt_add_rowtable");
+  return DVT_OK;
+}
+
+int dvt_copy2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t src_ld, int64_t dst_ld,
+               int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && rows >= 0 && cols >= 0 && src_ld >= 0 && dst_ld >= cols, "dvt_copy2d: bad arguments");
+  if (rows == 0 || cols == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = (cols % 8 == 0) && (src_ld % 8 == 0) && (dst_ld % 8 == 0) && dvt_aligned16(src) && dvt_aligned16(dst);
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((copy2d_kernel<T>), dim3(grid_for(rows * (vec ? cols >> 3 : cols))),
+                                        dim3(kBlock), 0, st, (const T*)src, (T*)dst, rows, cols, src_ld, dst_ld, vec));
+  DVT_LAUNCH_CHECK("dvt_copy2d");
+  return DVT_OK;
+}
+
+int dvt_rows_sum(const void* src, int64_t row_stride, int64_t rows, int64_t cols, float* out, int dtype,
+                 int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(src && out && rows >= 0 && cols > 0, "dvt_rows_sum: bad arguments");
+  DVT_REQUIRE(cols % 8 == 0 && row_stride % 8 == 0 && dvt_aligned16(src) && dvt_aligned16(out),
+              "dvt_rows_sum: cols / row stride must be multiples of 8 and buffers 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((strided_rows_sum_kernel<T>), dim3((unsigned)(cols >> 3)), dim3(kBlock), 0,
+                                        st, (const T*)src, row_stride, rows, out, accumulate));
+  DVT_LAUNCH_CHECK("dvt_rows_sum");
+  return DVT_OK;
+}
+
+int dvt_permute_021(const void* src, void* dst, int64_t A, int64_t B, int64_t C, int dtype,
+                    dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && A >= 0 && B >= 0 && C > 0 && C % 8 == 0, "dvt_permute_021: bad arguments (C % 8 == 0)");
+  DVT_REQUIRE(dvt_aligned16(src) && dvt_aligned16(dst), "dvt_permute_021: misaligned buffer");
+  if (A == 0 || B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((permute021_kernel<T>), dim3(grid_for(A * B * (C >> 3))), dim3(kBlock), 0,
+                                        st, (const T*)src, (T*)dst, A, B, C));
+  DVT_LAUNCH_CHECK("dvt_permute_021");
   return DVT_OK;
 }
 
@@ -644,6 +782,32 @@ int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, fl
                          (const Tt*)dout, (T + 1) * d, B, dtok, accumulate);
   });
   DVT_LAUNCH_CHECK("dvt_rows_gather_bwd");
+  return DVT_OK;
+}
+
+int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, int dtype,
+                      dvt_stream_t stream) {
+  DVT_REQUIRE(x && out && B >= 0 && L > 0 && d > 0 && d % 8 == 0, "dvt_mean_rows_fwd: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(out), "dvt_mean_rows_fwd: misaligned buffer");
+  if (B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((mean_rows_kernel<T, true>), dim3(grid_for(B * (d >> 3))), dim3(kBlock), 0,
+                                        st, (const T*)x, (T*)out, B, L, d));
+  DVT_LAUNCH_CHECK("dvt_mean_rows_fwd");
+  return DVT_OK;
+}
+
+int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, int dtype,
+                      dvt_stream_t stream) {
+  DVT_REQUIRE(dout && dx && B >= 0 && L > 0 && d > 0 && d % 8 == 0, "dvt_mean_rows_bwd: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(dout) && dvt_aligned16(dx), "dvt_mean_rows_bwd: misaligned buffer");
+  if (B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL((mean_rows_kernel<T, false>), dim3(grid_for(B * L * (d >> 3))),
+                                        dim3(kBlock), 0, st, (const T*)dout, (T*)dx, B, L, d));
+  DVT_LAUNCH_CHECK("dvt_mean_rows_bwd");
   return DVT_OK;
 }
 

@@ -385,6 +385,21 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
 # ---------------------------------------------------------------------------
 # Residual branches of the pre-norm Transformer (vit.py:30-75)
 # ---------------------------------------------------------------------------
+def _split_qkv(qkv: Tensor, S: int, N: int, heads: int, dh: int, seq_first: bool):
+    """Packed [rows, 3*h*dh] -> three [S(batch), H, N(seq), dh] strided views (no copies).
+    Rows are (s n) for batch-first input and (n s) for seq-first input."""
+    if seq_first:
+        q5 = qkv.view(N, S, 3, heads, dh)
+        return tuple(q5[:, :, i].permute(1, 2, 0, 3) for i in range(3))
+    q5 = qkv.view(S, N, 3, heads, dh)
+    return tuple(q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+
+
+def _heads_view(o_mem: Tensor, seq_first: bool) -> Tensor:
+    """[S,N,H,dh] (or [N,S,H,dh] seq-first) memory -> [S, H, N, dh] view."""
+    return o_mem.permute(1, 2, 0, 3) if seq_first else o_mem.permute(0, 2, 1, 3)
+
+
 class _AttnBlock(torch.autograd.Function):
     """y = [x +] to_out(attention(to_qkv([LN](x))))   -- ``PreNorm(Attention)`` + residual.
 
@@ -394,10 +409,15 @@ class _AttnBlock(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps):
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv=None,
+                seq_first=False):
+        # seq_first: x is [L, B, E] (torch nn.MultiheadAttention layout, frame_transformer.py:204-207)
         shp = x.shape
         d = shp[-1]
-        S, N = (shp[0], shp[1]) if x.dim() == 3 else (1, shp[0])
+        if seq_first:
+            N, S = shp[0], shp[1]          # N = sequence length, S = batch
+        else:
+            S, N = (shp[0], shp[1]) if x.dim() == 3 else (1, shp[0])
         x2 = x.reshape(-1, d)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -412,11 +432,10 @@ class _AttnBlock(torch.autograd.Function):
         wq = _wc(w_qkv, T)
         inner = wq.shape[0] // 3
         dh = inner // heads
-        qkv = ops.linear_fwd(xn, wq)                                   # [M, 3*inner]
-        qkv5 = qkv.view(S, N, 3, heads, dh)
-        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # [S,H,N,dh] views
-        o_mem = torch.empty((S, N, heads, dh), dtype=T, device=x.device)
-        lse = ops.attention_fwd(q, k, v, o_mem.permute(0, 2, 1, 3), dh ** -0.5)
+        qkv = ops.linear_fwd(xn, wq, _f32(b_qkv))                      # [M, 3*inner]
+        q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)          # [S,H,N,dh] views
+        o_mem = torch.empty((N, S, heads, dh) if seq_first else (S, N, heads, dh), dtype=T, device=x.device)
+        lse = ops.attention_fwd(q, k, v, _heads_view(o_mem, seq_first), dh ** -0.5)
         o2 = o_mem.view(M, inner)
         if w_out is not None:
             wo = _wc(w_out, T)
@@ -428,15 +447,16 @@ class _AttnBlock(torch.autograd.Function):
             wo = None
             y = ops.add(o2, x2) if residual else o2
         ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, wq, wo, qkv, o_mem, lse)
-        ctx.cfg = (S, N, heads, dh, inner, prenorm, residual, w_out is not None, b_out is not None)
+        ctx.cfg = (S, N, heads, dh, inner, prenorm, residual, w_out is not None, b_out is not None,
+                   b_qkv is not None, seq_first)
         ctx.xshape = shp
-        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
+        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out, b_qkv))
         return y.view(*shp[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, dy):
         x2, g, mean, rstd, xn, wq, wo, qkv, o_mem, lse = ctx.saved_tensors
-        S, N, heads, dh, inner, prenorm, residual, has_out, has_bias = ctx.cfg
+        S, N, heads, dh, inner, prenorm, residual, has_out, has_bias, has_qkv_bias, seq_first = ctx.cfg
         M = x2.shape[0]
         T = x2.dtype
         if xn is None:
@@ -450,14 +470,13 @@ class _AttnBlock(torch.autograd.Function):
                 dbo = _emit_colsum(ctx.sinks[4], dy2)
         else:
             do2 = dy2
-        qkv5 = qkv.view(S, N, 3, heads, dh)
-        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)
         dqkv = torch.empty_like(qkv)
-        d5 = dqkv.view(S, N, 3, heads, dh)
-        dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        ops.attention_bwd(q, k, v, o_mem.permute(0, 2, 1, 3), lse,
-                          do2.view(S, N, heads, dh).permute(0, 2, 1, 3), dq, dk, dv, dh ** -0.5)
+        dq, dk, dv = _split_qkv(dqkv, S, N, heads, dh, seq_first)
+        ops.attention_bwd(q, k, v, _heads_view(o_mem, seq_first), lse,
+                          _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5)
         dwq = _emit_wgrad(ctx.sinks[2], dqkv, xn)
+        dbq = _emit_colsum(ctx.sinks[5], dqkv) if has_qkv_bias else None
         dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
         dg = db = None
         if prenorm:
@@ -465,11 +484,12 @@ class _AttnBlock(torch.autograd.Function):
                                  dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
-        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None
+        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None, dbq, None
 
 
-def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, residual=True, eps=1e-5):
-    return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps)
+def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, residual=True, eps=1e-5,
+               b_qkv=None, seq_first=False):
+    return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first)
 
 
 class _MlpBlock(torch.autograd.Function):
@@ -578,3 +598,143 @@ class _CeArgmax(torch.autograd.Function):
 def cross_entropy_argmax(student: Tensor, teacher: Tensor) -> Tensor:
     """CrossEntropyLoss(student, argmax(teacher, -1)) -- the hard-label distillation term."""
     return _CeArgmax.apply(student, teacher)
+
+
+# ---------------------------------------------------------------------------
+# Sinusoidal positional encoding add and row concatenation (frame_transformer.py:19-34,
+# transformer.py:74-82)
+# ---------------------------------------------------------------------------
+class _AddRowTable(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, rows_per_entry):
+        return ops.add_rowtable(x.contiguous(), _f32(table).contiguous(), rows_per_entry)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+def add_positional_table(x: Tensor, pe: Tensor) -> Tensor:
+    """x [L, B, E] seq-first; pe [max_len, 1, E] buffer: x + pe[:L] (broadcast over B)."""
+    Ln, B = x.shape[0], x.shape[1]
+    if pe.shape[0] < Ln:
+        raise ValueError(f"positional table has {pe.shape[0]} rows but the sequence has {Ln} "
+                         "(frame_transformer.py:92-93: max_len must cover the sequence)")
+    return _AddRowTable.apply(x, pe[:Ln].reshape(Ln, -1), B)
+
+
+class _ConcatRows(torch.autograd.Function):
+    """cat((a, b), dim=0) for contiguous tensors sharing trailing dims (device copies only)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=b.dtype, device=b.device)
+        ops.copy_(out[: a.shape[0]], a)
+        ops.copy_(out[a.shape[0]:], b)
+        ctx.na, ctx.adt = a.shape[0], a.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = torch.empty(dy[: ctx.na].shape, dtype=ctx.adt, device=dy.device)
+        ops.copy_(da, dy[: ctx.na])
+        db = torch.empty_like(dy[ctx.na:])
+        ops.copy_(db, dy[ctx.na:])
+        return da, db
+
+
+def concat_rows(a: Tensor, b: Tensor) -> Tensor:
+    return _ConcatRows.apply(a, b)
+
+
+class _MeanRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.L = x.shape[1]
+        return ops.mean_rows_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mean_rows_bwd(dy, ctx.L)
+
+
+def mean_rows(x: Tensor) -> Tensor:
+    """x [B, L, d] -> mean over L (``x.mean(dim=1)``, vit.py:126)."""
+    return _MeanRows.apply(x)
+
+
+class _Permute021(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.permute_021(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.permute_021(dy)
+
+
+def to_seq_first(x: Tensor) -> Tensor:
+    """'b s d -> s b d' (frame_transformer.py:205); also its own inverse."""
+    return _Permute021.apply(x)
+
+
+class _SelectRow(torch.autograd.Function):
+    """seq [S, B, E] -> seq[i]  ([B, E]); the gradient is zero elsewhere."""
+
+    @staticmethod
+    def forward(ctx, seq, i):
+        seq = seq.contiguous()
+        ctx.shape, ctx.i = tuple(seq.shape), i
+        out = torch.empty(seq.shape[1:], dtype=seq.dtype, device=seq.device)
+        ops.copy_(out, seq[i])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        ops.copy_(dx[ctx.i], dy.contiguous())
+        return dx, None
+
+
+def select_seq_first_row(seq: Tensor, i: int) -> Tensor:
+    return _SelectRow.apply(seq, i)
+
+
+class _ClsConcat(torch.autograd.Function):
+    """Per-sample cat((cls, data[b]), dim=0): data [B, S, X], cls [X] (learnable, broadcast)
+    -> [B, S+1, X]  (frame_transformer.py:194-197, 213-217)."""
+
+    @staticmethod
+    def forward(ctx, data, cls):
+        data = data.contiguous()
+        B, S, X = data.shape
+        c = _as(cls.detach().reshape(-1).contiguous(), data.dtype)
+        out = torch.empty((B, S + 1, X), dtype=data.dtype, device=data.device)
+        ops.copy2d(c, out, B, X, 0, (S + 1) * X)                       # broadcast row 0 of every sample
+        ops.copy2d(data, out[:, 1:], B, S * X, S * X, (S + 1) * X)
+        ctx.dims = (B, S, X)
+        ctx.cls_shape, ctx.data_grad = tuple(cls.shape), data.requires_grad
+        ctx.sink = _sink(cls)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, X = ctx.dims
+        dout = dout.contiguous()
+        ddata = None
+        if ctx.needs_input_grad[0]:
+            ddata = torch.empty((B, S, X), dtype=dout.dtype, device=dout.device)
+            ops.copy2d(dout[:, 1:], ddata, B, S * X, (S + 1) * X, S * X)
+        sk = ctx.sink
+        if sk is not None:
+            ops.rows_sum(dout, (S + 1) * X, B, X, out=sk.buf.view(-1), accumulate=not sk.fresh)
+            sk.mark_written()
+            return ddata, None
+        dcls = ops.rows_sum(dout, (S + 1) * X, B, X).view(ctx.cls_shape)
+        return ddata, dcls
+
+
+def cls_concat(data: Tensor, cls: Tensor) -> Tensor:
+    return _ClsConcat.apply(data, cls)

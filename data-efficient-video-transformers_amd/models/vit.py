@@ -190,9 +190,7 @@ class ViViT(nn.Module):
         sn = self.space_transformer.norm
         seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)  # :119-123
         z = self.temporal_transformer(seq)                                          # :125
-        if self.pool == 'mean':
-            raise NotImplementedError("pool='mean' (vit.py:126) has no HIP kernel yet; use pool='cls'")
-        pooled = F.select_first_row(z)                                              # :126
+        pooled = F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)  # :126
         hn, hl = self.mlp_head[0], self.mlp_head[1]
         h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)
         return F.linear(h, hl.weight, hl.bias, out_f32=True)                        # :128

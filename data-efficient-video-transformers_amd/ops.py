@@ -86,6 +86,56 @@ def add(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
+def add_rowtable(x: Tensor, table: Tensor, rows_per_entry: int) -> Tensor:
+    """out[r] = x[r] + table[r // rows_per_entry]; x [rows, d], table [rows/rows_per_entry, d] f32."""
+    _need_cuda(x, table)
+    assert x.is_contiguous() and table.is_contiguous() and table.dtype == torch.float32
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert table.shape[-1] == d and table.numel() // d * rows_per_entry >= rows
+    out = torch.empty_like(x)
+    L.check(L.load().dvt_add_rowtable(x.data_ptr(), table.data_ptr(), out.data_ptr(), rows, d, rows_per_entry,
+                                      dt(x), _stream()), "dvt_add_rowtable")
+    return out
+
+
+def copy_(dst: Tensor, src: Tensor) -> Tensor:
+    """Contiguous device copy (optionally converting dtype) through dvt_cast."""
+    _need_cuda(dst, src)
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    L.check(L.load().dvt_cast(src.data_ptr(), dt(src), dst.data_ptr(), dt(dst), src.numel(), _stream()), "dvt_cast")
+    return dst
+
+
+def copy2d(src: Tensor, dst: Tensor, rows: int, cols: int, src_ld: int, dst_ld: int) -> None:
+    """dst[r*dst_ld + c] = src[r*src_ld + c] on the raw storages starting at the tensors' data pointers."""
+    _need_cuda(src, dst)
+    assert src.dtype == dst.dtype
+    L.check(L.load().dvt_copy2d(src.data_ptr(), dst.data_ptr(), rows, cols, src_ld, dst_ld, dt(src), _stream()),
+            "dvt_copy2d")
+
+
+def rows_sum(src: Tensor, row_stride: int, rows: int, cols: int, *, out: Optional[Tensor] = None,
+             accumulate: bool = False) -> Tensor:
+    _need_cuda(src)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((cols,), dtype=torch.float32, device=src.device)
+    L.check(L.load().dvt_rows_sum(src.data_ptr(), row_stride, rows, cols, out.data_ptr(), dt(src), int(accumulate),
+                                  _stream()), "dvt_rows_sum")
+    return out
+
+
+def permute_021(x: Tensor) -> Tensor:
+    """[A, B, C] -> [B, A, C] (contiguous)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    A, B, Cc = x.shape
+    out = torch.empty((B, A, Cc), dtype=x.dtype, device=x.device)
+    L.check(L.load().dvt_permute_021(x.data_ptr(), out.data_ptr(), A, B, Cc, dt(x), _stream()), "dvt_permute_021")
+    return out
+
+
 def axpby_f32_(dst: Tensor, src: Tensor, alpha: float = 1.0, beta: float = 1.0) -> Tensor:
     """dst(f32) = beta*dst + alpha*src."""
     _need_cuda(dst, src)
@@ -197,6 +247,26 @@ def rows_gather_bwd(dout: Tensor, dsrc: Tensor, row_stride: int, want_tok: bool,
     L.check(L.load().dvt_rows_gather_bwd(dout.data_ptr(), dsrc.data_ptr(), row_stride, _p(dtok), B, T, d, dt(dout),
                                          int(accumulate), _stream()), "dvt_rows_gather_bwd")
     return dtok
+
+
+def mean_rows_fwd(x: Tensor) -> Tensor:
+    """[B, L, d] -> [B, d] mean over L."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, Ln, d = x.shape
+    out = torch.empty((B, d), dtype=x.dtype, device=x.device)
+    L.check(L.load().dvt_mean_rows_fwd(x.data_ptr(), out.data_ptr(), B, Ln, d, dt(x), _stream()), "dvt_mean_rows_fwd")
+    return out
+
+
+def mean_rows_bwd(dout: Tensor, Ln: int) -> Tensor:
+    _need_cuda(dout)
+    dout = dout.contiguous()
+    B, d = dout.shape
+    dx = torch.empty((B, Ln, d), dtype=dout.dtype, device=dout.device)
+    L.check(L.load().dvt_mean_rows_bwd(dout.data_ptr(), dx.data_ptr(), B, Ln, d, dt(dout), _stream()),
+            "dvt_mean_rows_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------ LayerNorm

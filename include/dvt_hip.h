@@ -58,6 +58,22 @@ int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 /* out = a + b (residual adds `attn(x) + x`, `ff(x) + x`: src/models/vit.py:73-74
  * when the producing GEMM is not the one fusing it). */
 int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_stream_t stream);
+/* out[r, :] = x[r, :] + table[r / rows_per_entry, :]  -- sinusoidal PositionalEncoding on
+ * seq-first [L, B, E] activations: `x + self.pe[:x.size(0)]`, frame_transformer.py:32-34
+ * (rows_per_entry = B).  table: [rows / rows_per_entry, d] f32. */
+int dvt_add_rowtable(const void* x, const float* table, void* out, int64_t rows, int64_t d,
+                     int64_t rows_per_entry, int dtype, dvt_stream_t stream);
+/* Strided 2-D copy: dst[r*dst_ld + c] = src[r*src_ld + c], r < rows, c < cols (elements).
+ * src_ld == 0 broadcasts one row.  Used for the per-sample CLS-clip concatenation
+ * (frame_transformer.py:194-197) and sequence slices. */
+int dvt_copy2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t src_ld, int64_t dst_ld,
+               int dtype, dvt_stream_t stream);
+/* out[c] (+)= sum_{r<rows} src[r*row_stride + c]   (f32 out; gradient of a broadcast). */
+int dvt_rows_sum(const void* src, int64_t row_stride, int64_t rows, int64_t cols, float* out,
+                 int dtype, int accumulate, dvt_stream_t stream);
+/* [A, B, C] -> [B, A, C]   ('b s d -> s b d', frame_transformer.py:205; transformer.py:76). */
+int dvt_permute_021(const void* src, void* dst, int64_t A, int64_t B, int64_t C, int dtype,
+                    dvt_stream_t stream);
 /* dst(f32)[i] = beta * dst[i] + alpha * src[i]  (gradient accumulation). */
 int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float beta, int64_t n,
                   dvt_stream_t stream);
@@ -106,6 +122,14 @@ int dvt_rows_gather_fwd(const void* src, int64_t src_row_stride, const float* to
 int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, float* dtok,
                         int64_t B, int64_t T, int64_t d, int dtype, int accumulate,
                         dvt_stream_t stream);
+
+/* Mean over the middle dimension: out[b, :] = (1/L) sum_j x[b, j, :]  (`x.mean(dim=1)`,
+ * pool == 'mean', src/models/vit.py:126; global average pooling of frame features).
+ * bwd: dx[b, j, :] = dout[b, :] / L. */
+int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, int dtype,
+                      dvt_stream_t stream);
+int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, int dtype,
+                      dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- LayerNorm
  * nn.LayerNorm(d), eps 1e-5, affine: src/models/vit.py:11,64,105;

@@ -1,0 +1,184 @@
+"""Parity of the FrameTransformer / PTN token paths (SURVEY section 8 rows a8, a9, a10 and
+a15/a16 token parts, a17-a19) on the GPU against the golden vectors and the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_path as O
+from tests.util import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_transformer_base_matches_torch_encoder_golden(device, dtype, tol):
+    """TransformerBase == nn.TransformerEncoder (post-norm, ReLU, seq-first, eval)."""
+    from dvt_amd.models.frame_transformer import TransformerBase
+    g = golden("encoder_postnorm.npz")
+    net = TransformerBase(64, 64, int(g["nhead"]), 96, 2, 0.5)
+    net.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w:")})
+    net = net.cuda().eval()
+    x = T(g["x"]).to(dtype).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_l2(y, T(g["y"])) < tol
+    y.backward(T(g["gy"]).to(dtype).cuda())
+    assert rel_l2(x.grad, T(g["gx"])) < 2 * tol
+
+
+def test_positional_encoding_matches_reference(device):
+    from dvt_amd.models.frame_transformer import PositionalEncoding
+    g = golden("posenc.npz")
+    for d, L in ((896, 14), (2048, 14), (64, 9)):
+        pe = PositionalEncoding(d, 0.5, max_len=L).cuda().eval()
+        assert torch.allclose(pe.pe.cpu(), T(g[f"pe_{d}_{L}"]), atol=1e-6)   # host libm may differ in the last ulp
+        out = pe(torch.ones(L, 2, d, device="cuda"))
+        assert torch.allclose(out.cpu(), T(g[f"fwd_{d}_{L}"]), atol=1e-6)
+    with pytest.raises(ValueError, match="positional table"):
+        pe(torch.ones(L + 1, 2, d, device="cuda"))
+    pe.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        pe(torch.ones(L, 2, d, device="cuda"))
+
+
+def _oracle_encoder(x, P, prefix, patch):
+    """Oracle counterpart of PatchLinearEncoder: patchify -> Linear -> mean -> Linear."""
+    if x.dim() == 5:
+        n, c, t, h, w = x.shape
+        x = x.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w)
+    else:
+        n = x.shape[0]
+    pt = O.patchify(x[None], patch)[0]                       # [frames, np, pd]
+    e = O.linear(pt, P[prefix + "embed.weight"], P[prefix + "embed.bias"])
+    e = e.reshape(n, -1, e.shape[-1]).mean(dim=1)
+    return O.linear(e, P[prefix + "fc.weight"], P[prefix + "fc.bias"])
+
+
+def _make_ft(mode, dtype):
+    from dvt_amd.models.frame_transformer import FrameTransformer, PatchLinearEncoder
+    torch.manual_seed(1130)
+    d = 64
+    cfg = dict(batch_size=2, seq_len=4, cls=1, model=mode, opt="adamW", learning_rate=5e-6, weight_decay=0.09,
+               momentum=0.005, d_model=d, tokens=5, frame_len=2, clip_size=16, img_size=32, vid_nhead=2,
+               vid_nhid=96, scene_nhead=2, scene_nhid=96, compute_dtype=dtype,
+               vid_encoder=PatchLinearEncoder(3, 8, 32, d, dtype), img_encoder=PatchLinearEncoder(3, 8, 32, d, dtype))
+    net = FrameTransformer(**cfg)
+    # the reference's 3-layer head has 512/128 hidden units (frame_transformer.py:106)
+    return net.cuda().eval()
+
+
+def _oracle_ft_vid(net, vid):
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()
+         if v.dtype.is_floating_point}
+    B = vid.shape[0]
+    cls = P["vid_cls"]                                                       # [1, T, 3, H, W]
+    data = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)   # [B, 5, T, 3, H, W]
+    data = data.reshape(-1, *data.shape[2:]).permute(0, 2, 1, 3, 4)
+    emb = _oracle_encoder(data, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    seq = emb + P["position_encoder.pe"][:5]
+    seq = O.transformer_base(seq, P, "distil_transformer.", 4, 2)
+    return O.mlp_head3(seq[0], P), P
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_frame_transformer_vid_mode_fwd_bwd(device, dtype, tol):
+    net = _make_ft("vid", dtype)
+    g = torch.Generator().manual_seed(3)
+    vid = torch.randn(2, 4, 2, 3, 16, 16, generator=g)
+    img = torch.randn(2, 4, 3, 32, 32, generator=g)
+    target = (torch.rand(2, 19, generator=g) < 0.3).float()
+    ref_logits, P = _oracle_ft_vid(net, vid)
+    ref_loss = O.bce_with_logits(ref_logits, target)
+    ref_loss.backward()
+    loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (1e-5 if dtype == torch.float32 else 5e-3)
+    for k in ("vid_cls", "img_mlp_head.0.weight", "img_mlp_head.4.bias", "vid_model.embed.weight",
+              "distil_transformer.transformer.layers.0.self_attn.in_proj_weight",
+              "distil_transformer.transformer.layers.3.linear2.weight",
+              "distil_transformer.transformer.layers.1.norm1.weight"):
+        got = dict(net.named_parameters())[k].grad
+        assert rel_l2(got, P[k].grad) < 3 * tol, k
+    # the reference's surface
+    assert net.hparams.seq_len == 5 and isinstance(net.running_logits, list)
+    net.validation_step((target.cuda(), img.cuda(), vid.cuda()), 0)
+    assert len(net.running_logits) == 1 and net.running_logits[0].shape == (2, 19)
+
+
+@pytest.mark.parametrize("mode", ["sum", "distil", "frame"])
+def test_frame_transformer_cross_modal_modes(device, mode):
+    """Cross-modal injection: the video CLS embedding is appended to the image tokens and
+    they self-attend jointly (frame_transformer.py:225-226), fp32 mode vs the oracle."""
+    net = _make_ft(mode, torch.float32)
+    g = torch.Generator().manual_seed(4)
+    vid = torch.randn(2, 4, 2, 3, 16, 16, generator=g)
+    img = torch.randn(2, 4, 3, 32, 32, generator=g)
+    P = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    B = 2
+    icls = P["img_cls"]
+    idata = torch.cat((icls.unsqueeze(0).expand(B, *icls.shape), img), dim=1).reshape(-1, 3, 32, 32)
+    iemb = _oracle_encoder(idata, P, "img_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    with torch.no_grad():
+        vlog, Pv = _oracle_ft_vid(net, vid)
+    if mode == "frame":
+        seq = O.transformer_base(iemb + P["position_encoder.pe"][:5], P, "scene_transformer.", 4, 2)
+        ref = O.mlp_head3(seq[0], P)
+        out = net(img.cuda(), None)
+        assert rel_l2(out, ref) < 2e-4
+        return
+    # video CLS embedding (before the head)
+    cls = P["vid_cls"]
+    vdata = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)
+    vdata = vdata.reshape(-1, *vdata.shape[2:]).permute(0, 2, 1, 3, 4)
+    vemb = _oracle_encoder(vdata, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    vseq = O.transformer_base(vemb + P["position_encoder.pe"][:5], P, "distil_transformer.", 4, 2)
+    joint = torch.cat((iemb, vseq[0].unsqueeze(0)), dim=0)                  # 6 tokens
+    seq = O.transformer_base(joint + P["position_encoder.pe"][:6], P, "scene_transformer.", 4, 2)
+    img_cls, vid_tkn = seq[0], seq[-1]
+    if mode == "sum":
+        ref = O.mlp_head3(img_cls + vid_tkn, P)
+        out = net(img.cuda(), vid.cuda())
+        assert rel_l2(out, ref) < 2e-4
+    else:
+        s, t = net(img.cuda(), vid.cuda())
+        assert rel_l2(s, O.mlp_head3(img_cls, P)) < 2e-4 and rel_l2(t, O.mlp_head3(vid_tkn, P)) < 2e-4
+        target = (torch.rand(2, 19, generator=g) < 0.3).float()
+        loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
+        ref_loss = O.bce_with_logits(O.mlp_head3(img_cls, P), target) + \
+            O.cross_entropy_hard(O.mlp_head3(img_cls, P), O.mlp_head3(vid_tkn, P))
+        assert abs(float(loss.detach()) - float(ref_loss)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_simple_transformer_ptn(device, dtype, tol):
+    from dvt_amd.models.transformer import SimpleTransformer
+    torch.manual_seed(7)
+    net = SimpleTransformer(batch_size=3, seq_len=4, cls=1, dropout=0.5, input_dimension=64, nhead=2, nhid=96,
+                            nlayers=2, model="ptn", learning_rate=1e-3, momentum=0.9, weight_decay=0.0,
+                            compute_dtype=dtype).cuda().eval()
+    g = torch.Generator().manual_seed(8)
+    data = torch.randn(3, 4, 3, 64, generator=g)                           # [B, S, E=3 experts, D]
+    label = (torch.rand(3, 15, generator=g) < 0.3).float()
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()
+         if v.dtype.is_floating_point}
+    total = 0
+    for i in range(3):
+        seq = torch.cat((P["cls"], data[:, :, i].permute(1, 0, 2)), dim=0) + P["position_encoder.pe"][:5]
+        seq = O.layernorm(seq, P["norm.weight"], P["norm.bias"])
+        if i < 2:
+            seq = O.transformer_base(seq, {k.replace(f"transformer_encoder{i}.", "transformer."): v
+                                           for k, v in P.items()}, "", 2, 2)
+        total = total + seq[0]
+    ref = O.linear(O.layernorm(total, P["mlp_head.0.weight"], P["mlp_head.0.bias"]), P["mlp_head.1.weight"],
+                   P["mlp_head.1.bias"])
+    ref_loss = O.bce_with_logits(ref, label)
+    ref_loss.backward()
+    loss = net.training_step({"experts": data.cuda(), "label": label.cuda()}, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (1e-5 if dtype == torch.float32 else 5e-3)
+    for k in ("cls", "norm.weight", "transformer_encoder0.layers.1.linear1.weight",
+              "transformer_encoder1.layers.0.self_attn.in_proj_bias", "mlp_head.1.weight"):
+        assert rel_l2(dict(net.named_parameters())[k].grad, P[k].grad) < 3 * tol, k
