@@ -211,13 +211,23 @@ def main():
         names = {(1, 1): "gemm_mfma_kernel<k-major,k-major> (forward Linear)",
                  (1, 0): "gemm_mfma_kernel<k-major,mn-major> (dgrad)",
                  (0, 0): "gemm_mfma_kernel<mn-major,mn-major> (wgrad, split-K incl. reduce)"}
+        pmc = {}
+        try:   # per-launch HBM bytes of each family from the committed PMC profile (rocprofv3 --pmc)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)["families"]
+        except Exception:
+            pmc = {}
+        pmc_key = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}
         if fam:
             dom = max(fam, key=lambda k: fam[k][0])
             ms, fl, cnt = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(ach, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
+                    "traffic": (pmc.get(pmc_key.get(dom, ""), {}) or {}).get("hbm_bytes_corrected"),
+                    "traffic_note": "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/r01_pmc_traffic.json; "
+                                    "FETCH_SIZE includes Infinity-Cache hits (upper bound of HBM reads)",
+                    "algorithmic_bytes_per_launch": None, "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
                     "families": {names.get(k, str(k)): {"ms_per_step": round(v[0] / nprof, 3),
                                                         "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                  for k, v in fam.items()}}
