@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("aux", c_p), ("ldaux", c_i64),
         ("alpha", c_f), ("split_k", C.c_int32),
         ("workspace", c_p),
+        ("colsum_out", c_p), ("colsum_accumulate", C.c_int32),
     ]
 
 

@@ -222,10 +222,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
 // C (+)= sum_z slab[z]   (fixed order => reproducible)
 template <typename OutT>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
-                                     OutT* __restrict__ C, int64_t ldc, int accumulate) {
+                                     OutT* __restrict__ C, int64_t ldc, int accumulate,
+                                     const float* __restrict__ cs_slab, float* __restrict__ cs_out,
+                                     int cs_accumulate) {
   const int64_t nvec = (int64_t)M * N / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t MN = (int64_t)M * N;
+  if (cs_slab) {   // fused bias gradient: cs_out[m] (+)= sum_z cs_slab[z][m]
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+      float t = 0.f;
+      for (int z = 0; z < splits; ++z) t += cs_slab[(int64_t)z * M + m];
+      cs_out[m] = cs_accumulate ? cs_out[m] + t : t;
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int64_t e = i * 8;
     const int m = (int)(e / N), n = (int)(e % N);
@@ -558,10 +567,21 @@ int check_desc(const dvt_gemm_desc* d) {
 
 extern "C" {
 
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace = [split-K slabs][bias-gradient slabs or stand-alone colsum scratch]
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
-  if (!d || !mfma_eligible(d) || d->K <= 0) return 0;
+  if (!d) return 0;
+  size_t cs = 0;
+  if (d->colsum_out) {
+    const size_t fused = (size_t)64 * (size_t)d->M * sizeof(float);            // <= 64 K slices
+    const size_t alone = dvt_colsum_workspace_bytes(d->K, d->M);
+    cs = fused > alone ? fused : alone;
+  }
+  if (!mfma_eligible(d) || d->K <= 0) return cs;
   const GemmPlan pl = plan_gemm(d);
-  return pl.split > 1 ? (size_t)pl.split * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
+  const size_t slab = pl.split > 1 ? (size_t)pl.split * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
+  return align256(slab) + cs;
 }
 
 int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
@@ -569,6 +589,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   if (rc) return rc;
   if (d->M == 0 || d->N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
+  DVT_REQUIRE(!d->colsum_out || (!d->a_kmajor && d->workspace), "dvt_gemm: colsum_out needs an mn-major A and a workspace");
 
   if (mfma_eligible(d) && d->K > 0) {
     GemmPlan pl = plan_gemm(d);
@@ -588,6 +609,16 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     p.k_per_split = pl.kps;
     p.slab = split > 1 ? (float*)d->workspace : nullptr;
     p.tiles_n = 0;
+    // bias gradient fused into the LDS-DMA weight-gradient kernel (split-K slab path, cfg 0)
+    const size_t slab_bytes = split > 1 ? align256((size_t)split * (size_t)d->M * (size_t)d->N * sizeof(float)) : 0;
+    float* cs_scratch = d->colsum_out ? (float*)((char*)d->workspace + slab_bytes) : nullptr;
+    const bool cs_fused = d->colsum_out && pl.use256 && pl.cfg == 0 && split > 1 && !d->a_kmajor && !d->b_kmajor &&
+                          d->epilogue == DVT_EPI_NONE && p.out_f32;
+    p.colsum_slab = cs_fused ? cs_scratch : nullptr;
+    if (d->colsum_out && !cs_fused) {   // same semantics through the stand-alone reduction
+      rc = dvt_colsum(d->A, d->lda, d->colsum_out, cs_scratch, d->K, d->M, d->in_dtype, d->colsum_accumulate, stream);
+      if (rc) return rc;
+    }
     if (pl.use256) {
       rc = dvt_gemm_dma_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, split, pl.cfg, st);
       if (rc < 0) return rc;
@@ -626,15 +657,21 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
                            (const float*)p.slab, split, p);
       else if (p.out_f32)
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate);
+                           (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate,
+                           (const float*)p.colsum_slab, d->colsum_out, d->colsum_accumulate);
       else
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float*)p.slab, split, p.M, p.N, (bf16*)d->C, d->ldc, 0);
+                           (const float*)p.slab, split, p.M, p.N, (bf16*)d->C, d->ldc, 0,
+                           (const float*)nullptr, (float*)nullptr, 0);
       DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce)");
     }
     return DVT_OK;
   }
 
+  if (d->colsum_out) {
+    rc = dvt_colsum(d->A, d->lda, d->colsum_out, d->workspace, d->K, d->M, d->in_dtype, d->colsum_accumulate, stream);
+    if (rc) return rc;
+  }
   GenericParams g;
   g.A = d->A; g.B = d->B; g.C = d->C;
   g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;

@@ -141,18 +141,24 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   const int wm = wid / WN, wn = wid % WN;      // every wave owns 128 x 64
   const int g = lane >> 4, li = lane & 15;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give
-  // each XCD a contiguous run of tiles so that consecutive n-tiles of one A row-panel
-  // hit the same L2.  Bijective for any tile count.
+  // XCD-aware order over the combined (K-slice, tile) space.  Blocks b and b+8 share an XCD
+  // (round-robin dispatch); each XCD gets one contiguous run of the linear index
+  // id = slice * ntiles + tile, bijective for any count.  Forward/dgrad (one slice):
+  // consecutive n-tiles of an A row-panel hit the same L2.  Split-K weight gradients: an XCD
+  // owns whole K-slices, so every byte of dY and x is fetched by exactly one XCD (PMC: the
+  // per-plane remap re-read the x slice once per XCD, 2.3x the algorithmic bytes).
   const int ntiles = gridDim.x;
-  int tile;
+  int tile, zsl;
   {
-    const int b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int total = ntiles * gridDim.z;
+    const int b = blockIdx.z * ntiles + blockIdx.x, xcd = b & 7, q = total >> 3, r = total & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    zsl = id / ntiles;
+    tile = id - zsl * ntiles;
   }
   const int m0 = (tile / p.tiles_n) * TM;
   const int n0 = (tile % p.tiles_n) * TN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = zsl * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (DVT_ABL == 5 || DVT_ABL == 6) ? 0 : (kend - kbeg) / TK;   // ablations 5/6: epilogue only
 
@@ -161,6 +167,15 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fused bias gradient (weight-gradient launches only): each wave of the n-tile-0 workgroups
+  // also accumulates sum_k A(m,k) for two of its eight m sub-tiles (wave wn takes t = 2wn, 2wn+1)
+  constexpr bool kCanColsum = !A_KMAJOR && OUT == OUT_SLAB && WN == 4;
+  const bool do_cs = kCanColsum && p.colsum_slab != nullptr && n0 == 0;
+  f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
 
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
@@ -203,11 +218,24 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[u], af[t], acc[u][th * 4 + t], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (kCanColsum && do_cs) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          csum[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              ones, frag<A_KMAJOR, TM, TK>(sa, wm * 128 + (2 * wn + tt) * 16, kk, g, li), csum[tt], 0, 0, 0);
+      }
     }
     st_cur = st_cur + 1 == NSTG ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == NSTG ? 0 : st_nxt + 1;
   }
   __builtin_amdgcn_s_barrier();                // all LDS reads done before the staging overlay
+  if (kCanColsum && do_cs && g == 0) {         // every row of the ones-product is the column sum: take row 0
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int m = m0 + wm * 128 + (2 * wn + tt) * 16 + li;
+      if (m < p.M) p.colsum_slab[(int64_t)zsl * p.M + m] = csum[tt][0];
+    }
+  }
 
   // ---- epilogue: per-wave staging region, 4 passes of 32 rows x 64 cols.
   // vmcnt counts loads and stores together in issue order, so a load issued after a
@@ -263,7 +291,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       const int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
       if (m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
         if (OUT == OUT_SLAB) {
-          store8<float>(p.slab + ((int64_t)blockIdx.z * p.M + m) * p.N + n, v[j]);
+          store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);
         } else if (OUT == OUT_F32) {
           float* o = (float*)p.C + (int64_t)m * p.ldc + n;
 #pragma unroll

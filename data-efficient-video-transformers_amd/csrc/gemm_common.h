@@ -18,6 +18,7 @@ struct GemmParams {
   int k_per_split;  // multiple of BK; == K rounded up when not splitting
   float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
   int tiles_n;
+  float* colsum_slab;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };
 
 __device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }

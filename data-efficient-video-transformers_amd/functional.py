@@ -54,6 +54,27 @@ def _emit_wgrad(sink, dy2: Tensor, x2: Tensor):
     return None
 
 
+def _emit_wgrad_bias(sink_w, sink_b, dy2: Tensor, x2: Tensor, has_bias: bool):
+    """(dW, db) from ONE pass over dy: the bias gradient rides on the weight-gradient GEMM."""
+    if not has_bias:
+        return _emit_wgrad(sink_w, dy2, x2), None
+    N, K = dy2.shape[1], x2.shape[1]
+    w_out = sink_w.buf.view(N, K) if sink_w is not None else None
+    if sink_b is not None:
+        b_out, b_acc = sink_b.buf.view(-1), not sink_b.fresh
+    else:
+        b_out, b_acc = torch.empty((N,), dtype=torch.float32, device=dy2.device), False
+    dw = ops.linear_wgrad(dy2, x2, out=w_out, accumulate=(not sink_w.fresh) if sink_w is not None else False,
+                          bias_out=b_out, bias_accumulate=b_acc)
+    if sink_w is not None:
+        sink_w.mark_written()
+        dw = None
+    if sink_b is not None:
+        sink_b.mark_written()
+        b_out = None
+    return dw, b_out
+
+
 def _emit_colsum(sink, dy2: Tensor):
     if sink is None:
         return ops.colsum(dy2)
@@ -119,8 +140,8 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, wc).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = _emit_wgrad(ctx.sinks[0], dy2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw, db = _emit_wgrad_bias(ctx.sinks[0], ctx.sinks[1], dy2, x2, ctx.has_bias and ctx.needs_input_grad[2])
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = _emit_colsum(ctx.sinks[1], dy2)
         return dx, dw, db, None
 
@@ -227,8 +248,7 @@ class _PatchEmbed(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dpatch = ops.linear_dgrad(demb, wc)
             dclip = ops.patchify_bwd(dpatch, ctx.clip_shape, ctx.patch, ctx.clip_dtype)
-        dw = _emit_wgrad(ctx.sinks[0], demb, patches) if ctx.needs_input_grad[1] else None
-        db = _emit_colsum(ctx.sinks[1], demb) if ctx.needs_input_grad[2] else None
+        dw, db = _emit_wgrad_bias(ctx.sinks[0], ctx.sinks[1], demb, patches, True)
         return dclip, dw, db, None, None
 
 
@@ -465,9 +485,7 @@ class _AttnBlock(torch.autograd.Function):
         dwo = dbo = None
         if has_out:
             do2 = ops.linear_dgrad(dy2, wo)                            # [M, inner]
-            dwo = _emit_wgrad(ctx.sinks[3], dy2, o_mem.view(M, inner))
-            if has_bias:
-                dbo = _emit_colsum(ctx.sinks[4], dy2)
+            dwo, dbo = _emit_wgrad_bias(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), has_bias)
         else:
             do2 = dy2
         q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)
@@ -475,8 +493,7 @@ class _AttnBlock(torch.autograd.Function):
         dq, dk, dv = _split_qkv(dqkv, S, N, heads, dh, seq_first)
         ops.attention_bwd(q, k, v, _heads_view(o_mem, seq_first), lse,
                           _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5)
-        dwq = _emit_wgrad(ctx.sinks[2], dqkv, xn)
-        dbq = _emit_colsum(ctx.sinks[5], dqkv) if has_qkv_bias else None
+        dwq, dbq = _emit_wgrad_bias(ctx.sinks[2], ctx.sinks[5], dqkv, xn, has_qkv_bias)
         dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
         dg = db = None
         if prenorm:
@@ -537,14 +554,12 @@ class _MlpBlock(torch.autograd.Function):
             xn = x2
         dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
         sk = ctx.sinks
-        dw2 = _emit_wgrad(sk[4], dy2, h)
-        db2 = _emit_colsum(sk[5], dy2) if has_b2 else None
+        dw2, db2 = _emit_wgrad_bias(sk[4], sk[5], dy2, h, has_b2)
         if act == "gelu":
             du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u)
         else:
             du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h)
-        dw1 = _emit_wgrad(sk[2], du, xn)
-        db1 = _emit_colsum(sk[3], du) if has_b1 else None
+        dw1, db1 = _emit_wgrad_bias(sk[2], sk[3], du, xn, has_b1)
         dxn = ops.linear_dgrad(du, w1c)
         dg = db = None
         if prenorm:

@@ -330,7 +330,7 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
          lda: int, ldb: int, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
          epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
          aux: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0,
-         split_k: int = 0) -> Tensor:
+         split_k: int = 0, colsum_out: Optional[Tensor] = None, colsum_accumulate: bool = False) -> Tensor:
     _need_cuda(A, B, bias, residual, aux)
     assert A.dtype == B.dtype
     if out_dtype is None:
@@ -355,6 +355,10 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
     d.ldaux = aux.stride(0) if aux is not None else 0
     d.alpha = alpha
     d.split_k = split_k
+    if colsum_out is not None:
+        assert colsum_out.dtype == torch.float32 and colsum_out.numel() == M and colsum_out.is_contiguous()
+    d.colsum_out = _p(colsum_out)
+    d.colsum_accumulate = int(colsum_accumulate)
     lib = L.load()
     ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device)
     d.workspace = _p(ws)
@@ -388,13 +392,16 @@ def linear_dgrad(dy: Tensor, w: Tensor, *, epilogue: int = L.EPI_NONE, aux: Opti
                 aux=aux)
 
 
-def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
-    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K]."""
+def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False,
+                 bias_out: Optional[Tensor] = None, bias_accumulate: bool = False) -> Tensor:
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K]; optionally also the bias gradient
+    bias_out[N] (+)= sum_m dy[m, :] from the same pass over dy."""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
     return gemm(dy, x, N, K, M, a_kmajor=False, b_kmajor=False, lda=dy.stride(0), ldb=x.stride(0), out=out,
-                out_dtype=torch.float32, accumulate=accumulate)
+                out_dtype=torch.float32, accumulate=accumulate, colsum_out=bias_out,
+                colsum_accumulate=bias_accumulate)
 
 
 def colsum(x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:

@@ -190,6 +190,11 @@ typedef struct dvt_gemm_desc {
   float alpha;          /* result scale applied to acc before the epilogue (1.0f default) */
   int32_t split_k;      /* 0 = library chooses; >1 forces that many K slices */
   void* workspace;      /* >= dvt_gemm_workspace_bytes(desc) bytes (may be NULL if that is 0) */
+  /* Optional, mn-major A only (weight gradients, A = dY): colsum_out[m] (+)= sum_k A(m,k),
+   * i.e. the bias gradient, produced by the same pass over dY (an extra MFMA against an
+   * all-ones fragment) instead of a separate reduction.  NULL = off. */
+  float* colsum_out;
+  int32_t colsum_accumulate;
 } dvt_gemm_desc;
 
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* desc);

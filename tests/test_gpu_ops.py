@@ -222,6 +222,12 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device):
     dw = dvt.ops.linear_wgrad(dy_d, x_d)                      # mn-major x mn-major, split-K
     assert rel_l2(dw, dy.t() @ x) < BF16_TOL
     assert torch.equal(dw, dvt.ops.linear_wgrad(dy_d, x_d))
+    # bias gradient fused into the same pass (all-ones MFMA), overwrite and accumulate
+    db = torch.full((N,), 7.0, device="cuda")
+    dw2 = dvt.ops.linear_wgrad(dy_d, x_d, bias_out=db)
+    assert torch.equal(dw2, dw) and rel_l2(db, dy.sum(0)) < 1e-5
+    dvt.ops.linear_wgrad(dy_d, x_d, bias_out=db, bias_accumulate=True)
+    assert rel_l2(db, 2 * dy.sum(0)) < 1e-5
     # ragged N (1000 = 3.9 tiles) and a narrower K
     w2_d, w2 = _rnd((1000, 192), torch.bfloat16, g, 0.1)
     x2_d, x2 = _rnd((M, 192), torch.bfloat16, g)

@@ -29,7 +29,9 @@ int main(int argc, char** argv) {
     {"ff2_dgrad [M,512]x[512,2048] dgelu", Mt, 2048, 512, true, false, DVT_EPI_DGELU, 1},
     {"ff1_dgrad [M,2048]x[2048,512]", Mt, 512, 2048, true, false, DVT_EPI_NONE, 1},
     {"ff1_wgrad [2048,M]x[M,512] split16", 2048, 512, Mt, false, false, DVT_EPI_NONE, 16},
-    {"square 4096^3", 4096, 4096, 4096, true, true, DVT_EPI_NONE, 1},
+    {"square 4096^3 k,k", 4096, 4096, 4096, true, true, DVT_EPI_NONE, 1},
+    {"square 4096^3 k,mn", 4096, 4096, 4096, true, false, DVT_EPI_NONE, 1},
+    {"square 4096^3 mn,mn", 4096, 4096, 4096, false, false, DVT_EPI_NONE, 1},
   };
   size_t maxA = (size_t)Mt * 2048, maxB = (size_t)Mt * 2048, maxC = (size_t)Mt * 2048;
   bf16 *A, *B, *C, *AUX, *RES; float* bias; float* slab;
