@@ -243,19 +243,15 @@ __device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int ta, int tb, i
                                               int li) {
   const int qq = li >> 2, pp = li & 3;
   const int u = col0 >> 4;
-  bf16x8 out;
+  bf16x4 half[2];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     const int r = 16 * (hf ? tb : ta) + 4 * g + qq;
     const char* a = img + r * kRowBytes + ((u ^ ((r >> 1) & 3)) << 5) + 8 * pp;
-    const bf16x4 v =
-        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
-    out[4 * hf + 0] = v[0];
-    out[4 * hf + 1] = v[1];
-    out[4 * hf + 2] = v[2];
-    out[4 * hf + 3] = v[3];
+    half[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
   }
-  return out;
+  // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
+  return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {

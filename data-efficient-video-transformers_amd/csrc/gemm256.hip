@@ -90,18 +90,15 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int base, int kk, int g
   } else {
     const int q = li >> 2, pp = li & 3;
     const int u = base >> 4;
-    bf16x8 out;
+    bf16x4 half[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int k = kk * 32 + 8 * g + 4 * hf + q;
       const char* a = tile + k * (ROWS * 2) + ((u ^ swz_mn(k)) << 5) + 8 * pp;
-      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
-      out[4 * hf + 0] = v[0];
-      out[4 * hf + 1] = v[1];
-      out[4 * hf + 2] = v[2];
-      out[4 * hf + 3] = v[3];
+      half[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
     }
-    return out;
+    // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
+    return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
 
