@@ -85,6 +85,18 @@ SIGNATURES = {
     "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "dvt_attention_fwd": (c_int, [C.POINTER(AttnDesc), c_p]),
     "dvt_attention_bwd": (c_int, [C.POINTER(AttnDesc), c_p]),
+    "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 7 + [c_i64, c_p]),
+    "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 7 + [c_i64, c_int, c_p]),
+    "dvt_conv_weight_pack": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_i64, c_p]),
+    "dvt_conv_weight_unpack_grad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p]),
+    "dvt_bn_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
+    "dvt_bn_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_int, c_p]),
+    "dvt_bn_eval_invstd": (c_int, [c_p, c_p, c_int, c_f, c_p]),
+    "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
+    "dvt_bn_bwd": (c_int, [c_p] * 11 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
+    "dvt_maxpool_bwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
+    "dvt_transpose_last2": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_bce_logits_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_bce_logits_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_ce_argmax_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),

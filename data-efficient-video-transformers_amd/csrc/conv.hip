@@ -1,0 +1,541 @@
+// conv.hip -- per-frame CNN encoder pieces (src/models/custom_resnet.py:19-153).
+//
+// Feature maps live in HBM as NHWC, i.e. as [N*H*W, C] row-major matrices, so that
+//   * a convolution is   im2col gather -> MFMA GEMM (gemm256.hip) -> [N*Ho*Wo, Cout]  (already NHWC),
+//     1x1 convolutions need no gather at all,
+//   * BatchNorm / ReLU / residual are column-statistics + row-streaming kernels,
+//   * global average pooling is the mean over rows of a [N, H*W, C] view.
+// The gather is explicit in this round (column order (ki, kj, c): contiguous C-runs);
+// fusing it into the GEMM's A-operand DMA (implicit GEMM) is the planned next step.
+// All kernels are HBM-bound streaming kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int kB = 256;
+
+inline int cgrid(int64_t items) {
+  int64_t b = dvt_cdiv(items, kB);
+  const int64_t cap = (int64_t)dvt_num_cus() * 8;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// ------------------------------------------------------------------ im2col / col2im
+// out[(n, ho, wo), (ki*kw + kj)*C + c] = x[n, ho*s - p + ki, wo*s - p + kj, c]   (0 outside)
+// columns [kh*kw*C, ld) are zero (K padding for the MFMA kernels).
+template <typename S, typename D, bool NCHW>
+__global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int N, int C, int H, int W,
+                              int kh, int kw, int stride, int pad, int Ho, int Wo, int64_t ld) {
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  const int K = kh * kw * C;
+  const int64_t total = rows * ld;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+    const int col = (int)(i % ld);
+    const int64_t r = i / ld;
+    float v = 0.f;
+    if (col < K) {
+      const int c = col % C, kk = col / C, kj = kk % kw, ki = kk / kw;
+      const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+      const int64_t n = r / ((int64_t)Wo * Ho);
+      const int h = ho * stride - pad + ki, w = wo * stride - pad + kj;
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = to_f32<S>(NCHW ? x[((n * C + c) * H + h) * W + w] : x[((n * H + h) * W + w) * C + c]);
+    }
+    out[i] = from_f32<D>(v);
+  }
+}
+
+// vectorised NHWC form: C % 8 == 0, one thread copies 8 channels of one (row, ki, kj)
+template <typename T>
+__global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C, int H,
+                                       int W, int kh, int kw, int stride, int pad, int Ho, int Wo,
+                                       int64_t ld) {
+  const int cv = C >> 3;
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  const int64_t items = rows * kh * kw * cv;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gs) {
+    const int c = (int)(it % cv) << 3;
+    int64_t t = it / cv;
+    const int kk = (int)(t % (kh * kw));
+    const int64_t r = t / (kh * kw);
+    const int kj = kk % kw, ki = kk / kw;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+    const int64_t n = r / ((int64_t)Wo * Ho);
+    const int h = ho * stride - pad + ki, w = wo * stride - pad + kj;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (h >= 0 && h < H && w >= 0 && w < W) load8<T>(x + ((n * H + h) * W + w) * C + c, v);
+    store8<T>(out + r * ld + (int64_t)kk * C + c, v);
+  }
+}
+
+// dx[n,h,w,c] = sum over (ki,kj) with (h+p-ki) % s == 0, (w+p-kj) % s == 0 of
+//               dcol[(n, (h+p-ki)/s, (w+p-kj)/s), (ki*kw+kj)*C + c]        (gather form: no atomics)
+template <typename T>
+__global__ void col2im_nhwc_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int C, int H,
+                                   int W, int kh, int kw, int stride, int pad, int Ho, int Wo, int64_t ld) {
+  const int cv = C >> 3;
+  const int64_t items = (int64_t)N * H * W * cv;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gs) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t px = it / cv;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const int64_t n = px / ((int64_t)W * H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ki = 0; ki < kh; ++ki) {
+      const int hh = h + pad - ki;
+      if (hh < 0 || hh % stride) continue;
+      const int ho = hh / stride;
+      if (ho >= Ho) continue;
+      for (int kj = 0; kj < kw; ++kj) {
+        const int ww = w + pad - kj;
+        if (ww < 0 || ww % stride) continue;
+        const int wo = ww / stride;
+        if (wo >= Wo) continue;
+        float v[8];
+        load8<T>(dcol + ((n * Ho + ho) * Wo + wo) * ld + (int64_t)(ki * kw + kj) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+    }
+    store8<T>(dx + px * C + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------ conv weight pack / unpack
+// pack:   dst[co, (ki*kw+kj)*Cin + ci] = (T) w[co, ci, ki, kj]; columns >= kh*kw*Cin are 0
+template <typename D>
+__global__ void weight_pack_kernel(const float* __restrict__ w, D* __restrict__ dst, int Cout, int Cin,
+                                   int kh, int kw, int64_t ld) {
+  const int64_t total = (int64_t)Cout * ld;
+  const int K = kh * kw * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ld), co = (int)(i / ld);
+    float v = 0.f;
+    if (col < K) {
+      const int ci = col % Cin, kk = col / Cin;
+      v = w[((int64_t)co * Cin + ci) * kh * kw + kk];
+    }
+    dst[i] = from_f32<D>(v);
+  }
+}
+// unpack: dw[co, ci, ki, kj] (+)= g[co, (ki*kw+kj)*Cin + ci]
+__global__ void weight_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int Cout, int Cin,
+                                     int kh, int kw, int64_t ld, int accumulate) {
+  const int64_t total = (int64_t)Cout * Cin * kh * kw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % (kh * kw));
+    const int ci = (int)((i / (kh * kw)) % Cin);
+    const int co = (int)(i / ((int64_t)kh * kw * Cin));
+    const float v = g[(int64_t)co * ld + (int64_t)kk * Cin + ci];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm (columns of [rows, C])
+// partial[b][0][c] = sum x, partial[b][1][c] = sum x^2 over the block's rows  (MODE 0)
+// partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat                 (MODE 1), dz = dy * (y > 0 if relu)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const T* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, int64_t rows, int C,
+                                                          int rows_per_block, int relu,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[2][8][32][8];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cl) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C) {
+    float mu[8], is[8];
+    if (MODE == 1) { load8<float>(mean + c, mu); load8<float>(invstd + c, is); }
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float xv[8];
+      load8<T>(x + r * C + c, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] += xv[k]; b[k] = fmaf(xv[k], xv[k], b[k]); }
+      } else {
+        float dv[8], yv[8];
+        load8<T>(dy + r * C + c, dv);
+        if (relu) load8<T>(y + r * C + c, yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
+          a[k] += dz;
+          b[k] = fmaf(dz, (xv[k] - mu[k]) * is[k], b[k]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][rl][cl][k] = a[k]; red[1][rl][cl][k] = b[k]; }
+  __syncthreads();
+  if (rl < 2 && c < C) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      t[k] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t[k] += red[rl][r][cl][k];
+    }
+    store8<float>(partial + ((int64_t)blockIdx.y * 2 + rl) * C + c, t);
+  }
+}
+
+// MODE 0: mean, invstd (biased var), running stats update.  MODE 1: dgamma = sum dz*xhat, dbeta = sum dz.
+template <int MODE>
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, float inv_rows,
+                                   float eps, float* __restrict__ o0, float* __restrict__ o1,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                   float unbias, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    s0 += partial[((int64_t)p * 2 + 0) * C + c];
+    s1 += partial[((int64_t)p * 2 + 1) * C + c];
+  }
+  if (MODE == 0) {
+    const float mu = s0 * inv_rows;
+    const float var = fmaxf(s1 * inv_rows - mu * mu, 0.f);
+    o0[c] = mu;
+    o1[c] = rsqrtf(var + eps);
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
+    }
+  } else {
+    o0[c] = accumulate ? o0[c] + s1 : s1;   // dgamma
+    o1[c] = accumulate ? o1[c] + s0 : s0;   // dbeta
+  }
+}
+
+__global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restrict__ out, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = rsqrtf(var[c] + eps);
+}
+
+// y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+template <typename T>
+__global__ void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const T* __restrict__ residual,
+                                    T* __restrict__ y, int64_t rows, int C, int relu) {
+  const int cv = C >> 3;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t off = (it / cv) * C + c;
+    float xv[8], mu[8], is[8], g[8], b[8], rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load8<T>(x + off, xv);
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is);
+    load8<float>(gamma + c, g); load8<float>(beta + c, b);
+    if (residual) load8<T>(residual + off, rv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = fmaf((xv[k] - mu[k]) * is[k], g[k], b[k]) + rv[k];
+      xv[k] = relu ? fmaxf(v, 0.f) : v;
+    }
+    store8<T>(y + off, xv);
+  }
+}
+
+// dz = dy * (y > 0 if relu);  dres = dz (if wanted);
+// train: dx = gamma*invstd*(dz - sum_dz/rows - xhat*sum_dzxhat/rows);  eval: dx = gamma*invstd*dz
+template <typename T>
+__global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
+                                    int64_t rows, int C, int relu, int training, float inv_rows) {
+  const int cv = C >> 3;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t off = (it / cv) * C + c;
+    float dv[8], xv[8], yv[8], mu[8], is[8], g[8], dg[8], db[8], o[8];
+    load8<T>(dy + off, dv); load8<T>(x + off, xv);
+    if (relu) load8<T>(y + off, yv);
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g);
+    load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
+      dv[k] = dz;
+      const float xh = (xv[k] - mu[k]) * is[k];
+      o[k] = training ? g[k] * is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : g[k] * is[k] * dz;
+    }
+    store8<T>(dx + off, o);
+    if (dres) store8<T>(dres + off, dv);
+  }
+}
+
+// ------------------------------------------------------------------ max pool (NHWC), first max wins
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                   int N, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+    const int64_t n = r / ((int64_t)Wo * Ho);
+    float best = -INFINITY;
+    int bi = -1;                        // first maximum in (ki, kj) scan order wins (torch semantics)
+    for (int ki = 0; ki < k; ++ki)
+      for (int kj = 0; kj < k; ++kj) {
+        const int h = ho * stride - pad + ki, w = wo * stride - pad + kj;
+        if (h < 0 || h >= H || w < 0 || w >= W) continue;
+        const float v = to_f32<T>(x[((n * H + h) * W + w) * C + c]);
+        if (bi < 0 || v > best) { best = v; bi = ki * k + kj; }
+      }
+    y[i] = from_f32<T>(best);
+    idx[i] = (unsigned char)(bi < 0 ? 0 : bi);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   T* __restrict__ dx, int N, int C, int H, int W, int k, int stride, int pad,
+                                   int Ho, int Wo) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t px = i / C;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const int64_t n = px / ((int64_t)W * H);
+    float acc = 0.f;
+    for (int ki = 0; ki < k; ++ki) {
+      const int hh = h + pad - ki;
+      if (hh < 0 || hh % stride) continue;
+      const int ho = hh / stride;
+      if (ho >= Ho) continue;
+      for (int kj = 0; kj < k; ++kj) {
+        const int ww = w + pad - kj;
+        if (ww < 0 || ww % stride) continue;
+        const int wo = ww / stride;
+        if (wo >= Wo) continue;
+        const int64_t o = ((n * Ho + ho) * Wo + wo) * C + c;
+        if (idx[o] == ki * k + kj) acc += to_f32<T>(dy[o]);
+      }
+    }
+    dx[i] = from_f32<T>(acc);
+  }
+}
+
+// ------------------------------------------------------------------ batched 2-D transpose [B, R, Cc] -> [B, Cc, R]
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
+  __shared__ T tile[32][33];
+  const int64_t b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < R && c < Cc) tile[j][tx] = src[(b * R + r) * Cc + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) dst[(b * Cc + c) * R + r] = tile[tx][j];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
+               int W, int kh, int kw, int stride, int pad, int64_t ld, dvt_stream_t stream) {
+  DVT_REQUIRE(x && out && N >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+              "dvt_im2col: bad arguments");
+  DVT_REQUIRE(ld >= (int64_t)kh * kw * C, "dvt_im2col: ld smaller than kh*kw*C");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  DVT_REQUIRE(Ho > 0 && Wo > 0, "dvt_im2col: empty output");
+  if (N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = N * Ho * Wo;
+  const bool vec = !x_nchw && x_dtype == out_dtype && C % 8 == 0 && ld % 8 == 0 && ld == (int64_t)kh * kw * C &&
+                   dvt_aligned16(x) && dvt_aligned16(out);
+  if (vec) {
+    DVT_DISPATCH_DTYPE(x_dtype, T, hipLaunchKernelGGL((im2col_nhwc_vec_kernel<T>), dim3(cgrid(rows * kh * kw * (C >> 3))),
+                                                      dim3(kB), 0, st, (const T*)x, (T*)out, (int)N, C, H, W, kh, kw,
+                                                      stride, pad, Ho, Wo, ld));
+  } else {
+#define DVT_IM2COL_CASE(SD, S, DD, D)                                                                        \
+  if (x_dtype == SD && out_dtype == DD) {                                                                    \
+    if (x_nchw) hipLaunchKernelGGL((im2col_kernel<S, D, true>), dim3(cgrid(rows * ld)), dim3(kB), 0, st,     \
+                                   (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, stride, pad, Ho, Wo, ld);  \
+    else hipLaunchKernelGGL((im2col_kernel<S, D, false>), dim3(cgrid(rows * ld)), dim3(kB), 0, st,           \
+                            (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, stride, pad, Ho, Wo, ld);         \
+    DVT_LAUNCH_CHECK("dvt_im2col");                                                                          \
+    return DVT_OK;                                                                                           \
+  }
+    DVT_IM2COL_CASE(DVT_F32, float, DVT_F32, float)
+    DVT_IM2COL_CASE(DVT_F32, float, DVT_BF16, bf16)
+    DVT_IM2COL_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+    DVT_IM2COL_CASE(DVT_BF16, bf16, DVT_F32, float)
+#undef DVT_IM2COL_CASE
+    DVT_UNSUPPORTED("dvt_im2col: dtype pair (%d, %d)", x_dtype, out_dtype);
+  }
+  DVT_LAUNCH_CHECK("dvt_im2col");
+  return DVT_OK;
+}
+
+int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int stride, int pad,
+               int64_t ld, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "dvt_col2im: bad arguments (C, ld %% 8)");
+  DVT_REQUIRE(dvt_aligned16(dcol) && dvt_aligned16(dx), "dvt_col2im: misaligned buffer");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  if (N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_nhwc_kernel<T>), dim3(cgrid(N * H * W * (C >> 3))), dim3(kB), 0,
+                                                  st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, stride, pad, Ho,
+                                                  Wo, ld));
+  DVT_LAUNCH_CHECK("dvt_col2im");
+  return DVT_OK;
+}
+
+int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw, int64_t ld,
+                         dvt_stream_t stream) {
+  DVT_REQUIRE(w && dst && Cout > 0 && Cin > 0 && ld >= (int64_t)Cin * kh * kw, "dvt_conv_weight_pack: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(cgrid((int64_t)Cout * ld)), dim3(kB),
+                                                      0, st, w, (T*)dst, Cout, Cin, kh, kw, ld));
+  DVT_LAUNCH_CHECK("dvt_conv_weight_pack");
+  return DVT_OK;
+}
+
+int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, int kh, int kw, int64_t ld,
+                                int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(g && dw && Cout > 0 && Cin > 0 && ld >= (int64_t)Cin * kh * kw, "dvt_conv_weight_unpack_grad: bad arguments");
+  hipLaunchKernelGGL(weight_unpack_kernel, dim3(cgrid((int64_t)Cout * Cin * kh * kw)), dim3(kB), 0, (hipStream_t)stream,
+                     g, dw, Cout, Cin, kh, kw, ld, accumulate);
+  DVT_LAUNCH_CHECK("dvt_conv_weight_unpack_grad");
+  return DVT_OK;
+}
+
+size_t dvt_bn_workspace_bytes(int64_t rows, int C) {
+  (void)rows;
+  return ((size_t)256 * 2 + 2) * (size_t)C * sizeof(float);
+}
+
+static int bn_parts(int64_t rows, int* rpb) {
+  int parts = (int)(rows / 64 < 256 ? rows / 64 : 256);
+  if (parts < 1) parts = 1;
+  *rpb = (int)dvt_cdiv(rows, parts);
+  return (int)dvt_cdiv(rows, *rpb);
+}
+
+int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                 void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0 && C % 8 == 0, "dvt_bn_stats: bad arguments (C %% 8)");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(workspace), "dvt_bn_stats: misaligned buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int rpb;
+  const int parts = bn_parts(rows, &rpb);
+  const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
+                                                  (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                  (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
+  DVT_LAUNCH_CHECK("dvt_bn_stats");
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st,
+                     (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
+                     running_var, momentum, unbias, 0);
+  DVT_LAUNCH_CHECK("dvt_bn_stats(finalize)");
+  return DVT_OK;
+}
+
+int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream) {
+  DVT_REQUIRE(running_var && invstd && C > 0, "dvt_bn_eval_invstd: bad arguments");
+  hipLaunchKernelGGL(rsqrt_eps_kernel, dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     running_var, invstd, C, eps);
+  DVT_LAUNCH_CHECK("dvt_bn_eval_invstd");
+  return DVT_OK;
+}
+
+int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0 && C % 8 == 0, "dvt_bn_apply_fwd: bad arguments");
+  if (rows == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                  (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
+                                                  rows, C, relu));
+  DVT_LAUNCH_CHECK("dvt_bn_apply_fwd");
+  return DVT_OK;
+}
+
+int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, int64_t rows,
+               int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && C % 8 == 0,
+              "dvt_bn_bwd: bad arguments");
+  DVT_REQUIRE(!relu || y, "dvt_bn_bwd: relu needs the forward output");
+  hipStream_t st = (hipStream_t)stream;
+  int rpb;
+  const int parts = bn_parts(rows, &rpb);
+  const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
+  // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
+  float* part = (float*)workspace;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
+                                                  (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+  DVT_LAUNCH_CHECK("dvt_bn_bwd(stats)");
+  float* loc = part + (size_t)parts * 2 * C;
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st, (const float*)part,
+                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
+  DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                  (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
+                                                  loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
+                                                  1.0f / (float)rows));
+  DVT_LAUNCH_CHECK("dvt_bn_bwd(apply)");
+  // publish dgamma / dbeta (overwrite or accumulate) from the local copy
+  int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
+  if (rc) return rc;
+  return dvt_axpby_f32(loc + C, DVT_F32, 1.f, dbeta, accumulate ? 1.f : 0.f, C, stream);
+}
+
+int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, int W, int k, int stride, int pad,
+                    int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && y && idx && N >= 0 && C > 0 && k > 0 && k * k <= 255 && stride > 0, "dvt_maxpool_fwd: bad arguments");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(cgrid(N * Ho * Wo * C)), dim3(kB), 0, st,
+                                                  (const T*)x, (T*)y, (unsigned char*)idx, (int)N, C, H, W, k, stride,
+                                                  pad, Ho, Wo));
+  DVT_LAUNCH_CHECK("dvt_maxpool_fwd");
+  return DVT_OK;
+}
+
+int dvt_maxpool_bwd(const void* dy, const void* idx, void* dx, int64_t N, int C, int H, int W, int k, int stride,
+                    int pad, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dy && idx && dx && N >= 0 && C > 0 && k > 0 && stride > 0, "dvt_maxpool_bwd: bad arguments");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(cgrid(N * H * W * C)), dim3(kB), 0, st,
+                                                  (const T*)dy, (const unsigned char*)idx, (T*)dx, (int)N, C, H, W, k,
+                                                  stride, pad, Ho, Wo));
+  DVT_LAUNCH_CHECK("dvt_maxpool_bwd");
+  return DVT_OK;
+}
+
+int dvt_transpose_last2(const void* src, void* dst, int64_t B, int R, int Cc, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && B >= 0 && R > 0 && Cc > 0 && B < 65536, "dvt_transpose_last2: bad arguments");
+  if (B == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)dvt_cdiv(Cc, 32), (unsigned)dvt_cdiv(R, 32), (unsigned)B);
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, R, Cc));
+  DVT_LAUNCH_CHECK("dvt_transpose_last2");
+  return DVT_OK;
+}
+
+}  // extern "C"

@@ -753,3 +753,123 @@ class _ClsConcat(torch.autograd.Function):
 
 def cls_concat(data: Tensor, cls: Tensor) -> Tensor:
     return _ClsConcat.apply(data, cls)
+
+
+# ---------------------------------------------------------------------------
+# Per-frame CNN encoder blocks (src/models/custom_resnet.py): conv -> BN -> (+res) -> ReLU
+# on NHWC feature maps stored as [N*H*W, C] matrices.
+# ---------------------------------------------------------------------------
+def _kpad(K: int, dtype: torch.dtype) -> int:
+    """Reduction length padded so that the LDS-DMA MFMA kernel is eligible (K % 64 == 0)."""
+    return K if dtype == torch.float32 else (K + 63) // 64 * 64
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
+    clip frames [N, Cin, H, W] for the stem.  Returns the NHWC matrix [N*Ho*Wo, Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype):
+        N, Cin, H, W, k, stride, pad, nchw = geom
+        Cout = w.shape[0]
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        K = k * k * Cin
+        direct = (k == 1 and stride == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
+        ld = K if direct else _kpad(K, dtype)
+        xc = x.contiguous()
+        col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
+        wp = ops.conv_weight_pack(w, ld, dtype)
+        z = ops.linear_fwd(col, wp)                                     # [N*Ho*Wo, Cout]
+        g32, b32 = _f32(gamma), _f32(beta)
+        if training:
+            mean, invstd = ops.bn_stats(z, run_mean, run_var, eps, momentum)
+        else:
+            mean, invstd = run_mean.detach().float(), ops.bn_eval_invstd(run_var.detach().float(), eps)
+        res = None if residual is None else residual.contiguous()
+        y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
+        ctx.save_for_backward(xc, wp, z, y if relu else None, mean, invstd, g32)
+        ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
+        ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
+        ctx.x_needs = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wp, z, y, mean, invstd, g32 = ctx.saved_tensors
+        geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
+        N, Cin, H, W, k, stride, pad, nchw = geom
+        sw, sg, sb = ctx.sinks
+        dy = _as(dy.contiguous(), z.dtype)
+        if sg is not None and sb is not None:
+            dz, dres, _, _ = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res,
+                                        dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
+            sg.mark_written(); sb.mark_written()
+            dgam = dbet = None
+        else:
+            dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
+        col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
+        dwp = ops.linear_wgrad(dz, col)                                  # [Cout, ld] fp32
+        if sw is not None:
+            ops.conv_weight_unpack_grad(dwp, wshape, out=sw.buf, accumulate=not sw.fresh)
+            sw.mark_written()
+            dw = None
+        else:
+            dw = ops.conv_weight_unpack_grad(dwp, wshape)
+        dx = None
+        if ctx.x_needs:
+            dcol = ops.linear_dgrad(dz, wp)                              # [rows, ld]
+            if direct:
+                dx = dcol
+            elif nchw:
+                raise NotImplementedError("gradient w.r.t. NCHW stem input (pixel-space CLS) is not built yet")
+            else:
+                dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
+                dtype=torch.bfloat16):
+    """geom = (N, Cin, H, W, nchw).  Kernel size / stride / padding come from ``conv``."""
+    N, Cin, H, W, nchw = geom
+    k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    assert conv.bias is None and conv.kernel_size[0] == conv.kernel_size[1] and conv.groups == 1
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        N, Cc, H, W, k, stride, pad = geom
+        y, idx = ops.maxpool_fwd(x.contiguous(), N, Cc, H, W, k, stride, pad)
+        ctx.save_for_backward(idx)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, Cc, H, W, k, stride, pad = ctx.geom
+        return ops.maxpool_bwd(dy.contiguous(), idx, N, Cc, H, W, k, stride, pad), None
+
+
+def maxpool_nhwc(x, N, Cc, H, W, k, stride, pad):
+    return _MaxPool.apply(x, (N, Cc, H, W, k, stride, pad))
+
+
+class _Transpose12(torch.autograd.Function):
+    """[B, R, C] <-> [B, C, R] (NHWC <-> NCHW at the module boundary)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.transpose_last2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.transpose_last2(dy)
+
+
+def transpose_last2(x):
+    return _Transpose12.apply(x)

@@ -522,3 +522,125 @@ def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Te
     L.check(L.load().dvt_adamw_step_dev(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                         exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps,
                                         weight_decay, step_dev.data_ptr(), _stream()), "dvt_adamw_step_dev")
+
+
+# ------------------------------------------------------------------ per-frame CNN encoder (csrc/conv.hip)
+def conv_out_hw(H: int, W: int, k: int, stride: int, pad: int) -> Tuple[int, int]:
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def im2col(x: Tensor, nchw: bool, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int, ld: int,
+           out_dtype: torch.dtype) -> Tensor:
+    _need_cuda(x)
+    assert x.is_contiguous()
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    out = torch.empty((N * Ho * Wo, ld), dtype=out_dtype, device=x.device)
+    L.check(L.load().dvt_im2col(x.data_ptr(), dt(x), int(nchw), out.data_ptr(), _DT[out_dtype], N, Cc, H, W, k, k,
+                                stride, pad, ld, _stream()), "dvt_im2col")
+    return out
+
+
+def col2im(dcol: Tensor, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int) -> Tensor:
+    _need_cuda(dcol)
+    assert dcol.is_contiguous()
+    dx = torch.empty((N * H * W, Cc), dtype=dcol.dtype, device=dcol.device)
+    L.check(L.load().dvt_col2im(dcol.data_ptr(), dx.data_ptr(), N, Cc, H, W, k, k, stride, pad, dcol.shape[1],
+                                dt(dcol), _stream()), "dvt_col2im")
+    return dx
+
+
+def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
+    _need_cuda(w)
+    w = w.detach().contiguous()
+    assert w.dtype == torch.float32 and w.dim() == 4
+    Cout, Cin, kh, kw = w.shape
+    out = torch.empty((Cout, ld), dtype=dtype, device=w.device)
+    L.check(L.load().dvt_conv_weight_pack(w.data_ptr(), out.data_ptr(), _DT[dtype], Cout, Cin, kh, kw, ld, _stream()),
+            "dvt_conv_weight_pack")
+    return out
+
+
+def conv_weight_unpack_grad(g: Tensor, shape, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _need_cuda(g)
+    Cout, Cin, kh, kw = shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=g.device)
+    L.check(L.load().dvt_conv_weight_unpack_grad(g.data_ptr(), out.data_ptr(), Cout, Cin, kh, kw, g.shape[1],
+                                                 int(accumulate), _stream()), "dvt_conv_weight_unpack_grad")
+    return out
+
+
+def bn_stats(z: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float,
+             momentum: float) -> Tuple[Tensor, Tensor]:
+    _need_cuda(z)
+    rows, Cc = z.shape
+    mean = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+    invstd = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+    lib = L.load()
+    ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
+    L.check(lib.dvt_bn_stats(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
+                             ws.data_ptr(), rows, Cc, eps, momentum, dt(z), _stream()), "dvt_bn_stats")
+    return mean, invstd
+
+
+def bn_eval_invstd(running_var: Tensor, eps: float) -> Tensor:
+    out = torch.empty_like(running_var)
+    L.check(L.load().dvt_bn_eval_invstd(running_var.data_ptr(), out.data_ptr(), running_var.numel(), eps, _stream()),
+            "dvt_bn_eval_invstd")
+    return out
+
+
+def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, residual: Optional[Tensor],
+                 relu: bool) -> Tensor:
+    rows, Cc = z.shape
+    y = torch.empty_like(z)
+    L.check(L.load().dvt_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                      beta.data_ptr(), _p(residual), y.data_ptr(), rows, Cc, int(relu), dt(z),
+                                      _stream()), "dvt_bn_apply_fwd")
+    return y
+
+
+def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
+           training: bool, want_dres: bool, *, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+           accumulate: bool = False):
+    rows, Cc = z.shape
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_dres else None
+    if dgamma is None:
+        assert not accumulate
+        dgamma = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+    lib = L.load()
+    ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
+    L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                           dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
+                           int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
+    return dz, dres, dgamma, dbeta
+
+
+def maxpool_fwd(x: Tensor, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int):
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    y = torch.empty((N * Ho * Wo, Cc), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N * Ho * Wo * Cc,), dtype=torch.uint8, device=x.device)
+    L.check(L.load().dvt_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, Cc, H, W, k, stride, pad, dt(x),
+                                     _stream()), "dvt_maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy: Tensor, idx: Tensor, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int) -> Tensor:
+    dx = torch.empty((N * H * W, Cc), dtype=dy.dtype, device=dy.device)
+    L.check(L.load().dvt_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, Cc, H, W, k, stride, pad,
+                                     dt(dy), _stream()), "dvt_maxpool_bwd")
+    return dx
+
+
+def transpose_last2(x: Tensor) -> Tensor:
+    """[B, R, C] -> [B, C, R] contiguous."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, R, Cc = x.shape
+    out = torch.empty((B, Cc, R), dtype=x.dtype, device=x.device)
+    L.check(L.load().dvt_transpose_last2(x.data_ptr(), out.data_ptr(), B, R, Cc, dt(x), _stream()),
+            "dvt_transpose_last2")
+    return out

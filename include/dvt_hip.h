@@ -239,6 +239,46 @@ size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);
 int dvt_attention_fwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- per-frame CNN encoder
+ * src/models/custom_resnet.py:19-153 (conv3x3 / 7x7 stem / 1x1 downsample, BatchNorm2d, ReLU,
+ * MaxPool2d(3,2,1), residual adds).  Feature maps are NHWC = [N*H*W, C] matrices, so a
+ * convolution is  dvt_im2col -> dvt_gemm -> [N*Ho*Wo, Cout];  weights nn.Conv2d [Cout,Cin,kh,kw]. */
+/* out[(n,ho,wo), (ki*kw+kj)*C + c] = x[n, ho*s-p+ki, wo*s-p+kj, c] (0 outside); columns
+ * [kh*kw*C, ld) are zero padding.  x is NCHW when x_nchw != 0 (the raw clip frames), else NHWC. */
+int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
+               int W, int kh, int kw, int stride, int pad, int64_t ld, dvt_stream_t stream);
+/* Adjoint gather (data gradient of the convolution), NHWC, C % 8 == 0. */
+int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int stride, int pad,
+               int64_t ld, int dtype, dvt_stream_t stream);
+/* w[Cout,Cin,kh,kw] f32 -> dst[Cout, ld] (column order (ki,kj,ci), zero padded) in dst_dtype, and the
+ * inverse for the fp32 weight gradient (dw (+)= g re-ordered). */
+int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw, int64_t ld,
+                         dvt_stream_t stream);
+int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, int kh, int kw, int64_t ld,
+                                int accumulate, dvt_stream_t stream);
+/* nn.BatchNorm2d over the rows of x[rows, C] (custom_resnet.py:30,33,104).  Training: batch mean and
+ * biased variance -> mean / invstd, running statistics updated with `momentum` (unbiased variance),
+ * as torch does.  Eval: dvt_bn_eval_invstd from running_var.  workspace >= dvt_bn_workspace_bytes. */
+size_t dvt_bn_workspace_bytes(int64_t rows, int C);
+int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                 void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream);
+int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream);
+/* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52). */
+int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream);
+/* dz = dy*(y>0 if relu); dres = dz (if dres != NULL); dgamma/dbeta (+)=; dx by the batch-statistics
+ * formula (training) or gamma*invstd*dz (eval). */
+int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, int64_t rows,
+               int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
+/* nn.MaxPool2d(k, stride, pad) on NHWC; idx: uint8 [N*Ho*Wo*C] window position of the (first) maximum. */
+int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, int W, int k, int stride, int pad,
+                    int dtype, dvt_stream_t stream);
+int dvt_maxpool_bwd(const void* dy, const void* idx, void* dx, int64_t N, int C, int H, int W, int k, int stride,
+                    int pad, int dtype, dvt_stream_t stream);
+/* [B, R, C] -> [B, C, R]  (NHWC <-> NCHW at the module boundary). */
+int dvt_transpose_last2(const void* src, void* dst, int64_t B, int R, int Cc, int dtype, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- losses
  * nn.BCEWithLogitsLoss() (mean): src/models/frame_transformer.py:89,263,268,273.
  * z: [n] dtype, target: [n] f32, loss: [1] f32. */

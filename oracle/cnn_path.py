@@ -1,0 +1,53 @@
+"""CPU oracle (TEST INFRASTRUCTURE) for the per-frame CNN encoder and the pyramid
+(src/models/custom_resnet.py, src/models/TPN.py).  Functional restatement over a reference
+state dict; the convolution / batch-norm / max-pool arithmetic is torch's own CPU
+implementation, which is what the reference delegates to.  Pinned by
+tests/test_oracle_golden.py against tests/golden/resnet18_pyramid.npz (generated from the
+imported reference)."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as TF
+
+Tensor = torch.Tensor
+
+
+def _bn(x: Tensor, P: Dict[str, Tensor], prefix: str, training: bool, stats: dict) -> Tensor:
+    """nn.BatchNorm2d (eps 1e-5, momentum 0.1).  In training mode the updated running statistics are
+    returned through ``stats`` (functional, the inputs are not modified)."""
+    rm, rv = P[prefix + "running_mean"].clone(), P[prefix + "running_var"].clone()
+    y = TF.batch_norm(x, rm, rv, P[prefix + "weight"], P[prefix + "bias"], training, 0.1, 1e-5)
+    stats[prefix] = (rm, rv)
+    return y
+
+
+def basic_block(x: Tensor, P, prefix: str, stride: int, training: bool, stats: dict) -> Tensor:
+    """BasicBlock.forward, custom_resnet.py:38-54."""
+    out = TF.conv2d(x, P[prefix + "conv1.weight"], None, stride, 1)
+    out = torch.relu(_bn(out, P, prefix + "bn1.", training, stats))
+    out = TF.conv2d(out, P[prefix + "conv2.weight"], None, 1, 1)
+    out = _bn(out, P, prefix + "bn2.", training, stats)
+    residual = x
+    if prefix + "downsample.0.weight" in P:
+        residual = TF.conv2d(x, P[prefix + "downsample.0.weight"], None, stride, 0)
+        residual = _bn(residual, P, prefix + "downsample.1.", training, stats)
+    return torch.relu(out + residual)
+
+
+def resnet_pyramid(x: Tensor, P: Dict[str, Tensor], layers: List[int], training: bool = True
+                   ) -> Tuple[Tensor, Tensor, Tensor, dict]:
+    """ResNet.forward with BasicBlocks, custom_resnet.py:138-153: returns (x2, x3, x4, running stats);
+    the discarded avgpool+fc tail is omitted."""
+    stats = {}
+    x = TF.conv2d(x, P["conv1.weight"], None, 2, 3)
+    x = torch.relu(_bn(x, P, "bn1.", training, stats))
+    x = TF.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li, nb in enumerate(layers):
+        for b in range(nb):
+            stride = 2 if (li > 0 and b == 0) else 1
+            x = basic_block(x, P, f"layer{li + 1}.{b}.", stride, training, stats)
+        feats.append(x)
+    return feats[1], feats[2], feats[3], stats

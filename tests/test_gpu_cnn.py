@@ -1,0 +1,126 @@
+"""Parity of the per-frame CNN encoder on the GPU: im2col + MFMA GEMM +
+BatchNorm/ReLU/max-pool kernels vs the golden vectors from the imported reference
+(tests/golden/resnet18_pyramid.npz) and vs the CPU oracle on small shapes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests.util import golden, rel_l2, fill_resnet_from_numpy
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dvt():
+    import dvt_amd
+    return dvt_amd
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("k,stride,pad,Cin,Cout,H", [(3, 1, 1, 16, 24, 10), (3, 2, 1, 8, 16, 9), (1, 2, 0, 16, 32, 8),
+                                                    (1, 1, 0, 16, 8, 6), (7, 2, 3, 3, 16, 20)])
+def test_conv_bn_relu_block(dvt, device, dtype, tol, k, stride, pad, Cin, Cout, H):
+    g = torch.Generator().manual_seed(31)
+    N, W = 3, H + 2
+    nchw_in = Cin == 3                                  # the stem reads raw NCHW frames
+    x = torch.randn(N, Cin, H, W, generator=g)
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride, pad, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+        bn.weight.copy_(1 + 0.1 * torch.randn(Cout, generator=g)); bn.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Cout, Ho, Wo, generator=g)
+    # ---- oracle (CPU, fp32, same rounded inputs)
+    xr = x.to(dtype).float().clone().requires_grad_(not nchw_in)
+    wr = conv.weight.detach().to(dtype).float().clone().requires_grad_(True)
+    gr, br = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    rr = res.to(dtype).float().clone().requires_grad_(True)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    z = TF.conv2d(xr, wr, None, stride, pad)
+    ref = torch.relu(TF.batch_norm(z, rm, rv, gr, br, True, 0.1, 1e-5) + rr)
+    # ---- device
+    convd, bnd = conv.cuda(), bn.cuda().train()
+    if nchw_in:
+        xd = x.to(dtype).cuda()
+    else:
+        xd = x.to(dtype).permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda().detach().requires_grad_(True)
+    rd = res.to(dtype).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda().detach().requires_grad_(True)
+    y = dvt.functional.conv_bn_act(xd, convd, bnd, (N, Cin, H, W, nchw_in), relu=True, residual=rd, dtype=dtype)
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert rel_l2(y, ref_nhwc) < tol
+    assert torch.allclose(bnd.running_mean.cpu(), rm, atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert torch.allclose(bnd.running_var.cpu(), rv, atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy.to(dtype).float())
+    y.backward(gy.to(dtype).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda())
+    assert rel_l2(convd.weight.grad, wr.grad) < 2 * tol
+    assert rel_l2(bnd.weight.grad, gr.grad) < 2 * tol and rel_l2(bnd.bias.grad, br.grad) < 2 * tol
+    assert rel_l2(rd.grad, rr.grad.permute(0, 2, 3, 1).reshape(-1, Cout)) < 2 * tol
+    if not nchw_in:
+        assert rel_l2(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)) < 2 * tol
+
+
+def test_maxpool_first_max_and_eval_bn(dvt, device):
+    g = torch.Generator().manual_seed(32)
+    N, C, H, W = 2, 8, 9, 11
+    x = torch.relu(torch.randn(N, C, H, W, generator=g))          # many exact zeros -> ties
+    xr = x.clone().requires_grad_(True)
+    ref = TF.max_pool2d(xr, 3, 2, 1)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda().requires_grad_(True)
+    y = dvt.functional.maxpool_nhwc(xd, N, C, H, W, 3, 2, 1)
+    assert torch.equal(y.cpu(), ref.permute(0, 2, 3, 1).reshape(-1, C))
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    y.backward(gy.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda())
+    assert torch.allclose(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, C), atol=1e-6)
+    # eval-mode BatchNorm uses the running statistics
+    conv = torch.nn.Conv2d(8, 8, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(8, generator=g)); bn.running_var.copy_(torch.rand(8, generator=g) + 0.5)
+    refe = torch.relu(bn(conv(x)))
+    ye = dvt.functional.conv_bn_act(xd.detach(), conv.cuda(), bn.cuda(), (N, 8, H, W, False), relu=True,
+                                    dtype=torch.float32)
+    assert rel_l2(ye, refe.permute(0, 2, 3, 1).reshape(-1, 8)) < 1e-5
+
+
+# bf16: 17 stacked conv+BN layers; the deepest scale (x4) accumulates ~4e-2 relative error
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 7e-2, 5e-1)])
+def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, tol_g):
+    """custom_resnet.resnet18 at 224x224, train mode, vs the imported reference."""
+    from dvt_amd.models.custom_resnet import resnet18
+    g = golden("resnet18_pyramid.npz")
+    net = resnet18(False, compute_dtype=dtype)
+    rng = np.random.default_rng(int(g["seed"]))
+    fill_resnet_from_numpy(net, rng)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 224, 224)).astype(np.float32))
+    net = net.cuda().train()
+    x2, x3, x4 = net(x.cuda())
+    assert x2.shape == (2, 128, 28, 28) and x3.shape == (2, 256, 14, 14) and x4.shape == (2, 512, 7, 7)
+    errs = [rel_l2(t, T(g[k])) for t, k in ((x2, "x2"), (x3, "x3"), (x4, "x4"))]
+    print(f"[resnet18/{dtype}] pyramid rel errors {errs}")
+    assert max(errs) < tol_out
+    gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (x2, x3, x4)]
+    # the scalar of the fixture: sum_i <x_i, g_i> / 1000  -> gradient g_i / 1000 on each output
+    torch.autograd.backward([x2, x3, x4], [gg.to(t.dtype).cuda() / 1000.0 for t, gg in zip((x2, x3, x4), gs)])
+    P = dict(net.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("g:"):
+            e = rel_l2(P[k[2:]].grad, T(g[k]))
+            worst = max(worst, e)
+            assert e < tol_g, (k, e)
+            # direction of the gradient (bf16 storage of 17 BatchNorm'd layers with batch-of-2
+            # statistics is noisy in magnitude at the stem, not in direction)
+            a, b = P[k[2:]].grad.double().cpu().reshape(-1), T(g[k]).double().reshape(-1)
+            assert float(a @ b / (a.norm() * b.norm())) > (0.9999 if dtype == torch.float32 else 0.90), k
+    names, norms = list(g["grad_names"]), g["grad_norms"]
+    for n, ref_norm in zip(names, norms):
+        got = float(P[str(n)].grad.double().norm())
+        assert abs(got - ref_norm) <= (0.02 if dtype == torch.float32 else 0.25) * ref_norm + 1e-6, n
+    print(f"[resnet18/{dtype}] worst stored-grad rel {worst:.2e}")
+    assert torch.allclose(net.bn1.running_mean.cpu(), T(g["rm:bn1"]), atol=1e-4 if dtype == torch.float32 else 2e-2)
+    assert P["fc.weight"].grad is None          # the reference's avgpool+fc tail is dead code

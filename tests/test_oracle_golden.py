@@ -112,3 +112,32 @@ def test_losses_against_torch():
     t = torch.randn(5, 19, dtype=torch.float64)
     ref = torch.nn.CrossEntropyLoss()(z, t.argmax(-1))
     assert abs(float(O.cross_entropy_hard(z, t)) - float(ref)) < 1e-12
+
+
+def test_resnet18_pyramid_oracle_matches_reference():
+    """oracle/cnn_path.py vs the imported reference custom_resnet.resnet18 (224x224, train mode)."""
+    from oracle import cnn_path as C
+    from tests.util import fill_resnet_from_numpy
+    g = golden("resnet18_pyramid.npz")
+    import dvt_amd
+    from dvt_amd.models.custom_resnet import resnet18
+    net = resnet18(False)                              # parameter container with the reference's keys/order
+    rng = np.random.default_rng(int(g["seed"]))
+    fill_resnet_from_numpy(net, rng)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 224, 224)).astype(np.float32))
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k in list(P):
+        if P[k].dtype.is_floating_point and "running" not in k:
+            P[k].requires_grad_(True)
+    x2, x3, x4, stats = C.resnet_pyramid(x, P, [2, 2, 2, 2], True)
+    for t, k in ((x2, "x2"), (x3, "x3"), (x4, "x4")):
+        assert rel_l2(t, T(g[k])) < 1e-5, k
+    gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (x2, x3, x4)]
+    loss = sum((t * gg).sum() for t, gg in zip((x2, x3, x4), gs)) / 1000.0
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-4
+    loss.backward()
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_l2(P[k[2:]].grad, T(g[k])) < 1e-4, k
+    assert torch.allclose(stats["bn1."][0], T(g["rm:bn1"]), atol=1e-6)
+    assert torch.allclose(stats["layer4.1.bn2."][1], T(g["rv:layer4.1.bn2"]), rtol=1e-4, atol=1e-6)

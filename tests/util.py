@@ -35,6 +35,24 @@ def fill_state_from_numpy(named_params, seed: int) -> None:
             p.copy_(torch.from_numpy(a).to(p.dtype))
 
 
+def fill_resnet_from_numpy(net, rng) -> None:
+    """Parameter fill shared by tools/gen_golden.py (reference ResNet) and the tests (the build's
+    mirror): He-scaled conv weights, 0.02 n for fc, 1 + 0.1 n BN scales, 0.1 n shifts, consumed in
+    ``named_parameters()`` order from one numpy Generator."""
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            a = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+            if p.dim() == 4:
+                a *= np.float32(np.sqrt(2.0 / (p.shape[0] * p.shape[2] * p.shape[3])))
+            elif p.dim() == 2:
+                a *= np.float32(0.02)
+            elif name.endswith("weight"):
+                a = 1 + np.float32(0.1) * a
+            else:
+                a = np.float32(0.1) * a
+            p.copy_(torch.from_numpy(a).to(p.dtype))
+
+
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().double().cpu().reshape(-1)
     b = b.detach().double().cpu().reshape(-1)

@@ -46,7 +46,7 @@ def _np(d):
 
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import fill_state_from_numpy  # noqa: E402  (shared with the tests)
+from tests.util import fill_state_from_numpy, fill_resnet_from_numpy  # noqa: E402  (shared with the tests)
 
 
 def fill_from_numpy(model: torch.nn.Module, seed: int) -> None:
@@ -169,6 +169,42 @@ def posenc_case():
     print("posenc: ok")
 
 
+def resnet_case():
+    """Reference custom_resnet.resnet18 at 224x224 (the only size its fixed AvgPool2d(7) admits),
+    train mode (BatchNorm batch statistics), batch 2.  Weights/inputs come from numpy streams and are
+    not stored; stored: the pyramid (x2, x3, x4), a few small gradients, gradient norms of every
+    parameter, and two updated running statistics."""
+    cr = _load("ref_custom_resnet", os.path.join(REF, "custom_resnet.py"))
+    net = cr.resnet18(False)
+    rng = np.random.default_rng(SEED + 20)
+    fill_resnet_from_numpy(net, rng)
+    net.train()
+    x = torch.from_numpy(rng.standard_normal((2, 3, 224, 224)).astype(np.float32))
+    x2, x3, x4 = net(x)
+    gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (x2, x3, x4)]
+    loss = sum((t * g).sum() for t, g in zip((x2, x3, x4), gs)) / 1000.0
+    loss.backward()
+    out = {"seed": np.array(SEED + 20), "x2": x2.detach().numpy(), "x3": x3.detach().numpy(),
+           "x4": x4.detach().numpy(), "loss": loss.detach().numpy()[None]}
+    keep = ["conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight",
+            "layer2.0.downsample.1.weight", "layer4.1.bn2.weight", "layer4.1.bn2.bias", "layer3.1.conv2.weight"]
+    names, norms = [], []
+    for name, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(name)
+        norms.append(float(p.grad.double().norm()))
+        if name in keep and p.grad.numel() < 700000:
+            out["g:" + name] = p.grad.numpy()
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms)
+    out["rm:bn1"] = net.bn1.running_mean.numpy(); out["rv:bn1"] = net.bn1.running_var.numpy()
+    out["rm:layer4.1.bn2"] = net.layer4[1].bn2.running_mean.numpy()
+    out["rv:layer4.1.bn2"] = net.layer4[1].bn2.running_var.numpy()
+    np.savez_compressed(os.path.join(OUT, "resnet18_pyramid.npz"), **out)
+    print("resnet18_pyramid: x2", tuple(x2.shape), "x3", tuple(x3.shape), "x4", tuple(x4.shape), "loss", float(loss))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -181,6 +217,7 @@ def main():
     block_cases(vit)
     encoder_layer_case()
     posenc_case()
+    resnet_case()
 
 
 if __name__ == "__main__":
