@@ -71,8 +71,8 @@ SIGNATURES = {
     "dvt_tokens_assemble_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_rows_gather_fwd": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_rows_gather_bwd": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
-    "dvt_mean_rows_fwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
-    "dvt_mean_rows_bwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_mean_rows_fwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    "dvt_mean_rows_bwd": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     "dvt_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                   c_i64, c_f, c_int, c_p]),
     "dvt_layernorm_bwd_workspace_bytes": (C.c_size_t, [c_i64]),

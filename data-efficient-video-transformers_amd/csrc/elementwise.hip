@@ -131,7 +131,10 @@ __global__ void act_kernel(const T* __restrict__ dy, const T* __restrict__ x, T*
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = to_f32<T>(x[i]);
     float r;
-    if (FWD) r = act == 1 ? gelu_erf_f(v) : fmaxf(v, 0.f);
+    if (act == 3) {                       // sigmoid (TPN.py:99)
+      const float sg = 1.0f / (1.0f + __expf(-v));
+      r = FWD ? sg : to_f32<T>(dy[i]) * sg * (1.0f - sg);
+    } else if (FWD) r = act == 1 ? gelu_erf_f(v) : fmaxf(v, 0.f);
     else r = to_f32<T>(dy[i]) * (act == 1 ? gelu_erf_grad_f(v) : (v > 0.f ? 1.f : 0.f));
     out[i] = from_f32<T>(r);
   }
@@ -369,9 +372,8 @@ __global__ void rows_gather_bwd_kernel(const T* __restrict__ dout, T* __restrict
 // ------------------------------------------------------------------ mean over rows
 template <typename T, bool FWD>
 __global__ void mean_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B, int64_t Ln,
-                                 int64_t d) {
+                                 int64_t d, float inv) {
   const int64_t dv = d >> 3;
-  const float inv = 1.0f / (float)Ln;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (FWD) {
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < B * dv; it += stride) {
@@ -527,7 +529,7 @@ int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_s
 }
 
 int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && y && n >= 0 && (act == 1 || act == 2), "dvt_act_fwd: bad arguments");
+  DVT_REQUIRE(x && y && n >= 0 && act >= 1 && act <= 3, "dvt_act_fwd: bad arguments");
   if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
@@ -539,7 +541,7 @@ int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_strea
 
 int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
                 dvt_stream_t stream) {
-  DVT_REQUIRE(dy && x && dx && n >= 0 && (act == 1 || act == 2), "dvt_act_bwd: bad arguments");
+  DVT_REQUIRE(dy && x && dx && n >= 0 && act >= 1 && act <= 3, "dvt_act_bwd: bad arguments");
   if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
@@ -785,7 +787,7 @@ int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, fl
   return DVT_OK;
 }
 
-int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, int dtype,
+int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, float scale, int dtype,
                       dvt_stream_t stream) {
   DVT_REQUIRE(x && out && B >= 0 && L > 0 && d > 0 && d % 8 == 0, "dvt_mean_rows_fwd: bad arguments");
   DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(out), "dvt_mean_rows_fwd: misaligned buffer");
@@ -793,12 +795,12 @@ int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d,
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL((mean_rows_kernel<T, true>), dim3(grid_for(B * (d >> 3))), dim3(kBlock), 0,
-                                        st, (const T*)x, (T*)out, B, L, d));
+                                        st, (const T*)x, (T*)out, B, L, d, scale));
   DVT_LAUNCH_CHECK("dvt_mean_rows_fwd");
   return DVT_OK;
 }
 
-int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, int dtype,
+int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, float scale, int dtype,
                       dvt_stream_t stream) {
   DVT_REQUIRE(dout && dx && B >= 0 && L > 0 && d > 0 && d % 8 == 0, "dvt_mean_rows_bwd: bad arguments");
   DVT_REQUIRE(dvt_aligned16(dout) && dvt_aligned16(dx), "dvt_mean_rows_bwd: misaligned buffer");
@@ -806,7 +808,7 @@ int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t 
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL((mean_rows_kernel<T, false>), dim3(grid_for(B * L * (d >> 3))),
-                                        dim3(kBlock), 0, st, (const T*)dout, (T*)dx, B, L, d));
+                                        dim3(kBlock), 0, st, (const T*)dout, (T*)dx, B, L, d, scale));
   DVT_LAUNCH_CHECK("dvt_mean_rows_bwd");
   return DVT_OK;
 }

@@ -666,18 +666,79 @@ def concat_rows(a: Tensor, b: Tensor) -> Tensor:
 
 class _MeanRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
-        ctx.L = x.shape[1]
-        return ops.mean_rows_fwd(x)
+    def forward(ctx, x, scale):
+        ctx.L, ctx.scale = x.shape[1], scale
+        return ops.mean_rows_fwd(x, scale)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.mean_rows_bwd(dy, ctx.L)
+        return ops.mean_rows_bwd(dy, ctx.L, ctx.scale), None
 
 
 def mean_rows(x: Tensor) -> Tensor:
-    """x [B, L, d] -> mean over L (``x.mean(dim=1)``, vit.py:126)."""
-    return _MeanRows.apply(x)
+    """x [B, L, d] -> mean over L (``x.mean(dim=1)``, vit.py:126; global AvgPool2d, TPN.py:6,20,33)."""
+    return _MeanRows.apply(x, None)
+
+
+def sum_rows(x: Tensor) -> Tensor:
+    """x [B, L, d] -> sum over L (``sum_group``, TPN.py:64-72)."""
+    return _MeanRows.apply(x, 1.0)
+
+
+def sigmoid(x: Tensor) -> Tensor:
+    return _Act.apply(x, ops.ACT_SIGMOID)
+
+
+class _ConcatCols(torch.autograd.Function):
+    """cat(tensors, dim=-1) of [rows, d_i] matrices (TPN.py:58), device copies only."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        rows = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        out = torch.empty((rows, sum(widths)), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        for x, w in zip(xs, widths):
+            ops.copy2d(x.contiguous(), out[:, off:], rows, w, w, out.shape[1])
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        rows, tot = dy.shape
+        outs, off = [], 0
+        for w in ctx.widths:
+            g = torch.empty((rows, w), dtype=dy.dtype, device=dy.device)
+            ops.copy2d(dy[:, off:], g, rows, w, tot, w)
+            outs.append(g)
+            off += w
+        return tuple(outs)
+
+
+def concat_cols(*xs: Tensor) -> Tensor:
+    return _ConcatCols.apply(*xs)
+
+
+class _ScaleF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        ops.axpby_f32_(out.view(-1), x.contiguous().view(-1), alpha, 0.0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        out = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        ops.axpby_f32_(out.view(-1), dy.contiguous().view(-1), ctx.alpha, 0.0)
+        return out, None
+
+
+def scale_f32(x: Tensor, alpha: float) -> Tensor:
+    """alpha * x as fp32 (the average of the three scale predictions, TPN.py:112)."""
+    return _ScaleF32.apply(x, alpha)
 
 
 class _Permute021(torch.autograd.Function):

@@ -146,7 +146,7 @@ def axpby_f32_(dst: Tensor, src: Tensor, alpha: float = 1.0, beta: float = 1.0) 
     return dst
 
 
-ACT_GELU, ACT_RELU = 1, 2
+ACT_GELU, ACT_RELU, ACT_SIGMOID = 1, 2, 3
 
 
 def act_fwd(x: Tensor, act: int) -> Tensor:
@@ -249,22 +249,25 @@ def rows_gather_bwd(dout: Tensor, dsrc: Tensor, row_stride: int, want_tok: bool,
     return dtok
 
 
-def mean_rows_fwd(x: Tensor) -> Tensor:
-    """[B, L, d] -> [B, d] mean over L."""
+def mean_rows_fwd(x: Tensor, scale: Optional[float] = None) -> Tensor:
+    """[B, L, d] -> [B, d]: scale * sum over L (default scale 1/L = mean)."""
     _need_cuda(x)
     x = x.contiguous()
     B, Ln, d = x.shape
     out = torch.empty((B, d), dtype=x.dtype, device=x.device)
-    L.check(L.load().dvt_mean_rows_fwd(x.data_ptr(), out.data_ptr(), B, Ln, d, dt(x), _stream()), "dvt_mean_rows_fwd")
+    sc = 1.0 / Ln if scale is None else scale
+    L.check(L.load().dvt_mean_rows_fwd(x.data_ptr(), out.data_ptr(), B, Ln, d, sc, dt(x), _stream()),
+            "dvt_mean_rows_fwd")
     return out
 
 
-def mean_rows_bwd(dout: Tensor, Ln: int) -> Tensor:
+def mean_rows_bwd(dout: Tensor, Ln: int, scale: Optional[float] = None) -> Tensor:
     _need_cuda(dout)
     dout = dout.contiguous()
     B, d = dout.shape
     dx = torch.empty((B, Ln, d), dtype=dout.dtype, device=dout.device)
-    L.check(L.load().dvt_mean_rows_bwd(dout.data_ptr(), dx.data_ptr(), B, Ln, d, dt(dout), _stream()),
+    sc = 1.0 / Ln if scale is None else scale
+    L.check(L.load().dvt_mean_rows_bwd(dout.data_ptr(), dx.data_ptr(), B, Ln, d, sc, dt(dout), _stream()),
             "dvt_mean_rows_bwd")
     return dx
 

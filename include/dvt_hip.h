@@ -79,7 +79,7 @@ int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float
                   dvt_stream_t stream);
 
 /* Stand-alone activations (the 3-layer GELU head, src/models/frame_transformer.py:106,
- * where no GEMM epilogue is worth fusing into).  act: 1 = GELU(erf), 2 = ReLU.
+ * where no GEMM epilogue is worth fusing into).  act: 1 = GELU(erf), 2 = ReLU, 3 = sigmoid (TPN.py:99).
  * fwd: y = act(x);  bwd: dx = dy * act'(x). */
 int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_stream_t stream);
 int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
@@ -123,12 +123,13 @@ int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, fl
                         int64_t B, int64_t T, int64_t d, int dtype, int accumulate,
                         dvt_stream_t stream);
 
-/* Mean over the middle dimension: out[b, :] = (1/L) sum_j x[b, j, :]  (`x.mean(dim=1)`,
- * pool == 'mean', src/models/vit.py:126; global average pooling of frame features).
- * bwd: dx[b, j, :] = dout[b, :] / L. */
-int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, int dtype,
+/* Scaled sum over the middle dimension: out[b, :] = scale * sum_j x[b, j, :].  scale = 1/L is
+ * `x.mean(dim=1)` (pool == 'mean', src/models/vit.py:126) and the global AvgPool2d of the feature
+ * pyramid (src/models/TPN.py:6,20,33); scale = 1 is `sum_group` (TPN.py:64-72).
+ * bwd: dx[b, j, :] = scale * dout[b, :]. */
+int dvt_mean_rows_fwd(const void* x, void* out, int64_t B, int64_t L, int64_t d, float scale, int dtype,
                       dvt_stream_t stream);
-int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, int dtype,
+int dvt_mean_rows_bwd(const void* dout, void* dx, int64_t B, int64_t L, int64_t d, float scale, int dtype,
                       dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- LayerNorm

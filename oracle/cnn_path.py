@@ -51,3 +51,30 @@ def resnet_pyramid(x: Tensor, P: Dict[str, Tensor], layers: List[int], training:
             x = basic_block(x, P, f"layer{li + 1}.{b}.", stride, training, stats)
         feats.append(x)
     return feats[1], feats[2], feats[3], stats
+
+
+# --------------------------------------------------------------------------
+# Pyramid head and temporal grouping (src/models/TPN.py)
+# --------------------------------------------------------------------------
+def pyramid_vector(feat: Tensor, w=None, b=None) -> Tensor:
+    """Feature_Pyramid_*: global AvgPool2d over the whole map (k = 28 / 14 / 7, TPN.py:6,20,33) then an
+    optional 1x1 convolution on the pooled vector (TPN.py:8,35); ``high`` has none (TPN.py:24-26)."""
+    v = feat.mean(dim=(2, 3))
+    if w is not None:
+        v = v @ w.reshape(w.shape[0], -1).t() + b
+    return v
+
+
+def reasoning(x: Tensor, P: Dict[str, Tensor], start: int = 2, max_group: int = 4) -> Tensor:
+    """Reasoning.forward (TPN.py:106-112), eval mode: for g in 2..4: sum_group -> ReLU -> Linear ->
+    ReLU -> Linear -> ReLU -> Linear -> Sigmoid; mean of the three predictions."""
+    from .clip_path import sum_group, linear
+    pred = 0
+    for g in range(start, max_group + 1):
+        p = f"relation.{g - start}."
+        s = sum_group(x, g)
+        s = linear(torch.relu(s), P[p + "1.weight"], P[p + "1.bias"])
+        s = linear(torch.relu(s), P[p + "4.weight"], P[p + "4.bias"])
+        s = torch.sigmoid(linear(torch.relu(s), P[p + "7.weight"], P[p + "7.bias"]))
+        pred = pred + s
+    return pred / (max_group - start + 1)

@@ -124,3 +124,56 @@ def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, 
     print(f"[resnet18/{dtype}] worst stored-grad rel {worst:.2e}")
     assert torch.allclose(net.bn1.running_mean.cpu(), T(g["rm:bn1"]), atol=1e-4 if dtype == torch.float32 else 2e-2)
     assert P["fc.weight"].grad is None          # the reference's avgpool+fc tail is dead code
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_tpn_pyramid_and_reasoning_match_reference(dvt, device, dtype, tol):
+    """pyramid pooling + 1x1 conv, sum_group, Reasoning MLPs vs the golden produced
+    by executing the reference's TPN.py."""
+    from dvt_amd.models.TPN import Reasoning, Feature_Pyramid_low, Feature_Pyramid_Mid, Feature_Pyramid_High, sum_group
+    g = golden("tpn_pieces.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    reason = Reasoning()
+    fill_resnet_from_numpy(reason, rng)
+    x = torch.from_numpy(rng.standard_normal((1, 20, 896)).astype(np.float32))
+    reason = reason.cuda().eval()
+    xd = x.to(dtype).cuda().requires_grad_(True)
+    y = reason(xd)
+    assert y.shape == (1, 15) and rel_l2(y, T(g["reason_out"])) < tol
+    gy = torch.from_numpy(rng.standard_normal((1, 15)).astype(np.float32))
+    y.backward(gy.cuda())
+    # bf16: ReLU masks of near-zero group sums flip under rounding -> input-gradient noise
+    assert rel_l2(xd.grad, T(g["reason_gx"])) < (3 * tol if dtype == torch.float32 else 0.15)
+    assert rel_l2(reason.relation[2][7].weight.grad, T(g["reason_gw_last"])) < 3 * tol
+    assert rel_l2(sum_group(x.to(dtype).cuda(), 3), T(g["sum_group3"])) < tol
+    with pytest.raises(NotImplementedError, match="Dropout"):
+        reason.train()(xd)
+    for name, cls, shape in (("low", Feature_Pyramid_low, (3, 128, 28, 28)), ("mid", Feature_Pyramid_Mid, (3, 256, 14, 14)),
+                             ("high", Feature_Pyramid_High, (3, 512, 7, 7))):
+        m = cls()
+        fill_resnet_from_numpy(m, rng)
+        f = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        N, C, H, W = shape
+        fm = (f.to(dtype).permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda(), N, H, W)
+        assert rel_l2(m.cuda()(fm), T(g["pyr_" + name])) < tol, name
+
+
+def test_tpn_end_to_end_tokens(dvt, device):
+    """TPN.frame_tokens on 20 frames (fp32 mode) vs the oracle composition resnet34 -> pyramid -> cat."""
+    from oracle import cnn_path as C
+    from dvt_amd.models.TPN import TPN
+    torch.manual_seed(5)
+    net = TPN(compute_dtype=torch.float32)
+    rng = np.random.default_rng(77)
+    fill_resnet_from_numpy(net, rng)
+    x = torch.from_numpy(rng.standard_normal((4, 3, 224, 224)).astype(np.float32))
+    P = {k: v.detach().clone() for k, v in net.net.state_dict().items()}
+    with torch.no_grad():
+        x2, x3, x4, _ = C.resnet_pyramid(x, P, [3, 4, 6, 3], True)
+        sd = net.state_dict()
+        ref = torch.cat((C.pyramid_vector(x4),
+                         C.pyramid_vector(x3, sd["pyramid_mid.channels_reduce.weight"], sd["pyramid_mid.channels_reduce.bias"]),
+                         C.pyramid_vector(x2, sd["pyramid_low.channels_reduce.weight"], sd["pyramid_low.channels_reduce.bias"])), dim=-1)
+    net = net.cuda().train()
+    tok = net.frame_tokens(x.cuda())
+    assert tok.shape == (4, 896) and rel_l2(tok, ref) < 2e-4

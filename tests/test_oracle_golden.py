@@ -141,3 +141,32 @@ def test_resnet18_pyramid_oracle_matches_reference():
             assert rel_l2(P[k[2:]].grad, T(g[k])) < 1e-4, k
     assert torch.allclose(stats["bn1."][0], T(g["rm:bn1"]), atol=1e-6)
     assert torch.allclose(stats["layer4.1.bn2."][1], T(g["rv:layer4.1.bn2"]), rtol=1e-4, atol=1e-6)
+
+
+def test_tpn_pieces_oracle_matches_reference():
+    """Reasoning / sum_group / Feature_Pyramid_* restatements vs the reference source executed with its
+    missing imports supplied (tools/gen_golden.py::tpn_case)."""
+    from oracle import cnn_path as C
+    from tests.util import fill_resnet_from_numpy
+    import dvt_amd
+    from dvt_amd.models.TPN import Reasoning, Feature_Pyramid_low, Feature_Pyramid_Mid, Feature_Pyramid_High
+    g = golden("tpn_pieces.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    reason = Reasoning()
+    fill_resnet_from_numpy(reason, rng)
+    x = torch.from_numpy(rng.standard_normal((1, 20, 896)).astype(np.float32)).requires_grad_(True)
+    P = {k: v.detach() for k, v in reason.state_dict().items()}
+    y = C.reasoning(x, P)
+    assert rel_l2(y, T(g["reason_out"])) < 1e-6
+    gy = torch.from_numpy(rng.standard_normal((1, 15)).astype(np.float32))
+    gx = torch.autograd.grad((y * gy).sum(), x)[0]
+    assert rel_l2(gx, T(g["reason_gx"])) < 1e-5
+    assert torch.allclose(O.sum_group(x.detach(), 3), T(g["sum_group3"]), atol=1e-6)
+    for name, cls, shape in (("low", Feature_Pyramid_low, (3, 128, 28, 28)), ("mid", Feature_Pyramid_Mid, (3, 256, 14, 14)),
+                             ("high", Feature_Pyramid_High, (3, 512, 7, 7))):
+        m = cls()
+        fill_resnet_from_numpy(m, rng)
+        f = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        sd = m.state_dict()
+        w, b = (None, None) if name == "high" else (sd["channels_reduce.weight"], sd["channels_reduce.bias"])
+        assert rel_l2(C.pyramid_vector(f, w, b), T(g["pyr_" + name])) < 1e-5, name

@@ -205,6 +205,36 @@ def resnet_case():
     print("resnet18_pyramid: x2", tuple(x2.shape), "x3", tuple(x3.shape), "x4", tuple(x4.shape), "loss", float(loss))
 
 
+def tpn_case():
+    """src/models/TPN.py has no import statements (NameError on import).  Its source is executed here
+    with the missing names supplied (torch, nn, a LightningModule stand-in, the reference's own
+    custom_resnet) so that Reasoning / sum_group / Feature_Pyramid_* run as written.  TPN() itself is not
+    instantiated (it downloads pretrained weights)."""
+    class _PL:
+        LightningModule = torch.nn.Module
+    ns = {"torch": torch, "nn": torch.nn, "pl": _PL, "custom_resnet": _load("ref_custom_resnet2", os.path.join(REF, "custom_resnet.py"))}
+    exec(compile(open(os.path.join(REF, "TPN.py")).read(), "TPN.py", "exec"), ns)
+    rng = np.random.default_rng(SEED + 30)
+    out = {"seed": np.array(SEED + 30)}
+    reason = ns["Reasoning"]().eval()
+    fill_resnet_from_numpy(reason, rng)                    # Linear weights 0.02 n, biases 0.1 n
+    x = torch.from_numpy(rng.standard_normal((1, 20, 896)).astype(np.float32)).requires_grad_(True)
+    y = reason(x)
+    gy = torch.from_numpy(rng.standard_normal((1, 15)).astype(np.float32))
+    (y * gy).sum().backward()
+    out["reason_out"] = y.detach().numpy(); out["reason_gx"] = x.grad.numpy()
+    out["reason_gw_last"] = reason.relation[2][7].weight.grad.numpy()
+    out["sum_group3"] = ns["sum_group"](x.detach(), 3).numpy()
+    for name, cls, shape in (("low", "Feature_Pyramid_low", (3, 128, 28, 28)), ("mid", "Feature_Pyramid_Mid", (3, 256, 14, 14)),
+                             ("high", "Feature_Pyramid_High", (3, 512, 7, 7))):
+        m = ns[cls]().eval()
+        fill_resnet_from_numpy(m, rng)
+        f = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        out["pyr_" + name] = m(f).squeeze().detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "tpn_pieces.npz"), **out)
+    print("tpn_pieces: reasoning out", tuple(y.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -218,6 +248,7 @@ def main():
     encoder_layer_case()
     posenc_case()
     resnet_case()
+    tpn_case()
 
 
 if __name__ == "__main__":
