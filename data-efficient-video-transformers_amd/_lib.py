@@ -85,8 +85,9 @@ SIGNATURES = {
     "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "dvt_attention_fwd": (c_int, [C.POINTER(AttnDesc), c_p]),
     "dvt_attention_bwd": (c_int, [C.POINTER(AttnDesc), c_p]),
-    "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 7 + [c_i64, c_p]),
-    "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 7 + [c_i64, c_int, c_p]),
+    "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
+    "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 9 + [c_i64, c_int, c_p]),
+    "dvt_col2im_nchw": (c_int, [c_p, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
     "dvt_conv_weight_pack": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_i64, c_p]),
     "dvt_conv_weight_unpack_grad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p]),
     "dvt_bn_workspace_bytes": (C.c_size_t, [c_i64, c_int]),

@@ -26,7 +26,7 @@ inline int cgrid(int64_t items) {
 // columns [kh*kw*C, ld) are zero (K padding for the MFMA kernels).
 template <typename S, typename D, bool NCHW>
 __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int N, int C, int H, int W,
-                              int kh, int kw, int stride, int pad, int Ho, int Wo, int64_t ld) {
+                              int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int64_t ld) {
   const int64_t rows = (int64_t)N * Ho * Wo;
   const int K = kh * kw * C;
   const int64_t total = rows * ld;
@@ -39,7 +39,7 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
       const int c = col % C, kk = col / C, kj = kk % kw, ki = kk / kw;
       const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
       const int64_t n = r / ((int64_t)Wo * Ho);
-      const int h = ho * stride - pad + ki, w = wo * stride - pad + kj;
+      const int h = ho * sh - ph + ki, w = wo * sw - pw + kj;
       if (h >= 0 && h < H && w >= 0 && w < W)
         v = to_f32<S>(NCHW ? x[((n * C + c) * H + h) * W + w] : x[((n * H + h) * W + w) * C + c]);
     }
@@ -50,7 +50,7 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
 // vectorised NHWC form: C % 8 == 0, one thread copies 8 channels of one (row, ki, kj)
 template <typename T>
 __global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C, int H,
-                                       int W, int kh, int kw, int stride, int pad, int Ho, int Wo,
+                                       int W, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
                                        int64_t ld) {
   const int cv = C >> 3;
   const int64_t rows = (int64_t)N * Ho * Wo;
@@ -64,7 +64,7 @@ __global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ 
     const int kj = kk % kw, ki = kk / kw;
     const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
     const int64_t n = r / ((int64_t)Wo * Ho);
-    const int h = ho * stride - pad + ki, w = wo * stride - pad + kj;
+    const int h = ho * sh - ph + ki, w = wo * sw - pw + kj;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (h >= 0 && h < H && w >= 0 && w < W) load8<T>(x + ((n * H + h) * W + w) * C + c, v);
     store8<T>(out + r * ld + (int64_t)kk * C + c, v);
@@ -75,7 +75,8 @@ __global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ 
 //               dcol[(n, (h+p-ki)/s, (w+p-kj)/s), (ki*kw+kj)*C + c]        (gather form: no atomics)
 template <typename T>
 __global__ void col2im_nhwc_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int C, int H,
-                                   int W, int kh, int kw, int stride, int pad, int Ho, int Wo, int64_t ld) {
+                                   int W, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
+                                   int64_t ld) {
   const int cv = C >> 3;
   const int64_t items = (int64_t)N * H * W * cv;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
@@ -86,14 +87,14 @@ __global__ void col2im_nhwc_kernel(const T* __restrict__ dcol, T* __restrict__ d
     const int64_t n = px / ((int64_t)W * H);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int ki = 0; ki < kh; ++ki) {
-      const int hh = h + pad - ki;
-      if (hh < 0 || hh % stride) continue;
-      const int ho = hh / stride;
+      const int hh = h + ph - ki;
+      if (hh < 0 || hh % sh) continue;
+      const int ho = hh / sh;
       if (ho >= Ho) continue;
       for (int kj = 0; kj < kw; ++kj) {
-        const int ww = w + pad - kj;
-        if (ww < 0 || ww % stride) continue;
-        const int wo = ww / stride;
+        const int ww = w + pw - kj;
+        if (ww < 0 || ww % sw) continue;
+        const int wo = ww / sw;
         if (wo >= Wo) continue;
         float v[8];
         load8<T>(dcol + ((n * Ho + ho) * Wo + wo) * ld + (int64_t)(ki * kw + kj) * C + c, v);
@@ -275,6 +276,97 @@ __global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
   }
 }
 
+// ------------------------------------------------------------------ scalar fallbacks (C % 8 != 0)
+// R(2+1)D mid-plane counts (45, 230, 460, 921) are not multiples of 8.  One thread per column.
+template <typename T, int MODE>
+__global__ void bn_colstats_scalar_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          int64_t rows, int C, int rows_per_block, int relu,
+                                          float* __restrict__ partial) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a = 0.f, b = 0.f;
+  const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float xv = to_f32<T>(x[r * C + c]);
+    if (MODE == 0) { a += xv; b = fmaf(xv, xv, b); }
+    else {
+      float dz = to_f32<T>(dy[r * C + c]);
+      if (relu && !(to_f32<T>(y[r * C + c]) > 0.f)) dz = 0.f;
+      a += dz;
+      b = fmaf(dz, (xv - mu) * is, b);
+    }
+  }
+  partial[((int64_t)blockIdx.y * 2 + 0) * C + c] = a;
+  partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = b;
+}
+
+template <typename T>
+__global__ void bn_apply_fwd_scalar_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, const T* __restrict__ residual,
+                                           T* __restrict__ y, int64_t rows, int C, int relu) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = fmaf((to_f32<T>(x[i]) - mean[c]) * invstd[c], gamma[c], beta[c]);
+    if (residual) v += to_f32<T>(residual[i]);
+    y[i] = from_f32<T>(relu ? fmaxf(v, 0.f) : v);
+  }
+}
+
+template <typename T>
+__global__ void bn_apply_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                           const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
+                                           int64_t rows, int C, int relu, int training, float inv_rows) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float dz = to_f32<T>(dy[i]);
+    if (relu && !(to_f32<T>(y[i]) > 0.f)) dz = 0.f;
+    const float xh = (to_f32<T>(x[i]) - mean[c]) * invstd[c];
+    const float o = training ? gamma[c] * invstd[c] * (dz - dbeta[c] * inv_rows - xh * dgamma[c] * inv_rows)
+                             : gamma[c] * invstd[c] * dz;
+    dx[i] = from_f32<T>(o);
+    if (dres) dres[i] = from_f32<T>(dz);
+  }
+}
+
+template <typename T, typename D, bool NCHW>
+__global__ void col2im_scalar_kernel(const T* __restrict__ dcol, D* __restrict__ dx, int N, int C, int H, int W,
+                                     int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int64_t ld) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c, w, h;
+    int64_t n;
+    if (NCHW) {   // i enumerates dx in NCHW order
+      w = (int)(i % W); h = (int)((i / W) % H); c = (int)((i / ((int64_t)W * H)) % C); n = i / ((int64_t)W * H * C);
+    } else {
+      c = (int)(i % C);
+      const int64_t px = i / C;
+      w = (int)(px % W); h = (int)((px / W) % H); n = px / ((int64_t)W * H);
+    }
+    float acc = 0.f;
+    for (int ki = 0; ki < kh; ++ki) {
+      const int hh = h + ph - ki;
+      if (hh < 0 || hh % sh) continue;
+      const int ho = hh / sh;
+      if (ho >= Ho) continue;
+      for (int kj = 0; kj < kw; ++kj) {
+        const int ww = w + pw - kj;
+        if (ww < 0 || ww % sw) continue;
+        const int wo = ww / sw;
+        if (wo >= Wo) continue;
+        acc += to_f32<T>(dcol[((n * Ho + ho) * Wo + wo) * ld + (int64_t)(ki * kw + kj) * C + c]);
+      }
+    }
+    dx[i] = from_f32<D>(acc);
+  }
+}
+
 // ------------------------------------------------------------------ max pool (NHWC), first max wins
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
@@ -351,11 +443,11 @@ __global__ void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst,
 extern "C" {
 
 int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
-               int W, int kh, int kw, int stride, int pad, int64_t ld, dvt_stream_t stream) {
-  DVT_REQUIRE(x && out && N >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+               int W, int kh, int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream) {
+  DVT_REQUIRE(x && out && N >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
               "dvt_im2col: bad arguments");
   DVT_REQUIRE(ld >= (int64_t)kh * kw * C, "dvt_im2col: ld smaller than kh*kw*C");
-  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   DVT_REQUIRE(Ho > 0 && Wo > 0, "dvt_im2col: empty output");
   if (N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -365,14 +457,14 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
   if (vec) {
     DVT_DISPATCH_DTYPE(x_dtype, T, hipLaunchKernelGGL((im2col_nhwc_vec_kernel<T>), dim3(cgrid(rows * kh * kw * (C >> 3))),
                                                       dim3(kB), 0, st, (const T*)x, (T*)out, (int)N, C, H, W, kh, kw,
-                                                      stride, pad, Ho, Wo, ld));
+                                                      sh, sw, ph, pw, Ho, Wo, ld));
   } else {
 #define DVT_IM2COL_CASE(SD, S, DD, D)                                                                        \
   if (x_dtype == SD && out_dtype == DD) {                                                                    \
     if (x_nchw) hipLaunchKernelGGL((im2col_kernel<S, D, true>), dim3(cgrid(rows * ld)), dim3(kB), 0, st,     \
-                                   (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, stride, pad, Ho, Wo, ld);  \
+                                   (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, ld);  \
     else hipLaunchKernelGGL((im2col_kernel<S, D, false>), dim3(cgrid(rows * ld)), dim3(kB), 0, st,           \
-                            (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, stride, pad, Ho, Wo, ld);         \
+                            (const S*)x, (D*)out, (int)N, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, ld);         \
     DVT_LAUNCH_CHECK("dvt_im2col");                                                                          \
     return DVT_OK;                                                                                           \
   }
@@ -387,16 +479,45 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
   return DVT_OK;
 }
 
-int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int stride, int pad,
-               int64_t ld, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "dvt_col2im: bad arguments (C, ld %% 8)");
-  DVT_REQUIRE(dvt_aligned16(dcol) && dvt_aligned16(dx), "dvt_col2im: misaligned buffer");
-  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t N, int C, int H, int W, int kh,
+                    int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream) {
+  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "dvt_col2im_nchw: bad arguments");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   if (N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_nhwc_kernel<T>), dim3(cgrid(N * H * W * (C >> 3))), dim3(kB), 0,
-                                                  st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, stride, pad, Ho,
-                                                  Wo, ld));
+  const dim3 grid(cgrid(N * H * W * C)), block(kB);
+#define DVT_C2I_CASE(SD, S, DD, D)                                                                              \
+  if (dtype == SD && dx_dtype == DD) {                                                                          \
+    hipLaunchKernelGGL((col2im_scalar_kernel<S, D, true>), grid, block, 0, st, (const S*)dcol, (D*)dx, (int)N, C, H, \
+                       W, kh, kw, sh, sw, ph, pw, Ho, Wo, ld);                                                  \
+    DVT_LAUNCH_CHECK("dvt_col2im_nchw");                                                                        \
+    return DVT_OK;                                                                                              \
+  }
+  DVT_C2I_CASE(DVT_F32, float, DVT_F32, float)
+  DVT_C2I_CASE(DVT_BF16, bf16, DVT_F32, float)
+  DVT_C2I_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+  DVT_C2I_CASE(DVT_F32, float, DVT_BF16, bf16)
+#undef DVT_C2I_CASE
+  DVT_UNSUPPORTED("dvt_col2im_nchw: dtype pair (%d, %d)", dtype, dx_dtype);
+}
+
+int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
+               int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0, "dvt_col2im: bad arguments");
+  const bool cvec = C % 8 == 0 && ld % 8 == 0 && dvt_aligned16(dcol) && dvt_aligned16(dx);
+  DVT_REQUIRE(sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "dvt_col2im: bad stride / padding");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  if (N == 0) return DVT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (cvec) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_nhwc_kernel<T>), dim3(cgrid(N * H * W * (C >> 3))), dim3(kB), 0,
+                                                    st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, sh, sw, ph, pw,
+                                                    Ho, Wo, ld));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_scalar_kernel<T, T, false>), dim3(cgrid(N * H * W * C)), dim3(kB), 0,
+                                                    st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, sh, sw, ph, pw,
+                                                    Ho, Wo, ld));
+  }
   DVT_LAUNCH_CHECK("dvt_col2im");
   return DVT_OK;
 }
@@ -422,7 +543,7 @@ int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, in
 
 size_t dvt_bn_workspace_bytes(int64_t rows, int C) {
   (void)rows;
-  return ((size_t)256 * 2 + 2) * (size_t)C * sizeof(float);
+  return (((size_t)256 * 2 + 2) * (size_t)C + 8) * sizeof(float);
 }
 
 static int bn_parts(int64_t rows, int* rpb) {
@@ -434,15 +555,20 @@ static int bn_parts(int64_t rows, int* rpb) {
 
 int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
                  void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0 && C % 8 == 0, "dvt_bn_stats: bad arguments (C %% 8)");
-  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(workspace), "dvt_bn_stats: misaligned buffer");
+  DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0, "dvt_bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, &rpb);
   const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
-                                                  (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                  (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
+  if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(workspace)) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                    (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                    (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_stats");
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
   hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st,
@@ -462,12 +588,19 @@ int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps
 
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0 && C % 8 == 0, "dvt_bn_apply_fwd: bad arguments");
+  DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0, "dvt_bn_apply_fwd: bad arguments");
   if (rows == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                  (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
-                                                  rows, C, relu));
+  if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(residual) && dvt_aligned16(mean) &&
+      dvt_aligned16(invstd) && dvt_aligned16(gamma) && dvt_aligned16(beta)) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                    (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
+                                                    rows, C, relu));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
+                                                    (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
+                                                    rows, C, relu));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_apply_fwd");
   return DVT_OK;
 }
@@ -475,8 +608,11 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, int64_t rows,
                int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && C % 8 == 0,
+  DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
               "dvt_bn_bwd: bad arguments");
+  const bool cvec = C % 8 == 0 && dvt_aligned16(dy) && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(dx) &&
+                    dvt_aligned16(dres) && dvt_aligned16(mean) && dvt_aligned16(invstd) && dvt_aligned16(gamma) &&
+                    dvt_aligned16(workspace);
   DVT_REQUIRE(!relu || y, "dvt_bn_bwd: relu needs the forward output");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
@@ -484,17 +620,30 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
   float* part = (float*)workspace;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
-                                                  (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+  if (cvec) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(stats)");
-  float* loc = part + (size_t)parts * 2 * C;
+  // keep the local dgamma/dbeta 16-byte aligned behind the partials
+  float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
   hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st, (const float*)part,
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                  (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
-                                                  loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
-                                                  1.0f / (float)rows));
+  if (cvec) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                    (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
+                                                    loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
+                                                    1.0f / (float)rows));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
+                                                    (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
+                                                    loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
+                                                    1.0f / (float)rows));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(apply)");
   // publish dgamma / dbeta (overwrite or accumulate) from the local copy
   int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);

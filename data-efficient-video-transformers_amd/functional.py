@@ -833,13 +833,14 @@ class _ConvBnAct(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype):
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout = w.shape[0]
+        (kh, kw), (sh, sw) = ops._pair(k), ops._pair(stride)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        K = k * k * Cin
-        direct = (k == 1 and stride == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
+        K = kh * kw * Cin
+        direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
         ld = K if direct else _kpad(K, dtype)
         xc = x.contiguous()
         col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
-        wp = ops.conv_weight_pack(w, ld, dtype)
+        wp = ops.conv_weight_pack(w.reshape(Cout, Cin, kh, kw), ld, dtype)
         z = ops.linear_fwd(col, wp)                                     # [N*Ho*Wo, Cout]
         g32, b32 = _f32(gamma), _f32(beta)
         if training:
@@ -852,6 +853,7 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
+        ctx.x_shape, ctx.x_dtype = tuple(x.shape), x.dtype
         return y
 
     @staticmethod
@@ -870,19 +872,21 @@ class _ConvBnAct(torch.autograd.Function):
             dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
         col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
         dwp = ops.linear_wgrad(dz, col)                                  # [Cout, ld] fp32
+        (kh, kw) = ops._pair(k)
+        w4 = (Cout, Cin, kh, kw)
         if sw is not None:
-            ops.conv_weight_unpack_grad(dwp, wshape, out=sw.buf, accumulate=not sw.fresh)
+            ops.conv_weight_unpack_grad(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
             sw.mark_written()
             dw = None
         else:
-            dw = ops.conv_weight_unpack_grad(dwp, wshape)
+            dw = ops.conv_weight_unpack_grad(dwp, w4).view(wshape)
         dx = None
         if ctx.x_needs:
             dcol = ops.linear_dgrad(dz, wp)                              # [rows, ld]
             if direct:
                 dx = dcol
-            elif nchw:
-                raise NotImplementedError("gradient w.r.t. NCHW stem input (pixel-space CLS) is not built yet")
+            elif nchw:      # gradient w.r.t. the raw NCHW frames (pixel-space CLS clip, frame_transformer.py:105)
+                dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
         return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None
@@ -892,12 +896,40 @@ def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, rel
                 dtype=torch.bfloat16):
     """geom = (N, Cin, H, W, nchw).  Kernel size / stride / padding come from ``conv``."""
     N, Cin, H, W, nchw = geom
-    k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    assert conv.bias is None and conv.kernel_size[0] == conv.kernel_size[1] and conv.groups == 1
+    assert conv.bias is None and conv.groups == 1
+    return conv_bn_act_raw(x, conv.weight, bn, geom, tuple(conv.kernel_size), tuple(conv.stride),
+                           tuple(conv.padding), relu=relu, residual=residual, dtype=dtype)
+
+
+def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16):
+    """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
+    Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
+    (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
+    N, Cin, H, W, nchw = geom
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+    return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
                             (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype)
+
+
+class _Subsample(torch.autograd.Function):
+    """Strided spatial subsampling of an NHWC matrix (the gather of a strided 1x1 convolution)."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        N, Cc, H, W, stride = geom
+        ctx.geom = geom
+        return ops.im2col(x.contiguous(), False, N, Cc, H, W, 1, stride, 0, Cc, x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W, stride = ctx.geom
+        return ops.col2im(dy.contiguous(), N, Cc, H, W, 1, stride, 0), None
+
+
+def subsample_nhwc(x, N, Cc, H, W, stride):
+    """stride: int or (h, w).  Returns [N*Ho*Wo, C]."""
+    return _Subsample.apply(x, (N, Cc, H, W, stride))
 
 
 class _MaxPool(torch.autograd.Function):

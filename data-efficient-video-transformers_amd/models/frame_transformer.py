@@ -15,12 +15,12 @@ distillation losses, the CLS-clip concatenation, and the cross-modal ``sum`` /
 ``distil`` injection (the video CLS embedding joins the image tokens and they
 self-attend jointly).
 
-NOT built yet: the CNN encoders (R(2+1)D-18 ``VidResNet`` / ResNet-18 ``ImgResNet``,
-frame_transformer.py:50-74; torchvision + pretrained weights are unavailable offline and
-the implicit-GEMM conv kernels are a later round).  ``vid_encoder`` / ``img_encoder``
-are therefore injectable modules mapping chunks to 896-d embeddings; the default raises.
-``PatchLinearEncoder`` is a build-defined stand-in (patch embedding + mean pooling) used
-by tests and smoke runs.
+CNN encoders: ``ImgResNet`` (ResNet-18 -> 896, frozen) and ``VidResNet`` (R(2+1)D-18 -> 896) are built on
+the im2col + MFMA-GEMM + BatchNorm kernels (models/custom_resnet.py, models/video_resnet.py) with
+torchvision's state-dict key layout; ``pretrained=True`` needs the network, so they start from random
+weights unless a state dict is loaded, and the R(2+1)D block is parity-UNPINNED (torchvision is not
+installed; checked against a torch-CPU conv3d restatement).  ``vid_encoder`` / ``img_encoder`` remain
+injectable; ``PatchLinearEncoder`` is a light build-defined stand-in used by the small tests.
 
 Deviations from the literal reference text, all where the reference does not execute
 (SURVEY section 8a notes): missing ``img_cls`` / ``img_model`` / ``scene_transformer``
@@ -153,15 +153,47 @@ class PatchLinearEncoder(nn.Module):
         return F.linear(F.mean_rows(tokens), self.fc.weight, self.fc.bias)
 
 
+class ImgResNet(LightningModule):
+    """frame_transformer.py:50-61: ResNet-18 backbone with ``fc -> Sequential(Linear(512, 896))``, run under
+    ``torch.no_grad()`` (frozen).  ``pretrained=True`` of the reference needs the network; weights are
+    random unless a state dict (torchvision resnet18 key layout) is loaded."""
+
+    def __init__(self, compute_dtype=torch.bfloat16):
+        super(ImgResNet, self).__init__()
+        from .custom_resnet import resnet18
+        self.backbone = resnet18(False, compute_dtype=compute_dtype)
+        num_filters = self.backbone.fc.in_features
+        self.backbone.fc = nn.Sequential(nn.Linear(num_filters, 896))
+
+    def forward(self, x):
+        with torch.no_grad():
+            x4, N, H, W = self.backbone.forward_nhwc(x)[-1]
+            pooled = F.mean_rows(x4.view(N, H * W, x4.shape[1]))            # avgpool + flatten
+            fc = self.backbone.fc[0]
+            return F.linear(pooled, fc.weight, fc.bias)
+
+
+class VidResNet(LightningModule):
+    """frame_transformer.py:64-74: R(2+1)D-18 backbone with ``fc -> Sequential(Linear(512, 896))``, trainable."""
+
+    def __init__(self, compute_dtype=torch.bfloat16):
+        super(VidResNet, self).__init__()
+        from .video_resnet import r2plus1d_18
+        self.backbone = r2plus1d_18(False, compute_dtype=compute_dtype)
+        num_filters = self.backbone.fc.in_features
+        self.backbone.fc = nn.Sequential(nn.Linear(num_filters, 896))
+
+    def forward(self, x):
+        return self.backbone(x)
+
+
 class _MissingEncoder(nn.Module):
     def __init__(self, what):
         super().__init__()
         self.what = what
 
     def forward(self, x):
-        raise NotImplementedError(
-            f"{self.what} is not built yet (SURVEY section 8 rows a10-a12: the conv stacks need the "
-            "implicit-GEMM HIP kernels of a later round); pass vid_encoder= / img_encoder= to FrameTransformer")
+        raise NotImplementedError(f"{self.what}: pass vid_encoder= / img_encoder= to FrameTransformer")
 
 
 class FrameTransformer(LightningModule):
@@ -184,8 +216,11 @@ class FrameTransformer(LightningModule):
         self.criterion = F.bce_with_logits                        # nn.BCEWithLogitsLoss()  :89
         self.distil_criterion = F.cross_entropy_argmax            # CE(student, argmax(teacher))  :90,250
         self.position_encoder = PositionalEncoding(d, drop, max_len=self.tokens + 1)      # :91-93 (+1: injected token)
-        self.img_model = hp.get("img_encoder", None) or _MissingEncoder("ImgResNet (ResNet-18 -> 896)")   # :94
-        self.vid_model = hp.get("vid_encoder", None) or _MissingEncoder("VidResNet (R(2+1)D-18 -> 896)")  # :95
+        # default encoders = the reference's (random init: no pretrained download); injectable for other sizes
+        self.img_model = hp.get("img_encoder", None) or (ImgResNet(self.compute_dtype) if d == 896 else
+                                                         _MissingEncoder("img_encoder for d_model != 896"))   # :94
+        self.vid_model = hp.get("vid_encoder", None) or (VidResNet(self.compute_dtype) if d == 896 else
+                                                         _MissingEncoder("vid_encoder for d_model != 896"))   # :95
         self.scene_transformer = TransformerBase(d, d, hp.get("scene_nhead", 4), hp.get("scene_nhid", 896), 4, drop)  # :98
         self.distil_transformer = TransformerBase(d, 128, hp.get("vid_nhead", 2), hp.get("vid_nhid", 512), 4, drop)  # :99
         self.running_labels = []

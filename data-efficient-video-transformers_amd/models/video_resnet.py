@@ -1,0 +1,162 @@
+"""R(2+1)D-18 video backbone (``torchvision.models.video.r2plus1d_18``, used by the reference's
+``VidResNet``, src/models/frame_transformer.py:64-74) on HIP kernels.  SURVEY section 8 row a11.
+
+torchvision is not installed in the build image and its pretrained weights need the network, so
+this module restates the public architecture (same module tree => same state-dict keys:
+``stem.{0,1,3,4}``, ``layer{1..4}.{i}.conv{1,2}.0.{0,1,3}``, ``...conv{1,2}.1``,
+``...downsample.{0,1}``, ``fc``); parity against torchvision itself is UNPINNED (no golden vectors
+can be produced here) and is checked against a torch-CPU conv3d restatement only.
+
+Layout: activations are NDHWC matrices [(n t h w), C].  The factorised convolutions map onto the
+2-D path: (1,k,k) spatial = a 2-D conv over the N*T frames; (3,1,1) temporal = a (3,1) conv over
+the [T, H*W] view of each clip; the strided 1x1x1 downsample = two strided row gathers + a GEMM.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+
+
+class Conv2Plus1D(nn.Sequential):
+    def __init__(self, in_planes, out_planes, midplanes, stride=1, padding=1):
+        super().__init__(
+            nn.Conv3d(in_planes, midplanes, kernel_size=(1, 3, 3), stride=(1, stride, stride),
+                      padding=(0, padding, padding), bias=False),
+            nn.BatchNorm3d(midplanes),
+            nn.ReLU(inplace=True),
+            nn.Conv3d(midplanes, out_planes, kernel_size=(3, 1, 1), stride=(stride, 1, 1),
+                      padding=(padding, 0, 0), bias=False),
+        )
+
+    @staticmethod
+    def get_downsample_stride(stride):
+        return stride, stride, stride
+
+
+def _spatial(fm, conv, bn, relu, dtype):
+    """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames."""
+    y, N, T, H, W = fm
+    k, s, p = conv.kernel_size[1:], conv.stride[1:], conv.padding[1:]
+    out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, conv.in_channels, H, W, False), k, s, p, relu=relu, dtype=dtype)
+    Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    return (out, N, T, Ho, Wo)
+
+
+def _temporal(fm, conv, bn, relu, dtype, residual=None):
+    """(3,1,1) conv + BN(+res)(+ReLU): a (kt,1) conv over the [T, H*W] view of each clip."""
+    y, N, T, H, W = fm
+    kt, st, pt = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    out = F.conv_bn_act_raw(y, conv.weight, bn, (N, conv.in_channels, T, H * W, False), (kt, 1), (st, 1), (pt, 0),
+                            relu=relu, residual=residual, dtype=dtype)
+    To = (T + 2 * pt - kt) // st + 1
+    return (out, N, To, H, W)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, conv_builder, stride=1, downsample=None):
+        midplanes = (inplanes * planes * 3 * 3 * 3) // (inplanes * 3 * 3 + 3 * planes)
+        super().__init__()
+        self.conv1 = nn.Sequential(conv_builder(inplanes, planes, midplanes, stride), nn.BatchNorm3d(planes),
+                                   nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(conv_builder(planes, planes, midplanes), nn.BatchNorm3d(planes))
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_ndhwc(self, fm, dtype):
+        y, N, T, H, W = fm
+        c1, c2 = self.conv1[0], self.conv2[0]
+        out = _spatial(fm, c1[0], c1[1], True, dtype)
+        out = _temporal(out, c1[3], self.conv1[1], True, dtype)
+        residual = y
+        if self.downsample is not None:
+            ds, dbn = self.downsample[0], self.downsample[1]
+            st = ds.stride
+            C = ds.in_channels
+            r = F.subsample_nhwc(y, N * T, C, H, W, (st[1], st[2]))                       # spatial stride
+            Hs, Ws = (H - 1) // st[1] + 1, (W - 1) // st[2] + 1
+            r = F.subsample_nhwc(r, N, C, T, Hs * Ws, (st[0], 1))                        # temporal stride
+            Ts = (T - 1) // st[0] + 1
+            residual = F.conv_bn_act_raw(r, ds.weight, dbn, (N * Ts, C, Hs, Ws, False), 1, 1, 0, relu=False, dtype=dtype)
+        out = _spatial(out, c2[0], c2[1], True, dtype)
+        return _temporal(out, c2[3], self.conv2[1], True, dtype, residual=residual)     # out += residual; relu
+
+
+class R2Plus1dStem(nn.Sequential):
+    def __init__(self):
+        super().__init__(
+            nn.Conv3d(3, 45, kernel_size=(1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False),
+            nn.BatchNorm3d(45), nn.ReLU(inplace=True),
+            nn.Conv3d(45, 64, kernel_size=(3, 1, 1), stride=(1, 1, 1), padding=(1, 0, 0), bias=False),
+            nn.BatchNorm3d(64), nn.ReLU(inplace=True))
+
+
+class VideoResNet(nn.Module):
+    def __init__(self, layers=(2, 2, 2, 2), num_classes=400, *, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.inplanes = 64
+        self.stem = R2Plus1dStem()
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = nn.Linear(512, num_classes)
+        self.compute_dtype = compute_dtype
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            ds = Conv2Plus1D.get_downsample_stride(stride)
+            downsample = nn.Sequential(nn.Conv3d(self.inplanes, planes, kernel_size=1, stride=ds, bias=False),
+                                       nn.BatchNorm3d(planes))
+        layers = [BasicBlock(self.inplanes, planes, Conv2Plus1D, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(self.inplanes, planes, Conv2Plus1D))
+        return nn.Sequential(*layers)
+
+    def features(self, x):
+        """x [N, 3, T, H, W] -> pooled [N, 512]."""
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise ValueError("VideoResNet expects clips [N, 3, T, H, W]")
+        dt = self.compute_dtype
+        N, _, T, H, W = x.shape
+        frames = x.permute(0, 2, 1, 3, 4)                  # [N, T, 3, H, W]: per-frame NCHW
+        if not frames.is_contiguous():
+            frames = frames.contiguous()
+        s0, b0, s3, b3 = self.stem[0], self.stem[1], self.stem[3], self.stem[4]
+        k, s, p = s0.kernel_size[1:], s0.stride[1:], s0.padding[1:]
+        y = F.conv_bn_act_raw(frames.view(N * T, 3, H, W), s0.weight, b0, (N * T, 3, H, W, True), k, s, p, relu=True, dtype=dt)
+        H1, W1 = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+        fm = _temporal((y, N, T, H1, W1), s3, b3, True, dt)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                fm = blk.forward_ndhwc(fm, dt)
+        y, N, T, H, W = fm
+        return F.mean_rows(y.view(N, T * H * W, y.shape[1]))          # AdaptiveAvgPool3d(1)
+
+    def forward(self, x):
+        feats = self.features(x)
+        fc = self.fc[0] if isinstance(self.fc, nn.Sequential) else self.fc
+        return F.linear(feats, fc.weight, fc.bias)
+
+
+def r2plus1d_18(pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained=True downloads Kinetics weights (torchvision); there is no network here -- "
+                           "load a state_dict explicitly")
+    return VideoResNet((2, 2, 2, 2), **kwargs)

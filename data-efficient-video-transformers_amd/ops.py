@@ -528,27 +528,46 @@ def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Te
 
 
 # ------------------------------------------------------------------ per-frame CNN encoder (csrc/conv.hip)
-def conv_out_hw(H: int, W: int, k: int, stride: int, pad: int) -> Tuple[int, int]:
-    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
-def im2col(x: Tensor, nchw: bool, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int, ld: int,
+def conv_out_hw(H: int, W: int, k, stride, pad) -> Tuple[int, int]:
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
+    return (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+
+
+def im2col(x: Tensor, nchw: bool, N: int, Cc: int, H: int, W: int, k, stride, pad, ld: int,
            out_dtype: torch.dtype) -> Tensor:
+    """k / stride / pad: int or (h, w) pair."""
     _need_cuda(x)
     assert x.is_contiguous()
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     out = torch.empty((N * Ho * Wo, ld), dtype=out_dtype, device=x.device)
-    L.check(L.load().dvt_im2col(x.data_ptr(), dt(x), int(nchw), out.data_ptr(), _DT[out_dtype], N, Cc, H, W, k, k,
-                                stride, pad, ld, _stream()), "dvt_im2col")
+    L.check(L.load().dvt_im2col(x.data_ptr(), dt(x), int(nchw), out.data_ptr(), _DT[out_dtype], N, Cc, H, W, kh, kw,
+                                sh, sw, ph, pw, ld, _stream()), "dvt_im2col")
     return out
 
 
-def col2im(dcol: Tensor, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int) -> Tensor:
+def col2im(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad) -> Tensor:
     _need_cuda(dcol)
     assert dcol.is_contiguous()
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     dx = torch.empty((N * H * W, Cc), dtype=dcol.dtype, device=dcol.device)
-    L.check(L.load().dvt_col2im(dcol.data_ptr(), dx.data_ptr(), N, Cc, H, W, k, k, stride, pad, dcol.shape[1],
+    L.check(L.load().dvt_col2im(dcol.data_ptr(), dx.data_ptr(), N, Cc, H, W, kh, kw, sh, sw, ph, pw, dcol.shape[1],
                                 dt(dcol), _stream()), "dvt_col2im")
+    return dx
+
+
+def col2im_nchw(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad, dx_dtype: torch.dtype) -> Tensor:
+    """Adjoint gather written as an NCHW tensor [N, C, H, W] in ``dx_dtype`` (stem input gradient)."""
+    _need_cuda(dcol)
+    assert dcol.is_contiguous()
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
+    dx = torch.empty((N, Cc, H, W), dtype=dx_dtype, device=dcol.device)
+    L.check(L.load().dvt_col2im_nchw(dcol.data_ptr(), dt(dcol), dx.data_ptr(), _DT[dx_dtype], N, Cc, H, W, kh, kw, sh,
+                                     sw, ph, pw, dcol.shape[1], _stream()), "dvt_col2im_nchw")
     return dx
 
 

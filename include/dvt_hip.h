@@ -244,13 +244,20 @@ int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
  * src/models/custom_resnet.py:19-153 (conv3x3 / 7x7 stem / 1x1 downsample, BatchNorm2d, ReLU,
  * MaxPool2d(3,2,1), residual adds).  Feature maps are NHWC = [N*H*W, C] matrices, so a
  * convolution is  dvt_im2col -> dvt_gemm -> [N*Ho*Wo, Cout];  weights nn.Conv2d [Cout,Cin,kh,kw]. */
-/* out[(n,ho,wo), (ki*kw+kj)*C + c] = x[n, ho*s-p+ki, wo*s-p+kj, c] (0 outside); columns
- * [kh*kw*C, ld) are zero padding.  x is NCHW when x_nchw != 0 (the raw clip frames), else NHWC. */
+/* out[(n,ho,wo), (ki*kw+kj)*C + c] = x[n, ho*sh-ph+ki, wo*sw-pw+kj, c] (0 outside); columns
+ * [kh*kw*C, ld) are zero padding.  x is NCHW when x_nchw != 0 (the raw clip frames), else NHWC.
+ * Rectangular kernels / strides / paddings also serve the factorised R(2+1)D convolutions
+ * (frame_transformer.py:67): (1,3,3) spatial = per-frame 2-D conv; (3,1,1) temporal = a (3,1) conv over
+ * the [T, H*W] view of each clip. */
 int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
-               int W, int kh, int kw, int stride, int pad, int64_t ld, dvt_stream_t stream);
+               int W, int kh, int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream);
 /* Adjoint gather (data gradient of the convolution), NHWC, C % 8 == 0. */
-int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int stride, int pad,
-               int64_t ld, int dtype, dvt_stream_t stream);
+int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
+               int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream);
+/* Same adjoint written in NCHW order and in the clip's own dtype: the gradient of the stem w.r.t. the raw
+ * frames (needed by the learnable pixel-space CLS clip, frame_transformer.py:105,195). */
+int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t N, int C, int H, int W, int kh,
+                    int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream);
 /* w[Cout,Cin,kh,kw] f32 -> dst[Cout, ld] (column order (ki,kj,ci), zero padded) in dst_dtype, and the
  * inverse for the fp32 weight gradient (dw (+)= g re-ordered). */
 int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw, int64_t ld,

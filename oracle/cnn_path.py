@@ -78,3 +78,40 @@ def reasoning(x: Tensor, P: Dict[str, Tensor], start: int = 2, max_group: int = 
         s = torch.sigmoid(linear(torch.relu(s), P[p + "7.weight"], P[p + "7.bias"]))
         pred = pred + s
     return pred / (max_group - start + 1)
+
+
+# --------------------------------------------------------------------------
+# R(2+1)D-18 (torchvision.models.video.r2plus1d_18, used at frame_transformer.py:67).
+# Restated from the public architecture; NOT pinned against torchvision (not installed here).
+# --------------------------------------------------------------------------
+def _bn3(x, P, prefix, training):
+    return TF.batch_norm(x, P[prefix + "running_mean"].clone(), P[prefix + "running_var"].clone(),
+                         P[prefix + "weight"], P[prefix + "bias"], training, 0.1, 1e-5)
+
+
+def _conv2plus1d(x, P, prefix, stride, training):
+    x = TF.conv3d(x, P[prefix + "0.weight"], None, (1, stride, stride), (0, 1, 1))
+    x = torch.relu(_bn3(x, P, prefix + "1.", training))
+    return TF.conv3d(x, P[prefix + "3.weight"], None, (stride, 1, 1), (1, 0, 0))
+
+
+def r2plus1d_features(x: Tensor, P: Dict[str, Tensor], layers=(2, 2, 2, 2), training: bool = True) -> Tensor:
+    """x [N, 3, T, H, W] -> pooled [N, 512]."""
+    x = TF.conv3d(x, P["stem.0.weight"], None, (1, 2, 2), (0, 3, 3))
+    x = torch.relu(_bn3(x, P, "stem.1.", training))
+    x = TF.conv3d(x, P["stem.3.weight"], None, 1, (1, 0, 0))
+    x = torch.relu(_bn3(x, P, "stem.4.", training))
+    for li, nb in enumerate(layers):
+        for b in range(nb):
+            pre = f"layer{li + 1}.{b}."
+            stride = 2 if (li > 0 and b == 0) else 1
+            out = _conv2plus1d(x, P, pre + "conv1.0.", stride, training)
+            out = torch.relu(_bn3(out, P, pre + "conv1.1.", training))
+            out = _conv2plus1d(out, P, pre + "conv2.0.", 1, training)
+            out = _bn3(out, P, pre + "conv2.1.", training)
+            res = x
+            if pre + "downsample.0.weight" in P:
+                res = TF.conv3d(x, P[pre + "downsample.0.weight"], None, stride)
+                res = _bn3(res, P, pre + "downsample.1.", training)
+            x = torch.relu(out + res)
+    return x.mean(dim=(2, 3, 4))

@@ -177,3 +177,69 @@ def test_tpn_end_to_end_tokens(dvt, device):
     net = net.cuda().train()
     tok = net.frame_tokens(x.cuda())
     assert tok.shape == (4, 896) and rel_l2(tok, ref) < 2e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 8e-2)])
+def test_r2plus1d_18_matches_conv3d_restatement(dvt, device, dtype, tol):
+    """R(2+1)D-18 features (factorised (1,3,3)+(3,1,1) convolutions, BatchNorm3d, strided
+    1x1x1 downsample) vs a torch-CPU conv3d restatement.  UNPINNED against torchvision (not installed)."""
+    from oracle import cnn_path as C
+    from dvt_amd.models.video_resnet import r2plus1d_18
+    net = r2plus1d_18(False, compute_dtype=dtype)
+    rng = np.random.default_rng(91)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            a = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+            if p.dim() == 5:
+                a *= np.float32(np.sqrt(2.0 / (p.shape[1] * p.shape[2] * p.shape[3] * p.shape[4])))
+            elif p.dim() == 2:
+                a *= np.float32(0.02)
+            elif name.endswith("weight"):
+                a = 1 + np.float32(0.1) * a
+            else:
+                a = np.float32(0.1) * a
+            p.copy_(torch.from_numpy(a))
+    x = torch.from_numpy(rng.standard_normal((2, 3, 4, 32, 32)).astype(np.float32))
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k in P:
+        if P[k].dtype.is_floating_point and "running" not in k:
+            P[k].requires_grad_(True)
+    # fp32: train mode (batch statistics).  bf16: eval mode -- at this toy size the deepest BatchNorms see
+    # 8-32 samples, whose batch statistics are too ill-conditioned for a bf16 comparison.
+    training = dtype == torch.float32
+    ref = C.r2plus1d_features(x, P, training=training)
+    gy = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * gy).sum().backward()
+    net = net.cuda().train(training)
+    out = net.features(x.cuda())
+    assert out.shape == (2, 512)
+    e = rel_l2(out, ref)
+    print(f"[r2plus1d/{dtype}] feature rel {e:.2e}")
+    assert e < tol
+    out.backward(gy.to(out.dtype).cuda())
+    Pn = dict(net.named_parameters())
+    for k in ("layer4.1.conv2.0.3.weight", "layer3.0.downsample.0.weight", "layer2.0.conv1.0.0.weight", "stem.3.weight",
+              "layer4.1.conv2.1.weight"):
+        ge = rel_l2(Pn[k].grad, P[k].grad)
+        print(f"[r2plus1d/{dtype}] grad {k} rel {ge:.2e}")
+        # fp32 bound: the deepest maps here are 8 x 1152; ONE ReLU-mask flip of an activation that is 0 +- 1 ulp
+        # (seen: 3.8e-7 vs 0.0) moves every upstream gradient by ~1/sqrt(9216) = 1e-2.  Without a flip the
+        # error is ~3e-6 (measured on isolated blocks).
+        assert ge < (3e-2 if dtype == torch.float32 else 0.25), (k, ge)
+
+
+def test_frame_transformer_with_reference_encoders(dvt, device):
+    """The default FrameTransformer (VidResNet R(2+1)D-18 encoder, 14 tokens x 896, 19 classes) runs a
+    training step end to end on [B, 13, 12, 3, 112, 112] chunks (batch contract of MMX_Light_dl.py:286)."""
+    from dvt_amd.models.frame_transformer import FrameTransformer
+    torch.manual_seed(1)
+    net = FrameTransformer(batch_size=1, seq_len=13, cls=1, model="vid", opt="adamW", learning_rate=5e-6,
+                           weight_decay=0.09, momentum=0.005, frame_len=4).cuda().eval()   # 4-frame chunks keep it light
+    g = torch.Generator().manual_seed(2)
+    vid = torch.randn(1, 13, 4, 3, 112, 112, generator=g).cuda()
+    target = (torch.rand(1, 19, generator=g) < 0.3).float().cuda()
+    loss = net.training_step((target, None, vid), 0)
+    loss.backward()
+    assert torch.isfinite(loss.detach()).item()
+    assert net.vid_cls.grad is not None and torch.isfinite(net.vid_cls.grad).all()
+    assert torch.isfinite(net.vid_model.backbone.stem[0].weight.grad).all()
