@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
                     "replaying one captured hipGraph per step (single-GPU only)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
+                    "rank (rehearses the multi-GPU code path on a single GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +122,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import dvt_amd
@@ -156,13 +160,13 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # Single GPU: the whole step (fwd + loss + bwd + AdamW + weight cast) is captured once as a
     # hipGraph and replayed.  Multi GPU: eager launches, so that the bucketed RCCL all-reduces
     # stay ordinary asynchronous collectives overlapped with backward.
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not use_dist and not args.no_graph
     run = step
     if use_graph:
         from dvt_amd.graph import capture_step
@@ -184,7 +188,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -257,7 +261,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
