@@ -640,6 +640,35 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
 
 __global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
+// torch.optim.SGD (dampening 0, no nesterov): d = g + wd p; buf = mu buf + d; p -= lr buf   (buf starts at 0,
+// which reproduces torch's "first step: buf = d" rule).  mu == 0: plain p -= lr d, buf untouched.
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                           int64_t n, float lr, float mu, float wd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i];
+    float d = fmaf(wd, pi, g[i]);
+    if (mu != 0.f) {
+      d = fmaf(mu, buf[i], d);
+      buf[i] = d;
+    }
+    p[i] = pi - lr * d;
+  }
+}
+
+// torch.optim.Adagrad: d = g + wd p; sum += d^2; p -= clr d / (sqrt(sum) + eps)
+__global__ void adagrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sum,
+                               int64_t n, float clr, float eps, float wd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float pi = p[i];
+    const float d = fmaf(wd, pi, g[i]);
+    const float si = fmaf(d, d, sum[i]);
+    sum[i] = si;
+    p[i] = pi - clr * (d / (sqrtf(si) + eps));
+  }
+}
+
 template <typename S, typename D, bool FWD>
 int patchify_dispatch(const void* x, void* out, void* dx, const void* dout, int64_t frames, int C,
                       int H, int W, int P, hipStream_t st, const char* name) {
@@ -873,6 +902,27 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                      exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2));
   DVT_LAUNCH_CHECK("dvt_adamw_step");
+  return DVT_OK;
+}
+
+int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float weight_decay, dvt_stream_t stream) {
+  DVT_REQUIRE(param && grad && n >= 0 && (momentum == 0.f || momentum_buf), "dvt_sgd_step: bad arguments");
+  if (n == 0) return DVT_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, momentum_buf,
+                     n, lr, momentum, weight_decay);
+  DVT_LAUNCH_CHECK("dvt_sgd_step");
+  return DVT_OK;
+}
+
+int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
+                     float eps, float weight_decay, int64_t step, dvt_stream_t stream) {
+  DVT_REQUIRE(param && grad && state_sum && n >= 0 && step >= 1, "dvt_adagrad_step: bad arguments");
+  if (n == 0) return DVT_OK;
+  const float clr = (float)((double)lr / (1.0 + (double)(step - 1) * (double)lr_decay));
+  hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, state_sum,
+                     n, clr, eps, weight_decay);
+  DVT_LAUNCH_CHECK("dvt_adagrad_step");
   return DVT_OK;
 }
 

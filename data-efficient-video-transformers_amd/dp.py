@@ -185,6 +185,24 @@ class FlatParameters:
                             beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.sync_compute_copy()
 
+    def sgd_step(self, lr: float, momentum: float = 0.0, weight_decay: float = 0.0) -> None:
+        """torch.optim.SGD semantics (frame_transformer.py:124-126) in one launch over the flat buffers."""
+        if momentum != 0.0 and getattr(self, "momentum_buf", None) is None:
+            self.momentum_buf = torch.zeros_like(self.data)
+        self.step_count += 1
+        ops.sgd_step_(self.data, self.grad, getattr(self, "momentum_buf", None), lr=lr, momentum=momentum,
+                      weight_decay=weight_decay)
+        self.sync_compute_copy()
+
+    def adagrad_step(self, lr: float, weight_decay: float = 0.0, lr_decay: float = 0.0, eps: float = 1e-10) -> None:
+        """torch.optim.Adagrad semantics (frame_transformer.py:130-132) in one launch over the flat buffers."""
+        if getattr(self, "state_sum", None) is None:
+            self.state_sum = torch.zeros_like(self.data)
+        self.step_count += 1
+        ops.adagrad_step_(self.data, self.grad, self.state_sum, lr=lr, lr_decay=lr_decay, eps=eps,
+                          weight_decay=weight_decay, step=self.step_count)
+        self.sync_compute_copy()
+
     def init_optimizer_state(self) -> None:
         self.exp_avg = torch.zeros_like(self.data)
         self.exp_avg_sq = torch.zeros_like(self.data)

@@ -509,6 +509,70 @@ def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, resid
     return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first)
 
 
+class _CrossAttnBlock(torch.autograd.Function):
+    """y = x + to_out(attention(q = to_q(LN_q(x)), k,v = to_kv(LN_kv(c))))  -- the cross-modal attention
+    block (BASELINE configs[3]: video tokens attend to audio tokens; Lq != Lk).  x [B, Lq, d], c [B, Lk, dc];
+    to_q / to_kv have no bias (same convention as vit.py:39); kv is kept packed [B*Lk, 2*h*dh] and read by the
+    attention kernel through strides, like the self-attention form."""
+
+    @staticmethod
+    def forward(ctx, x, c, lnq_w, lnq_b, lnk_w, lnk_b, w_q, w_kv, w_out, b_out, heads, eps):
+        B, Lq, d = x.shape
+        Lk = c.shape[1]
+        T = x.dtype
+        x2 = x.reshape(B * Lq, d).contiguous()
+        c2 = _as(c.reshape(B * Lk, c.shape[-1]).contiguous(), T)
+        gq, bq, gk, bk = _f32(lnq_w), _f32(lnq_b), _f32(lnk_w), _f32(lnk_b)
+        xn, mq, rq = ops.layernorm_fwd(x2, gq, bq, eps)
+        cn, mk, rk = ops.layernorm_fwd(c2, gk, bk, eps)
+        wq, wkv, wo = _wc(w_q, T), _wc(w_kv, T), _wc(w_out, T)
+        inner = wq.shape[0]
+        dh = inner // heads
+        q = ops.linear_fwd(xn, wq)                                       # [B*Lq, inner]
+        kv = ops.linear_fwd(cn, wkv)                                     # [B*Lk, 2*inner]
+        q4 = q.view(B, Lq, heads, dh).permute(0, 2, 1, 3)
+        kv5 = kv.view(B, Lk, 2, heads, dh)
+        k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
+        o_mem = torch.empty((B, Lq, heads, dh), dtype=T, device=x.device)
+        lse = ops.attention_fwd(q4, k4, v4, o_mem.permute(0, 2, 1, 3), dh ** -0.5)
+        y = ops.linear_fwd(o_mem.view(B * Lq, inner), wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2)
+        ctx.save_for_backward(x2, c2, gq, gk, mq, rq, mk, rk, xn, cn, wq, wkv, wo, q, kv, o_mem, lse)
+        ctx.cfg = (B, Lq, Lk, heads, dh, inner, tuple(x.shape), tuple(c.shape), c.dtype)
+        ctx.sinks = tuple(_sink(t) for t in (lnq_w, lnq_b, lnk_w, lnk_b, w_q, w_kv, w_out, b_out))
+        return y.view(B, Lq, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, c2, gq, gk, mq, rq, mk, rk, xn, cn, wq, wkv, wo, q, kv, o_mem, lse = ctx.saved_tensors
+        B, Lq, Lk, heads, dh, inner, xshape, cshape, cdt = ctx.cfg
+        s = ctx.sinks
+        T = x2.dtype
+        dy2 = _as(dy.reshape(B * Lq, -1).contiguous(), T)
+        do2 = ops.linear_dgrad(dy2, wo)
+        dwo, dbo = _emit_wgrad_bias(s[6], s[7], dy2, o_mem.view(B * Lq, inner), True)
+        q4 = q.view(B, Lq, heads, dh).permute(0, 2, 1, 3)
+        kv5 = kv.view(B, Lk, 2, heads, dh)
+        k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dkv5 = dkv.view(B, Lk, 2, heads, dh)
+        ops.attention_bwd(q4, k4, v4, o_mem.permute(0, 2, 1, 3), lse, do2.view(o_mem.shape).permute(0, 2, 1, 3),
+                          dq.view(B, Lq, heads, dh).permute(0, 2, 1, 3), dkv5[:, :, 0].permute(0, 2, 1, 3),
+                          dkv5[:, :, 1].permute(0, 2, 1, 3), dh ** -0.5)
+        dwq = _emit_wgrad(s[4], dq, xn)
+        dwkv = _emit_wgrad(s[5], dkv, cn)
+        dx, dgq, dbq = _ln_bwd(ops.linear_dgrad(dq, wq), x2, gq, mq, rq, s[0], s[1], dx_add=dy2)
+        dc = dgk = dbk = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
+            dc, dgk, dbk = _ln_bwd(ops.linear_dgrad(dkv, wkv), c2, gk, mk, rk, s[2], s[3])
+            dc = _as(dc, cdt).view(cshape)
+        return dx.view(xshape), dc, dgq, dbq, dgk, dbk, dwq, dwkv, dwo, dbo, None, None
+
+
+def cross_attn_block(x, c, lnq_w, lnq_b, lnk_w, lnk_b, w_q, w_kv, w_out, b_out, heads, eps=1e-5):
+    return _CrossAttnBlock.apply(x, c, lnq_w, lnq_b, lnk_w, lnk_b, w_q, w_kv, w_out, b_out, heads, eps)
+
+
 class _MlpBlock(torch.autograd.Function):
     """y = [x +] W2 act(W1 [LN](x) + b1) + b2   -- ``PreNorm(FeedForward)`` + residual
     (vit.py:17-28,73-74).  act: 'gelu' (exact erf) or 'relu'."""
@@ -932,6 +996,47 @@ def subsample_nhwc(x, N, Cc, H, W, stride):
     return _Subsample.apply(x, (N, Cc, H, W, stride))
 
 
+class _Im2Col(torch.autograd.Function):
+    """NHWC matrix [N*H*W, C] -> column matrix [N*Ho*Wo, kh*kw*C] (adjoint: col2im)."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        N, Cc, H, W, k, stride, pad = geom
+        ctx.geom = geom
+        (kh, kw) = ops._pair(k)
+        return ops.im2col(x.contiguous(), False, N, Cc, H, W, k, stride, pad, kh * kw * Cc, x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W, k, stride, pad = ctx.geom
+        return ops.col2im(dy.contiguous(), N, Cc, H, W, k, stride, pad), None
+
+
+def im2col_nhwc(x, N, Cc, H, W, k, stride, pad):
+    return _Im2Col.apply(x, (N, Cc, H, W, k, stride, pad))
+
+
+class _Col2Im(torch.autograd.Function):
+    """Column matrix [N*Ho*Wo, kh*kw*C] -> NHWC matrix [N*H*W, C] (overlap-add; with k == stride this is the
+    pixel shuffle of a transposed convolution).  Adjoint: im2col."""
+
+    @staticmethod
+    def forward(ctx, col, geom):
+        N, Cc, H, W, k, stride, pad = geom
+        ctx.geom = geom
+        return ops.col2im(col.contiguous(), N, Cc, H, W, k, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W, k, stride, pad = ctx.geom
+        (kh, kw) = ops._pair(k)
+        return ops.im2col(dy.contiguous(), False, N, Cc, H, W, k, stride, pad, kh * kw * Cc, dy.dtype), None
+
+
+def col2im_nhwc(col, N, Cc, H, W, k, stride, pad):
+    return _Col2Im.apply(col, (N, Cc, H, W, k, stride, pad))
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, geom):
@@ -966,3 +1071,36 @@ class _Transpose12(torch.autograd.Function):
 
 def transpose_last2(x):
     return _Transpose12.apply(x)
+
+
+# ---------------------------------------------------------------------------
+# activation checkpointing (BASELINE configs[4]: T=64, 288^2 long-clip stress)
+# ---------------------------------------------------------------------------
+class _Checkpoint(torch.autograd.Function):
+    """Runs ``fn(x)`` without recording, keeps only ``x``; backward re-runs ``fn`` with recording and
+    back-propagates through it.  Parameter gradients are produced by the inner backward (into the
+    ``dp.FlatParameters`` sinks, or accumulated into ``.grad`` by autograd) -- the ``params`` inputs only
+    make the output require grad when ``x`` itself does not."""
+
+    @staticmethod
+    def forward(ctx, fn, x, *params):
+        ctx.fn = fn
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return fn(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        xin = x.detach().requires_grad_(True)
+        with torch.enable_grad():
+            y = ctx.fn(xin)
+        torch.autograd.backward(y, dy)
+        return (None, xin.grad) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def checkpoint(fn, x: Tensor, params=()) -> Tensor:
+    """y = fn(x) storing only x for backward (one extra forward of ``fn`` per step)."""
+    if not torch.is_grad_enabled():
+        return fn(x)
+    return _Checkpoint.apply(fn, x, *params)

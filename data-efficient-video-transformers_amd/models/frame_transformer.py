@@ -39,6 +39,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
+from .. import optim
 from ..lightning_compat import LightningModule
 
 
@@ -240,12 +241,12 @@ class FrameTransformer(LightningModule):
     def configure_optimizers(self):
         hp = self.hparams
         if hp.opt == "sgd":
-            return torch.optim.SGD(self.parameters(), lr=hp.learning_rate, momentum=hp.momentum,
+            return optim.SGD(self.parameters(), lr=hp.learning_rate, momentum=hp.momentum,
                                    weight_decay=hp.weight_decay)
         if hp.opt == "adamW":
-            return torch.optim.AdamW(self.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+            return optim.AdamW(self.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
         if hp.opt == "adagrad":
-            return torch.optim.Adagrad(self.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+            return optim.Adagrad(self.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
         raise ValueError(f"unknown optimizer {hp.opt!r}")
 
     # ------------------------------------------------------------------ heads

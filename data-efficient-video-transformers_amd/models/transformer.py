@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
+from .. import optim
 from .. import ops
 from ..lightning_compat import LightningModule
 from .frame_transformer import Encoder, EncoderLayer, PositionalEncoding
@@ -47,7 +48,7 @@ class SimpleTransformer(LightningModule):
 
     def configure_optimizers(self):
         hp = self.hparams
-        return torch.optim.SGD(self.parameters(), lr=hp.learning_rate, momentum=hp.momentum,
+        return optim.SGD(self.parameters(), lr=hp.learning_rate, momentum=hp.momentum,
                                weight_decay=hp.weight_decay)
 
     def add_pos_cls(self, data):

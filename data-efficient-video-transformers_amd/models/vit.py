@@ -11,7 +11,8 @@ there is no torch arithmetic and no CPU path.
 
 Build-side additions (keyword-only, defaults keep reference behaviour):
 ``compute_dtype`` -- activation / GEMM dtype (torch.bfloat16 default, torch.float32
-for the fp32 parity mode).
+for the fp32 parity mode); ``activation_checkpointing`` -- keep one activation per
+transformer block and recompute the block in backward (BASELINE configs[4]).
 """
 from __future__ import annotations
 
@@ -123,6 +124,7 @@ class Transformer(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([])
         self.norm = nn.LayerNorm(dim)
+        self.checkpoint = False          # build-side: recompute each block in backward (saves ~11 of 12 activations)
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
                 PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
@@ -132,8 +134,14 @@ class Transformer(nn.Module):
     def forward_layers(self, x):
         """All residual blocks, without the final norm."""
         for attn, ff in self.layers:
-            x = attn.fn(x, _norm=attn.norm, _residual=True)
-            x = ff.fn(x, _norm=ff.norm, _residual=True)
+            if self.checkpoint and self.training and torch.is_grad_enabled():
+                def block(t, attn=attn, ff=ff):
+                    t = attn.fn(t, _norm=attn.norm, _residual=True)
+                    return ff.fn(t, _norm=ff.norm, _residual=True)
+                x = F.checkpoint(block, x, tuple(attn.parameters()) + tuple(ff.parameters()))
+            else:
+                x = attn.fn(x, _norm=attn.norm, _residual=True)
+                x = ff.fn(x, _norm=ff.norm, _residual=True)
         return x
 
     def forward(self, x):
@@ -146,7 +154,7 @@ class ViViT(nn.Module):
 
     def __init__(self, image_size, patch_size, num_classes, num_frames, dim=192, depth=4, heads=3,
                  pool='cls', in_channels=3, dim_head=64, dropout=0., emb_dropout=0., scale_dim=4, *,
-                 compute_dtype: torch.dtype = torch.bfloat16):
+                 compute_dtype: torch.dtype = torch.bfloat16, activation_checkpointing: bool = False):
         super().__init__()
         assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
         assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
@@ -172,6 +180,8 @@ class ViViT(nn.Module):
         self.num_frames = num_frames
         self.emb_dropout_p = emb_dropout
         self.compute_dtype = compute_dtype
+        self.space_transformer.checkpoint = activation_checkpointing
+        self.temporal_transformer.checkpoint = activation_checkpointing
 
     def forward(self, x):
         _no_dropout(self.emb_dropout_p, self.training, "ViViT(emb_dropout)")

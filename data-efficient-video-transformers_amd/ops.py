@@ -515,6 +515,22 @@ def adamw_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
             "dvt_adamw_step")
 
 
+def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
+              weight_decay: float) -> None:
+    _need_cuda(param)
+    assert param.dtype == grad.dtype == torch.float32 and param.is_contiguous() and grad.is_contiguous()
+    L.check(L.load().dvt_sgd_step(param.data_ptr(), grad.data_ptr(), _p(momentum_buf), param.numel(), lr, momentum,
+                                  weight_decay, _stream()), "dvt_sgd_step")
+
+
+def adagrad_step_(param: Tensor, grad: Tensor, state_sum: Tensor, *, lr: float, lr_decay: float, eps: float,
+                  weight_decay: float, step: int) -> None:
+    _need_cuda(param)
+    assert param.dtype == grad.dtype == torch.float32 and param.is_contiguous() and grad.is_contiguous()
+    L.check(L.load().dvt_adagrad_step(param.data_ptr(), grad.data_ptr(), state_sum.data_ptr(), param.numel(), lr,
+                                      lr_decay, eps, weight_decay, step, _stream()), "dvt_adagrad_step")
+
+
 def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev: Tensor, *,
                     lr: float, beta1: float, beta2: float, eps: float, weight_decay: float) -> None:
     """AdamW with the step counter on the device (hipGraph-capturable)."""

@@ -313,6 +313,14 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_dev, dvt_stream_t stream);
+/* torch.optim.SGD(lr, momentum, weight_decay) (frame_transformer.py:124-126; config.yaml momentum 0.005):
+ * d = g + wd*p; buf = momentum*buf + d; p -= lr*buf.  momentum_buf starts zeroed (may be NULL when momentum == 0). */
+int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float weight_decay, dvt_stream_t stream);
+/* torch.optim.Adagrad(lr, weight_decay) (frame_transformer.py:130-132): d = g + wd*p; sum += d*d;
+ * p -= lr/(1+(step-1)*lr_decay) * d / (sqrt(sum) + eps); step counts from 1. */
+int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
+                     float eps, float weight_decay, int64_t step, dvt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -390,3 +390,36 @@ def test_adamw_matches_torch(dvt, device):
         gr = torch.randn(1000, generator=g2)
         dvt.ops.adamw_step_dev_(p2, gr.cuda(), m2, v2, sd, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.09)
     assert int(sd) == 3 and rel_l2(p2, pr) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["sgd", "sgd_nomom", "adagrad", "adamW"])
+def test_optimizer_classes_match_torch(dvt, device, kind):
+    """configure_optimizers() choices of the reference (frame_transformer.py:123-134) behind the
+    torch.optim.Optimizer interface, against torch's own CPU optimizers (3 steps, 2 tensors)."""
+    from dvt_amd import optim
+    g = torch.Generator().manual_seed(17)
+    shapes = [(37, 19), (130,)]
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    got = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    if kind == "sgd":
+        o_ref = torch.optim.SGD(ref, lr=5e-2, momentum=0.005, weight_decay=0.09)          # config.yaml:10-12
+        o_got = optim.SGD(got, lr=5e-2, momentum=0.005, weight_decay=0.09)
+    elif kind == "sgd_nomom":
+        o_ref = torch.optim.SGD(ref, lr=5e-2, weight_decay=0.01)
+        o_got = optim.SGD(got, lr=5e-2, weight_decay=0.01)
+    elif kind == "adagrad":
+        o_ref = torch.optim.Adagrad(ref, lr=5e-2, weight_decay=0.09)
+        o_got = optim.Adagrad(got, lr=5e-2, weight_decay=0.09)
+    else:
+        o_ref = torch.optim.AdamW(ref, lr=5e-3, weight_decay=0.09)
+        o_got = optim.AdamW(got, lr=5e-3, weight_decay=0.09)
+    for _ in range(3):
+        for r, t in zip(ref, got):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad, t.grad = gr.clone(), gr.cuda()
+        o_ref.step()
+        o_got.step()
+    for r, t in zip(ref, got):
+        assert rel_l2(t, r) < 1e-6
+    sd = o_got.state_dict()                                    # torch-compatible state layout
+    assert set(sd) == {"state", "param_groups"}

@@ -1,0 +1,101 @@
+"""BASELINE configs[2] / configs[3]: the 3-scale pyramid front-end feeding the
+space -> time transformer, the cross-modal (video queries, audio keys/values; Lq != Lk) attention block and
+the distillation head, on the GPU against the CPU oracle composition (oracle/pyramid_path.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_path as O
+from oracle import pyramid_path as PP
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() == 1 and name.endswith("weight"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "token" in name or "pos_embedding" in name:
+                p.copy_(torch.randn(p.shape, generator=g))
+            elif p.dim() == 4:
+                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[1]) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 6e-2)])
+def test_cross_attention_block(device, dtype, tol):
+    """Lq = 9 video tokens attend to Lk = 32 audio tokens (dh = 64: the MFMA attention kernel in bf16)."""
+    from dvt_amd.models.pyramid_vivit import CrossAttention
+    torch.manual_seed(0)
+    blk = CrossAttention(128, heads=2, dim_head=64)
+    _randomise(blk, 3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 9, 128, generator=g).requires_grad_(True)
+    c = torch.randn(3, 32, 128, generator=g).requires_grad_(True)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    ref = PP.cross_attention(x, c, P, "", 2)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    blk = blk.cuda()
+    xd = x.detach().to(dtype).cuda().requires_grad_(True)
+    cd = c.detach().to(dtype).cuda().requires_grad_(True)
+    out = blk(xd, cd)
+    out.backward(gy.to(dtype).cuda())
+    assert rel_l2(out, ref) < tol
+    assert rel_l2(xd.grad, x.grad) < 2 * tol and rel_l2(cd.grad, c.grad) < 2 * tol
+    for k, p in blk.named_parameters():
+        assert rel_l2(p.grad, P[k].grad) < 3 * tol, k
+
+
+@pytest.mark.parametrize("dtype,variant", [(torch.float32, "pyramid"), (torch.float32, "crossmodal"),
+                                           (torch.bfloat16, "crossmodal")])
+def test_pyramid_vivit_matches_oracle(device, dtype, variant):
+    from dvt_amd.models.pyramid_vivit import PyramidViViT
+    audio_tokens = 32 if variant == "crossmodal" else 0
+    torch.manual_seed(0)
+    net = PyramidViViT(64, 19, 4, dim=128, depth=2, heads=2, dim_head=64, audio_tokens=audio_tokens, audio_dim=24,
+                       distill=variant == "crossmodal", compute_dtype=dtype)
+    _randomise(net, 7)
+    g = torch.Generator().manual_seed(8)
+    clip = torch.randn(2, 4, 3, 64, 64, generator=g)
+    audio = torch.randn(2, 32, 24, generator=g) if audio_tokens else None
+    target = (torch.rand(2, 19, generator=g) < 0.3).float()
+    # BatchNorm on running statistics: the 8-frame toy batch gives 2x2 maps at the deepest level, whose batch
+    # statistics are too ill-conditioned for a tolerance test (see tests/test_gpu_cnn.py on R(2+1)D)
+    net.eval()
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k in P:
+        if P[k].dtype.is_floating_point and "running" not in k:
+            P[k].requires_grad_(True)
+    ref = PP.pyramid_vivit_forward(clip, audio, P, depth=2, heads=2, training_bn=False, distill=variant == "crossmodal")
+    if variant == "crossmodal":
+        ref_loss = O.bce_with_logits(ref[0], target) + O.cross_entropy_hard(ref[0], ref[1])
+    else:
+        ref_loss = O.bce_with_logits(ref, target)
+    ref_loss.backward()
+    net = net.cuda()
+    batch = (target.cuda(), clip.cuda(), audio.cuda()) if audio_tokens else (target.cuda(), clip.cuda())
+    loss = net.training_step(batch)
+    loss.backward()
+    fp32 = dtype == torch.float32
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (2e-5 if fp32 else 2e-2)
+    keys = ["lat2.weight", "lat3.bias", "lat4.weight", "pos_embedding", "space_token", "backbone.conv1.weight",
+            "backbone.layer3.1.bn2.weight", "space_transformer.layers.1.0.fn.to_qkv.weight",
+            "temporal_transformer.layers.0.1.fn.net.3.weight", "mlp_head.1.weight"]
+    if variant == "crossmodal":
+        keys += ["audio_proj.weight", "cross.to_kv.weight", "cross.norm_q.bias", "cross.to_out.bias"]
+    Pn = dict(net.named_parameters())
+    for k in keys:
+        e = rel_l2(Pn[k].grad, P[k].grad)
+        assert e < (2e-3 if fp32 else 0.25), (k, e)
+    if variant == "crossmodal":
+        s, t = net(clip.cuda(), audio.cuda())
+        assert rel_l2(s, ref[0]) < (1e-4 if fp32 else 5e-2) and rel_l2(t, ref[1]) < (1e-4 if fp32 else 5e-2)
+        # the teacher branch receives no gradient from the hard-label CE (argmax), like the reference
+        assert Pn["distill_head.1.weight"].grad is None or float(Pn["distill_head.1.weight"].grad.abs().max()) == 0.0

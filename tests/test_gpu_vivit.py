@@ -101,3 +101,25 @@ def test_metric_shape_bf16_tracks_fp32_mode(device):
         worst = max(worst, rel_l2(p.grad, q.grad))
     print(f"[metric-shape] worst grad rel {worst:.2e}")
     assert worst < 6e-2
+
+
+def test_activation_checkpointing_same_gradients_less_memory(device):
+    """BASELINE configs[4] asks for activation checkpointing: recomputing each block in backward must give
+    bit-identical gradients (same kernels, same accumulation order) and a smaller activation peak."""
+    from dvt_amd.models.vit import ViViT
+    res = {}
+    for ck in (False, True):
+        torch.manual_seed(5)
+        net = ViViT(64, 8, 19, 8, dim=128, depth=3, heads=2, dim_head=64, activation_checkpointing=ck).cuda().train()
+        x = torch.randn(4, 8, 3, 64, 64, generator=torch.Generator().manual_seed(6)).cuda()
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = net(x)
+        out.float().square().mean().backward()
+        torch.cuda.synchronize()
+        res[ck] = (out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                   torch.cuda.max_memory_allocated() - base)
+    assert torch.equal(res[False][0], res[True][0])
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
+    assert res[True][2] < 0.6 * res[False][2], (res[True][2], res[False][2])
