@@ -101,6 +101,18 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                       f"{dt:.2f} s/step"}
 
 
+WORKLOADS = {
+    "vivit": "ViViT metric shape (SURVEY 8 'M'; BASELINE configs[2]/[3] transformer): "
+             "B=8/GPU, T=32, 3x224x224, patch 16, d=512, depth 4+4, heads 8, dim_head 64; "
+             "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+    "pyramid": "BASELINE configs[2]: per-frame ResNet-18 3-scale pyramid (train-mode BatchNorm) -> FPN lateral tokens "
+               "(196/frame) -> the metric-shape transformer; B=8/GPU, T=32, 3x224x224; "
+               "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+    "crossmodal": "BASELINE configs[3]: configs[2] + 32 audio tokens (128-d), cross-attention block (video queries, "
+                  "audio keys/values), distillation token + head, loss = BCE + hard-label CE; B=8/GPU, T=32, 3x224x224",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +124,10 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
                     "replaying one captured hipGraph per step (single-GPU only)")
+    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal"], default="vivit",
+                    help="vivit = the metric workload (default); pyramid = BASELINE configs[2] (ResNet-18 3-scale "
+                    "pyramid front-end -> the same transformer); crossmodal = configs[3] (+ 32 audio tokens, "
+                    "cross-attention block, distillation head).  Secondary lines, same JSON contract.")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
                     "rank (rehearses the multi-GPU code path on a single GPU)")
     args = ap.parse_args()
@@ -136,8 +152,15 @@ def main():
 
     cfg = dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64)
     torch.manual_seed(1130)                                       # src/main.py:25
-    net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
-                heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=torch.bfloat16).cuda()
+    if args.workload == "vivit":
+        net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
+                    heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=torch.bfloat16).cuda()
+    else:
+        from dvt_amd.models.pyramid_vivit import PyramidViViT
+        cm = args.workload == "crossmodal"
+        net = PyramidViViT(cfg["image"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"], heads=cfg["heads"],
+                           dim_head=cfg["dh"], audio_tokens=32 if cm else 0, audio_dim=128, distill=cm,
+                           compute_dtype=torch.bfloat16).cuda().train()
     flat = FlatParameters(net, bucket_mb=args.bucket_mb)
     flat.broadcast_parameters(0)
     flat.sync_compute_copy()
@@ -149,11 +172,16 @@ def main():
     y[:, 0] = 1.0
     y = y.cuda()
     gloss = torch.full((), flat.loss_scale, device="cuda")
+    audio = None
+    if args.workload == "crossmodal":       # one 128-d VGGish-style vector per 1-s chunk (SURVEY 8d synthetic inputs)
+        audio = torch.randn(B, 32, 128, generator=gen).to(torch.bfloat16).cuda()
 
     def step():
         flat.zero_grad()
-        logits = net(x)
-        loss = F.bce_with_logits(logits, y)
+        if args.workload == "vivit":
+            loss = F.bce_with_logits(net(x), y)
+        else:
+            loss = net.training_step((y, x, audio) if audio is not None else (y, x))
         loss.backward(gloss)
         flat.finish_backward()
         flat.adamw_step(lr=5e-6, weight_decay=0.09)              # config.yaml:3,12
@@ -243,22 +271,22 @@ def main():
         fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
                                               3 * cfg["patch"] ** 2, n_tok - 1)
         out = {
-            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16",
+            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16" + ("" if args.workload == "vivit" else
+                                                                        f" [{args.workload} workload]"),
             "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViViT metric shape (SURVEY 8 'M'; BASELINE configs[2]/[3] transformer): "
-                                   "B=8/GPU, T=32, 3x224x224, patch 16, d=512, depth 4+4, heads 8, dim_head 64; "
-                                   "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+            "config": {"workload": WORKLOADS[args.workload],
                        "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
             "launch": "hipGraph replay" if use_graph else "eager",
-            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1),
-            "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1) if args.workload == "vivit" else None,
+            "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+            if args.workload == "vivit" else None,
             "final_loss": round(final_loss, 5),
         }
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -4,7 +4,9 @@ import numpy as np
 import torch
 
 from oracle import clip_path as O
-from tests.util import golden, rel_l2, fill_state_from_numpy
+import pytest
+
+from tests.util import golden, rel_l2, fill_state_from_numpy, digest_inputs, check_grad_digest
 
 T = lambda a: torch.from_numpy(np.asarray(a))
 
@@ -84,6 +86,25 @@ def test_vivit_c1_end_to_end():
     assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-6
     for k, gr in grads.items():
         assert rel_l2(gr, T(g["g:" + k])) < 5e-5, k
+
+
+@pytest.mark.parametrize("tag", ["c2_digest", "metric_digest"])
+def test_vivit_large_configs_against_reference_digest(tag):
+    """BASELINE configs[1] (d=384, T=16, 224^2) and the metric shape (d=512, T=32, 224^2), one clip each: the
+    oracle against the logits / loss / gradient digest written by the executed reference."""
+    g = golden(f"vivit_{tag}.npz")
+    cfg, x, y = digest_inputs(g)
+    import dvt_amd.models.vit as V        # parameter container only (names/shapes in the reference's order)
+    net = V.ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["frames"], dim=cfg["dim"], depth=cfg["depth"],
+                  heads=cfg["heads"], dim_head=cfg["dim_head"])
+    fill_state_from_numpy(net.named_parameters(), int(g["fill_seed"]))
+    P = {k: v.detach() for k, v in net.named_parameters()}
+    loss, grads = O.vivit_step_fwd_bwd(x, y, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
+    assert abs(float(loss) - float(g["loss"][0])) < 2e-6
+    with torch.no_grad():
+        logits = O.vivit_forward(x, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
+    assert rel_l2(logits, T(g["logits"])) < 1e-5
+    check_grad_digest(g, grads, 2e-4, tag)
 
 
 def test_posenc_base_1000():

@@ -62,3 +62,28 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def max_abs(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def digest_inputs(npz):
+    """Clip regenerated from the numpy seed stored in a ``vivit_*_digest.npz`` fixture (the generator drew it
+    from the same PCG64 stream)."""
+    cfg = {k[4:]: int(npz[k]) for k in npz.files if k.startswith("cfg_")}
+    rng = np.random.default_rng(int(npz["x_seed"]))
+    x = rng.standard_normal((int(npz["batch"]), cfg["frames"], 3, cfg["image"], cfg["image"])).astype(np.float32)
+    return cfg, torch.from_numpy(x), torch.from_numpy(npz["target"])
+
+
+def check_grad_digest(npz, grads, tol, label=""):
+    """grads: name -> tensor.  Every gradient's L2 norm and its 256 evenly spaced entries against the digest."""
+    worst = ("", 0.0)
+    for k in [f[3:] for f in npz.files if f.startswith("gs:")]:
+        g = grads[k].detach().float().cpu().reshape(-1)
+        idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
+        ref_s, ref_n = torch.from_numpy(npz["gs:" + k]), float(npz["gn:" + k])
+        e_s = float((g[torch.from_numpy(idx)] - ref_s).norm() / (ref_s.norm() + 1e-30))
+        e_n = abs(float(g.double().norm()) - ref_n) / (ref_n + 1e-30)
+        e = max(e_s, e_n)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < tol, (label, k, e_s, e_n)
+    return worst

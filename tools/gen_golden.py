@@ -235,6 +235,35 @@ def tpn_case():
     print("tpn_pieces: reasoning out", tuple(y.shape))
 
 
+def vivit_digest_case(vit, tag, cfg, batch, seed):
+    """Large configurations (BASELINE configs[1] and the metric shape): the clip and the weights are
+    regenerated from numpy seeds by the tests, so only the reference's outputs are stored -- logits, loss
+    and, per parameter gradient, its L2 norm plus 256 evenly spaced entries."""
+    torch.manual_seed(seed)
+    net = vit.ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["frames"], dim=cfg["dim"],
+                    depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"])
+    fill_from_numpy(net, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    x = torch.from_numpy(rng.standard_normal(
+        (batch, cfg["frames"], 3, cfg["image"], cfg["image"])).astype(np.float32))
+    y = torch.from_numpy((rng.random((batch, cfg["classes"])) < 0.2).astype(np.float32))
+    y[:, 0] = 1.0
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+    out = {"target": y.numpy(), "logits": logits.detach().numpy(), "loss": loss.detach().numpy()[None],
+           "fill_seed": np.array(seed + 1), "x_seed": np.array(seed + 2), "batch": np.array(batch)}
+    for k, v in cfg.items():
+        out["cfg_" + k] = np.array(v)
+    for name, p in net.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
+        out["gn:" + name] = np.array(float(g.double().norm()))
+        out["gs:" + name] = g[torch.from_numpy(idx)].numpy()
+    np.savez_compressed(os.path.join(OUT, f"vivit_{tag}.npz"), **out)
+    print(f"vivit_{tag}: logits {tuple(logits.shape)} loss {loss.item():.6f}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -244,6 +273,11 @@ def main():
     # BASELINE.json configs[0]: T=4, 64x64, d=128, 2 layers (plumbing config)
     c1 = dict(image=64, patch=16, classes=19, frames=4, dim=128, depth=2, heads=2, dim_head=64)
     vivit_case(vit, "c1", c1, batch=2, store_weights=False, seed=SEED + 10)
+    # BASELINE.json configs[1]: single-modal video path d=384, T=16, 224^2 (one clip); and the metric shape
+    c2 = dict(image=224, patch=16, classes=19, frames=16, dim=384, depth=4, heads=6, dim_head=64)
+    vivit_digest_case(vit, "c2_digest", c2, batch=1, seed=SEED + 20)
+    cm = dict(image=224, patch=16, classes=19, frames=32, dim=512, depth=4, heads=8, dim_head=64)
+    vivit_digest_case(vit, "metric_digest", cm, batch=1, seed=SEED + 30)
     block_cases(vit)
     encoder_layer_case()
     posenc_case()
