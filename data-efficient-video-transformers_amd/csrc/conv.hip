@@ -47,6 +47,34 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
   }
 }
 
+// NCHW stem (C = 3): one thread builds 8 consecutive columns of one row and stores them with one 16-byte
+// write; the column -> (ki, kj, c) decomposition uses compile-time divisors.  The reads hit L2 (every input
+// pixel is used kh*kw/(sh*sw) times), the kernel is bound by its output write.
+template <typename S, typename D, int CC, int KH, int KW>
+__global__ void im2col_nchw_stem_kernel(const S* __restrict__ x, D* __restrict__ out, int N, int H, int W, int sh,
+                                        int sw, int ph, int pw, int Ho, int Wo, int ld) {
+  constexpr int K = KH * KW * CC;
+  const int chunks = ld >> 3;
+  const int64_t items = (int64_t)N * Ho * Wo * chunks;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(it % chunks);
+    const int64_t r = it / chunks;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+    const int64_t n = r / ((int64_t)Wo * Ho);
+    const S* xn = x + n * CC * (int64_t)H * W;
+    const int h0 = ho * sh - ph, w0 = wo * sw - pw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = ch * 8 + e;
+      const int c = col % CC, kk = col / CC, kj = kk % KW, ki = kk / KW;
+      const int h = h0 + ki, w = w0 + kj;
+      v[e] = (col < K && h >= 0 && h < H && w >= 0 && w < W) ? to_f32<S>(xn[((int64_t)c * H + h) * W + w]) : 0.f;
+    }
+    store8<D>(out + r * ld + ch * 8, v);
+  }
+}
+
 // vectorised NHWC form: C % 8 == 0, one thread copies 8 channels of one (row, ki, kj)
 template <typename T>
 __global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C, int H,
@@ -143,18 +171,21 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int64_t rows, int C,
-                                                          int rows_per_block, int relu,
+                                                          int rows_per_block, int relu, int vc_log2,
                                                           float* __restrict__ partial) {
-  __shared__ float red[2][8][32][8];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = (blockIdx.x * 32 + cl) * 8;
+  // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
+  // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.
+  __shared__ float red[2][256][8];
+  const int vc = 1 << vc_log2, nrl = 256 >> vc_log2;
+  const int cl = threadIdx.x & (vc - 1), rl = threadIdx.x >> vc_log2;
+  const int c = (blockIdx.x * vc + cl) * 8;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
     float mu[8], is[8];
     if (MODE == 1) { load8<float>(mean + c, mu); load8<float>(invstd + c, is); }
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float xv[8];
       load8<T>(x + r * C + c, xv);
       if (MODE == 0) {
@@ -174,33 +205,44 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { red[0][rl][cl][k] = a[k]; red[1][rl][cl][k] = b[k]; }
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = a[k]; red[1][threadIdx.x][k] = b[k]; }
   __syncthreads();
-  if (rl < 2 && c < C) {
-    float t[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      t[k] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) t[k] += red[rl][r][cl][k];
+  // thread t < 2*vc*8 sums one (stat, column) over the row lanes in a fixed order
+  for (int t = threadIdx.x; t < 2 * vc * 8; t += 256) {
+    const int st = t / (vc * 8), col = t % (vc * 8), cv = col >> 3, k = col & 7;
+    const int cc = (blockIdx.x * vc + cv) * 8 + k;
+    if (cc < C) {
+      float acc = 0.f;
+      for (int r = 0; r < nrl; ++r) acc += red[st][(r << vc_log2) + cv][k];
+      partial[((int64_t)blockIdx.y * 2 + st) * C + cc] = acc;
     }
-    store8<float>(partial + ((int64_t)blockIdx.y * 2 + rl) * C + c, t);
   }
 }
 
 // MODE 0: mean, invstd (biased var), running stats update.  MODE 1: dgamma = sum dz*xhat, dbeta = sum dz.
 template <int MODE>
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, float inv_rows,
-                                   float eps, float* __restrict__ o0, float* __restrict__ o1,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
-                                   float unbias, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                           float inv_rows, float eps, float* __restrict__ o0,
+                                                           float* __restrict__ o1, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float momentum, float unbias,
+                                                           int accumulate) {
+  // block = 32 columns x 32 part lanes; fixed summation order (lane-strided partial sums, then a lane tree)
+  __shared__ float red[2][32][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s0 = 0.f, s1 = 0.f;
-  for (int p = 0; p < nparts; ++p) {
-    s0 += partial[((int64_t)p * 2 + 0) * C + c];
-    s1 += partial[((int64_t)p * 2 + 1) * C + c];
+  if (c < C) {
+    for (int p = pl; p < nparts; p += 32) {
+      s0 += partial[((int64_t)p * 2 + 0) * C + c];
+      s1 += partial[((int64_t)p * 2 + 1) * C + c];
+    }
   }
+  red[0][pl][cl] = s0;
+  red[1][pl][cl] = s1;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  s0 = 0.f; s1 = 0.f;
+  for (int p = 0; p < 32; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
   if (MODE == 0) {
     const float mu = s0 * inv_rows;
     const float var = fmaxf(s1 * inv_rows - mu * mu, 0.f);
@@ -420,6 +462,78 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
   }
 }
 
+// vectorised forms (C % 8 == 0): one thread owns 8 channels of one pixel, 16-byte loads, 8-byte index stores
+template <typename T>
+__global__ void maxpool_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                       int N, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  const int cv = C >> 3;
+  const int64_t items = (int64_t)N * Ho * Wo * cv;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t r = it / cv;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+    const int64_t n = r / ((int64_t)Wo * Ho);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+    for (int ki = 0; ki < k; ++ki) {
+      const int h = ho * stride - pad + ki;
+      if (h < 0 || h >= H) continue;
+      for (int kj = 0; kj < k; ++kj) {
+        const int w = wo * stride - pad + kj;
+        if (w < 0 || w >= W) continue;
+        float v[8];
+        load8<T>(x + ((n * H + h) * W + w) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (bi[e] < 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = ki * k + kj; }
+      }
+    }
+    store8<T>(y + r * C + c, best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(unsigned char)(bi[e] < 0 ? 0 : bi[e]) << (8 * e);
+    *reinterpret_cast<unsigned long long*>(idx + r * C + c) = packed;
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_vec_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                       T* __restrict__ dx, int N, int C, int H, int W, int k, int stride, int pad,
+                                       int Ho, int Wo) {
+  const int cv = C >> 3;
+  const int64_t items = (int64_t)N * H * W * cv;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t px = it / cv;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const int64_t n = px / ((int64_t)W * H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ki = 0; ki < k; ++ki) {
+      const int hh = h + pad - ki;
+      if (hh < 0 || hh % stride) continue;
+      const int ho = hh / stride;
+      if (ho >= Ho) continue;
+      for (int kj = 0; kj < k; ++kj) {
+        const int ww = w + pad - kj;
+        if (ww < 0 || ww % stride) continue;
+        const int wo = ww / stride;
+        if (wo >= Wo) continue;
+        const int64_t o = ((n * Ho + ho) * Wo + wo) * C + c;
+        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(idx + o);
+        float v[8];
+        load8<T>(dy + o, v);
+        const unsigned tap = (unsigned)(ki * k + kj);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((packed >> (8 * e)) & 0xffu) == tap) acc[e] += v[e];
+      }
+    }
+    store8<T>(dx + px * C + c, acc);
+  }
+}
+
 // ------------------------------------------------------------------ batched 2-D transpose [B, R, Cc] -> [B, Cc, R]
 template <typename T>
 __global__ void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
@@ -454,6 +568,20 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
   const int64_t rows = N * Ho * Wo;
   const bool vec = !x_nchw && x_dtype == out_dtype && C % 8 == 0 && ld % 8 == 0 && ld == (int64_t)kh * kw * C &&
                    dvt_aligned16(x) && dvt_aligned16(out);
+  if (x_nchw && C == 3 && kh == 7 && kw == 7 && ld % 8 == 0 && ld < (1 << 20) && dvt_aligned16(out)) {
+#define DVT_STEM_CASE(SD, S, DD, D)                                                                                   \
+  if (x_dtype == SD && out_dtype == DD) {                                                                             \
+    hipLaunchKernelGGL((im2col_nchw_stem_kernel<S, D, 3, 7, 7>), dim3(cgrid(rows * (ld >> 3))), dim3(kB), 0, st,      \
+                       (const S*)x, (D*)out, (int)N, H, W, sh, sw, ph, pw, Ho, Wo, (int)ld);                           \
+    DVT_LAUNCH_CHECK("dvt_im2col(stem)");                                                                             \
+    return DVT_OK;                                                                                                    \
+  }
+    DVT_STEM_CASE(DVT_F32, float, DVT_F32, float)
+    DVT_STEM_CASE(DVT_F32, float, DVT_BF16, bf16)
+    DVT_STEM_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+    DVT_STEM_CASE(DVT_BF16, bf16, DVT_F32, float)
+#undef DVT_STEM_CASE
+  }
   if (vec) {
     DVT_DISPATCH_DTYPE(x_dtype, T, hipLaunchKernelGGL((im2col_nhwc_vec_kernel<T>), dim3(cgrid(rows * kh * kw * (C >> 3))),
                                                       dim3(kB), 0, st, (const T*)x, (T*)out, (int)N, C, H, W, kh, kw,
@@ -543,11 +671,24 @@ int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, in
 
 size_t dvt_bn_workspace_bytes(int64_t rows, int C) {
   (void)rows;
-  return (((size_t)256 * 2 + 2) * (size_t)C + 8) * sizeof(float);
+  return (((size_t)2048 * 2 + 2) * (size_t)C + 8) * sizeof(float);
 }
 
-static int bn_parts(int64_t rows, int* rpb) {
-  int parts = (int)(rows / 64 < 256 ? rows / 64 : 256);
+// Column-vector lanes per block (log2) of the vectorised column-statistics kernel.
+static int bn_vc_log2(int C) {
+  int l = 3;                       // 8 column vectors = 64 channels
+  while (l < 5 && (16 << l) <= C) ++l;
+  return l;
+}
+
+// Row partition: about 2048 workgroups in total (8 per CU), at least 4 passes of the row lanes per workgroup.
+static int bn_parts(int64_t rows, int C, int* rpb) {
+  const int vcl = bn_vc_log2(C);
+  const int64_t gx = dvt_cdiv(C, 8 << vcl);
+  const int nrl = 256 >> vcl;
+  int64_t parts = 2048 / gx;
+  const int64_t cap = rows / (4 * nrl);
+  if (parts > cap) parts = cap;
   if (parts < 1) parts = 1;
   *rpb = (int)dvt_cdiv(rows, parts);
   return (int)dvt_cdiv(rows, *rpb);
@@ -558,20 +699,22 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
   DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0, "dvt_bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
-  const int parts = bn_parts(rows, &rpb);
-  const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
+  const int parts = bn_parts(rows, C, &rpb);
+  const int vcl = bn_vc_log2(C);
+  const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
+  const dim3 grid_s((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(workspace)) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
                                                     (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                    (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
+                                                    (const float*)nullptr, rows, C, rpb, 0, vcl, (float*)workspace));
   } else {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 0>), grid_s, dim3(256), 0, st, (const T*)x,
                                                     (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
                                                     (const float*)nullptr, rows, C, rpb, 0, (float*)workspace));
   }
   DVT_LAUNCH_CHECK("dvt_bn_stats");
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st,
                      (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
                      running_var, momentum, unbias, 0);
   DVT_LAUNCH_CHECK("dvt_bn_stats(finalize)");
@@ -616,21 +759,23 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   DVT_REQUIRE(!relu || y, "dvt_bn_bwd: relu needs the forward output");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
-  const int parts = bn_parts(rows, &rpb);
-  const dim3 grid((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
+  const int parts = bn_parts(rows, C, &rpb);
+  const int vcl = bn_vc_log2(C);
+  const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
+  const dim3 grid_s((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
   float* part = (float*)workspace;
   if (cvec) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part));
   } else {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid_s, dim3(256), 0, st, (const T*)x,
                                                     (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(stats)");
   // keep the local dgamma/dbeta 16-byte aligned behind the partials
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 256)), dim3(256), 0, st, (const float*)part,
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {
@@ -657,9 +802,15 @@ int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, 
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   if (N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(cgrid(N * Ho * Wo * C)), dim3(kB), 0, st,
-                                                  (const T*)x, (T*)y, (unsigned char*)idx, (int)N, C, H, W, k, stride,
-                                                  pad, Ho, Wo));
+  if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(y) && ((uintptr_t)idx & 7) == 0) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_vec_kernel<T>), dim3(cgrid(N * Ho * Wo * (C >> 3))), dim3(kB),
+                                                    0, st, (const T*)x, (T*)y, (unsigned char*)idx, (int)N, C, H, W, k,
+                                                    stride, pad, Ho, Wo));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(cgrid(N * Ho * Wo * C)), dim3(kB), 0, st,
+                                                    (const T*)x, (T*)y, (unsigned char*)idx, (int)N, C, H, W, k, stride,
+                                                    pad, Ho, Wo));
+  }
   DVT_LAUNCH_CHECK("dvt_maxpool_fwd");
   return DVT_OK;
 }
@@ -670,9 +821,15 @@ int dvt_maxpool_bwd(const void* dy, const void* idx, void* dx, int64_t N, int C,
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   if (N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(cgrid(N * H * W * C)), dim3(kB), 0, st,
-                                                  (const T*)dy, (const unsigned char*)idx, (T*)dx, (int)N, C, H, W, k,
-                                                  stride, pad, Ho, Wo));
+  if (C % 8 == 0 && dvt_aligned16(dy) && dvt_aligned16(dx) && ((uintptr_t)idx & 7) == 0) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_vec_kernel<T>), dim3(cgrid(N * H * W * (C >> 3))), dim3(kB), 0,
+                                                    st, (const T*)dy, (const unsigned char*)idx, (T*)dx, (int)N, C, H, W,
+                                                    k, stride, pad, Ho, Wo));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(cgrid(N * H * W * C)), dim3(kB), 0, st,
+                                                    (const T*)dy, (const unsigned char*)idx, (T*)dx, (int)N, C, H, W, k,
+                                                    stride, pad, Ho, Wo));
+  }
   DVT_LAUNCH_CHECK("dvt_maxpool_bwd");
   return DVT_OK;
 }

