@@ -103,6 +103,8 @@ SIGNATURES = {
     "dvt_ce_argmax_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     "dvt_ce_argmax_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),
     "dvt_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p]),
+    "dvt_frames_preprocess_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
+    "dvt_frames_preprocess": (c_int, [c_p, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

@@ -515,6 +515,28 @@ def adamw_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
             "dvt_adamw_step")
 
 
+def frames_preprocess(frames: Tensor, resize: int, crop: int, mean, std, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """uint8 RGB frames [F, H0, W0, 3] -> [F, 3, crop, crop]: Resize(resize) + CenterCrop(crop) + ToTensor +
+    Normalize(mean, std), bit-exact with PIL / torch in fp32 (MMX_Light_dl.py:203-217)."""
+    _need_cuda(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise ValueError("frames must be uint8 [F, H0, W0, 3]")
+    frames = frames.contiguous()
+    Fr, H0, W0, _ = frames.shape
+    lib = L.load()
+    nbytes = lib.dvt_frames_preprocess_workspace_bytes(Fr, H0, W0, resize, crop)
+    if nbytes == 0:
+        raise ValueError(f"crop {crop} exceeds the frame resized to shorter side {resize} ({H0}x{W0})")
+    ws = workspace(nbytes, frames.device)
+    out = torch.empty((Fr, 3, crop, crop), dtype=out_dtype, device=frames.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    L.check(lib.dvt_frames_preprocess(frames.data_ptr(), out.data_ptr(), _DT[out_dtype], Fr, H0, W0, resize, crop,
+                                      C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p), ws.data_ptr(),
+                                      _stream()), "dvt_frames_preprocess")
+    return out
+
+
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
               weight_decay: float) -> None:
     _need_cuda(param)

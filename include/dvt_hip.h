@@ -240,6 +240,16 @@ size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);
 int dvt_attention_fwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- on-device input stage
+ * transforms.Compose([Resize(resize), CenterCrop(crop), ToTensor(), Normalize(mean, std)]) of the reference's loader
+ * (src/dataloaders/mmx/MMX_Light_dl.py:203-217; val_transform :195-201) applied to decoded uint8 RGB frames
+ * src[F, H0, W0, 3] already resident in HBM; dst[F, 3, crop, crop] (f32: bit-exact with PIL + torch; bf16: that
+ * value rounded to nearest even).  Resize = Pillow 8-bit bilinear resample (antialiased triangle filter, 22-bit fixed
+ * point, horizontal then vertical pass through a uint8 intermediate in the workspace).  mean/std are host arrays of 3. */
+size_t dvt_frames_preprocess_workspace_bytes(int64_t frames, int H0, int W0, int resize, int crop);
+int dvt_frames_preprocess(const void* src, void* dst, int dst_dtype, int64_t frames, int H0, int W0, int resize,
+                          int crop, const float* mean, const float* std, void* workspace, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- per-frame CNN encoder
  * src/models/custom_resnet.py:19-153 (conv3x3 / 7x7 stem / 1x1 downsample, BatchNorm2d, ReLU,
  * MaxPool2d(3,2,1), residual adds).  Feature maps are NHWC = [N*H*W, C] matrices, so a

@@ -264,6 +264,43 @@ def vivit_digest_case(vit, tag, cfg, batch, seed):
     print(f"vivit_{tag}: logits {tuple(logits.shape)} loss {loss.item():.6f}")
 
 
+def input_stage_case():
+    """Resize + CenterCrop + ToTensor + Normalize (MMX_Light_dl.py:203-217) through Pillow itself (the resize is
+    Pillow arithmetic) and torch (ToTensor / Normalize restated: torchvision is not installed)."""
+    from PIL import Image
+    rng = np.random.default_rng(SEED + 40)
+    out = {}
+    mean, std = (0.43216, 0.394666, 0.37645), (0.22803, 0.22145, 0.216989)
+    cases = [("down_wide", (3, 90, 160), 40, 32), ("down_tall", (2, 150, 84), 36, 36), ("up", (2, 48, 64), 56, 56),
+             ("train_vid", (1, 135, 240), 120, 112), ("identity", (1, 32, 32), 32, 32)]
+    for tag, (F_, H0, W0), resize, crop in cases:
+        noise = rng.integers(0, 256, (F_, H0, W0, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:H0, 0:W0]
+        smooth = np.stack([(yy * 255 // max(H0 - 1, 1)), (xx * 255 // max(W0 - 1, 1)), ((yy + xx) % 256)], -1).astype(np.uint8)
+        frames = noise.copy()
+        frames[0] = smooth if F_ > 1 else noise[0]
+        res = []
+        for f in range(F_):
+            img = Image.fromarray(frames[f])
+            w, h = img.size
+            if w <= h:
+                ow, oh = resize, int(resize * h / w)
+            else:
+                oh, ow = resize, int(resize * w / h)
+            img = img.resize((ow, oh), Image.BILINEAR)
+            top, left = int(round((oh - crop) / 2.0)), int(round((ow - crop) / 2.0))
+            img = img.crop((left, top, left + crop, top + crop))
+            t = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).to(torch.float32).div(255)
+            t = (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+            res.append(t.numpy())
+        out[f"{tag}:frames"] = frames
+        out[f"{tag}:out"] = np.stack(res)
+        out[f"{tag}:cfg"] = np.array([resize, crop])
+    out["mean"], out["std"] = np.array(mean), np.array(std)
+    np.savez_compressed(os.path.join(OUT, "input_stage.npz"), **out)
+    print("input_stage:", [c[0] for c in cases])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -283,6 +320,7 @@ def main():
     posenc_case()
     resnet_case()
     tpn_case()
+    input_stage_case()
 
 
 if __name__ == "__main__":
