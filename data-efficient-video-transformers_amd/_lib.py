@@ -105,6 +105,10 @@ SIGNATURES = {
     "dvt_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_frames_preprocess_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
     "dvt_frames_preprocess": (c_int, [c_p, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
+    "dvt_f1_samples_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
+    "dvt_f1_samples": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_int, c_p, c_p, c_p]),
+    "dvt_average_precision_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
+    "dvt_average_precision": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

@@ -6,7 +6,7 @@ custom_resnet.py:138-153; the factorised space -> time ``Transformer`` of vit.py
 token-injection + CLS/"distillation token" read-out and the BCE + hard-label CE distillation loss of
 frame_transformer.py:225-239,246-252) but no module that wires them at these shapes.  This module is
 that wiring -- **build-defined**, not a mirror of one reference class; every stage is the mirrored
-reference component or an operator already pinned by the oracle:
+reference component or an operator already covered by the parity tests:
 
   frames [b*t, 3, H, W] -> resnet pyramid (x2 128 x 2s x 2s, x3 256 x s x s, x4 512 x s/2 x s/2, s = H/16)
   -> three lateral projections onto the middle grid, summed (FPN-style):

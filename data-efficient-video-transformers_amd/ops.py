@@ -537,6 +537,44 @@ def frames_preprocess(frames: Tensor, resize: int, crop: int, mean, std, out_dty
     return out
 
 
+def f1_samples(probs: Tensor, labels: Tensor, thresholds) -> Tensor:
+    """samples-averaged F1 of ``probs > t`` for every t (callbacks.py:38-41) -> f32 [T] on the device."""
+    _need_cuda(probs, labels)
+    probs = probs.contiguous() if probs.dtype == torch.float32 else cast(probs.contiguous(), torch.float32)
+    lab = labels.contiguous()
+    if lab.dtype != torch.uint8:
+        lab = (lab != 0).to(torch.uint8)          # dtype plumbing of a label mask
+    N, Cn = probs.shape
+    th = [float(t) for t in thresholds]
+    lib = L.load()
+    ws = workspace(lib.dvt_f1_samples_workspace_bytes(N, len(th)), probs.device)
+    out = torch.empty((len(th),), dtype=torch.float32, device=probs.device)
+    arr = (C.c_float * len(th))(*th)
+    L.check(lib.dvt_f1_samples(probs.data_ptr(), lab.data_ptr(), N, Cn, C.cast(arr, C.c_void_p), len(th),
+                               out.data_ptr(), ws.data_ptr(), _stream()), "dvt_f1_samples")
+    return out
+
+
+def average_precision(probs: Tensor, labels: Tensor):
+    """-> (samples-averaged AP [1], support-weighted AP [1], per-class AP [C]) f32 device tensors
+    (``average_precision_score`` of callbacks.py:48-54)."""
+    _need_cuda(probs, labels)
+    probs = probs.contiguous() if probs.dtype == torch.float32 else cast(probs.contiguous(), torch.float32)
+    lab = labels.contiguous()
+    if lab.dtype != torch.uint8:
+        lab = (lab != 0).to(torch.uint8)
+    N, Cn = probs.shape
+    lib = L.load()
+    nbytes = lib.dvt_average_precision_workspace_bytes(N, Cn)
+    if nbytes == 0:
+        raise ValueError("average_precision: empty input or N*C >= 2^31")
+    ws = workspace(nbytes, probs.device)
+    out = torch.empty((2 + Cn,), dtype=torch.float32, device=probs.device)
+    L.check(lib.dvt_average_precision(probs.data_ptr(), lab.data_ptr(), N, Cn, out.data_ptr(), out[1:].data_ptr(),
+                                      out[2:].data_ptr(), ws.data_ptr(), _stream()), "dvt_average_precision")
+    return out[0:1], out[1:2], out[2:]
+
+
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
               weight_decay: float) -> None:
     _need_cuda(param)

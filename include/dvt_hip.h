@@ -250,6 +250,20 @@ size_t dvt_frames_preprocess_workspace_bytes(int64_t frames, int H0, int W0, int
 int dvt_frames_preprocess(const void* src, void* dst, int dst_dtype, int64_t frames, int H0, int W0, int resize,
                           int crop, const float* mean, const float* std, void* workspace, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- evaluation reductions
+ * scikit-learn calls of src/callbacks/callbacks.py:36-55 on running_logits / running_labels, on the device.
+ * probs [N, C] f32 (sigmoid outputs, frame_transformer.py:331), labels [N, C] u8 (0 / non-zero).
+ * dvt_f1_samples: out[j] = f1_score(labels, probs > thresholds[j], average="samples", zero_division=0);
+ * thresholds is a host array of T <= 16 values (callbacks.py:38: 0, 0.1 .. 0.8).
+ * dvt_average_precision: average_precision_score(labels, probs, average="samples" / "weighted" / None) ->
+ * out_samples[1], out_weighted[1], out_per_class[C] (device f32); C <= 64. */
+size_t dvt_f1_samples_workspace_bytes(int64_t N, int T);
+int dvt_f1_samples(const float* probs, const unsigned char* labels, int64_t N, int C, const float* thresholds, int T,
+                   float* out, void* workspace, dvt_stream_t stream);
+size_t dvt_average_precision_workspace_bytes(int64_t N, int C);
+int dvt_average_precision(const float* probs, const unsigned char* labels, int64_t N, int C, float* out_samples,
+                          float* out_weighted, float* out_per_class, void* workspace, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- per-frame CNN encoder
  * src/models/custom_resnet.py:19-153 (conv3x3 / 7x7 stem / 1x1 downsample, BatchNorm2d, ReLU,
  * MaxPool2d(3,2,1), residual adds).  Feature maps are NHWC = [N*H*W, C] matrices, so a

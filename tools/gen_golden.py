@@ -301,6 +301,30 @@ def input_stage_case():
     print("input_stage:", [c[0] for c in cases])
 
 
+def eval_metrics_case():
+    """callbacks.py:36-55 through scikit-learn itself (the reference's dependency)."""
+    import warnings
+    from sklearn.metrics import average_precision_score, f1_score
+    rng = np.random.default_rng(SEED + 50)
+    N, C = 300, 19
+    y = (rng.random((N, C)) < 0.2).astype(np.uint8)
+    y[:, 14] = 0                                    # a class without positives (TVMovie is rare)
+    y[5, :] = 0                                     # a sample without positives
+    s = rng.random((N, C)).astype(np.float32)
+    s[:, 7] = np.round(s[:, 7], 1)                  # heavy ties
+    s[::9, 2] = 0.5
+    t = [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = {"probs": s, "labels": y, "thresholds": np.array(t),
+               "f1": np.array([f1_score(y, (s > tt).astype(int), average="samples", zero_division=0) for tt in t]),
+               "ap_samples": np.array(average_precision_score(y, s, average="samples")),
+               "ap_weighted": np.array(average_precision_score(y, s, average="weighted")),
+               "ap_class": np.array(average_precision_score(y, s, average=None))}
+    np.savez_compressed(os.path.join(OUT, "eval_metrics.npz"), **out)
+    print("eval_metrics: ap_samples", float(out["ap_samples"]), "weighted", float(out["ap_weighted"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -321,6 +345,7 @@ def main():
     resnet_case()
     tpn_case()
     input_stage_case()
+    eval_metrics_case()
 
 
 if __name__ == "__main__":
