@@ -109,6 +109,12 @@ SIGNATURES = {
     "dvt_f1_samples": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_int, c_p, c_p, c_p]),
     "dvt_average_precision_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
     "dvt_average_precision": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
+    "dvt_l2norm_rows_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_f, c_int, c_p]),
+    "dvt_l2norm_rows_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_int, c_p]),
+    "dvt_gate_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_gate_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_contrastive_fwd": (c_int, [c_p, c_int, c_f, c_p, c_p, c_p, c_p]),
+    "dvt_contrastive_bwd": (c_int, [c_p, c_p, c_int, c_f, c_p, c_p, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

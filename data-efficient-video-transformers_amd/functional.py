@@ -1113,3 +1113,74 @@ def checkpoint(fn, x: Tensor, params=()) -> Tensor:
     if not torch.is_grad_enabled():
         return fn(x)
     return _Checkpoint.apply(fn, x, *params)
+
+
+# ---------------------------------------------------------------------------
+# Multi-modal gating and the contrastive objective (collabgating.py, losses/ntxent.py)
+# ---------------------------------------------------------------------------
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, inv = ops.l2norm_rows_fwd(x.reshape(-1, x.shape[-1]), eps)
+        ctx.save_for_backward(y, inv)
+        ctx.eps, ctx.shape = eps, tuple(x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_rows_bwd(_as(dy.reshape(y.shape), y.dtype), y, inv, ctx.eps).view(ctx.shape), None
+
+
+def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.normalize(x, dim=-1) (collabgating.py:70)."""
+    return _L2Normalize.apply(x, eps)
+
+
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.gate_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        return ops.gate_bwd(_as(dy, a.dtype), a, b)
+
+
+def gate(a: Tensor, b: Tensor) -> Tensor:
+    """a * sigmoid(b): ``F.glu(cat(x, x + x1), -1)`` with a = x, b = x + x1 (collabgating.py:83-86)."""
+    return _Gate.apply(a, b)
+
+
+class _Contrastive(torch.autograd.Function):
+    """ContrastiveLoss.forward (ntxent.py:53-75) on reps = cat(z_i, z_j) [M, D] (fp32 arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, reps, temperature):
+        r32 = _as(reps.contiguous(), torch.float32)
+        zn, inv = ops.l2norm_rows_fwd(r32, 1e-8)                         # F.cosine_similarity eps
+        M, D = zn.shape
+        sim = ops.gemm(zn, zn, M, M, D, a_kmajor=True, b_kmajor=True, lda=D, ldb=D, out_dtype=torch.float32)
+        loss, lse = ops.contrastive_fwd(sim, temperature)
+        ctx.save_for_backward(zn, inv, sim, lse)
+        ctx.t, ctx.dtype = temperature, reps.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        zn, inv, sim, lse = ctx.saved_tensors
+        M, D = zn.shape
+        g = _as(gloss.contiguous().reshape(1), torch.float32)
+        dsim = ops.contrastive_bwd(sim, lse, ctx.t, g)
+        # sim = zn zn^T  =>  dzn = dsim zn + dsim^T zn
+        dzn = ops.gemm(dsim, zn, M, D, M, a_kmajor=True, b_kmajor=False, lda=M, ldb=D, out_dtype=torch.float32)
+        ops.gemm(dsim, zn, M, D, M, a_kmajor=False, b_kmajor=False, lda=M, ldb=D, out=dzn, out_dtype=torch.float32,
+                 accumulate=True)
+        return _as(ops.l2norm_rows_bwd(dzn, zn, inv, 1e-8), ctx.dtype), None
+
+
+def contrastive_loss(z_i: Tensor, z_j: Tensor, temperature: float) -> Tensor:
+    return _Contrastive.apply(concat_rows(z_i, z_j), temperature)

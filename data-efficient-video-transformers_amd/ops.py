@@ -575,6 +575,61 @@ def average_precision(probs: Tensor, labels: Tensor):
     return out[0:1], out[1:2], out[2:]
 
 
+def l2norm_rows_fwd(x: Tensor, eps: float):
+    _need_cuda(x)
+    x = x.contiguous()
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    L.check(L.load().dvt_l2norm_rows_fwd(x.data_ptr(), y.data_ptr(), inv.data_ptr(), rows, D, eps, dt(x), _stream()),
+            "dvt_l2norm_rows_fwd")
+    return y, inv
+
+
+def l2norm_rows_bwd(dy: Tensor, y: Tensor, inv: Tensor, eps: float) -> Tensor:
+    dy = dy.contiguous()
+    rows, D = y.shape
+    dx = torch.empty_like(y)
+    L.check(L.load().dvt_l2norm_rows_bwd(dy.data_ptr(), y.data_ptr(), inv.data_ptr(), dx.data_ptr(), rows, D, eps, dt(y),
+                                         _stream()), "dvt_l2norm_rows_bwd")
+    return dx
+
+
+def gate_fwd(a: Tensor, b: Tensor) -> Tensor:
+    _need_cuda(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    assert a.shape == b.shape and a.dtype == b.dtype
+    y = torch.empty_like(a)
+    L.check(L.load().dvt_gate_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), dt(a), _stream()), "dvt_gate_fwd")
+    return y
+
+
+def gate_bwd(dy: Tensor, a: Tensor, b: Tensor):
+    dy = dy.contiguous()
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    L.check(L.load().dvt_gate_bwd(dy.data_ptr(), a.data_ptr(), b.data_ptr(), da.data_ptr(), db.data_ptr(), a.numel(), dt(a),
+                                  _stream()), "dvt_gate_bwd")
+    return da, db
+
+
+def contrastive_fwd(sim: Tensor, temperature: float):
+    _need_cuda(sim)
+    M = sim.shape[0]
+    assert sim.dtype == torch.float32 and sim.is_contiguous() and sim.shape == (M, M)
+    buf = torch.empty((2 * M + 1,), dtype=torch.float32, device=sim.device)
+    L.check(L.load().dvt_contrastive_fwd(sim.data_ptr(), M, temperature, buf[2 * M:].data_ptr(), buf.data_ptr(),
+                                         buf[M:].data_ptr(), _stream()), "dvt_contrastive_fwd")
+    return buf[2 * M:].view(()), buf[:M]                     # loss, row_lse
+
+
+def contrastive_bwd(sim: Tensor, row_lse: Tensor, temperature: float, gloss: Tensor) -> Tensor:
+    M = sim.shape[0]
+    dsim = torch.empty_like(sim)
+    L.check(L.load().dvt_contrastive_bwd(sim.data_ptr(), row_lse.data_ptr(), M, temperature, gloss.data_ptr(),
+                                         dsim.data_ptr(), _stream()), "dvt_contrastive_bwd")
+    return dsim
+
+
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
               weight_decay: float) -> None:
     _need_cuda(param)

@@ -250,6 +250,25 @@ size_t dvt_frames_preprocess_workspace_bytes(int64_t frames, int H0, int W0, int
 int dvt_frames_preprocess(const void* src, void* dst, int dst_dtype, int64_t frames, int H0, int W0, int resize,
                           int crop, const float* mean, const float* std, void* workspace, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- multi-modal gating + contrastive loss
+ * F.normalize(x) (collabgating.py:70) and the normaliser of F.cosine_similarity (ntxent.py:63):
+ * y = x / max(||x||_2, eps) per row of [rows, D]; inv_norm[rows] is kept for backward. */
+int dvt_l2norm_rows_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int D, float eps, int dtype,
+                        dvt_stream_t stream);
+int dvt_l2norm_rows_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int D, float eps,
+                        int dtype, dvt_stream_t stream);
+/* ContextGating: F.glu(cat(x, x + x1), -1) = x * sigmoid(x + x1) (collabgating.py:83-86): y = a * sigmoid(b). */
+int dvt_gate_fwd(const void* a, const void* b, void* y, int64_t n, int dtype, dvt_stream_t stream);
+int dvt_gate_bwd(const void* dy, const void* a, const void* b, void* da, void* db, int64_t n, int dtype,
+                 dvt_stream_t stream);
+/* ContrastiveLoss.forward on the cosine-similarity matrix sim[M, M] f32, M = 2 * batch (ntxent.py:63-75):
+ * loss = mean_k( log sum_{j != k} exp(sim_kj / T) - sim_{k, (k + M/2) mod M} / T ).  row_lse[M], row_loss[M]: scratch /
+ * saved for backward.  bwd: dsim = dloss/dsim scaled by gloss[0]. */
+int dvt_contrastive_fwd(const float* sim, int M, float temperature, float* loss, float* row_lse, float* row_loss,
+                        dvt_stream_t stream);
+int dvt_contrastive_bwd(const float* sim, const float* row_lse, int M, float temperature, const float* gloss,
+                        float* dsim, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- evaluation reductions
  * scikit-learn calls of src/callbacks/callbacks.py:36-55 on running_logits / running_labels, on the device.
  * probs [N, C] f32 (sigmoid outputs, frame_transformer.py:331), labels [N, C] u8 (0 / non-zero).

@@ -116,3 +116,34 @@ def test_bucket_layout_covers_every_parameter_once():
     assert p0.data.data_ptr() == flat.data.data_ptr() and p0.grad.data_ptr() == flat.grad.data_ptr()
     # buckets are formed from the END of the buffer (backward completion order)
     assert flat.bucket_ranges[0][1] == flat.total and flat.bucket_ranges[-1][0] == 0
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvt_amd.metrics import gather_rows
+    rows = 3 if rank == 0 else 5                        # ranks hold different numbers of validation samples
+    t = torch.arange(rows * 4, dtype=torch.float32).view(rows, 4) + 100 * rank
+    g = gather_rows(t)
+    if rank == 0:
+        out.put(g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eval_accumulators_gather_across_ranks():
+    """metrics.gather_rows: every rank ends up with all ranks' running_logits rows, in rank order."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    b = np.arange(20, dtype=np.float32).reshape(5, 4) + 100
+    assert np.array_equal(got, np.concatenate([a, b]))

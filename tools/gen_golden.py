@@ -325,6 +325,53 @@ def eval_metrics_case():
     print("eval_metrics: ap_samples", float(out["ap_samples"]), "weighted", float(out["ap_weighted"]))
 
 
+def fusion_case():
+    """ContrastiveLoss from the imported reference (losses/ntxent.py) and CollaborativeGating from the executed
+    reference text (collabgating.py has no imports: torch / nn / F / a LightningModule stand-in are supplied)."""
+    import torch.nn.functional as TF
+    nt = _load("ref_ntxent", os.path.join(REF, "losses", "ntxent.py"))
+    rng = np.random.default_rng(SEED + 60)
+    out = {}
+    B, D = 6, 40
+    zi = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).requires_grad_(True)
+    zj = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).requires_grad_(True)
+    loss = nt.ContrastiveLoss(B, 0.5)(zi, zj)
+    loss.backward()
+    out.update({"cl_zi": zi.detach().numpy(), "cl_zj": zj.detach().numpy(), "cl_loss": loss.detach().numpy()[None],
+                "cl_gzi": zi.grad.numpy(), "cl_gzj": zj.grad.numpy()})
+
+    class _PL:
+        LightningModule = torch.nn.Module
+    ns = {"torch": torch, "nn": torch.nn, "F": TF, "pl": _PL}
+    exec(compile(open(os.path.join(REF, "collabgating.py")).read(), "collabgating.py", "exec"), ns)
+    cg = ns["CollaborativeGating"]().eval()
+    wrng = np.random.default_rng(SEED + 61)                    # weights are regenerated by the tests from this seed
+    with torch.no_grad():
+        for name, p in cg.named_parameters():
+            a = wrng.standard_normal(tuple(p.shape)).astype(np.float32)
+            p.copy_(torch.from_numpy(a * np.float32(0.02 if p.dim() == 2 else 0.1)))
+    out["cg_wseed"] = np.array(SEED + 61)
+    out["cg_wnames"] = np.array([n for n, _ in cg.named_parameters()])
+    dims = (2048, 2048, 128)                                   # the third expert is stretched to 2048
+    feats = [[[torch.from_numpy(rng.standard_normal((1, d)).astype(np.float32)) for d in dims] for _ in range(2)]
+             for _ in range(2)]
+    for bi, scenes in enumerate(feats):
+        for si, experts in enumerate(scenes):
+            for ei, t in enumerate(experts):
+                out[f"cg_x:{bi}:{si}:{ei}"] = t.numpy().copy()
+    y = cg([[list(e) for e in scenes] for scenes in feats])    # the reference mutates the expert lists
+    gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * gy).sum().backward()
+    out["cg_out"], out["cg_gy"] = y.detach().numpy(), gy.numpy()
+    for name, p in cg.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
+        out["gn:" + name] = np.array(float(g.double().norm()))
+        out["gs:" + name] = g[torch.from_numpy(idx)].numpy()
+    np.savez_compressed(os.path.join(OUT, "fusion.npz"), **out)
+    print("fusion: contrastive loss", float(loss.detach()), "gating out", tuple(y.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -346,6 +393,7 @@ def main():
     tpn_case()
     input_stage_case()
     eval_metrics_case()
+    fusion_case()
 
 
 if __name__ == "__main__":
