@@ -115,6 +115,8 @@ SIGNATURES = {
     "dvt_gate_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_contrastive_fwd": (c_int, [c_p, c_int, c_f, c_p, c_p, c_p, c_p]),
     "dvt_contrastive_bwd": (c_int, [c_p, c_p, c_int, c_f, c_p, c_p, c_p]),
+    "dvt_adamw_step_scaled": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_int, c_f,
+                                      c_f, c_p, c_f, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

@@ -220,72 +220,78 @@ __device__ __forceinline__ int img_off(int r, int c) {
 }
 
 // stage rows [0, rows_pad) of a [L][64] bf16 matrix (row stride sl) into an image; rows >= L are 0
-__device__ __forceinline__ void stage_image(char* img, const bf16* src, int64_t sl, int L,
+template <typename E>
+__device__ __forceinline__ void stage_image(char* img, const E* src, int64_t sl, int L,
                                             int rows_pad) {
   for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
     const int r = idx >> 3, c = idx & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < L) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * sl + c * 8);
-    *reinterpret_cast<bf16x8*>(img + img_off(r, c)) = v;
+    typename Elem16<E>::v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < L) v = *reinterpret_cast<const typename Elem16<E>::v8*>(src + (int64_t)r * sl + c * 8);
+    *reinterpret_cast<typename Elem16<E>::v8*>(img + img_off(r, c)) = v;
   }
 }
 
 // row fragment: lane (g, li) gets M[row0 + li][kk*32 + 8g .. +7]   (MFMA A/B operand, k = feature)
-__device__ __forceinline__ bf16x8 img_row_frag(const char* img, int row0, int kk, int g, int li) {
-  return *reinterpret_cast<const bf16x8*>(img + img_off(row0 + li, kk * 4 + g));
+template <typename E>
+__device__ __forceinline__ typename Elem16<E>::v8 img_row_frag(const char* img, int row0, int kk, int g, int li) {
+  return *reinterpret_cast<const typename Elem16<E>::v8*>(img + img_off(row0 + li, kk * 4 + g));
 }
 
 // transposed fragment for a k-step whose 32 reduction rows are the two 16-row tiles
 // ta, tb:  element j of lane (g, li) = M[16*(j<4 ? ta : tb) + 4g + (j&3)][col0 + li]
 // (col0 multiple of 16).  This is the k order of an accumulator pair used as the
 // other operand (see file header).
-__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int ta, int tb, int col0, int g,
+template <typename E>
+__device__ __forceinline__ typename Elem16<E>::v8 img_tr_frag(const char* img, int ta, int tb, int col0, int g,
                                               int li) {
   const int qq = li >> 2, pp = li & 3;
   const int u = col0 >> 4;
-  bf16x4 half[2];
+  typename Elem16<E>::v4 half[2];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     const int r = 16 * (hf ? tb : ta) + 4 * g + qq;
     const char* a = img + r * kRowBytes + ((u ^ ((r >> 1) & 3)) << 5) + 8 * pp;
-    half[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+    half[hf] = Elem16<E>::tr_read(a);
   }
   // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
   return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
-  bf16x8 o;
+template <typename E>
+__device__ __forceinline__ typename Elem16<E>::v8 pack_pair(const f32x4& a, const f32x4& b) {
+  typename Elem16<E>::v8 o;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    o[r] = (bf16)a[r];
-    o[4 + r] = (bf16)b[r];
+    o[r] = (E)a[r];
+    o[4 + r] = (E)b[r];
   }
   return o;
 }
 
-__device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
-  bf16x4 o;
+template <typename E>
+__device__ __forceinline__ void store4(E* p, const f32x4& v, float s) {
+  typename Elem16<E>::v4 o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = (bf16)(v[r] * s);
-  *reinterpret_cast<bf16x4*>(p) = o;
+  for (int r = 0; r < 4; ++r) o[r] = (E)(v[r] * s);
+  *reinterpret_cast<typename Elem16<E>::v4*>(p) = o;
 }
 
 // ---------------------------------------------------------------- forward
+template <typename E>
 __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
-  bf16* ob = (bf16*)p.out + b * p.o_sb + h * p.o_sh;
+  const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
+  const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+  const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+  E* ob = (E*)p.out + b * p.o_sb + h * p.o_sh;
   float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
   char* ks = smem;
   char* vs = smem + p.Lkp * kRowBytes;
-  stage_image(ks, kb, p.k_sl, p.Lk, p.Lkp);
-  stage_image(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  stage_image<E>(ks, kb, p.k_sl, p.Lk, p.Lkp);
+  stage_image<E>(vs, vb, p.v_sl, p.Lk, p.Lkp);
   __syncthreads();
 
   const float c2 = p.scale * kLog2e;
@@ -293,10 +299,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
   for (int qt = wid; qt < nqt; qt += W) {
     const int qi = qt * 16 + li;
     const int qrow = qi < p.Lq ? qi : p.Lq - 1;
-    bf16x8 qf[2];
+    typename Elem16<E>::v8 qf[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+      qf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -308,8 +314,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
         s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              img_row_frag(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt], 0, 0, 0);
+          s[tt] = Elem16<E>::mma(
+              img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt]);
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -336,12 +342,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
         }
       l = fmaf(l, alpha, ps);
       m = mn;
-      const bf16x8 pf = pack_pair(s[0], s[1]);
+      const typename Elem16<E>::v8 pf = pack_pair<E>(s[0], s[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         o[dt] *= alpha;
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            img_tr_frag(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt], 0, 0, 0);
+        o[dt] = Elem16<E>::mma(
+            img_tr_frag<E>(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt]);
       }
     }
     l += __shfl_xor(l, 16, 64);
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
     const float inv = 1.0f / l;
     if (qi < p.Lq) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store4(ob + (int64_t)qi * p.o_sl + dt * 16 + 4 * g, o[dt], inv);
+      for (int dt = 0; dt < 4; ++dt) store4<E>(ob + (int64_t)qi * p.o_sl + dt * 16 + 4 * g, o[dt], inv);
       if (g == 0) lse[qi] = (m + __builtin_amdgcn_logf(l)) * kLn2;
     }
   }
@@ -357,22 +363,23 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
 
 // ---------------------------------------------------------------- backward: dq
 // Query on the lane.  dQ^T[d][q] = sum_key K[key][d] * dS^T[key][q].
+template <typename E>
 __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
-  const bf16* ob = (const bf16*)p.o + b * p.o_sb + h * p.o_sh;
-  const bf16* gb = (const bf16*)p.d_o + b * p.o_sb + h * p.o_sh;
-  bf16* dqb = (bf16*)p.dq + b * p.q_sb + h * p.q_sh;
+  const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
+  const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+  const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+  const E* ob = (const E*)p.o + b * p.o_sb + h * p.o_sh;
+  const E* gb = (const E*)p.d_o + b * p.o_sb + h * p.o_sh;
+  E* dqb = (E*)p.dq + b * p.q_sb + h * p.q_sh;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
   char* ks = smem;
   char* vs = smem + p.Lkp * kRowBytes;
-  stage_image(ks, kb, p.k_sl, p.Lk, p.Lkp);
-  stage_image(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  stage_image<E>(ks, kb, p.k_sl, p.Lk, p.Lkp);
+  stage_image<E>(vs, vb, p.v_sl, p.Lk, p.Lkp);
   __syncthreads();
 
   const float c2 = p.scale * kLog2e;
@@ -380,13 +387,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnPara
   for (int qt = wid; qt < nqt; qt += W) {
     const int qi = qt * 16 + li;
     const int qrow = qi < p.Lq ? qi : p.Lq - 1;
-    bf16x8 qf[2], gf[2];
+    typename Elem16<E>::v8 qf[2], gf[2];
     float dl = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
-      gf[kk] = *reinterpret_cast<const bf16x8*>(gb + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(ob + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+      qf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+      gf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(gb + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+      const typename Elem16<E>::v8 of = *reinterpret_cast<const typename Elem16<E>::v8*>(ob + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl = fmaf((float)gf[kk][j], (float)of[j], dl);
     }
@@ -404,10 +411,10 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnPara
         dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              img_row_frag(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              img_row_frag(vs, (2 * kp + tt) * 16, kk, g, li), gf[kk], dp[tt], 0, 0, 0);
+          s[tt] = Elem16<E>::mma(
+              img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt]);
+          dp[tt] = Elem16<E>::mma(
+              img_row_frag<E>(vs, (2 * kp + tt) * 16, kk, g, li), gf[kk], dp[tt]);
         }
       }
 #pragma unroll
@@ -418,15 +425,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnPara
           const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2));
           s[tt][r] = key < p.Lk ? pr * (dp[tt][r] - dl) * p.scale : 0.f;
         }
-      const bf16x8 dsf = pack_pair(s[0], s[1]);
+      const typename Elem16<E>::v8 dsf = pack_pair<E>(s[0], s[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            img_tr_frag(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li), dsf, acc[dt], 0, 0, 0);
+        acc[dt] = Elem16<E>::mma(
+            img_tr_frag<E>(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li), dsf, acc[dt]);
     }
     if (qi < p.Lq) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store4(dqb + (int64_t)qi * p.q_sl + dt * 16 + 4 * g, acc[dt], 1.0f);
+      for (int dt = 0; dt < 4; ++dt) store4<E>(dqb + (int64_t)qi * p.q_sl + dt * 16 + 4 * g, acc[dt], 1.0f);
     }
   }
 }
@@ -435,32 +442,33 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnPara
 // Key on the lane.  S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO row fragments
 // from LDS images, B = K / V rows straight from HBM);
 // dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key].
+template <typename E>
 __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const bf16* qb = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kb = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const bf16* vb = (const bf16*)p.v + b * p.v_sb + h * p.v_sh;
-  const bf16* ob = (const bf16*)p.o + b * p.o_sb + h * p.o_sh;
-  const bf16* gb = (const bf16*)p.d_o + b * p.o_sb + h * p.o_sh;
-  bf16* dkb = (bf16*)p.dk + b * p.k_sb + h * p.k_sh;
-  bf16* dvb = (bf16*)p.dv + b * p.v_sb + h * p.v_sh;
+  const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
+  const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+  const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+  const E* ob = (const E*)p.o + b * p.o_sb + h * p.o_sh;
+  const E* gb = (const E*)p.d_o + b * p.o_sb + h * p.o_sh;
+  E* dkb = (E*)p.dk + b * p.k_sb + h * p.k_sh;
+  E* dvb = (E*)p.dv + b * p.v_sb + h * p.v_sh;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
   char* qs = smem;
   char* gs = smem + p.Lqp * kRowBytes;
   float* l2s = reinterpret_cast<float*>(smem + 2 * p.Lqp * kRowBytes);  // lse * log2e, [Lqp]
   float* dls = l2s + p.Lqp;                                              // delta, [Lqp]
-  stage_image(qs, qb, p.q_sl, p.Lq, p.Lqp);
-  stage_image(gs, gb, p.o_sl, p.Lq, p.Lqp);
+  stage_image<E>(qs, qb, p.q_sl, p.Lq, p.Lqp);
+  stage_image<E>(gs, gb, p.o_sl, p.Lq, p.Lqp);
   // per-row statistics: 8 consecutive threads share one query row
   for (int idx = threadIdx.x; idx < p.Lqp * 8; idx += blockDim.x) {
     const int r = idx >> 3, c = idx & 7;
     float d = 0.f;
     if (r < p.Lq) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(gb + (int64_t)r * p.o_sl + c * 8);
-      const bf16x8 o = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * p.o_sl + c * 8);
+      const typename Elem16<E>::v8 a = *reinterpret_cast<const typename Elem16<E>::v8*>(gb + (int64_t)r * p.o_sl + c * 8);
+      const typename Elem16<E>::v8 o = *reinterpret_cast<const typename Elem16<E>::v8*>(ob + (int64_t)r * p.o_sl + c * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) d = fmaf((float)a[j], (float)o[j], d);
     }
@@ -479,11 +487,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnPar
   for (int kt = wid; kt < nkt; kt += W) {
     const int kj = kt * 16 + li;
     const int krow = kj < p.Lk ? kj : p.Lk - 1;
-    bf16x8 kf[2], vf[2];
+    typename Elem16<E>::v8 kf[2], vf[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      kf[kk] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
-      vf[kk] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
+      kf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
+      vf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
     }
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -500,10 +508,10 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnPar
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           // D[row = query 4g+r][col = key li]:  A = Q / dO rows (image), B = K / V rows (regs)
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              img_row_frag(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              img_row_frag(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt], 0, 0, 0);
+          s[tt] = Elem16<E>::mma(
+              img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt]);
+          dp[tt] = Elem16<E>::mma(
+              img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt]);
         }
       }
 #pragma unroll
@@ -518,21 +526,21 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnPar
           dp[tt][r] = pr * (dp[tt][r] - dl[r]) * p.scale;
         }
       }
-      const bf16x8 pf = pack_pair(s[0], s[1]);
-      const bf16x8 dsf = pack_pair(dp[0], dp[1]);
+      const typename Elem16<E>::v8 pf = pack_pair<E>(s[0], s[1]);
+      const typename Elem16<E>::v8 dsf = pack_pair<E>(dp[0], dp[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            img_tr_frag(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            img_tr_frag(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt], 0, 0, 0);
+        dv[dt] = Elem16<E>::mma(
+            img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt]);
+        dk[dt] = Elem16<E>::mma(
+            img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt]);
       }
     }
     if (kj < p.Lk) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store4(dkb + (int64_t)kj * p.k_sl + dt * 16 + 4 * g, dk[dt], 1.0f);
-        store4(dvb + (int64_t)kj * p.v_sl + dt * 16 + 4 * g, dv[dt], 1.0f);
+        store4<E>(dkb + (int64_t)kj * p.k_sl + dt * 16 + 4 * g, dk[dt], 1.0f);
+        store4<E>(dvb + (int64_t)kj * p.v_sl + dt * 16 + 4 * g, dv[dt], 1.0f);
       }
     }
   }
@@ -569,7 +577,7 @@ bool strides_vec_ok(const dvt_attn_desc* d) {
 }
 
 bool mfma_fwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
-  return d->dtype == DVT_BF16 && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
+  return dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
          dvt_aligned16(d->k) && dvt_aligned16(d->v) && dvt_aligned16(d->o) &&
          2 * p.Lkp * kRowBytes <= kMaxLds;
 }
@@ -610,9 +618,11 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (mfma_fwd_ok(d, p)) {
     const size_t lds = (size_t)2 * p.Lkp * kRowBytes;
-    set_lds(attn_fwd_mfma_kernel, lds);
     const int W = pick_waves((p.Lq + 15) / 16);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(p.B * p.H)), dim3(64 * W), lds, st, p);
+    DVT_DISPATCH_16BIT(d->dtype, E, {
+      set_lds(attn_fwd_mfma_kernel<E>, lds);
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)), dim3(64 * W), lds, st, p);
+    });
     DVT_LAUNCH_CHECK("dvt_attention_fwd(mfma)");
     return DVT_OK;
   }
@@ -626,6 +636,9 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   } else if (d->dtype == DVT_BF16) {
     set_lds(attn_fwd_generic_kernel<bf16>, lds);
     hipLaunchKernelGGL((attn_fwd_generic_kernel<bf16>), grid, block, lds, st, p);
+  } else if (d->dtype == DVT_F16) {
+    set_lds(attn_fwd_generic_kernel<f16>, lds);
+    hipLaunchKernelGGL((attn_fwd_generic_kernel<f16>), grid, block, lds, st, p);
   } else {
     DVT_UNSUPPORTED("dvt_attention_fwd: dtype %d not supported", d->dtype);
   }
@@ -642,13 +655,14 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   if (mfma_bwd_ok(d, p)) {
     const size_t lds_q = (size_t)2 * p.Lkp * kRowBytes;
     const size_t lds_kv = (size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float);
-    set_lds(attn_bwd_dq_mfma_kernel, lds_q);
-    set_lds(attn_bwd_dkv_mfma_kernel, lds_kv);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((unsigned)(p.B * p.H)),
-                       dim3(64 * pick_waves((p.Lq + 15) / 16)), lds_q, st, p);
-    DVT_LAUNCH_CHECK("dvt_attention_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((unsigned)(p.B * p.H)),
-                       dim3(64 * pick_waves((p.Lk + 15) / 16)), lds_kv, st, p);
+    DVT_DISPATCH_16BIT(d->dtype, E, {
+      set_lds(attn_bwd_dq_mfma_kernel<E>, lds_q);
+      set_lds(attn_bwd_dkv_mfma_kernel<E>, lds_kv);
+      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
+                         dim3(64 * pick_waves((p.Lq + 15) / 16)), lds_q, st, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
+                         dim3(64 * pick_waves((p.Lk + 15) / 16)), lds_kv, st, p);
+    });
     DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
     return DVT_OK;
   }
@@ -670,6 +684,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   } while (0)
   if (d->dtype == DVT_F32) DVT_ATTN_BWD_GENERIC(float);
   else if (d->dtype == DVT_BF16) DVT_ATTN_BWD_GENERIC(bf16);
+  else if (d->dtype == DVT_F16) DVT_ATTN_BWD_GENERIC(f16);
   else DVT_UNSUPPORTED("dvt_attention_bwd: dtype %d not supported", d->dtype);
 #undef DVT_ATTN_BWD_GENERIC
   DVT_LAUNCH_CHECK("dvt_attention_bwd(generic)");

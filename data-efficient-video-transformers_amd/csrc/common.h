@@ -11,6 +11,9 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -36,6 +39,7 @@ int dvt_fail_hip(hipError_t e, const char* where);
 
 static inline bool dvt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t dvt_dtype_size(int dt) { return dt == DVT_F32 ? 4 : 2; }
+static inline bool dvt_is_16bit(int dt) { return dt == DVT_BF16 || dt == DVT_F16; }
 static inline int64_t dvt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int dvt_num_cus();
 
@@ -43,7 +47,9 @@ int dvt_num_cus();
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
 
@@ -51,6 +57,11 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
 template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[8]) {
   bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void load8<f16>(const f16* p, float (&o)[8]) {
+  f16x8 v = *reinterpret_cast<const f16x8*>(p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
 }
@@ -67,6 +78,12 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&
   for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
   *reinterpret_cast<bf16x8*>(p) = v;
 }
+template <> __device__ __forceinline__ void store8<f16>(f16* p, const float (&o)[8]) {
+  f16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (f16)o[i];
+  *reinterpret_cast<f16x8*>(p) = v;
+}
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
   f32x4 a, b;
 #pragma unroll
@@ -74,6 +91,33 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
   *reinterpret_cast<f32x4*>(p) = a;
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
+
+// ---------------------------------------------------------------- device: 16-bit MFMA element traits
+// bf16 and fp16 share every data path (LDS images, DMA, swizzles); only the matrix instruction, the
+// transposing LDS read and the conversions differ.
+template <typename E> struct Elem16;
+template <> struct Elem16<bf16> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr_read(const char* lds) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4*)(lds));
+  }
+};
+template <> struct Elem16<f16> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr_read(const char* lds) {
+    typedef __attribute__((ext_vector_type(4))) short i16x4;    // same instruction, 16-bit payload reinterpreted
+    const i16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lds));
+    return __builtin_bit_cast(v4, r);
+  }
+};
 
 // ---------------------------------------------------------------- device: wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
@@ -122,5 +166,14 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   do {                                                                      \
     if ((dtype) == DVT_F32) { typedef float T; __VA_ARGS__; }               \
     else if ((dtype) == DVT_BF16) { typedef bf16 T; __VA_ARGS__; }          \
+    else if ((dtype) == DVT_F16) { typedef f16 T; __VA_ARGS__; }            \
     else DVT_UNSUPPORTED("dtype %d not supported by this kernel", (int)(dtype)); \
+  } while (0)
+
+// Same for kernels that exist for the two 16-bit element types only (MFMA paths).
+#define DVT_DISPATCH_16BIT(dtype, E, ...)                                   \
+  do {                                                                      \
+    if ((dtype) == DVT_BF16) { typedef bf16 E; __VA_ARGS__; }               \
+    else if ((dtype) == DVT_F16) { typedef f16 E; __VA_ARGS__; }            \
+    else DVT_UNSUPPORTED("dtype %d is not a 16-bit MFMA element type", (int)(dtype)); \
   } while (0)

@@ -578,8 +578,11 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
   }
     DVT_STEM_CASE(DVT_F32, float, DVT_F32, float)
     DVT_STEM_CASE(DVT_F32, float, DVT_BF16, bf16)
+    DVT_STEM_CASE(DVT_F32, float, DVT_F16, f16)
     DVT_STEM_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+    DVT_STEM_CASE(DVT_F16, f16, DVT_F16, f16)
     DVT_STEM_CASE(DVT_BF16, bf16, DVT_F32, float)
+    DVT_STEM_CASE(DVT_F16, f16, DVT_F32, float)
 #undef DVT_STEM_CASE
   }
   if (vec) {
@@ -598,8 +601,11 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
   }
     DVT_IM2COL_CASE(DVT_F32, float, DVT_F32, float)
     DVT_IM2COL_CASE(DVT_F32, float, DVT_BF16, bf16)
+    DVT_IM2COL_CASE(DVT_F32, float, DVT_F16, f16)
     DVT_IM2COL_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+    DVT_IM2COL_CASE(DVT_F16, f16, DVT_F16, f16)
     DVT_IM2COL_CASE(DVT_BF16, bf16, DVT_F32, float)
+    DVT_IM2COL_CASE(DVT_F16, f16, DVT_F32, float)
 #undef DVT_IM2COL_CASE
     DVT_UNSUPPORTED("dvt_im2col: dtype pair (%d, %d)", x_dtype, out_dtype);
   }
@@ -623,8 +629,11 @@ int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t
   }
   DVT_C2I_CASE(DVT_F32, float, DVT_F32, float)
   DVT_C2I_CASE(DVT_BF16, bf16, DVT_F32, float)
+  DVT_C2I_CASE(DVT_F16, f16, DVT_F32, float)
   DVT_C2I_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+  DVT_C2I_CASE(DVT_F16, f16, DVT_F16, f16)
   DVT_C2I_CASE(DVT_F32, float, DVT_BF16, bf16)
+  DVT_C2I_CASE(DVT_F32, float, DVT_F16, f16)
 #undef DVT_C2I_CASE
   DVT_UNSUPPORTED("dvt_col2im_nchw: dtype pair (%d, %d)", dtype, dx_dtype);
 }

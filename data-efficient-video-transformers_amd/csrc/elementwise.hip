@@ -508,9 +508,12 @@ int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
     return DVT_OK;                                                                         \
   }
   DVT_CAST_CASE(DVT_F32, float, DVT_BF16, bf16)
+  DVT_CAST_CASE(DVT_F32, float, DVT_F16, f16)
   DVT_CAST_CASE(DVT_BF16, bf16, DVT_F32, float)
+  DVT_CAST_CASE(DVT_F16, f16, DVT_F32, float)
   DVT_CAST_CASE(DVT_F32, float, DVT_F32, float)
   DVT_CAST_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+  DVT_CAST_CASE(DVT_F16, f16, DVT_F16, f16)
 #undef DVT_CAST_CASE
   DVT_UNSUPPORTED("dvt_cast: dtype pair (%d -> %d) not supported", src_dtype, dst_dtype);
 }
@@ -640,6 +643,52 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
 
 __global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
+// ---- fp16 loss scaling (BASELINE configs[4]: "fp16 + loss scaling"), all state on the device so the step stays
+// hipGraph-capturable: scale[0], found_inf[0] (int32), good_steps[0] (int32), loss_grad[0] = scale * base.
+__global__ void check_finite_kernel(const float* __restrict__ g, int64_t n, int* __restrict__ found_inf) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i];
+    bad |= !(fabsf(v) <= 3.402823466e38f);          // inf or nan
+  }
+  if (bad) atomicOr(found_inf, 1);
+}
+
+__global__ void adamw_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                    const int64_t* __restrict__ step_dev, const float* __restrict__ scale,
+                                    const int* __restrict__ found_inf) {
+  if (found_inf[0]) return;                           // overflow: skip the whole update
+  const float inv_scale = 1.0f / scale[0];
+  const float t = (float)(step_dev[0] + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+    pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// after the step: step counter, dynamic scale (torch.cuda.amp.GradScaler rule), flag reset, next loss gradient
+__global__ void loss_scale_update_kernel(int64_t* step_dev, float* scale, int* found_inf, int* good_steps,
+                                         int growth_interval, float growth, float backoff, float* loss_grad,
+                                         float base) {
+  if (found_inf[0]) {
+    scale[0] *= backoff;
+    good_steps[0] = 0;
+  } else {
+    step_dev[0] += 1;
+    if (++good_steps[0] >= growth_interval) { scale[0] *= growth; good_steps[0] = 0; }
+  }
+  found_inf[0] = 0;
+  loss_grad[0] = scale[0] * base;
+}
+
 // torch.optim.SGD (dampening 0, no nesterov): d = g + wd p; buf = mu buf + d; p -= lr buf   (buf starts at 0,
 // which reproduces torch's "first step: buf = d" rule).  mu == 0: plain p -= lr d, buf untouched.
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
@@ -709,8 +758,11 @@ int patchify_entry(const void* pix, int pix_dtype, const void* vec, int vec_dtyp
                                         C, H, W, P, st, name);
   DVT_PATCH_CASE(DVT_F32, float, DVT_F32, float)
   DVT_PATCH_CASE(DVT_F32, float, DVT_BF16, bf16)
+  DVT_PATCH_CASE(DVT_F32, float, DVT_F16, f16)
   DVT_PATCH_CASE(DVT_BF16, bf16, DVT_BF16, bf16)
+  DVT_PATCH_CASE(DVT_F16, f16, DVT_F16, f16)
   DVT_PATCH_CASE(DVT_BF16, bf16, DVT_F32, float)
+  DVT_PATCH_CASE(DVT_F16, f16, DVT_F32, float)
 #undef DVT_PATCH_CASE
   DVT_UNSUPPORTED("%s: dtype pair (%d, %d) not supported", name, pix_dtype, vec_dtype);
 }
@@ -902,6 +954,26 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                      exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2));
   DVT_LAUNCH_CHECK("dvt_adamw_step");
+  return DVT_OK;
+}
+
+int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float* scale,
+                          int32_t* found_inf, int32_t* good_steps, int growth_interval, float growth, float backoff,
+                          float* loss_grad, float loss_grad_base, dvt_stream_t stream) {
+  DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && scale && found_inf && good_steps && loss_grad &&
+                  n >= 0 && growth_interval > 0 && growth >= 1.f && backoff > 0.f && backoff <= 1.f,
+              "dvt_adamw_step_scaled: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0) {
+    hipLaunchKernelGGL(check_finite_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, grad, n, (int*)found_inf);
+    hipLaunchKernelGGL(adamw_scaled_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev, (const float*)scale,
+                       (const int*)found_inf);
+  }
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, st, step_dev, scale, (int*)found_inf,
+                     (int*)good_steps, growth_interval, growth, backoff, loss_grad, loss_grad_base);
+  DVT_LAUNCH_CHECK("dvt_adamw_step_scaled");
   return DVT_OK;
 }
 

@@ -79,29 +79,31 @@ __device__ __forceinline__ void r2s(char* tile, int tid, const bf16x8 (&r)[4]) {
 
 // ---- LDS -> MFMA fragment: lane (g = lane>>4, li = lane&15) gets
 //      element j <-> (index = base + li, k = kk*32 + 8g + j)
-template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int base, int kk, int g, int li) {
+template <typename E, bool KMAJOR>
+__device__ __forceinline__ typename Elem16<E>::v8 lds_frag(const char* tile, int base, int kk, int g, int li) {
+  typedef typename Elem16<E>::v8 V8;
   if (KMAJOR) {
     const int row = base + li;
     const int c = kk * 4 + g;
-    return *reinterpret_cast<const bf16x8*>(tile + row * (BK * 2) + ((c ^ (row & 7)) << 4));
+    return *reinterpret_cast<const V8*>(tile + row * (BK * 2) + ((c ^ (row & 7)) << 4));
   } else {
     const int q = li >> 2, p = li & 3;
     const int u = base >> 4;  // 32-byte unit of the 16-column block
-    bf16x4 half[2];
+    typename Elem16<E>::v4 half[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int k = kk * 32 + 8 * g + 4 * hf + q;
       const char* a = tile + k * (BM * 2) + ((u ^ swz_mn(k)) << 5) + 8 * p;
-      half[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+      half[hf] = Elem16<E>::tr_read(a);
     }
     // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
     return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <typename E, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams p) {
+  typedef typename Elem16<E>::v8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -141,16 +143,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      V8 af[4], bfr[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = lds_frag<A_KMAJOR>(sa, wm * 64 + t * 16, kk, g, li);
+      for (int t = 0; t < 4; ++t) af[t] = lds_frag<E, A_KMAJOR>(sa, wm * 64 + t * 16, kk, g, li);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bfr[u] = lds_frag<B_KMAJOR>(sb, wn * 64 + u * 16, kk, g, li);
+      for (int u = 0; u < 4; ++u) bfr[u] = lds_frag<E, B_KMAJOR>(sb, wn * 64 + u * 16, kk, g, li);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[u], af[t], acc[u][t], 0, 0, 0);
+          acc[u][t] = Elem16<E>::mma(bfr[u], af[t], acc[u][t]);
     }
     if (more) {
       char* da = smem + ((kt + 1) & 1) * kStageBytes;
@@ -195,11 +197,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
       continue;
     }
     float ld[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
-    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, ld);
+    if (p.epilogue == DVT_EPI_RESIDUAL) load8<E>((const E*)p.residual + (int64_t)m * p.ldr + n, ld);
     if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
-      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, ld);
+      load8<E>((const E*)p.aux + (int64_t)m * p.ldaux + n, ld);
     epi_apply8(p.epilogue, v, bias, ld, pre);
-    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<E>((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
     if (p.out_f32) {
       float* o = (float*)p.C + (int64_t)m * p.ldc + n;
       if (p.accumulate) {
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
       }
       store8<float>(o, v);
     } else {
-      store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v);
+      store8<E>((E*)p.C + (int64_t)m * p.ldc + n, v);
     }
   }
 }
@@ -255,6 +257,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 // Split-K reduce with the fused epilogue (bias / activation / residual), bf16 output:
 // lets small-M GEMMs (the 33-token temporal encoder, M = 264) spread their K loop over
 // many workgroups instead of running one latency-bound loop per tile.
+template <typename E>
 __global__ void splitk_reduce_epi_kernel(const float* __restrict__ slab, int splits, const GemmParams p) {
   const int64_t nvec = (int64_t)p.M * p.N / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -271,12 +274,12 @@ __global__ void splitk_reduce_epi_kernel(const float* __restrict__ slab, int spl
     }
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ld[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
     if (p.bias) load8<float>(p.bias + n, bias);
-    if (p.epilogue == DVT_EPI_RESIDUAL) load8<bf16>((const bf16*)p.residual + (int64_t)m * p.ldr + n, ld);
+    if (p.epilogue == DVT_EPI_RESIDUAL) load8<E>((const E*)p.residual + (int64_t)m * p.ldr + n, ld);
     if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
-      load8<bf16>((const bf16*)p.aux + (int64_t)m * p.ldaux + n, ld);
+      load8<E>((const E*)p.aux + (int64_t)m * p.ldaux + n, ld);
     // (the slabs already carry alpha)
     epi_apply8(p.epilogue, v, bias, ld, pre);
-    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+    if (p.epilogue == DVT_EPI_GELU && p.aux) store8<E>((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
     if (p.out_f32) {
       float* o = (float*)p.C + (int64_t)m * p.ldc + n;
       if (p.accumulate) {
@@ -287,7 +290,7 @@ __global__ void splitk_reduce_epi_kernel(const float* __restrict__ slab, int spl
       }
       store8<float>(o, v);
     } else {
-      store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v);
+      store8<E>((E*)p.C + (int64_t)m * p.ldc + n, v);
     }
   }
 }
@@ -459,8 +462,8 @@ constexpr int kColsumParts = 128;
 
 // ---------------------------------------------------------------- host side
 bool mfma_eligible(const dvt_gemm_desc* d) {
-  if (d->in_dtype != DVT_BF16) return false;
-  if (!(d->out_dtype == DVT_BF16 || d->out_dtype == DVT_F32)) return false;
+  if (!dvt_is_16bit(d->in_dtype)) return false;
+  if (!(d->out_dtype == d->in_dtype || d->out_dtype == DVT_F32)) return false;
   if (d->K % 8 || d->N % 8) return false;
   if (d->lda % 8 || d->ldb % 8 || d->ldc % 8) return false;
   if (!d->a_kmajor && d->M % 8) return false;
@@ -544,7 +547,7 @@ int check_desc(const dvt_gemm_desc* d) {
   DVT_REQUIRE(d, "dvt_gemm: null descriptor");
   DVT_REQUIRE(d->A && d->B && d->C, "dvt_gemm: null operand pointer");
   DVT_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "dvt_gemm: negative dimension");
-  DVT_REQUIRE(d->in_dtype == DVT_F32 || d->in_dtype == DVT_BF16, "dvt_gemm: in_dtype %d unsupported",
+  DVT_REQUIRE(d->in_dtype == DVT_F32 || dvt_is_16bit(d->in_dtype), "dvt_gemm: in_dtype %d unsupported",
               d->in_dtype);
   DVT_REQUIRE(d->out_dtype == d->in_dtype || d->out_dtype == DVT_F32,
               "dvt_gemm: out_dtype must equal in_dtype or be f32");
@@ -602,6 +605,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
     p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
     p.alpha = d->alpha;
+    p.elem = d->in_dtype;
     p.k_per_split = pl.kps;
     p.slab = split > 1 ? (float*)d->workspace : nullptr;
     p.tiles_n = 0;
@@ -624,22 +628,21 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     const int tiles_m = (int)dvt_cdiv(d->M, BM);
     p.tiles_n = (int)dvt_cdiv(d->N, BN);
     const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(NTHREADS);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-      attr_set = true;
-    }
-    if (d->a_kmajor && d->b_kmajor)
-      hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, block, kSmemBytes, st, p);
-    else if (d->a_kmajor && !d->b_kmajor)
-      hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, block, kSmemBytes, st, p);
-    else if (!d->a_kmajor && d->b_kmajor)
-      hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, block, kSmemBytes, st, p);
-    else
-      hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, block, kSmemBytes, st, p);
+    const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
+    DVT_DISPATCH_16BIT(d->in_dtype, E, {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        attr_set = true;
+      }
+      if (ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, true, true>), grid, block, kSmemBytes, st, p);
+      else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, true, false>), grid, block, kSmemBytes, st, p);
+      else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, false, true>), grid, block, kSmemBytes, st, p);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<E, false, false>), grid, block, kSmemBytes, st, p);
+    });
     DVT_LAUNCH_CHECK("dvt_gemm(mfma)");
     }
     if (split > 1) {
@@ -649,16 +652,16 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
       if (blocks > cap) blocks = cap;
       const bool plain = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
       if (!plain)
-        hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float*)p.slab, split, p);
+        DVT_DISPATCH_16BIT(d->in_dtype, E, hipLaunchKernelGGL((splitk_reduce_epi_kernel<E>), dim3((unsigned)blocks),
+                                                              dim3(256), 0, st, (const float*)p.slab, split, p));
       else if (p.out_f32)
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate,
                            (const float*)p.colsum_slab, d->colsum_out, d->colsum_accumulate);
       else
-        hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float*)p.slab, split, p.M, p.N, (bf16*)d->C, d->ldc, 0,
-                           (const float*)nullptr, (float*)nullptr, 0);
+        DVT_DISPATCH_16BIT(d->in_dtype, E, hipLaunchKernelGGL((splitk_reduce_kernel<E>), dim3((unsigned)blocks), dim3(256),
+                                                              0, st, (const float*)p.slab, split, p.M, p.N, (E*)d->C,
+                                                              d->ldc, 0, (const float*)nullptr, (float*)nullptr, 0));
       DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce)");
     }
     return DVT_OK;
@@ -677,8 +680,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   g.accumulate = d->accumulate; g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
   g.aux = d->aux; g.ldaux = d->ldaux; g.alpha = d->alpha;
   const dim3 grid((unsigned)dvt_cdiv(d->N, 64), (unsigned)dvt_cdiv(d->M, 64)), block(256);
-  if (d->in_dtype == DVT_F32) hipLaunchKernelGGL((gemm_generic_kernel<float>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_generic_kernel<bf16>), grid, block, 0, st, g);
+  DVT_DISPATCH_DTYPE(d->in_dtype, T, hipLaunchKernelGGL((gemm_generic_kernel<T>), grid, block, 0, st, g));
   DVT_LAUNCH_CHECK("dvt_gemm(generic)");
   return DVT_OK;
 }

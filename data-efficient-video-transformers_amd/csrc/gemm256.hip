@@ -81,21 +81,22 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
 
 // MFMA operand fragment of 16 rows (k-major) / 16 columns (mn-major) starting at `base`,
 // k-step kk (32 k each): lane (g, li) gets element j <-> (base + li, kk*32 + 8g + j).
-template <bool KMAJOR, int ROWS, int TK>
-__device__ __forceinline__ bf16x8 frag(const char* tile, int base, int kk, int g, int li) {
+template <typename E, bool KMAJOR, int ROWS, int TK>
+__device__ __forceinline__ typename Elem16<E>::v8 frag(const char* tile, int base, int kk, int g, int li) {
+  typedef typename Elem16<E>::v8 V8;
   if (KMAJOR) {
     const int row = base + li;
     const int c = kk * 4 + g;
-    return *reinterpret_cast<const bf16x8*>(tile + row * (TK * 2) + ((c ^ swz_k<TK>(row)) << 4));
+    return *reinterpret_cast<const V8*>(tile + row * (TK * 2) + ((c ^ swz_k<TK>(row)) << 4));
   } else {
     const int q = li >> 2, pp = li & 3;
     const int u = base >> 4;
-    bf16x4 half[2];
+    typename Elem16<E>::v4 half[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int k = kk * 32 + 8 * g + 4 * hf + q;
       const char* a = tile + k * (ROWS * 2) + ((u ^ swz_mn(k)) << 5) + 8 * pp;
-      half[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+      half[hf] = Elem16<E>::tr_read(a);
     }
     // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
     return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -125,9 +126,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 //      4 x 4 unrolled passes was ~19k ISA lines per kernel and thrashed the I-cache).
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT>
+template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT>
 __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const GemmParams p) {
   typedef Cfg<CFG> C;
+  typedef typename Elem16<E>::v8 V8;
   constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
   constexpr int kATile = TM * TK * 2, kBTile = TN * TK * 2, kStage = kATile + kBTile;
   constexpr int kPPT = (kATile + kBTile) / 1024 / NW;   // DMA instructions per thread per k-tile
@@ -170,9 +172,9 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   constexpr bool kCanColsum = !A_KMAJOR && OUT == OUT_SLAB && WN == 4;
   const bool do_cs = kCanColsum && p.colsum_slab != nullptr && n0 == 0;
   f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  bf16x8 ones;
+  V8 ones;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  for (int j = 0; j < 8; ++j) ones[j] = (E)1.0f;
 
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
@@ -198,28 +200,27 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     const char* sb = sa + kATile;
 #pragma unroll
     for (int kk = 0; kk < (DVT_ABL == 1 ? 0 : TK / 32); ++kk) {
-      bf16x8 bfr[4];
+      V8 bfr[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bfr[u] = frag<B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
+      for (int u = 0; u < 4; ++u) bfr[u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
 #pragma unroll
       for (int th = 0; th < 2; ++th) {
-        bf16x8 af[4];
+        V8 af[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = frag<A_KMAJOR, TM, TK>(sa, wm * 128 + (th * 4 + t) * 16, kk, g, li);
+        for (int t = 0; t < 4; ++t) af[t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (th * 4 + t) * 16, kk, g, li);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            acc[u][th * 4 + t] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[u], af[t], acc[u][th * 4 + t], 0, 0, 0);
+            acc[u][th * 4 + t] = Elem16<E>::mma(bfr[u], af[t], acc[u][th * 4 + t]);
         __builtin_amdgcn_s_setprio(0);
       }
       if (kCanColsum && do_cs) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
-          csum[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              ones, frag<A_KMAJOR, TM, TK>(sa, wm * 128 + (2 * wn + tt) * 16, kk, g, li), csum[tt], 0, 0, 0);
+          csum[tt] = Elem16<E>::mma(ones, frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (2 * wn + tt) * 16, kk, g, li),
+                                    csum[tt]);
       }
     }
     st_cur = st_cur + 1 == NSTG ? 0 : st_cur + 1;
@@ -245,16 +246,16 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   const int n = wcol0 + c;
   const bool n_ok = n < p.N;
   constexpr bool kNeedLd = OUT == OUT_BF16 && (EPI == DVT_EPI_RESIDUAL || EPI == DVT_EPI_DGELU || EPI == DVT_EPI_DRELU);
-  const bf16* ldp = EPI == DVT_EPI_RESIDUAL ? (const bf16*)p.residual : (const bf16*)p.aux;
+  const E* ldp = EPI == DVT_EPI_RESIDUAL ? (const E*)p.residual : (const E*)p.aux;
   const int64_t ldl = EPI == DVT_EPI_RESIDUAL ? p.ldr : p.ldaux;
   float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (OUT != OUT_SLAB && p.bias && n_ok) load8<float>(p.bias + n, bias);
-  bf16x8 nxt[4];
+  V8 nxt[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    nxt[j] = V8{0, 0, 0, 0, 0, 0, 0, 0};
     const int m = wrow0 + (lane >> 3) + 8 * j;
-    if (kNeedLd && n_ok && m < p.M) nxt[j] = *reinterpret_cast<const bf16x8*>(ldp + (int64_t)m * ldl + n);
+    if (kNeedLd && n_ok && m < p.M) nxt[j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + n);
   }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
             acc[u][ps * 2 + tt] * p.alpha;
     wave_lds_fence();
     float v[4][8];
-    bf16x8 cur[4];
+    V8 cur[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = (lane >> 3) + 8 * j;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int m = wrow0 + (ps + 1) * 32 + (lane >> 3) + 8 * j;
-        if (n_ok && m < p.M) nxt[j] = *reinterpret_cast<const bf16x8*>(ldp + (int64_t)m * ldl + n);
+        if (n_ok && m < p.M) nxt[j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + n);
       }
     }
 #pragma unroll
@@ -307,12 +308,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
             const float ld = (float)cur[j][k];
             v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
-          if (EPI == DVT_EPI_GELU && p.aux) store8<bf16>((bf16*)p.aux + (int64_t)m * p.ldaux + n, pre);
+          if (EPI == DVT_EPI_GELU && p.aux) store8<E>((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
           if (DVT_ABL == 6) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(v[j][k]));
           } else {
-            store8<bf16>((bf16*)p.C + (int64_t)m * p.ldc + n, v[j]);
+            store8<E>((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
           }
         }
       }
@@ -322,20 +323,20 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
 }
 
 // ---------------------------------------------------------------- host side
-template <bool AK, bool BK, int CFG, int EPI, int OUT>
+template <typename E, bool AK, bool BK, int CFG, int EPI, int OUT>
 int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<AK, BK, CFG, EPI, OUT>,
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, AK, BK, CFG, EPI, OUT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_dma_kernel<AK, BK, CFG, EPI, OUT>), grid, block, smem_bytes, st, p);
+  hipLaunchKernelGGL((gemm_dma_kernel<E, AK, BK, CFG, EPI, OUT>), grid, block, smem_bytes, st, p);
   DVT_LAUNCH_CHECK("dvt_gemm(dma)");
   return DVT_OK;
 }
 
-template <int CFG>
+template <typename E, int CFG>
 int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t st) {
   typedef Cfg<CFG> C;
   constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
@@ -346,20 +347,20 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
   const int e = p.epilogue;
   if (p.slab) {
-    if (!ak && !bk) return launch_one<false, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
-    if (ak && bk) return launch_one<true, true, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
-    if (ak && !bk) return launch_one<true, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+    if (!ak && !bk) return launch_one<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+    if (ak && bk) return launch_one<E, true, true, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
+    if (ak && !bk) return launch_one<E, true, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
   } else if (p.out_f32) {
-    if (!ak && !bk && e == DVT_EPI_NONE) return launch_one<false, false, CFG, DVT_EPI_NONE, OUT_F32>(p, grid, block, kSmem, st);
+    if (!ak && !bk && e == DVT_EPI_NONE) return launch_one<E, false, false, CFG, DVT_EPI_NONE, OUT_F32>(p, grid, block, kSmem, st);
   } else if (ak && bk) {
-    if (e == DVT_EPI_NONE) return launch_one<true, true, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
-    if (e == DVT_EPI_GELU) return launch_one<true, true, CFG, DVT_EPI_GELU, OUT_BF16>(p, grid, block, kSmem, st);
-    if (e == DVT_EPI_RELU) return launch_one<true, true, CFG, DVT_EPI_RELU, OUT_BF16>(p, grid, block, kSmem, st);
-    if (e == DVT_EPI_RESIDUAL) return launch_one<true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_NONE) return launch_one<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_GELU) return launch_one<E, true, true, CFG, DVT_EPI_GELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_RELU) return launch_one<E, true, true, CFG, DVT_EPI_RELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_RESIDUAL) return launch_one<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16>(p, grid, block, kSmem, st);
   } else if (ak && !bk) {
-    if (e == DVT_EPI_NONE) return launch_one<true, false, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
-    if (e == DVT_EPI_DGELU) return launch_one<true, false, CFG, DVT_EPI_DGELU, OUT_BF16>(p, grid, block, kSmem, st);
-    if (e == DVT_EPI_DRELU) return launch_one<true, false, CFG, DVT_EPI_DRELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_NONE) return launch_one<E, true, false, CFG, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_DGELU) return launch_one<E, true, false, CFG, DVT_EPI_DGELU, OUT_BF16>(p, grid, block, kSmem, st);
+    if (e == DVT_EPI_DRELU) return launch_one<E, true, false, CFG, DVT_EPI_DRELU, OUT_BF16>(p, grid, block, kSmem, st);
   }
   return 1;   // combination not instantiated: caller falls back to the 128x128 kernel
 }
@@ -369,5 +370,8 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
 // combination has no LDS-DMA instantiation.
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
-  return cfg == 0 ? launch_cfg<0>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<1>(p, a_kmajor, b_kmajor, split, st);
+  if (p.elem == DVT_F16)       // fp16: the 256x256x64 configuration only (cfg 1 is an experiment knob)
+    return launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
+  return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
+                  : launch_cfg<bf16, 1>(p, a_kmajor, b_kmajor, split, st);
 }

@@ -175,11 +175,33 @@ class FlatParameters:
         return 1.0 / self.world
 
     # ------------------------------------------------------------------ optimizer
+    # ------------------------------------------------------------------ fp16 loss scaling (BASELINE configs[4])
+    def enable_loss_scaling(self, init_scale: float = 65536.0, growth_interval: int = 2000, growth: float = 2.0,
+                            backoff: float = 0.5) -> torch.Tensor:
+        """Dynamic loss scaling with every piece of scaler state on the device (no host sync, hipGraph-capturable).
+        Returns ``loss_grad``, the device scalar to seed backward with: ``loss.backward(flat.loss_grad)``; it holds
+        ``scale / world`` and is refreshed by every ``adamw_step``.  A step whose all-reduced gradient contains a
+        non-finite value is skipped on the device and halves the scale."""
+        dev = self.data.device
+        self.scaler = dict(growth_interval=int(growth_interval), growth=float(growth), backoff=float(backoff))
+        self.scale_dev = torch.full((1,), float(init_scale), dtype=torch.float32, device=dev)
+        self.found_inf = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.good_steps = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss_grad = torch.full((), float(init_scale) * self.loss_scale, dtype=torch.float32, device=dev)
+        return self.loss_grad
+
     def adamw_step(self, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
         """torch.optim.AdamW semantics (frame_transformer.py:127-129) in one launch."""
         if self.exp_avg is None:
             self.init_optimizer_state()
         self.step_count += 1
+        if getattr(self, "scaler", None) is not None:
+            ops.adamw_step_scaled_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.scale_dev,
+                                   self.found_inf, self.good_steps, self.loss_grad, lr=lr, beta1=betas[0],
+                                   beta2=betas[1], eps=eps, weight_decay=weight_decay, loss_grad_base=self.loss_scale,
+                                   **self.scaler)
+            self.sync_compute_copy()
+            return
         # step counter lives on the device so the launch can be captured in a hipGraph
         ops.adamw_step_dev_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
                             beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)

@@ -15,8 +15,8 @@ from . import _lib as L
 
 Tensor = torch.Tensor
 
-_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
-_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16}
 
 
 def dt(t: Tensor) -> int:
@@ -628,6 +628,20 @@ def contrastive_bwd(sim: Tensor, row_lse: Tensor, temperature: float, gloss: Ten
     L.check(L.load().dvt_contrastive_bwd(sim.data_ptr(), row_lse.data_ptr(), M, temperature, gloss.data_ptr(),
                                          dsim.data_ptr(), _stream()), "dvt_contrastive_bwd")
     return dsim
+
+
+def adamw_step_scaled_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev: Tensor, scale: Tensor,
+                       found_inf: Tensor, good_steps: Tensor, loss_grad: Tensor, *, lr: float, beta1: float, beta2: float,
+                       eps: float, weight_decay: float, growth_interval: int, growth: float, backoff: float,
+                       loss_grad_base: float) -> None:
+    """AdamW under dynamic loss scaling, all scaler state on the device (hipGraph-capturable)."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev, scale, found_inf, good_steps, loss_grad)
+    assert found_inf.dtype == torch.int32 and good_steps.dtype == torch.int32 and step_dev.dtype == torch.int64
+    L.check(L.load().dvt_adamw_step_scaled(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                           param.numel(), lr, beta1, beta2, eps, weight_decay, step_dev.data_ptr(),
+                                           scale.data_ptr(), found_inf.data_ptr(), good_steps.data_ptr(), growth_interval,
+                                           growth, backoff, loss_grad.data_ptr(), loss_grad_base, _stream()),
+            "dvt_adamw_step_scaled")
 
 
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,

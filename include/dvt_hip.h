@@ -356,6 +356,15 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_dev, dvt_stream_t stream);
+/* AdamW under dynamic loss scaling (BASELINE configs[4]: fp16 + loss scaling; torch.cuda.amp.GradScaler rule).
+ * grad holds the gradient of (scale * loss).  On the device, in stream order: found_inf |= any non-finite grad;
+ * unless found_inf: the dvt_adamw_step_dev update with grad / scale and step_dev += 1; then
+ * found_inf ? scale *= backoff : (every growth_interval clean steps: scale *= growth); found_inf = 0;
+ * loss_grad[0] = scale * loss_grad_base (the seed of the next backward, e.g. base = 1 / world).  No host sync. */
+int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float* scale,
+                          int32_t* found_inf, int32_t* good_steps, int growth_interval, float growth, float backoff,
+                          float* loss_grad, float loss_grad_base, dvt_stream_t stream);
 /* torch.optim.SGD(lr, momentum, weight_decay) (frame_transformer.py:124-126; config.yaml momentum 0.005):
  * d = g + wd*p; buf = momentum*buf + d; p -= lr*buf.  momentum_buf starts zeroed (may be NULL when momentum == 0). */
 int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,

@@ -37,7 +37,7 @@ def _rnd(shape, dtype, gen, scale=1.0):
     return x.cuda(), x.float()
 
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 # ------------------------------------------------------------------ elementwise
@@ -192,29 +192,30 @@ def test_gemm_epilogues(dvt, device, dtype, K):
     assert rel_l2(dr, (dy @ w) * (hpos > 0)) < tol
 
 
-def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device):
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
+def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     """Shapes large enough for the 256x256 LDS-DMA kernel (>= 96 tiles), with ragged
     M (6208 = 24.25 tiles) and N edges, all three operand layouts, split-K and every
     fused epilogue."""
     L = dvt._lib
     g = torch.Generator().manual_seed(21)
     M, N, K = 6208, 1024, 1024
-    x_d, x = _rnd((M, K), torch.bfloat16, g)
-    w_d, w = _rnd((N, K), torch.bfloat16, g, 1 / math.sqrt(K))
+    x_d, x = _rnd((M, K), dt16, g)
+    w_d, w = _rnd((N, K), dt16, g, 1 / math.sqrt(K))
     bias = 0.5 * torch.randn(N, generator=g)
     pre = x @ w.t() + bias
     y = dvt.ops.linear_fwd(x_d, w_d, bias.cuda())
     assert rel_l2(y, pre) < BF16_TOL
-    aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    aux = torch.empty((M, N), dtype=dt16, device="cuda")
     h = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_GELU, aux=aux)
     assert rel_l2(aux, pre) < BF16_TOL and rel_l2(h, O.gelu_erf(pre)) < BF16_TOL
-    res_d, res = _rnd((M, N), torch.bfloat16, g)
+    res_d, res = _rnd((M, N), dt16, g)
     yr = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d)
     assert rel_l2(yr, pre + res) < BF16_TOL
-    dy_d, dy = _rnd((M, N), torch.bfloat16, g)
+    dy_d, dy = _rnd((M, N), dt16, g)
     dx = dvt.ops.linear_dgrad(dy_d, w_d)                      # k-major x mn-major
     assert rel_l2(dx, dy @ w) < BF16_TOL
-    u_d, u = _rnd((M, K), torch.bfloat16, g)
+    u_d, u = _rnd((M, K), dt16, g)
     uu = u.clone().requires_grad_(True)
     O.gelu_erf(uu).backward(dy @ w)
     du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d)
@@ -229,8 +230,8 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device):
     dvt.ops.linear_wgrad(dy_d, x_d, bias_out=db, bias_accumulate=True)
     assert rel_l2(db, 2 * dy.sum(0)) < 1e-5
     # ragged N (1000 = 3.9 tiles) and a narrower K
-    w2_d, w2 = _rnd((1000, 192), torch.bfloat16, g, 0.1)
-    x2_d, x2 = _rnd((M, 192), torch.bfloat16, g)
+    w2_d, w2 = _rnd((1000, 192), dt16, g, 0.1)
+    x2_d, x2 = _rnd((M, 192), dt16, g)
     y2 = dvt.ops.linear_fwd(x2_d, w2_d)
     assert rel_l2(y2, x2 @ w2.t()) < BF16_TOL
 
@@ -423,3 +424,46 @@ def test_optimizer_classes_match_torch(dvt, device, kind):
         assert rel_l2(t, r) < 1e-6
     sd = o_got.state_dict()                                    # torch-compatible state layout
     assert set(sd) == {"state", "param_groups"}
+
+
+def test_fp16_loss_scaling_skips_overflow_and_recovers(dvt, device):
+    """BASELINE configs[4] (fp16 + loss scaling): the scaler lives on the device.  A step whose gradient overflows
+    is skipped and halves the scale; clean steps apply AdamW on grad / scale and grow the scale every interval."""
+    from dvt_amd.dp import FlatParameters
+    lin = torch.nn.Linear(16, 8).cuda()
+    flat = FlatParameters(lin, compute_dtype=torch.float16)
+    seed = flat.enable_loss_scaling(init_scale=1024.0, growth_interval=2)
+    assert float(seed) == 1024.0
+    ref = torch.nn.Linear(16, 8)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in lin.state_dict().items()})
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.09)
+    g = torch.Generator().manual_seed(0)
+
+    def step(grads, overflow=False):
+        scale = float(flat.scale_dev)
+        flat.zero_grad()
+        for p, gr in zip(lin.parameters(), grads):
+            buf = p._dvt_sink.buf
+            buf.copy_((gr * scale).cuda())
+            if overflow:
+                buf.view(-1)[0] = float("inf")
+            p._dvt_sink.mark_written()
+        flat.finish_backward()
+        flat.adamw_step(lr=1e-2, weight_decay=0.09)
+
+    grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+    before = flat.data.clone()
+    step(grads, overflow=True)
+    assert torch.equal(flat.data, before) and float(flat.scale_dev) == 512.0 and int(flat.step_dev) == 0
+    assert float(flat.loss_grad) == 512.0 and int(flat.found_inf) == 0
+    for _ in range(2):
+        grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+        for p, gr in zip(ref.parameters(), grads):
+            p.grad = gr.clone()
+        opt.step()
+        step(grads)
+    assert int(flat.step_dev) == 2 and float(flat.scale_dev) == 1024.0          # grew after 2 clean steps
+    for p, q in zip(lin.parameters(), ref.parameters()):
+        assert rel_l2(p, q) < 1e-6
+    w16 = lin.weight._dvt_compute
+    assert w16.dtype == torch.float16 and torch.equal(w16.float().cpu(), lin.weight.detach().cpu().half().float())
