@@ -108,6 +108,8 @@ WORKLOADS = {
     "pyramid": "BASELINE configs[2]: per-frame ResNet-18 3-scale pyramid (train-mode BatchNorm) -> FPN lateral tokens "
                "(196/frame) -> the metric-shape transformer; B=8/GPU, T=32, 3x224x224; "
                "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+    "longclip": "BASELINE configs[4]: ViViT d=512, depth 4+4, T=64, 3x288x288 (325 tokens/frame), fp16 kernels + dynamic loss "
+                "scaling (device-side), activation checkpointing (one saved activation per block); B=8/GPU",
     "crossmodal": "BASELINE configs[3]: configs[2] + 32 audio tokens (128-d), cross-attention block (video queries, "
                   "audio keys/values), distillation token + head, loss = BCE + hard-label CE; B=8/GPU, T=32, 3x224x224",
 }
@@ -124,10 +126,12 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
                     "replaying one captured hipGraph per step (single-GPU only)")
-    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal"], default="vivit",
+    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal", "longclip"], default="vivit",
                     help="vivit = the metric workload (default); pyramid = BASELINE configs[2] (ResNet-18 3-scale "
                     "pyramid front-end -> the same transformer); crossmodal = configs[3] (+ 32 audio tokens, "
-                    "cross-attention block, distillation head).  Secondary lines, same JSON contract.")
+                    "cross-attention block, distillation head); longclip = configs[4] (T=64, 288^2, fp16 + dynamic loss "
+                    "scaling, activation checkpointing; reports HBM GB/s of the streaming kernels and the activation "
+                    "peak).  Secondary lines, same JSON contract.")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
                     "rank (rehearses the multi-GPU code path on a single GPU)")
     args = ap.parse_args()
@@ -151,34 +155,41 @@ def main():
     from dvt_amd.models.vit import ViViT
 
     cfg = dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64)
+    cdt = torch.bfloat16
+    if args.workload == "longclip":
+        cfg.update(image=288, T=64)
+        cdt = torch.float16
     torch.manual_seed(1130)                                       # src/main.py:25
-    if args.workload == "vivit":
+    if args.workload in ("vivit", "longclip"):
         net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
-                    heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=torch.bfloat16).cuda()
+                    heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=cdt,
+                    activation_checkpointing=args.workload == "longclip").cuda().train()
     else:
         from dvt_amd.models.pyramid_vivit import PyramidViViT
         cm = args.workload == "crossmodal"
         net = PyramidViViT(cfg["image"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"], heads=cfg["heads"],
                            dim_head=cfg["dh"], audio_tokens=32 if cm else 0, audio_dim=128, distill=cm,
                            compute_dtype=torch.bfloat16).cuda().train()
-    flat = FlatParameters(net, bucket_mb=args.bucket_mb)
+    flat = FlatParameters(net, bucket_mb=args.bucket_mb, compute_dtype=cdt)
     flat.broadcast_parameters(0)
     flat.sync_compute_copy()
 
     gen = torch.Generator().manual_seed(1130 + rank)
     B = args.batch
-    x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(torch.bfloat16).cuda()
+    x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(cdt).cuda()
     y = (torch.rand(B, cfg["classes"], generator=gen) < 0.2).float()
     y[:, 0] = 1.0
     y = y.cuda()
     gloss = torch.full((), flat.loss_scale, device="cuda")
+    if cdt == torch.float16:
+        gloss = flat.enable_loss_scaling(init_scale=4096.0, growth_interval=1000)     # device-resident seed
     audio = None
     if args.workload == "crossmodal":       # one 128-d VGGish-style vector per 1-s chunk (SURVEY 8d synthetic inputs)
         audio = torch.randn(B, 32, 128, generator=gen).to(torch.bfloat16).cuda()
 
     def step():
         flat.zero_grad()
-        if args.workload == "vivit":
+        if args.workload in ("vivit", "longclip"):
             loss = F.bce_with_logits(net(x), y)
         else:
             loss = net.training_step((y, x, audio) if audio is not None else (y, x))
@@ -235,7 +246,21 @@ def main():
         ops.set_profiler(None)
         summ = prof.summary()
         fam = {}
-        for (tag, ak, bk, M, N, K), (ms, fl, cnt) in summ.items():
+        hbm = {}
+        big = {}
+        for key in summ:                       # per kernel: its largest launch shape (the space-transformer one)
+            if key[0] == "hbm" and (key[1] not in big or key[2] > big[key[1]][2]):
+                big[key[1]] = key
+        for name, key in big.items():
+            ms, units, cnt = summ[key]
+            hbm[name] = {"us_per_launch": round(ms * 1e3 / cnt, 1), "launches_per_step": cnt // nprof,
+                         "algorithmic_MB_per_launch": round(units / cnt / 1e6, 1),
+                         "algorithmic_GBps": round(units / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+        for key, (ms, fl, cnt) in summ.items():
+            if key[0] != "gemm":
+                continue
+            tag, ak, bk, M, N, K = key
             if M * N * K < (1 << 30):      # launch-bound temporal/head GEMMs: not this kernel's regime
                 continue
             f = fam.setdefault((ak, bk), [0.0, 0.0, 0])
@@ -262,7 +287,8 @@ def main():
                     "algorithmic_bytes_per_launch": None, "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
                     "families": {names.get(k, str(k)): {"ms_per_step": round(v[0] / nprof, 3),
                                                         "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
-                                 for k, v in fam.items()}}
+                                 for k, v in fam.items()},
+                    "hbm_kernels": hbm}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -271,19 +297,23 @@ def main():
         fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
                                               3 * cfg["patch"] ** 2, n_tok - 1)
         out = {
-            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16" + ("" if args.workload == "vivit" else
-                                                                        f" [{args.workload} workload]"),
+            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16" if args.workload == "vivit" else
+                      f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}",
             "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
                        "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
             "launch": "hipGraph replay" if use_graph else "eager",
-            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1) if args.workload == "vivit" else None,
+            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1)
+            if args.workload in ("vivit", "longclip") else None,
             "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
-            if args.workload == "vivit" else None,
+            if args.workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
+            "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
+        if cdt == torch.float16:
+            out["loss_scale"] = float(flat.scale_dev)
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":

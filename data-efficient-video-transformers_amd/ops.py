@@ -53,6 +53,25 @@ def set_profiler(p) -> None:
     _profiler = p
 
 
+class _timed:
+    """``with _timed(key, units):`` -- bracket a launch with the profiler's events when one is installed
+    (units = algorithmic bytes for the HBM-bound kernels, flops for GEMMs)."""
+
+    __slots__ = ("key", "units", "prof")
+
+    def __init__(self, key, units):
+        self.key, self.units, self.prof = key, units, _profiler
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.prof.begin(self.key, self.units)
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            self.prof.end(self.key)
+        return False
+
+
 
 def workspace(nbytes: int, device, slot: str = "main") -> Optional[Tensor]:
     """Grow-only scratch buffer per (device, slot).  Kernels on one stream run in
@@ -174,8 +193,9 @@ def patchify(x: Tensor, patch: int, out_dtype: torch.dtype) -> Tensor:
     frames = x.numel() // (Cc * H * W)
     n = (H // patch) * (W // patch)
     out = torch.empty((frames * n, patch * patch * Cc), dtype=out_dtype, device=x.device)
-    L.check(L.load().dvt_patchify(x.data_ptr(), dt(x), out.data_ptr(), _DT[out_dtype], frames, Cc, H, W, patch,
-                                  _stream()), "dvt_patchify")
+    with _timed(("hbm", "patchify", x.numel()), x.numel() * x.element_size() + out.numel() * out.element_size()):
+        L.check(L.load().dvt_patchify(x.data_ptr(), dt(x), out.data_ptr(), _DT[out_dtype], frames, Cc, H, W, patch,
+                                      _stream()), "dvt_patchify")
     return out
 
 
@@ -199,8 +219,9 @@ def tokens_assemble_fwd(emb: Tensor, cls: Tensor, pos: Tensor, S: int, T: int, n
     assert emb.is_contiguous() and cls.is_contiguous() and pos.is_contiguous()
     assert cls.dtype == torch.float32 and pos.dtype == torch.float32
     out = torch.empty((S, n + 1, d), dtype=emb.dtype, device=emb.device)
-    L.check(L.load().dvt_tokens_assemble_fwd(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), S, T,
-                                             n, d, pos.shape[-2], dt(emb), _stream()), "dvt_tokens_assemble_fwd")
+    with _timed(("hbm", "tokens_assemble_fwd", emb.numel()), (emb.numel() + out.numel()) * emb.element_size() + pos.numel() * 4):
+        L.check(L.load().dvt_tokens_assemble_fwd(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), S, T,
+                                                 n, d, pos.shape[-2], dt(emb), _stream()), "dvt_tokens_assemble_fwd")
     return out
 
 
@@ -295,9 +316,10 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, *, 
     nrows = n0 * n1
     mean = torch.empty((nrows,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((nrows,), dtype=torch.float32, device=x.device)
-    L.check(L.load().dvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                       mean.data_ptr(), rstd.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1, eps,
-                                       dt(x), _stream()), "dvt_layernorm_fwd")
+    with _timed(("hbm", "layernorm_fwd", nrows), nrows * (2 * d * x.element_size() + 8)):
+        L.check(L.load().dvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1, eps,
+                                           dt(x), _stream()), "dvt_layernorm_fwd")
     return out, mean, rstd
 
 
@@ -322,9 +344,10 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
         db = torch.empty((d,), dtype=torch.float32, device=x.device)
     lib = L.load()
     ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
-    L.check(lib.dvt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                  _p(dx_add), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d,
-                                  xs0, xs1, ys0, ys1, dt(x), int(accumulate), _stream()), "dvt_layernorm_bwd")
+    with _timed(("hbm", "layernorm_bwd", n0 * n1), n0 * n1 * ((3 + (dx_add is not None)) * d * x.element_size() + 8)):
+        L.check(lib.dvt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      _p(dx_add), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d,
+                                      xs0, xs1, ys0, ys1, dt(x), int(accumulate), _stream()), "dvt_layernorm_bwd")
     return dx, dg, db
 
 
@@ -449,7 +472,9 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float) -> T
     B, H, Lq, _ = q.shape
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, lse, scale)
-    L.check(L.load().dvt_attention_fwd(C.byref(d), _stream()), "dvt_attention_fwd")
+    nb = (2 * q.numel() + k.numel() + v.numel()) * q.element_size()          # read q, k, v; write o
+    with _timed(("hbm", "attention_fwd", q.numel()), nb):
+        L.check(L.load().dvt_attention_fwd(C.byref(d), _stream()), "dvt_attention_fwd")
     return lse
 
 
@@ -466,7 +491,10 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: T
     lib = L.load()
     ws = workspace(lib.dvt_attention_bwd_workspace_bytes(C.byref(d)), q.device)
     d.workspace = _p(ws)
-    L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
+    # two kernels: dq reads q,k,v,o,dO writes dq; dkdv reads q,k,v,o,dO writes dk,dv
+    nb = (7 * q.numel() + 3 * k.numel() + 3 * v.numel()) * q.element_size()
+    with _timed(("hbm", "attention_bwd", q.numel()), nb):
+        L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
 
 
 # ------------------------------------------------------------------ losses / optimizer
