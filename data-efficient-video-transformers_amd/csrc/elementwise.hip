@@ -643,6 +643,42 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
 
 __global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
+// ---- dropout (nn.Dropout in training mode: frame_transformer.py:22,41-44; TPN.py:92,95; vit.py:23,25,43,104)
+// Counter-based Philox4x32-10: element i draws word (i & 3) of block (offset + i / 4) under the key (seed).  No mask
+// is stored: backward re-draws the same words.  state[0] = seed, state[1] = per-step base offset live on the device
+// (advanced by dvt_rng_advance once per step), so a captured hipGraph draws fresh masks on every replay.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t threshold, float scale,
+                               const uint64_t* __restrict__ state, uint64_t call_offset) {
+  const uint64_t seed = state[0], base = state[1] + call_offset;
+  const int64_t nblk = (n + 3) >> 2;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t ctr = base + (uint64_t)b;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = b * 4 + e;
+      if (i < n) y[i] = from_f32<T>(r[e] >= threshold ? to_f32<T>(x[i]) * scale : 0.f);
+    }
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* state, uint64_t delta) { state[1] += delta; }
+
 // ---- fp16 loss scaling (BASELINE configs[4]: "fp16 + loss scaling"), all state on the device so the step stays
 // hipGraph-capturable: scale[0], found_inf[0] (int32), good_steps[0] (int32), loss_grad[0] = scale * base.
 __global__ void check_finite_kernel(const float* __restrict__ g, int64_t n, int* __restrict__ found_inf) {
@@ -954,6 +990,28 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                      exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2));
   DVT_LAUNCH_CHECK("dvt_adamw_step");
+  return DVT_OK;
+}
+
+int dvt_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* rng_state, uint64_t call_offset, int dtype,
+                dvt_stream_t stream) {
+  DVT_REQUIRE(x && y && rng_state && n >= 0 && p >= 0.f && p < 1.f, "dvt_dropout: bad arguments (0 <= p < 1)");
+  if (n == 0) return DVT_OK;
+  // keep iff word >= threshold, threshold = round(p * 2^32): P(drop) = p to 2^-32
+  const double th = (double)p * 4294967296.0;
+  const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(th + 0.5);
+  const float scale = 1.0f / (1.0f - p);
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for((n + 3) >> 2)), dim3(kBlock), 0,
+                                                  (hipStream_t)stream, (const T*)x, (T*)y, n, threshold, scale, rng_state,
+                                                  call_offset));
+  DVT_LAUNCH_CHECK("dvt_dropout");
+  return DVT_OK;
+}
+
+int dvt_rng_advance(uint64_t* rng_state, uint64_t delta, dvt_stream_t stream) {
+  DVT_REQUIRE(rng_state, "dvt_rng_advance: null state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, delta);
+  DVT_LAUNCH_CHECK("dvt_rng_advance");
   return DVT_OK;
 }
 

@@ -120,6 +120,10 @@ class FlatParameters:
         self.step_count = 0
 
     # ------------------------------------------------------------------ compute copy
+    def _after_step(self) -> None:
+        from . import functional as F       # dropout generator: move past this step's sites (device-side add)
+        F.next_step()
+
     def sync_compute_copy(self) -> None:
         """One cast launch: fp32 masters -> bf16 copy used by the GEMMs."""
         if self.compute is not None:
@@ -201,11 +205,13 @@ class FlatParameters:
                                    beta2=betas[1], eps=eps, weight_decay=weight_decay, loss_grad_base=self.loss_scale,
                                    **self.scaler)
             self.sync_compute_copy()
+            self._after_step()
             return
         # step counter lives on the device so the launch can be captured in a hipGraph
         ops.adamw_step_dev_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
                             beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.sync_compute_copy()
+        self._after_step()
 
     def sgd_step(self, lr: float, momentum: float = 0.0, weight_decay: float = 0.0) -> None:
         """torch.optim.SGD semantics (frame_transformer.py:124-126) in one launch over the flat buffers."""
@@ -215,6 +221,7 @@ class FlatParameters:
         ops.sgd_step_(self.data, self.grad, getattr(self, "momentum_buf", None), lr=lr, momentum=momentum,
                       weight_decay=weight_decay)
         self.sync_compute_copy()
+        self._after_step()
 
     def adagrad_step(self, lr: float, weight_decay: float = 0.0, lr_decay: float = 0.0, eps: float = 1e-10) -> None:
         """torch.optim.Adagrad semantics (frame_transformer.py:130-132) in one launch over the flat buffers."""
@@ -224,6 +231,7 @@ class FlatParameters:
         ops.adagrad_step_(self.data, self.grad, self.state_sum, lr=lr, lr_decay=lr_decay, eps=eps,
                           weight_decay=weight_decay, step=self.step_count)
         self.sync_compute_copy()
+        self._after_step()
 
     def init_optimizer_state(self) -> None:
         self.exp_avg = torch.zeros_like(self.data)

@@ -1095,6 +1095,7 @@ class _Checkpoint(torch.autograd.Function):
     def forward(ctx, fn, x, *params):
         ctx.fn = fn
         ctx.save_for_backward(x)
+        ctx.site = _rng.site                 # the recomputation must draw the same dropout masks
         with torch.no_grad():
             return fn(x)
 
@@ -1102,8 +1103,10 @@ class _Checkpoint(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         xin = x.detach().requires_grad_(True)
+        site_now, _rng.site = _rng.site, ctx.site
         with torch.enable_grad():
             y = ctx.fn(xin)
+        _rng.site = site_now
         torch.autograd.backward(y, dy)
         return (None, xin.grad) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -1184,3 +1187,63 @@ class _Contrastive(torch.autograd.Function):
 
 def contrastive_loss(z_i: Tensor, z_j: Tensor, temperature: float) -> Tensor:
     return _Contrastive.apply(concat_rows(z_i, z_j), temperature)
+
+
+# ---------------------------------------------------------------------------
+# Dropout (training mode)
+# ---------------------------------------------------------------------------
+class DropoutRng:
+    """Device-resident generator state {seed, step base offset} plus the host-side offset of the next dropout site
+    of the current step.  ``F.manual_seed`` / ``F.next_step`` are the only controls: call ``next_step()`` once per
+    optimisation step (``dp.FlatParameters`` optimizer steps do) -- it advances the base on the device, so the masks
+    change from step to step even when the step is a replayed hipGraph."""
+
+    def __init__(self):
+        self.state = None
+        self.site = 0
+        self.seed = 1130                                   # src/main.py:25
+
+    def tensor(self, device) -> Tensor:
+        if self.state is None or self.state.device != device:
+            self.state = torch.tensor([self.seed, 0], dtype=torch.int64, device=device)
+        return self.state
+
+    def take(self, n: int) -> int:
+        off = self.site
+        self.site += (n + 3) // 4
+        return off
+
+
+_rng = DropoutRng()
+
+
+def manual_seed(seed: int) -> None:
+    _rng.seed, _rng.state, _rng.site = int(seed), None, 0
+
+
+def next_step() -> None:
+    """Advance the dropout generator past every site drawn in this step (device-side add) and restart site numbering."""
+    if _rng.state is not None and _rng.site:
+        ops.rng_advance_(_rng.state, _rng.site)
+    _rng.site = 0
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        st = _rng.tensor(x.device)
+        ctx.p, ctx.off, ctx.state = p, _rng.take(x.numel()), st
+        return ops.dropout(x, p, st, ctx.off)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.state, ctx.off), None
+
+
+def dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    """nn.Dropout(p)(x): identity unless ``training`` and p > 0."""
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _Dropout.apply(x, float(p))

@@ -99,15 +99,13 @@ class Reasoning(nn.Module):
             self.relation += [fc_fusion]
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("Reasoning: Dropout(0.6/0.5) in training mode has no HIP kernel yet; use eval()")
         prediction = None
         for segment_group in range(self.start, self.num_groups + 1):
             net = self.relation[segment_group - self.start]
             s = sum_group(x, groups=segment_group)
             s = F.linear(F.relu(s), net[1].weight, net[1].bias)
-            s = F.linear(F.relu(s), net[4].weight, net[4].bias)
-            s = F.sigmoid(F.linear(F.relu(s), net[7].weight, net[7].bias))
+            s = F.linear(F.dropout(F.relu(s), net[3].p, self.training), net[4].weight, net[4].bias)       # TPN.py:91-93
+            s = F.sigmoid(F.linear(F.dropout(F.relu(s), net[6].p, self.training), net[7].weight, net[7].bias))  # :94-97
             prediction = s if prediction is None else F.add(prediction, s)
         return F.scale_f32(prediction, 1.0 / (self.num_groups - self.start + 1))
 

@@ -27,7 +27,7 @@ Deviations from the literal reference text, all where the reference does not exe
 members are created; ``torch.cat((data, distil_inject))`` gets the missing
 ``unsqueeze(0)``; the positional table is sized to the sequence actually used;
 ``distil`` returns 19-d logits for both streams; ``view(batch_size, ...)`` uses the
-tensor's batch, not ``hparams.batch_size``; dropout p > 0 in training mode raises
+tensor's batch, not ``hparams.batch_size``; dropout p > 0 in training mode uses the Philox dropout kernel (was: raises
 (no RNG-matching kernel; parity is defined in eval mode).
 """
 from __future__ import annotations
@@ -41,13 +41,6 @@ from torch import nn
 from .. import functional as F
 from .. import optim
 from ..lightning_compat import LightningModule
-
-
-def _train_dropout_guard(module: nn.Module, p: float, where: str) -> None:
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            f"{where}: dropout p={p} in training mode has no HIP kernel yet (parity is defined in eval "
-            "mode; construct with dropout=0.0 to train)")
 
 
 class PositionalEncoding(LightningModule):
@@ -67,8 +60,7 @@ class PositionalEncoding(LightningModule):
         self.register_buffer('pe', pe)
 
     def forward(self, x):
-        _train_dropout_guard(self, self.p, "PositionalEncoding")
-        return F.add_positional_table(x, self.pe)
+        return F.dropout(F.add_positional_table(x, self.pe), self.p, self.training)       # :33-34
 
 
 class EncoderLayer(nn.Module):
@@ -97,9 +89,18 @@ class EncoderLayer(nn.Module):
         self.nhead = nhead
 
     def forward(self, x):
-        """x [L, B, E]:  x = LN1(x + SA(x));  x = LN2(x + W2 relu(W1 x))."""
-        _train_dropout_guard(self, self.p, "TransformerEncoderLayer")
+        """x [L, B, E]:  x = LN1(x + drop(SA(x)));  x = LN2(x + drop(W2 drop(relu(W1 x)))).
+        Training-mode dropout (p > 0) runs the unfused composition with the Philox dropout kernel at torch's
+        three hidden-state sites (dropout1, dropout, dropout2).  Deviation: torch additionally drops attention
+        probabilities inside ``MultiheadAttention(dropout=p)``; the fused attention kernel does not."""
         a = self.self_attn
+        if self.training and self.p > 0.0:
+            sa = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
+                              prenorm=False, residual=False, b_qkv=a.in_proj_bias, seq_first=True)
+            x = F.layernorm(F.add(x, F.dropout(sa, self.p, True)), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            h = F.dropout(F.relu(F.linear(x, self.linear1.weight, self.linear1.bias)), self.p, True)
+            y = F.dropout(F.linear(h, self.linear2.weight, self.linear2.bias), self.p, True)
+            return F.layernorm(F.add(x, y), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
                          prenorm=False, residual=True, b_qkv=a.in_proj_bias, seq_first=True)
         x = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)

@@ -22,13 +22,6 @@ from torch import nn
 from .. import functional as F
 
 
-def _no_dropout(p: float, training: bool, where: str) -> None:
-    if p > 0.0 and training:
-        raise NotImplementedError(
-            f"{where}: dropout p={p} in training mode has no HIP kernel yet; use p=0 (the "
-            "reference's ViViT default, vit.py:80-81) or eval()")
-
-
 class Patchify(nn.Module):
     """Position 0 of ``to_patch_embedding`` (the reference's einops ``Rearrange``,
     vit.py:90).  Parameter-free; the gather itself is fused into ``F.patch_embed``."""
@@ -80,8 +73,12 @@ class FeedForward(nn.Module):
         self.dropout_p = dropout
 
     def forward(self, x, _norm=None, _residual=False):
-        _no_dropout(self.dropout_p, self.training, "FeedForward")
         l1, l2 = self.net[0], self.net[3]
+        if self.training and self.dropout_p > 0.0:         # unfused: Linear - GELU - Dropout - Linear - Dropout (:20-26)
+            h = F.layernorm(x, _norm.weight, _norm.bias, _norm.eps) if _norm is not None else x
+            h = F.dropout(F.gelu(F.linear(h, l1.weight, l1.bias)), self.dropout_p, True)
+            y = F.dropout(F.linear(h, l2.weight, l2.bias), self.dropout_p, True)
+            return F.add(x, y) if _residual else y
         return F.mlp_block(x, _norm.weight if _norm is not None else None,
                            _norm.bias if _norm is not None else None,
                            l1.weight, l1.bias, l2.weight, l2.bias, act="gelu",
@@ -107,9 +104,14 @@ class Attention(nn.Module):
         self.dropout_p = dropout
 
     def forward(self, x, _norm=None, _residual=False):
-        _no_dropout(self.dropout_p, self.training, "Attention")
         w_out = self.to_out[0].weight if self.project_out else None
         b_out = self.to_out[0].bias if self.project_out else None
+        if self.training and self.dropout_p > 0.0 and self.project_out:     # to_out = Linear + Dropout (:41-44)
+            y = F.attn_block(x, _norm.weight if _norm is not None else None, _norm.bias if _norm is not None else None,
+                             self.to_qkv.weight, w_out, b_out, self.heads, prenorm=_norm is not None, residual=False,
+                             eps=_norm.eps if _norm is not None else 1e-5)
+            y = F.dropout(y, self.dropout_p, True)
+            return F.add(x, y) if _residual else y
         return F.attn_block(x, _norm.weight if _norm is not None else None,
                             _norm.bias if _norm is not None else None,
                             self.to_qkv.weight, w_out, b_out, self.heads,
@@ -184,7 +186,6 @@ class ViViT(nn.Module):
         self.temporal_transformer.checkpoint = activation_checkpointing
 
     def forward(self, x):
-        _no_dropout(self.emb_dropout_p, self.training, "ViViT(emb_dropout)")
         if x.dim() != 5:
             raise ValueError("ViViT expects a clip tensor [b, t, c, H, W]")
         b, t = x.shape[0], x.shape[1]
@@ -196,6 +197,7 @@ class ViViT(nn.Module):
         pe = self.to_patch_embedding[1]
         emb = F.patch_embed(x, pe.weight, pe.bias, self.patch_size, T)              # vit.py:110
         tok = F.tokens_assemble(emb, self.space_token, self.pos_embedding, b * t, t, n)   # :113-115
+        tok = F.dropout(tok, self.emb_dropout_p, self.training)                            # :116
         s = self.space_transformer.forward_layers(tok)                              # :118-119
         sn = self.space_transformer.norm
         seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)  # :119-123

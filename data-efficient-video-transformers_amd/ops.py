@@ -672,6 +672,20 @@ def adamw_step_scaled_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq:
             "dvt_adamw_step_scaled")
 
 
+def dropout(x: Tensor, p: float, rng_state: Tensor, call_offset: int) -> Tensor:
+    """y = x * keep / (1 - p); keep is a pure function of (rng_state on the device, call_offset, element index)."""
+    _need_cuda(x, rng_state)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().dvt_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, rng_state.data_ptr(), call_offset, dt(x),
+                                 _stream()), "dvt_dropout")
+    return y
+
+
+def rng_advance_(rng_state: Tensor, delta: int) -> None:
+    L.check(L.load().dvt_rng_advance(rng_state.data_ptr(), delta, _stream()), "dvt_rng_advance")
+
+
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
               weight_decay: float) -> None:
     _need_cuda(param)

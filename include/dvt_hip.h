@@ -85,6 +85,17 @@ int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_strea
 int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
                 dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- dropout
+ * nn.Dropout(p) in training mode (frame_transformer.py:22,41-44 p = 0.5; TPN.py:92,95; vit.py:23,25,43,104):
+ * y[i] = keep_i ? x[i] / (1 - p) : 0.  keep_i comes from Philox4x32-10 word (i & 3) of counter
+ * rng_state[1] + call_offset + i / 4 under key rng_state[0]; rng_state is a device array {seed, step base offset}.
+ * The same call with dy in place of x is the backward pass (no mask is stored).  call_offset separates the dropout
+ * sites of one step (advance it by ceil(n / 4) per site); dvt_rng_advance moves the base once per step on the
+ * device, so a captured hipGraph draws new masks on every replay.  torch's own generator stream is not reproduced. */
+int dvt_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* rng_state, uint64_t call_offset, int dtype,
+                dvt_stream_t stream);
+int dvt_rng_advance(uint64_t* rng_state, uint64_t delta, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- patchify
  * Rearrange 'b t c (h p1) (w p2) -> b t (h w) (p1 p2 c)'  (src/models/vit.py:90).
  * x: [frames, C, H, W] in x_dtype; out: [frames * (H/P) * (W/P), P*P*C] in

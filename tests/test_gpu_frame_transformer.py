@@ -39,9 +39,12 @@ def test_positional_encoding_matches_reference(device):
         assert torch.allclose(out.cpu(), T(g[f"fwd_{d}_{L}"]), atol=1e-6)
     with pytest.raises(ValueError, match="positional table"):
         pe(torch.ones(L + 1, 2, d, device="cuda"))
-    pe.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
-        pe(torch.ones(L, 2, d, device="cuda"))
+    pe.train()                                   # p = 0.5: half the entries dropped, survivors doubled
+    out = pe(torch.ones(L, 2, d, device="cuda"))
+    ev = pe.eval()(torch.ones(L, 2, d, device="cuda"))
+    kept = out != 0
+    assert 0.4 < float(kept.float().mean()) < 0.6
+    assert torch.allclose(out[kept], 2.0 * ev[kept], atol=1e-6)
 
 
 def _oracle_encoder(x, P, prefix, patch):

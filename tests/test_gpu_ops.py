@@ -467,3 +467,52 @@ def test_fp16_loss_scaling_skips_overflow_and_recovers(dvt, device):
         assert rel_l2(p, q) < 1e-6
     w16 = lin.weight._dvt_compute
     assert w16.dtype == torch.float16 and torch.equal(w16.float().cpu(), lin.weight.detach().cpu().half().float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_philox(dvt, device, dtype):
+    """nn.Dropout in training mode: Philox mask from (device state, site offset, index); survivors scaled by
+    1 / (1 - p); backward re-draws the same mask; a new step (device-side advance) draws a new one."""
+    F = dvt.functional
+    F.manual_seed(77)
+    x = torch.randn(1 << 16, generator=torch.Generator().manual_seed(1)).to(dtype).cuda().requires_grad_(True)
+    y = F.dropout(x, 0.3, True)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.7) < 0.01
+    assert torch.allclose(y[kept].float(), (x.detach()[kept].float() / 0.7), rtol=1e-2 if dtype != torch.float32 else 1e-6)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, kept)                                  # same mask in backward
+    y2 = F.dropout(x.detach(), 0.3, True)                                  # next site of the same step: new mask
+    assert not torch.equal(y2 != 0, kept)
+    F.manual_seed(77)
+    y3 = F.dropout(x.detach(), 0.3, True)                                  # same seed, same site: same mask
+    assert torch.equal(y3, y.detach())
+    F.next_step()                                                          # device-side advance
+    y4 = F.dropout(x.detach(), 0.3, True)
+    assert not torch.equal(y4 != 0, kept)
+    assert F.dropout(x, 0.3, False) is x and F.dropout(x, 0.0, True) is x   # eval / p = 0: identity
+    # the 4 Philox words of a block are independent: no structure at stride 4
+    k4 = kept.view(-1, 4).float()
+    assert float((k4[:, 0] * k4[:, 1]).mean()) == pytest.approx(0.49, abs=0.02)
+
+
+def test_dropout_training_step_and_checkpoint_consistency(dvt, device):
+    """ViViT with dropout > 0 in train mode runs end to end, and activation checkpointing replays the same masks
+    (gradients identical with and without recomputation)."""
+    from dvt_amd.models.vit import ViViT
+    F = dvt.functional
+    res = {}
+    for ck in (False, True):
+        torch.manual_seed(3)
+        F.manual_seed(5)
+        net = ViViT(32, 8, 19, 3, dim=64, depth=2, heads=2, dim_head=32, dropout=0.2, emb_dropout=0.1,
+                    compute_dtype=torch.float32, activation_checkpointing=ck).cuda().train()
+        x = torch.randn(2, 3, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+        out = net(x)
+        out.square().mean().backward()
+        res[ck] = (out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert torch.equal(res[False][0], res[True][0])
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
+    ev = net.eval()(x)
+    assert not torch.equal(ev, res[True][0])                               # dropout really was active
