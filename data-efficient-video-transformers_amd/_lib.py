@@ -37,6 +37,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p),
@@ -119,6 +124,9 @@ SIGNATURES = {
                                       c_f, c_p, c_f, c_p]),
     "dvt_dropout": (c_int, [c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_p]),
     "dvt_rng_advance": (c_int, [c_p, C.c_uint64, c_p]),
+    "dvt_conv_weight_pack_dgrad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_conv2d_implicit_supported": (c_int, [C.POINTER(ConvDesc)]),
+    "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

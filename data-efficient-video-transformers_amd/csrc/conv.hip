@@ -164,6 +164,23 @@ __global__ void weight_unpack_kernel(const float* __restrict__ g, float* __restr
   }
 }
 
+// data-gradient operand: dst[ci, ((kh-1-ki)*kw + (kw-1-kj))*Cout + co] = (T) w[co, ci, ki, kj]
+// (180-degree rotated taps, channels transposed): dx = conv(dz, dst) with padding k-1-p for a stride-1 convolution
+template <typename D>
+__global__ void weight_pack_dgrad_kernel(const float* __restrict__ w, D* __restrict__ dst, int Cout, int Cin, int kh,
+                                         int kw) {
+  const int64_t K = (int64_t)kh * kw * Cout;
+  const int64_t total = (int64_t)Cin * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / K);
+    const int col = (int)(i % K);
+    const int co = col % Cout, tap = col / Cout;
+    const int kir = tap / kw, kjr = tap % kw;
+    const int ki = kh - 1 - kir, kj = kw - 1 - kjr;
+    dst[i] = from_f32<D>(w[(((int64_t)co * Cin + ci) * kh + ki) * kw + kj]);
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm (columns of [rows, C])
 // partial[b][0][c] = sum x, partial[b][1][c] = sum x^2 over the block's rows  (MODE 0)
 // partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat                 (MODE 1), dz = dy * (y > 0 if relu)
@@ -666,6 +683,15 @@ int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int
   DVT_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(cgrid((int64_t)Cout * ld)), dim3(kB),
                                                       0, st, w, (T*)dst, Cout, Cin, kh, kw, ld));
   DVT_LAUNCH_CHECK("dvt_conv_weight_pack");
+  return DVT_OK;
+}
+
+int dvt_conv_weight_pack_dgrad(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw,
+                               dvt_stream_t stream) {
+  DVT_REQUIRE(w && dst && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "dvt_conv_weight_pack_dgrad: bad arguments");
+  DVT_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((weight_pack_dgrad_kernel<T>), dim3(cgrid((int64_t)Cout * Cin * kh * kw)),
+                                                      dim3(kB), 0, (hipStream_t)stream, w, (T*)dst, Cout, Cin, kh, kw));
+  DVT_LAUNCH_CHECK("dvt_conv_weight_pack_dgrad");
   return DVT_OK;
 }
 

@@ -685,6 +685,41 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   return DVT_OK;
 }
 
+// ---------------------------------------------------------------- implicit-GEMM convolution
+static bool conv_implicit_ok(const dvt_conv_desc* d) {
+  if (!d || !d->x || !d->w || !d->y) return false;
+  if (!dvt_is_16bit(d->dtype)) return false;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->kh <= 0 || d->kw <= 0 || d->sh <= 0 || d->sw <= 0 || d->ph < 0 || d->pw < 0)
+    return false;
+  const int tk = d->Cout <= 128 ? 32 : 64;
+  if (d->C % tk || d->Cout % 8) return false;
+  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (Ho <= 0 || Wo <= 0) return false;
+  if (d->N * Ho * Wo >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
+  if ((int64_t)d->kh * d->kw * d->C >= ((int64_t)1 << 31)) return false;
+  return dvt_aligned16(d->x) && dvt_aligned16(d->w) && dvt_aligned16(d->y);
+}
+
+int dvt_conv2d_implicit_supported(const dvt_conv_desc* d) { return conv_implicit_ok(d) ? 1 : 0; }
+
+int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
+  DVT_REQUIRE(d, "dvt_conv2d_implicit: null descriptor");
+  if (!conv_implicit_ok(d))
+    DVT_UNSUPPORTED("dvt_conv2d_implicit: needs a 16-bit dtype, C %% 64 == 0 (C %% 32 for Cout <= 128), Cout %% 8 == 0 and "
+                    "16-byte aligned buffers");
+  const int Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  GemmParams p;
+  p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
+  p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = d->kh * d->kw * d->C;
+  p.lda = 0; p.ldb = p.K; p.ldc = d->Cout;
+  p.epilogue = DVT_EPI_NONE; p.out_f32 = 0; p.accumulate = 0;
+  p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0;
+  p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = p.K; p.slab = nullptr; p.tiles_n = 0; p.colsum_slab = nullptr;
+  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckw = d->kw;
+  p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
+  return dvt_conv_dma_launch(p, d->Cout <= 128 ? 1 : 0, (hipStream_t)stream);
+}
+
 size_t dvt_colsum_workspace_bytes(int64_t M, int64_t N) {
   (void)M;
   return (size_t)kColsumParts * (size_t)(N > 0 ? N : 0) * sizeof(float);

@@ -79,6 +79,45 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
   }
 }
 
+// 16 zero bytes in global memory: the DMA source of every padded (out-of-image) tap of the implicit convolution
+__device__ __attribute__((aligned(16))) unsigned int dvt_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Implicit-GEMM A operand: row = output pixel (n, ho, wo), k = (ki, kj, c) of an NHWC map x[N, H, W, C].
+// C % TK == 0, so a whole k-tile lies inside one filter tap: per k-tile a lane only adds the tap's (ki, kj) to the
+// pixel coordinates it pre-computed once for its PPW rows, checks the bounds and points padded taps at dvt_zero16.
+template <int ROWS, int TK, int NW>
+struct ConvRows {
+  enum { PIECES = ROWS * TK * 2 / 1024, PPW = PIECES / NW, CPR = TK / 8, RPP = 64 / CPR };
+  int pix[PPW], h0[PPW], w0[PPW], coff[PPW];
+  __device__ __forceinline__ void init(const GemmParams& p, int m0, int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (wid * PPW + i) * RPP + lane / CPR;
+      int grow = m0 + row;
+      grow = grow < p.M ? grow : p.M - 1;
+      const int hw = p.cHo * p.cWo;
+      const int n = grow / hw, r = grow - n * hw;
+      const int ho = r / p.cWo, wo = r - ho * p.cWo;
+      pix[i] = n * p.cH * p.cW;
+      h0[i] = ho * p.csh - p.cph;
+      w0[i] = wo * p.csw - p.cpw;
+      coff[i] = ((lane % CPR) ^ swz_k<TK>(row)) * 8;
+    }
+  }
+  __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) const {
+    const int tap = k0 / p.cC, c0 = k0 - tap * p.cC;
+    const int ki = tap / p.ckw, kj = tap - ki * p.ckw;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int hi = h0[i] + ki, wi = w0[i] + kj;
+      const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+      const bf16* src = ok ? p.A + ((int64_t)(pix[i] + hi * p.cW + wi) * p.cC + c0 + coff[i])
+                           : reinterpret_cast<const bf16*>(dvt_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wid * PPW + i) * 1024), 16, 0, 0);
+    }
+  }
+};
+
 // MFMA operand fragment of 16 rows (k-major) / 16 columns (mn-major) starting at `base`,
 // k-step kk (32 k each): lane (g, li) gets element j <-> (base + li, kk*32 + 8g + j).
 template <typename E, bool KMAJOR, int ROWS, int TK>
@@ -126,8 +165,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 //      4 x 4 unrolled passes was ~19k ISA lines per kernel and thrashed the I-cache).
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
-template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT>
+template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false>
 __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const GemmParams p) {
+  static_assert(!A_CONV || A_KMAJOR, "the gathered operand is k-major");
   typedef Cfg<CFG> C;
   typedef typename Elem16<E>::v8 V8;
   constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
@@ -176,11 +216,15 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (E)1.0f;
 
+  ConvRows<TM, TK, NW> cv;
+  if (A_CONV) cv.init(p, m0, wid, lane);
+
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s)
     if (s < nk) {
-      dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
+      if (A_CONV) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
+      else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
     }
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
@@ -193,7 +237,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     __builtin_amdgcn_s_barrier();
     if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
-      dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
+      if (A_CONV) cv.dma(p, k0, smem + st_nxt * kStage, wid);
+      else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
     }
     const char* sa = smem + st_cur * kStage;
@@ -365,7 +410,33 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   return 1;   // combination not instantiated: caller falls back to the 128x128 kernel
 }
 
+template <typename E, int CFG>
+int launch_conv(const GemmParams& pin, hipStream_t st) {
+  typedef Cfg<CFG> C;
+  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  GemmParams p = pin;
+  const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
+  p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, 1), block(C::NW * 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>), grid, block, kSmem, st, p);
+  DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma)");
+  return DVT_OK;
+}
+
 }  // namespace
+
+// Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
+// fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32.
+int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
+  if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : launch_conv<f16, 1>(p, st);
+  return cfg == 0 ? launch_conv<bf16, 0>(p, st) : launch_conv<bf16, 1>(p, st);
+}
 
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
 // combination has no LDS-DMA instantiation.

@@ -19,7 +19,9 @@ struct GemmParams {
   float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
   int tiles_n;
   int elem;             // DVT_BF16 or DVT_F16: element type of A, B (and of C / residual / aux when not f32)
-  float* colsum_slab;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
+  float* colsum_slab;
+  // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
+  int cH, cW, cC, cHo, cWo, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };
 
 __device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
@@ -73,4 +75,5 @@ __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (
 
 // LDS-DMA kernels (gemm256.hip).  cfg 0: 256x256x64, 1 workgroup / CU;  cfg 1: 256x128x32,
 // 2 workgroups / CU.  K (and each K split) must be a multiple of 64.
+int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st);
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st);

@@ -893,6 +893,9 @@ def _kpad(K: int, dtype: torch.dtype) -> int:
 # backward: ~9x the activation bytes per 3x3 layer (8 GB for ResNet-18 on 256 frames of 224^2) -- affordable in
 # 288 GB of HBM and one gather pass per layer cheaper.  Set False to trade the memory back.
 SAVE_CONV_COLUMNS = True
+# Implicit-GEMM convolution (gather fused into the GEMM operand DMA) for the forward pass and, for stride-1
+# convolutions, the data gradient, wherever the geometry allows (16-bit dtype, Cin a multiple of 32/64).
+IMPLICIT_CONV = True
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -909,9 +912,16 @@ class _ConvBnAct(torch.autograd.Function):
         direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
         ld = K if direct else _kpad(K, dtype)
         xc = x.contiguous()
-        col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
-        wp = ops.conv_weight_pack(w.reshape(Cout, Cin, kh, kw), ld, dtype)
-        z = ops.linear_fwd(col, wp)                                     # [N*Ho*Wo, Cout]
+        w4 = w.reshape(Cout, Cin, kh, kw)
+        wp = ops.conv_weight_pack(w4, ld, dtype)
+        implicit = (IMPLICIT_CONV and not direct and not nchw and ld == K and xc.dtype == dtype and
+                    ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
+        if implicit:
+            col = None
+            z = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad)
+        else:
+            col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
+            z = ops.linear_fwd(col, wp)                                 # [N*Ho*Wo, Cout]
         g32, b32 = _f32(gamma), _f32(beta)
         if training:
             mean, invstd = ops.bn_stats(z, run_mean, run_var, eps, momentum)
@@ -919,9 +929,10 @@ class _ConvBnAct(torch.autograd.Function):
             mean, invstd = run_mean.detach().float(), ops.bn_eval_invstd(run_var.detach().float(), eps)
         res = None if residual is None else residual.contiguous()
         y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
-        keep_col = SAVE_CONV_COLUMNS and not direct
+        keep_col = SAVE_CONV_COLUMNS and not direct and col is not None
         ctx.save_for_backward(None if keep_col else xc, wp, z, y if relu else None, mean, invstd, g32,
                               col if keep_col else None)
+        ctx.w4 = w4.detach() if implicit else None
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -954,7 +965,15 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             dw = ops.conv_weight_unpack_grad(dwp, w4).view(wshape)
         dx = None
-        if ctx.x_needs:
+        (sh_, sw_), (ph_, pw_) = ops._pair(stride), ops._pair(pad)
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        if (ctx.x_needs and ctx.w4 is not None and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0 and kw - 1 - pw_ >= 0
+                and (Ho, Wo) == (H + 2 * ph_ - kh + 1, W + 2 * pw_ - kw + 1)):
+            wd = ops.conv_weight_pack_dgrad(ctx.w4, dtype)               # [Cin, kh*kw*Cout]
+            pd = (kh - 1 - ph_, kw - 1 - pw_)
+            if ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
+                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd)     # [N*H*W, Cin], no dcol / col2im
+        if ctx.x_needs and dx is None:
             dcol = ops.linear_dgrad(dz, wp)                              # [rows, ld]
             if direct:
                 dx = dcol

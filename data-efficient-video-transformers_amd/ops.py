@@ -74,11 +74,11 @@ class _timed:
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> Optional[Tensor]:
-    """Grow-only scratch buffer per (device, slot).  Kernels on one stream run in
-    order, so consecutive operators may share it."""
+    """Grow-only scratch buffer per (device, stream, slot).  Kernels on one stream run in
+    order, so consecutive operators on it may share the buffer; another stream gets its own."""
     if nbytes <= 0:
         return None
-    key = (str(device), slot)
+    key = (str(device), slot, _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
@@ -758,6 +758,38 @@ def col2im_nchw(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad, d
     return dx
 
 
+def _conv_desc(x: Tensor, wp: Tensor, y, N, Cc, H, W, Cout, k, stride, pad):
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
+    d = L.ConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), (y.data_ptr() if y is not None else 1 << 4)
+    d.N, d.H, d.W, d.C, d.Cout = N, H, W, Cc, Cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw = kh, kw, sh, sw, ph, pw
+    d.dtype = dt(x)
+    return d
+
+
+def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
+        return False
+    (kh, kw) = _pair(k)
+    if not (x.is_contiguous() and wp.is_contiguous() and wp.shape == (Cout, kh * kw * Cc)):
+        return False
+    return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad))))
+
+
+def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad) -> Tensor:
+    """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM."""
+    _need_cuda(x, wp)
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
+    d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad)
+    prof = _profiler
+    (kh, kw) = _pair(k)
+    with _timed(("gemm", 1, 1, N * Ho * Wo, Cout, kh * kw * Cc), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
+        L.check(L.load().dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
+    return y
+
+
 def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
     _need_cuda(w)
     w = w.detach().contiguous()
@@ -766,6 +798,17 @@ def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
     out = torch.empty((Cout, ld), dtype=dtype, device=w.device)
     L.check(L.load().dvt_conv_weight_pack(w.data_ptr(), out.data_ptr(), _DT[dtype], Cout, Cin, kh, kw, ld, _stream()),
             "dvt_conv_weight_pack")
+    return out
+
+
+def conv_weight_pack_dgrad(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """[Cout, Cin, kh, kw] f32 -> [Cin, kh*kw*Cout]: rotated taps, transposed channels (data-gradient operand)."""
+    _need_cuda(w)
+    w = w.detach().contiguous()
+    Cout, Cin, kh, kw = w.shape
+    out = torch.empty((Cin, kh * kw * Cout), dtype=dtype, device=w.device)
+    L.check(L.load().dvt_conv_weight_pack_dgrad(w.data_ptr(), out.data_ptr(), _DT[dtype], Cout, Cin, kh, kw, _stream()),
+            "dvt_conv_weight_pack_dgrad")
     return out
 
 

@@ -312,6 +312,26 @@ int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int k
  * frames (needed by the learnable pixel-space CLS clip, frame_transformer.py:105,195). */
 int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t N, int C, int H, int W, int kh,
                     int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream);
+/* Implicit-GEMM convolution: y[N*Ho*Wo, Cout] = sum_{ki,kj,c} x[n, ho*sh-ph+ki, wo*sw-pw+kj, c] * w[co, (ki*kw+kj)*C + c]
+ * with the gather fused into the GEMM's A-operand LDS-DMA -- no column matrix in HBM (nn.Conv2d of
+ * custom_resnet.py:19-22,128; the (1,3,3)/(3,1,1) convolutions of R(2+1)D).  x NHWC, w = dvt_conv_weight_pack(...,
+ * ld = kh*kw*C).  The data gradient of a stride-1 convolution is the same call on dz with the 180-degree-rotated,
+ * channel-transposed weights and padding k-1-p.  16-bit dtypes, C % 64 == 0 (C % 32 == 0 when Cout <= 128),
+ * Cout % 8 == 0; dvt_conv2d_implicit_supported tells (callers fall back to dvt_im2col + dvt_gemm otherwise). */
+/* w[Cout,Cin,kh,kw] f32 -> dst[Cin, (kh*kw)*Cout]: taps rotated by 180 degrees, channels transposed (the weight
+ * operand of the data-gradient convolution, see dvt_conv2d_implicit). */
+int dvt_conv_weight_pack_dgrad(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw,
+                               dvt_stream_t stream);
+typedef struct dvt_conv_desc {
+  const void* x;
+  const void* w;
+  void* y;
+  int64_t N;
+  int32_t H, W, C, Cout, kh, kw, sh, sw, ph, pw;
+  int32_t dtype;
+} dvt_conv_desc;
+int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
+int dvt_conv2d_implicit(const dvt_conv_desc* desc, dvt_stream_t stream);
 /* w[Cout,Cin,kh,kw] f32 -> dst[Cout, ld] (column order (ki,kj,ci), zero padded) in dst_dtype, and the
  * inverse for the fp32 weight gradient (dw (+)= g re-ordered). */
 int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw, int64_t ld,

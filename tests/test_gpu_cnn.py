@@ -246,3 +246,46 @@ def test_frame_transformer_with_reference_encoders(dvt, device):
     assert torch.isfinite(loss.detach()).item()
     assert net.vid_cls.grad is not None and torch.isfinite(net.vid_cls.grad).all()
     assert torch.isfinite(net.vid_model.backbone.stem[0].weight.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (3, 64, 20, 20, 64, 3, 1, 1),          # layer1: cfg 256x128x32, ragged rows
+    (2, 64, 18, 22, 128, 3, 2, 1),         # strided 3x3
+    (2, 128, 14, 14, 256, 3, 1, 1),        # cfg 256x256x64
+    (2, 256, 9, 11, 512, (3, 1), 1, (1, 0)),   # rectangular (temporal) kernel
+    (4, 64, 16, 16, 128, 1, 2, 0),         # 1x1 stride-2 downsample
+    (1, 512, 7, 7, 512, 3, 1, 1),
+])
+def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geom):
+    """dvt_conv2d_implicit (gather fused into the GEMM operand DMA) == dvt_im2col + dvt_gemm, forward and the
+    stride-1 data gradient (rotated weights); same MFMA products in the same k order, so the match is tight."""
+    ops = dvt.ops
+    N, Cin, H, W, Cout, k, stride, pad = geom
+    g = torch.Generator().manual_seed(123)
+    (kh, kw) = ops._pair(k)
+    x = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).cuda()
+    K = kh * kw * Cin
+    wp = ops.conv_weight_pack(w, K, dtype)
+    assert ops.conv2d_implicit_supported(x, wp, N, Cin, H, W, Cout, k, stride, pad)
+    y = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad)
+    col = ops.im2col(x, False, N, Cin, H, W, k, stride, pad, K, dtype)
+    ref = ops.linear_fwd(col, wp)
+    assert y.shape == ref.shape and rel_l2(y, ref) < 1e-3
+    xr = x.float().cpu().view(N, H, W, Cin).permute(0, 3, 1, 2)
+    cpu = torch.nn.functional.conv2d(xr, w.cpu(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert rel_l2(y, cpu) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    if ops._pair(stride) == (1, 1):
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
+        wd = ops.conv_weight_pack_dgrad(w, dtype)
+        (ph, pw) = ops._pair(pad)
+        dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw))
+        dref = ops.col2im(ops.linear_dgrad(dz, wp), N, Cin, H, W, k, stride, pad)
+        assert dx.shape == dref.shape and rel_l2(dx, dref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    # unsupported geometry is reported, not mis-computed
+    x45 = torch.zeros(4 * 8 * 8, 40, dtype=dtype, device="cuda")
+    assert not ops.conv2d_implicit_supported(x45, ops.conv_weight_pack(torch.zeros(64, 40, 3, 3, device="cuda"), 360, dtype),
+                                             4, 40, 8, 8, 64, 3, 1, 1)
