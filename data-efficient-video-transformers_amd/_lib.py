@@ -39,7 +39,8 @@ class GemmDesc(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int64)] + \
-               [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")]
+               [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")] + \
+               [("workspace", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -127,6 +128,10 @@ SIGNATURES = {
     "dvt_conv_weight_pack_dgrad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv2d_implicit_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
+    "dvt_conv2d_implicit_wgrad_supported": (c_int, [C.POINTER(ConvDesc)]),
+    "dvt_conv2d_implicit_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "dvt_conv2d_implicit_wgrad": (c_int, [C.POINTER(ConvDesc), c_p]),
+    "dvt_conv_weight_unpack_grad_t": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),

@@ -164,6 +164,19 @@ __global__ void weight_unpack_kernel(const float* __restrict__ g, float* __restr
   }
 }
 
+// transposed scatter: dw[co, ci, ki, kj] (+)= gt[(ki*kw + kj)*Cin + ci, co]
+__global__ void weight_unpack_t_kernel(const float* __restrict__ gt, float* __restrict__ dw, int Cout, int Cin, int kh,
+                                       int kw, int accumulate) {
+  const int64_t total = (int64_t)Cout * Cin * kh * kw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % (kh * kw));
+    const int ci = (int)((i / (kh * kw)) % Cin);
+    const int co = (int)(i / ((int64_t)kh * kw * Cin));
+    const float v = gt[((int64_t)kk * Cin + ci) * Cout + co];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
 // data-gradient operand: dst[ci, ((kh-1-ki)*kw + (kw-1-kj))*Cout + co] = (T) w[co, ci, ki, kj]
 // (180-degree rotated taps, channels transposed): dx = conv(dz, dst) with padding k-1-p for a stride-1 convolution
 template <typename D>
@@ -683,6 +696,15 @@ int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int
   DVT_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(cgrid((int64_t)Cout * ld)), dim3(kB),
                                                       0, st, w, (T*)dst, Cout, Cin, kh, kw, ld));
   DVT_LAUNCH_CHECK("dvt_conv_weight_pack");
+  return DVT_OK;
+}
+
+int dvt_conv_weight_unpack_grad_t(const float* gt, float* dw, int Cout, int Cin, int kh, int kw, int accumulate,
+                                  dvt_stream_t stream) {
+  DVT_REQUIRE(gt && dw && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "dvt_conv_weight_unpack_grad_t: bad arguments");
+  hipLaunchKernelGGL(weight_unpack_t_kernel, dim3(cgrid((int64_t)Cout * Cin * kh * kw)), dim3(kB), 0, (hipStream_t)stream, gt,
+                     dw, Cout, Cin, kh, kw, accumulate);
+  DVT_LAUNCH_CHECK("dvt_conv_weight_unpack_grad_t");
   return DVT_OK;
 }
 

@@ -720,6 +720,75 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   return dvt_conv_dma_launch(p, d->Cout <= 128 ? 1 : 0, (hipStream_t)stream);
 }
 
+// ---- weight gradient: dWt[(ki,kj,c), co] = sum_rows col[row, (ki,kj,c)] * dz[row, co], col gathered on the fly
+struct ConvWgradPlan { int cfg, tk, split, kps; int64_t rows; int Ho, Wo, K; size_t slab_bytes; };
+
+static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
+  if (!d || !d->x || !d->w || !d->y || !dvt_is_16bit(d->dtype)) return false;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->kh <= 0 || d->kw <= 0 || d->sh <= 0 || d->sw <= 0 || d->ph < 0 || d->pw < 0)
+    return false;
+  if (d->C % 8 || d->Cout % 8) return false;
+  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (Ho <= 0 || Wo <= 0) return false;
+  const int64_t rows = d->N * Ho * Wo;
+  pl->cfg = d->Cout <= 128 ? 1 : 0;
+  pl->tk = pl->cfg ? 32 : 64;
+  if (rows % pl->tk || rows >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
+  pl->K = d->kh * d->kw * d->C;
+  pl->rows = rows; pl->Ho = (int)Ho; pl->Wo = (int)Wo;
+  const int tn = pl->cfg ? 128 : 256;
+  const int64_t tiles = dvt_cdiv(pl->K, 256) * dvt_cdiv(d->Cout, tn);
+  const int64_t target = (int64_t)dvt_num_cus() * (pl->cfg ? 2 : 1);       // cfg 1 runs two workgroups per CU
+  int64_t split = target / tiles;
+  if (split < 1) split = 1;
+  const int64_t ktiles = rows / pl->tk;
+  if (split > ktiles / 4) split = ktiles / 4 > 0 ? ktiles / 4 : 1;          // at least 4 k-tiles per slice
+  pl->kps = (int)(dvt_cdiv(ktiles, split) * pl->tk);
+  pl->split = (int)dvt_cdiv(rows, pl->kps);
+  pl->slab_bytes = (size_t)pl->split * (size_t)pl->K * (size_t)d->Cout * sizeof(float);
+  return dvt_aligned16(d->x) && dvt_aligned16(d->w) && dvt_aligned16(d->y);
+}
+
+int dvt_conv2d_implicit_wgrad_supported(const dvt_conv_desc* d) {
+  ConvWgradPlan pl;
+  return conv_wgrad_plan(d, &pl) ? 1 : 0;
+}
+
+size_t dvt_conv2d_implicit_wgrad_workspace_bytes(const dvt_conv_desc* d) {
+  ConvWgradPlan pl;
+  return conv_wgrad_plan(d, &pl) ? align256(pl.slab_bytes) : 0;
+}
+
+// x = d->x (NHWC input of the layer), dz = d->w ([rows, Cout]), dWt = d->y (f32 [kh*kw*C, Cout], overwritten)
+int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
+  ConvWgradPlan pl;
+  if (!conv_wgrad_plan(d, &pl))
+    DVT_UNSUPPORTED("dvt_conv2d_implicit_wgrad: needs a 16-bit dtype, C %% 8 == 0, Cout %% 8 == 0 and N*Ho*Wo a multiple of "
+                    "the k-tile (32 for Cout <= 128, else 64)");
+  DVT_REQUIRE(d->workspace, "dvt_conv2d_implicit_wgrad: workspace (dvt_conv2d_implicit_wgrad_workspace_bytes) required");
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p;
+  p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
+  p.M = pl.K; p.N = d->Cout; p.K = (int)pl.rows;
+  p.lda = 0; p.ldb = d->Cout; p.ldc = d->Cout;
+  p.epilogue = DVT_EPI_NONE; p.out_f32 = 1; p.accumulate = 0;
+  p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0;
+  p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = pl.kps; p.slab = (float*)d->workspace; p.tiles_n = 0;
+  p.colsum_slab = nullptr;
+  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = pl.Ho; p.cWo = pl.Wo; p.ckw = d->kw;
+  p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
+  int rc = dvt_conv_wgrad_dma_launch(p, pl.split, pl.cfg, st);
+  if (rc) return rc;
+  const int64_t nvec = (int64_t)p.M * p.N / 8;
+  int64_t blocks = dvt_cdiv(nvec, 256);
+  const int64_t cap = (int64_t)dvt_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p.slab, pl.split,
+                     p.M, p.N, (float*)d->y, (int64_t)d->Cout, 0, (const float*)nullptr, (float*)nullptr, 0);
+  DVT_LAUNCH_CHECK("dvt_conv2d_implicit_wgrad(reduce)");
+  return DVT_OK;
+}
+
 size_t dvt_colsum_workspace_bytes(int64_t M, int64_t N) {
   (void)M;
   return (size_t)kColsumParts * (size_t)(N > 0 ? N : 0) * sizeof(float);

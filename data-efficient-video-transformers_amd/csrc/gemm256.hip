@@ -118,6 +118,44 @@ struct ConvRows {
   }
 };
 
+// Implicit-GEMM mn-major operand (weight gradient): image [TK k-rows][ROWS m-columns], k = output pixel row of the
+// layer, m = (ki, kj, c) column of the never-materialised column matrix.  A lane's 16-byte chunk is 8 channels of one
+// tap of one pixel; its (tap, channel) is fixed for the whole K loop, only the pixel changes per k-tile.
+template <int ROWS, int TK, int NW>
+struct ConvColsMN {
+  enum { PIECES = ROWS * TK * 2 / 1024, PPW = PIECES / NW, CPR = ROWS / 8, RPP = 64 / CPR };
+  int kin[PPW], ki[PPW], kj[PPW], ci[PPW];
+  __device__ __forceinline__ void init(const GemmParams& p, int m0, int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int k = (wid * PPW + i) * RPP + lane / CPR;
+      const int cp = lane % CPR;
+      const int c = ((((cp >> 1) ^ swz_mn(k)) << 1) | (cp & 1));
+      int gmn = m0 + c * 8;
+      gmn = gmn < p.M ? gmn : p.M - 8;
+      const int tap = gmn / p.cC;
+      kin[i] = k;
+      ci[i] = gmn - tap * p.cC;
+      ki[i] = tap / p.ckw;
+      kj[i] = tap - ki[i] * p.ckw;
+    }
+  }
+  __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) const {
+    const int hw = p.cHo * p.cWo;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = k0 + kin[i];
+      const int n = row / hw, r = row - n * hw;
+      const int ho = r / p.cWo, wo = r - ho * p.cWo;
+      const int hi = ho * p.csh - p.cph + ki[i], wi = wo * p.csw - p.cpw + kj[i];
+      const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+      const bf16* src = ok ? p.A + ((int64_t)((n * p.cH + hi) * p.cW + wi) * p.cC + ci[i])
+                           : reinterpret_cast<const bf16*>(dvt_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wid * PPW + i) * 1024), 16, 0, 0);
+    }
+  }
+};
+
 // MFMA operand fragment of 16 rows (k-major) / 16 columns (mn-major) starting at `base`,
 // k-step kk (32 k each): lane (g, li) gets element j <-> (base + li, kk*32 + 8g + j).
 template <typename E, bool KMAJOR, int ROWS, int TK>
@@ -167,7 +205,7 @@ enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
 template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false>
 __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const GemmParams p) {
-  static_assert(!A_CONV || A_KMAJOR, "the gathered operand is k-major");
+  // A_CONV: the A operand is gathered from an NHWC map (k-major: forward / data gradient; mn-major: weight gradient)
   typedef Cfg<CFG> C;
   typedef typename Elem16<E>::v8 V8;
   constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
@@ -217,13 +255,16 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   for (int j = 0; j < 8; ++j) ones[j] = (E)1.0f;
 
   ConvRows<TM, TK, NW> cv;
-  if (A_CONV) cv.init(p, m0, wid, lane);
+  ConvColsMN<TM, TK, NW> cvm;
+  if (A_CONV && A_KMAJOR) cv.init(p, m0, wid, lane);
+  if (A_CONV && !A_KMAJOR) cvm.init(p, m0, wid, lane);
 
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s)
     if (s < nk) {
-      if (A_CONV) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
+      if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
+      else if (A_CONV) cvm.dma(p, kbeg + s * TK, smem + s * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
     }
@@ -237,7 +278,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     __builtin_amdgcn_s_barrier();
     if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
-      if (A_CONV) cv.dma(p, k0, smem + st_nxt * kStage, wid);
+      if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
+      else if (A_CONV) cvm.dma(p, k0, smem + st_nxt * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
     }
@@ -429,7 +471,32 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
   return DVT_OK;
 }
 
+template <typename E, int CFG>
+int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
+  typedef Cfg<CFG> C;
+  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  GemmParams p = pin;
+  const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
+  p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB, true>), grid, block, kSmem, st, p);
+  DVT_LAUNCH_CHECK("dvt_conv2d_implicit_wgrad(dma)");
+  return DVT_OK;
+}
+
 }  // namespace
+
+// Weight gradient with the column matrix gathered on the fly: slab[z][M = kh*kw*C][N = Cout] partial sums.
+int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st) {
+  if (p.elem == DVT_F16) return cfg == 0 ? launch_conv_wgrad<f16, 0>(p, split, st) : launch_conv_wgrad<f16, 1>(p, split, st);
+  return cfg == 0 ? launch_conv_wgrad<bf16, 0>(p, split, st) : launch_conv_wgrad<bf16, 1>(p, split, st);
+}
 
 // Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
 // fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32.

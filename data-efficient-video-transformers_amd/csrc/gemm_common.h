@@ -76,4 +76,5 @@ __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (
 // LDS-DMA kernels (gemm256.hip).  cfg 0: 256x256x64, 1 workgroup / CU;  cfg 1: 256x128x32,
 // 2 workgroups / CU.  K (and each K split) must be a multiple of 64.
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st);
+int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st);
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st);

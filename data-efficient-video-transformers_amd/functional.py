@@ -929,10 +929,14 @@ class _ConvBnAct(torch.autograd.Function):
             mean, invstd = run_mean.detach().float(), ops.bn_eval_invstd(run_var.detach().float(), eps)
         res = None if residual is None else residual.contiguous()
         y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
-        keep_col = SAVE_CONV_COLUMNS and not direct and col is not None
+        # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
+        wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
+                       ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad))
+        keep_col = SAVE_CONV_COLUMNS and not direct and col is not None and not wg_implicit
         ctx.save_for_backward(None if keep_col else xc, wp, z, y if relu else None, mean, invstd, g32,
                               col if keep_col else None)
         ctx.w4 = w4.detach() if implicit else None
+        ctx.wg_implicit = wg_implicit
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -953,17 +957,21 @@ class _ConvBnAct(torch.autograd.Function):
             dgam = dbet = None
         else:
             dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
-        if col is None:
-            col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
-        dwp = ops.linear_wgrad(dz, col)                                  # [Cout, ld] fp32
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
+        if ctx.wg_implicit:
+            dwt = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad)      # [kh*kw*Cin, Cout] fp32
+            unpack, dwp = ops.conv_weight_unpack_grad_t, dwt
+        else:
+            if col is None:
+                col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
+            unpack, dwp = ops.conv_weight_unpack_grad, ops.linear_wgrad(dz, col)             # [Cout, ld] fp32
         if sw is not None:
-            ops.conv_weight_unpack_grad(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
+            unpack(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
             sw.mark_written()
             dw = None
         else:
-            dw = ops.conv_weight_unpack_grad(dwp, w4).view(wshape)
+            dw = unpack(dwp, w4).view(wshape)
         dx = None
         (sh_, sw_), (ph_, pw_) = ops._pair(stride), ops._pair(pad)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)

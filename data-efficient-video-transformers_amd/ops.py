@@ -790,6 +790,39 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
     return y
 
 
+def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
+        return False
+    if not (x.is_contiguous() and dz.is_contiguous()):
+        return False
+    return bool(L.load().dvt_conv2d_implicit_wgrad_supported(C.byref(_conv_desc(x, dz, None, N, Cc, H, W, Cout, k, stride, pad))))
+
+
+def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad) -> Tensor:
+    """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised."""
+    _need_cuda(x, dz)
+    (kh, kw) = _pair(k)
+    out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
+    d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad)
+    lib = L.load()
+    ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device)
+    d.workspace = _p(ws)
+    rows = dz.shape[0]
+    with _timed(("gemm", 0, 0, kh * kw * Cc, Cout, rows), 2.0 * rows * Cout * kh * kw * Cc):
+        L.check(lib.dvt_conv2d_implicit_wgrad(C.byref(d), _stream()), "dvt_conv2d_implicit_wgrad")
+    return out
+
+
+def conv_weight_unpack_grad_t(gt: Tensor, shape, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    Cout, Cin, kh, kw = shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=gt.device)
+    L.check(L.load().dvt_conv_weight_unpack_grad_t(gt.data_ptr(), out.data_ptr(), Cout, Cin, kh, kw, int(accumulate),
+                                                   _stream()), "dvt_conv_weight_unpack_grad_t")
+    return out
+
+
 def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
     _need_cuda(w)
     w = w.detach().contiguous()

@@ -329,9 +329,19 @@ typedef struct dvt_conv_desc {
   int64_t N;
   int32_t H, W, C, Cout, kh, kw, sh, sw, ph, pw;
   int32_t dtype;
+  void* workspace;   /* weight gradient only */
 } dvt_conv_desc;
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 int dvt_conv2d_implicit(const dvt_conv_desc* desc, dvt_stream_t stream);
+/* Weight gradient without a column matrix: with x = the layer input (NHWC), w = dz [N*Ho*Wo, Cout] and
+ * y = dWt f32 [kh*kw*C, Cout] (overwritten): dWt[(ki*kw+kj)*C + c, co] = sum_rows gather(x)[row, .] * dz[row, co];
+ * split-K over the rows with a fixed-order reduction (reproducible).  C % 8 == 0, Cout % 8 == 0, N*Ho*Wo a multiple
+ * of 64 (32 when Cout <= 128).  dvt_conv_weight_unpack_grad_t scatters dWt into the [Cout, Cin, kh, kw] master. */
+int dvt_conv2d_implicit_wgrad_supported(const dvt_conv_desc* desc);
+size_t dvt_conv2d_implicit_wgrad_workspace_bytes(const dvt_conv_desc* desc);
+int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* desc, dvt_stream_t stream);
+int dvt_conv_weight_unpack_grad_t(const float* gt, float* dw, int Cout, int Cin, int kh, int kw, int accumulate,
+                                  dvt_stream_t stream);
 /* w[Cout,Cin,kh,kw] f32 -> dst[Cout, ld] (column order (ki,kj,ci), zero padded) in dst_dtype, and the
  * inverse for the fp32 weight gradient (dw (+)= g re-ordered). */
 int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw, int64_t ld,

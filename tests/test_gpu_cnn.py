@@ -289,3 +289,34 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
     x45 = torch.zeros(4 * 8 * 8, 40, dtype=dtype, device="cuda")
     assert not ops.conv2d_implicit_supported(x45, ops.conv_weight_pack(torch.zeros(64, 40, 3, 3, device="cuda"), 360, dtype),
                                              4, 40, 8, 8, 64, 3, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [
+    (4, 64, 16, 16, 64, 3, 1, 1),          # rows 1024, cfg 256x128x32, M = 576 (ragged third tile), N = 64
+    (2, 64, 16, 16, 128, 3, 2, 1),         # strided
+    (4, 128, 8, 8, 256, 3, 1, 1),          # cfg 256x256x64
+    (4, 64, 16, 16, 128, 1, 2, 0),         # 1x1 stride-2 downsample
+    (2, 24, 8, 8, 72, 3, 1, 1),            # C % 8 only (tap boundaries inside a tile)
+])
+def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype, geom):
+    ops = dvt.ops
+    N, Cin, H, W, Cout, k, stride, pad = geom
+    g = torch.Generator().manual_seed(321)
+    (kh, kw) = ops._pair(k)
+    Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+    x = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
+    dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
+    assert ops.conv2d_implicit_wgrad_supported(x, dz, N, Cin, H, W, Cout, k, stride, pad)
+    dwt = ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad)
+    assert torch.equal(dwt, ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad))   # reproducible
+    K = kh * kw * Cin
+    col = ops.im2col(x, False, N, Cin, H, W, k, stride, pad, K, dtype)
+    ref = col.float().t() @ dz.float()                         # [K, Cout]
+    assert dwt.shape == ref.shape and rel_l2(dwt, ref) < 1e-5
+    dw = ops.conv_weight_unpack_grad_t(dwt, (Cout, Cin, kh, kw))
+    ref4 = ops.conv_weight_unpack_grad((dz.float().t() @ col.float()).contiguous(), (Cout, Cin, kh, kw))
+    assert rel_l2(dw, ref4) < 1e-5
+    acc = torch.ones_like(dw)
+    ops.conv_weight_unpack_grad_t(dwt, (Cout, Cin, kh, kw), out=acc, accumulate=True)
+    assert rel_l2(acc - 1.0, dw) < 1e-5
