@@ -502,7 +502,7 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       s = dvt_cdiv(cus, t256);
       const int64_t maxs = d->K / 1024;
       if (s > maxs) s = maxs;
-      if (s > 64) s = 64;
+      if (s > 256) s = 256;   // very deep K (convolution weight gradients over N*H*W rows): up to one slice per CU
       if (s < 1) s = 1;
     }
     if (!can_split) s = 1;
@@ -531,7 +531,7 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       s = dvt_cdiv(cus, tiles);
       const int64_t maxs = d->K / 128;     // at least two 64-wide k-tiles per slice
       if (s > maxs) s = maxs;
-      if (s > 32) s = 32;
+      if (s > 128) s = 128;
       if (s < 1) s = 1;
     }
   }
