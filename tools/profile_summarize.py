@@ -1,0 +1,126 @@
+"""Summarise the rocprofv3 runs of tools/run_profiles.sh into the committed files under profiles/.
+
+usage: python3 tools/profile_summarize.py <prof_dir> <out_dir> <tag>
+  <prof_dir>/stats  : --kernel-trace --stats            -> <tag>_bench_kernel_stats.{csv,md}
+  <prof_dir>/fetch, write : --pmc FETCH_SIZE / WRITE_SIZE -> <tag>_pmc_traffic.{json,md}
+  <prof_dir>/mfma   : --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -> <tag>_pmc_mfma.md
+gfx950 corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 64 B per 128-B request for wide
+coalesced reads -> doubled; WRITE_SIZE exact for 16-B/lane stores; both in units the CSV reports (bytes here: the
+counter values are multiplied by the unit factor printed below if rocprofv3 reports KiB)."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    f = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return f[-1] if f else None
+
+
+def short(name):
+    return name if len(name) <= 100 else name[:97] + "..."
+
+
+KIB = 1024.0
+
+
+def gemm_family(name):
+    """gemm_dma_kernel<E, A_KMAJOR, B_KMAJOR, CFG, EPI, OUT, A_CONV> -> fwd (k,k) / dgrad (k,mn) / wgrad (mn,mn).
+    rocprofv3 leaves some instantiations mangled (IDF16bLb<AK>ELb<BK>E...) and mis-demangles the bf16 argument of
+    the others as 'bool _Accum, bool, E, <BK>, ...' (A_KMAJOR is swallowed; only wgrad has A_KMAJOR = false and that
+    form stays mangled)."""
+    if "gemm_dma_kernel" not in name:
+        return None
+    m = re.search(r"gemm_dma_kernelIDF16[b_]Lb(\d)ELb(\d)E", name)
+    if m:
+        ak, bk = m.group(1) == "1", m.group(2) == "1"
+    else:
+        m = re.search(r"E, (true|false), \d", name)
+        if not m:
+            return None
+        ak, bk = True, m.group(1) == "true"
+    return "fwd" if (ak and bk) else "dgrad" if ak else "wgrad"
+
+
+def load_counters(d):
+    """-> {(kernel, grid): {"n": launches, counter: sum}}"""
+    f = find(d, "*counter_collection.csv")
+    out = defaultdict(lambda: defaultdict(float))
+    if not f:
+        return out
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        key = (r["Kernel_Name"], int(r["Grid_Size"]))
+        out[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        did = (r["Dispatch_Id"], r["Counter_Name"])
+        if r["Counter_Name"] and (r["Dispatch_Id"],) not in seen:
+            seen.add((r["Dispatch_Id"],))
+            out[key]["n"] += 1
+    return out
+
+
+def main():
+    prof, outd, tag = sys.argv[1:4]
+    os.makedirs(outd, exist_ok=True)
+    # ---- kernel stats
+    st = find(os.path.join(prof, "stats"), "*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(outd, f"{tag}_bench_kernel_stats.csv"))
+        rows = list(csv.DictReader(open(st)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        with open(os.path.join(outd, f"{tag}_bench_kernel_stats.md"), "w") as fh:
+            fh.write(f"# rocprofv3 --kernel-trace --stats ({tag})\n\nCommand: tools/run_profiles.sh (bench.py --steps 5 --warmup 2, "
+                     "hipGraph replay: 5 timed + 2 warm-up + 2 capture warm-up steps = 9 steps in the trace).\n\n"
+                     "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+            for r in rows[:32]:
+                fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+                         f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+            fh.write(f"\nTotal kernel time {tot/1e6:.2f} ms over 9 steps = {tot/9e6:.2f} ms/step.\n")
+    # ---- traffic
+    fe, wr = load_counters(os.path.join(prof, "fetch")), load_counters(os.path.join(prof, "write"))
+    if fe or wr:
+        keys = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe[k].get("FETCH_SIZE", 0) + wr[k].get("WRITE_SIZE", 0)))
+        fam = {}
+        with open(os.path.join(outd, f"{tag}_pmc_traffic.md"), "w") as fh:
+            fh.write(f"# HBM traffic per launch from PMC counters ({tag})\n\nrocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                     "(separate passes, --kernel-trace only), bench.py --steps 2 --warmup 1 --no-graph.  gfx950: FETCH_SIZE counts 64 B "
+                     "per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact.  FETCH_SIZE is counted at the L2 "
+                     "fabric side and includes Infinity-Cache hits (upper bound of HBM reads).  Values: MB per launch.\n\n"
+                     "| kernel | grid | launches | FETCH raw | WRITE | corrected 2F+W |\n|---|---|---|---|---|---|\n")
+            for k in keys[:40]:
+                n = max(fe[k].get("n", 0), wr[k].get("n", 0), 1)
+                f_mb = fe[k].get("FETCH_SIZE", 0) * KIB / n / 1e6      # rocprofv3 reports both counters in KiB
+                w_mb = wr[k].get("WRITE_SIZE", 0) * KIB / n / 1e6
+                fh.write(f"| `{short(k[0])}` | {k[1]} | {int(n)} | {f_mb:.1f} | {w_mb:.1f} | {2*f_mb+w_mb:.1f} |\n")
+                famname = gemm_family(k[0])
+                if famname:
+                    a = fam.setdefault(famname, [0.0, 0])
+                    a[0] += (2 * f_mb + w_mb) * 1e6 * n
+                    a[1] += n
+        json.dump({"families": {k: {"hbm_bytes_corrected": int(v[0] / max(v[1], 1)), "launches": int(v[1])} for k, v in fam.items()},
+                   "note": "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE, averaged over the family's launches"},
+                  open(os.path.join(outd, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    # ---- MFMA busy
+    mf = load_counters(os.path.join(prof, "mfma"))
+    if mf:
+        keys = sorted(mf, key=lambda k: -mf[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))
+        with open(os.path.join(outd, f"{tag}_pmc_mfma.md"), "w") as fh:
+            fh.write(f"# MFMA pipe utilisation from PMC counters ({tag})\n\nrocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                     "(--kernel-trace only).  util = MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs): the share of "
+                     "SIMD-cycles in which a matrix instruction occupies the pipe.\n\n| kernel | grid | launches | MFMA busy Mcyc | "
+                     "GUI active Mcyc/XCD | util |\n|---|---|---|---|---|---|\n")
+            for k in keys[:24]:
+                b, g = mf[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0), mf[k].get("GRBM_GUI_ACTIVE", 0) / 8
+                if b <= 0 or g <= 0:
+                    continue
+                fh.write(f"| `{short(k[0])}` | {k[1]} | {int(mf[k]['n'])} | {b/1e6:.1f} | {g/1e6:.2f} | {b/(g*1024):.3f} |\n")
+    print("wrote", sorted(os.listdir(outd)))
+
+
+if __name__ == "__main__":
+    main()
