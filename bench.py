@@ -108,6 +108,9 @@ WORKLOADS = {
     "pyramid": "BASELINE configs[2]: per-frame ResNet-18 3-scale pyramid (train-mode BatchNorm) -> FPN lateral tokens "
                "(196/frame) -> the metric-shape transformer; B=8/GPU, T=32, 3x224x224; "
                "step = fwd + BCE + bwd + DP grad all-reduce + fused AdamW",
+    "frametransformer": "reference default FrameTransformer(model='vid') (frame_transformer.py:83-121,192-210): R(2+1)D-18 "
+                        "encoder on [B, 14, 12, 3, 112, 112] chunks (learnable pixel-space CLS chunk included), 896-d tokens, "
+                        "4-layer post-norm encoder (dropout 0.5, training mode), BCE; B=2/GPU (config.yaml:2); unit = samples",
     "longclip": "BASELINE configs[4]: ViViT d=512, depth 4+4, T=64, 3x288x288 (325 tokens/frame), fp16 kernels + dynamic loss "
                 "scaling (device-side), activation checkpointing (one saved activation per block); B=8/GPU",
     "crossmodal": "BASELINE configs[3]: configs[2] + 32 audio tokens (128-d), cross-attention block (video queries, "
@@ -126,12 +129,14 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
                     "replaying one captured hipGraph per step (single-GPU only)")
-    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal", "longclip"], default="vivit",
+    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal", "longclip", "frametransformer"], default="vivit",
                     help="vivit = the metric workload (default); pyramid = BASELINE configs[2] (ResNet-18 3-scale "
                     "pyramid front-end -> the same transformer); crossmodal = configs[3] (+ 32 audio tokens, "
                     "cross-attention block, distillation head); longclip = configs[4] (T=64, 288^2, fp16 + dynamic loss "
                     "scaling, activation checkpointing; reports HBM GB/s of the streaming kernels and the activation "
-                    "peak).  Secondary lines, same JSON contract.")
+                    "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
+                    "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
+                    "(config.yaml:2).  Secondary lines, same JSON contract.")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
                     "rank (rehearses the multi-GPU code path on a single GPU)")
     args = ap.parse_args()
@@ -160,7 +165,13 @@ def main():
         cfg.update(image=288, T=64)
         cdt = torch.float16
     torch.manual_seed(1130)                                       # src/main.py:25
-    if args.workload in ("vivit", "longclip"):
+    if args.workload == "frametransformer":
+        from dvt_amd.models.frame_transformer import FrameTransformer
+        if args.batch == 8:
+            args.batch = 2                                     # config.yaml:2
+        net = FrameTransformer(batch_size=args.batch, seq_len=13, cls=1, model="vid", opt="adamW", learning_rate=5e-6,
+                               weight_decay=0.09, momentum=0.005).cuda().train()
+    elif args.workload in ("vivit", "longclip"):
         net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
                     heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=cdt,
                     activation_checkpointing=args.workload == "longclip").cuda().train()
@@ -176,7 +187,10 @@ def main():
 
     gen = torch.Generator().manual_seed(1130 + rank)
     B = args.batch
-    x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(cdt).cuda()
+    if args.workload == "frametransformer":
+        x = torch.randn(B, 13, 12, 3, 112, 112, generator=gen).cuda()     # MMX_Light_dl.py:286 batch contract
+    else:
+        x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(cdt).cuda()
     y = (torch.rand(B, cfg["classes"], generator=gen) < 0.2).float()
     y[:, 0] = 1.0
     y = y.cuda()
@@ -191,6 +205,8 @@ def main():
         flat.zero_grad()
         if args.workload in ("vivit", "longclip"):
             loss = F.bce_with_logits(net(x), y)
+        elif args.workload == "frametransformer":
+            loss = net.training_step((y, None, x), 0)
         else:
             loss = net.training_step((y, x, audio) if audio is not None else (y, x))
         loss.backward(gloss)
@@ -298,8 +314,10 @@ def main():
                                               3 * cfg["patch"] ** 2, n_tok - 1)
         out = {
             "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16" if args.workload == "vivit" else
-                      f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}",
-            "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                      ("samples/sec fwd+bwd [frametransformer workload], B=2 x 14 chunks x 12 x 3x112x112"
+                       if args.workload == "frametransformer" else
+                       f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}"),
+            "value": round(clips, 2), "unit": "samples/s" if args.workload == "frametransformer" else "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],

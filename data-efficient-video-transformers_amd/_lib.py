@@ -126,6 +126,8 @@ SIGNATURES = {
     "dvt_dropout": (c_int, [c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_p]),
     "dvt_rng_advance": (c_int, [c_p, C.c_uint64, c_p]),
     "dvt_conv_weight_pack_dgrad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_pad3_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_unpad3_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv2d_implicit_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
     "dvt_conv2d_implicit_wgrad_supported": (c_int, [C.POINTER(ConvDesc)]),

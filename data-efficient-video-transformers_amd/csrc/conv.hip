@@ -164,6 +164,30 @@ __global__ void weight_unpack_kernel(const float* __restrict__ g, float* __restr
   }
 }
 
+// zero-padding of a [A, B, K] f32 array to [Ap, Bp, K] and the adjoint slice (channel padding of convolution
+// weights / BatchNorm vectors: R(2+1)D mid-plane counts 45 / 230 / 460 / 921 are padded to MFMA-friendly multiples)
+__global__ void pad3_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int K, int Ap, int Bp) {
+  const int64_t total = (int64_t)Ap * Bp * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int b = (int)((i / K) % Bp);
+    const int a = (int)(i / ((int64_t)K * Bp));
+    dst[i] = (a < A && b < B) ? src[((int64_t)a * B + b) * K + k] : 0.f;
+  }
+}
+
+__global__ void unpad3_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int K, int Bp,
+                              int accumulate) {
+  const int64_t total = (int64_t)A * B * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int b = (int)((i / K) % B);
+    const int a = (int)(i / ((int64_t)K * B));
+    const float v = src[((int64_t)a * Bp + b) * K + k];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
 // transposed scatter: dw[co, ci, ki, kj] (+)= gt[(ki*kw + kj)*Cin + ci, co]
 __global__ void weight_unpack_t_kernel(const float* __restrict__ gt, float* __restrict__ dw, int Cout, int Cin, int kh,
                                        int kw, int accumulate) {
@@ -696,6 +720,21 @@ int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int
   DVT_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(cgrid((int64_t)Cout * ld)), dim3(kB),
                                                       0, st, w, (T*)dst, Cout, Cin, kh, kw, ld));
   DVT_LAUNCH_CHECK("dvt_conv_weight_pack");
+  return DVT_OK;
+}
+
+int dvt_pad3_f32(const float* src, float* dst, int A, int B, int K, int Ap, int Bp, dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && A > 0 && B > 0 && K > 0 && Ap >= A && Bp >= B, "dvt_pad3_f32: bad arguments");
+  hipLaunchKernelGGL(pad3_kernel, dim3(cgrid((int64_t)Ap * Bp * K)), dim3(kB), 0, (hipStream_t)stream, src, dst, A, B, K, Ap, Bp);
+  DVT_LAUNCH_CHECK("dvt_pad3_f32");
+  return DVT_OK;
+}
+
+int dvt_unpad3_f32(const float* src, float* dst, int A, int B, int K, int Bp, int accumulate, dvt_stream_t stream) {
+  DVT_REQUIRE(src && dst && A > 0 && B > 0 && K > 0 && Bp >= B, "dvt_unpad3_f32: bad arguments");
+  hipLaunchKernelGGL(unpad3_kernel, dim3(cgrid((int64_t)A * B * K)), dim3(kB), 0, (hipStream_t)stream, src, dst, A, B, K, Bp,
+                     accumulate);
+  DVT_LAUNCH_CHECK("dvt_unpad3_f32");
   return DVT_OK;
 }
 

@@ -900,19 +900,31 @@ IMPLICIT_CONV = True
 
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
-    clip frames [N, Cin, H, W] for the stem.  Returns the NHWC matrix [N*Ho*Wo, Cout]."""
+    clip frames [N, Cin, H, W] for the stem.  Returns the NHWC matrix [N*Ho*Wo, Cout].
+
+    Channel padding (``cpad`` > 0): Cout is rounded up to a multiple of ``cpad`` and x may carry more channels
+    than ``w`` has input planes (a padded predecessor); weights / BatchNorm vectors are zero-extended on the fly, so
+    the padded output channels are exactly zero and every kernel sees MFMA-friendly widths (R(2+1)D mid planes
+    45 / 230 / 460 / 921).  Parameters and their gradients keep the reference shapes."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype):
+    def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
+                cpad=0):
         N, Cin, H, W, k, stride, pad, nchw = geom
-        Cout = w.shape[0]
+        Cout_l, Cin_l = w.shape[0], w.shape[1]
+        Cout = (Cout_l + cpad - 1) // cpad * cpad if cpad else Cout_l
+        padded = Cout != Cout_l or Cin != Cin_l
+        if Cin < Cin_l:
+            raise ValueError("input has fewer channels than the convolution weight")
         (kh, kw), (sh, sw) = ops._pair(k), ops._pair(stride)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         K = kh * kw * Cin
         direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
         ld = K if direct else _kpad(K, dtype)
         xc = x.contiguous()
-        w4 = w.reshape(Cout, Cin, kh, kw)
+        w4 = w.reshape(Cout_l, Cin_l, kh, kw)
+        if padded:
+            w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
         wp = ops.conv_weight_pack(w4, ld, dtype)
         implicit = (IMPLICIT_CONV and not direct and not nchw and ld == K and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
@@ -923,11 +935,23 @@ class _ConvBnAct(torch.autograd.Function):
             col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
             z = ops.linear_fwd(col, wp)                                 # [N*Ho*Wo, Cout]
         g32, b32 = _f32(gamma), _f32(beta)
+        rm, rv = run_mean, run_var
+        if Cout != Cout_l:
+            g32 = ops.pad3_f32(g32, Cout_l, 1, 1, Cout, 1).view(-1)
+            b32 = ops.pad3_f32(b32, Cout_l, 1, 1, Cout, 1).view(-1)
+            if rm is not None:
+                rm = ops.pad3_f32(rm.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
+                rv = ops.pad3_f32(rv.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
         if training:
-            mean, invstd = ops.bn_stats(z, run_mean, run_var, eps, momentum)
+            mean, invstd = ops.bn_stats(z, rm, rv, eps, momentum)
+            if Cout != Cout_l and run_mean is not None:             # running statistics back into the module buffers
+                ops.unpad3_f32(rm, Cout_l, 1, 1, 1, out=run_mean)
+                ops.unpad3_f32(rv, Cout_l, 1, 1, 1, out=run_var)
         else:
-            mean, invstd = run_mean.detach().float(), ops.bn_eval_invstd(run_var.detach().float(), eps)
+            mean, invstd = rm.detach().float(), ops.bn_eval_invstd(rv.detach().float(), eps)
         res = None if residual is None else residual.contiguous()
+        if res is not None and res.shape[1] != Cout:
+            raise ValueError("residual width must equal the (padded) output width")
         y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
         # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
         wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
@@ -935,12 +959,13 @@ class _ConvBnAct(torch.autograd.Function):
         keep_col = SAVE_CONV_COLUMNS and not direct and col is not None and not wg_implicit
         ctx.save_for_backward(None if keep_col else xc, wp, z, y if relu else None, mean, invstd, g32,
                               col if keep_col else None)
-        ctx.w4 = w4.detach() if implicit else None
-        ctx.wg_implicit = wg_implicit
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
         ctx.x_shape, ctx.x_dtype = tuple(x.shape), x.dtype
+        ctx.w4 = w4.detach() if implicit else None
+        ctx.wg_implicit = wg_implicit
+        ctx.logical = (Cout_l, Cin_l, padded)
         return y
 
     @staticmethod
@@ -948,15 +973,25 @@ class _ConvBnAct(torch.autograd.Function):
         xc, wp, z, y, mean, invstd, g32, col = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
+        Cout_l, Cin_l, padded = ctx.logical
         sw, sg, sb = ctx.sinks
         dy = _as(dy.contiguous(), z.dtype)
-        if sg is not None and sb is not None:
+        if sg is not None and sb is not None and Cout == Cout_l:
             dz, dres, _, _ = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res,
                                         dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
             sg.mark_written(); sb.mark_written()
             dgam = dbet = None
         else:
             dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
+            if Cout != Cout_l:                                           # drop the padded channels
+                if sg is not None and sb is not None:
+                    ops.unpad3_f32(dgam, Cout_l, 1, 1, 1, out=sg.buf.view(-1), accumulate=not sg.fresh)
+                    ops.unpad3_f32(dbet, Cout_l, 1, 1, 1, out=sb.buf.view(-1), accumulate=not sb.fresh)
+                    sg.mark_written(); sb.mark_written()
+                    dgam = dbet = None
+                else:
+                    dgam = ops.unpad3_f32(dgam, Cout_l, 1, 1, 1).view(-1)
+                    dbet = ops.unpad3_f32(dbet, Cout_l, 1, 1, 1).view(-1)
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
         if ctx.wg_implicit:
@@ -966,7 +1001,15 @@ class _ConvBnAct(torch.autograd.Function):
             if col is None:
                 col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
             unpack, dwp = ops.conv_weight_unpack_grad, ops.linear_wgrad(dz, col)             # [Cout, ld] fp32
-        if sw is not None:
+        if padded:                                                       # full-width gradient, then the reference slice
+            dw_full = unpack(dwp, w4)
+            if sw is not None:
+                ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin, out=sw.buf, accumulate=not sw.fresh)
+                sw.mark_written()
+                dw = None
+            else:
+                dw = ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin).view(wshape)
+        elif sw is not None:
             unpack(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
             sw.mark_written()
             dw = None
@@ -989,7 +1032,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
@@ -1001,7 +1044,8 @@ def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, rel
                            tuple(conv.padding), relu=relu, residual=residual, dtype=dtype)
 
 
-def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16):
+def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16,
+                    cpad: int = 0):
     """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
     Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
     (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
@@ -1009,7 +1053,7 @@ def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype)
+                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad)
 
 
 class _Subsample(torch.autograd.Function):

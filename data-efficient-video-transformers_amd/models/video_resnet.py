@@ -35,11 +35,15 @@ class Conv2Plus1D(nn.Sequential):
         return stride, stride, stride
 
 
+CPAD = 64     # mid-plane counts 45 / 230 / 460 / 921 are zero-padded to multiples of 64 (MFMA / LDS-DMA tile widths)
+
+
 def _spatial(fm, conv, bn, relu, dtype):
     """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames."""
     y, N, T, H, W = fm
     k, s, p = conv.kernel_size[1:], conv.stride[1:], conv.padding[1:]
-    out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, conv.in_channels, H, W, False), k, s, p, relu=relu, dtype=dtype)
+    out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
+                            cpad=CPAD)
     Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
     return (out, N, T, Ho, Wo)
 
@@ -48,8 +52,8 @@ def _temporal(fm, conv, bn, relu, dtype, residual=None):
     """(3,1,1) conv + BN(+res)(+ReLU): a (kt,1) conv over the [T, H*W] view of each clip."""
     y, N, T, H, W = fm
     kt, st, pt = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    out = F.conv_bn_act_raw(y, conv.weight, bn, (N, conv.in_channels, T, H * W, False), (kt, 1), (st, 1), (pt, 0),
-                            relu=relu, residual=residual, dtype=dtype)
+    out = F.conv_bn_act_raw(y, conv.weight, bn, (N, y.shape[1], T, H * W, False), (kt, 1), (st, 1), (pt, 0),
+                            relu=relu, residual=residual, dtype=dtype, cpad=CPAD)
     To = (T + 2 * pt - kt) // st + 1
     return (out, N, To, H, W)
 
@@ -140,7 +144,8 @@ class VideoResNet(nn.Module):
             frames = frames.contiguous()
         s0, b0, s3, b3 = self.stem[0], self.stem[1], self.stem[3], self.stem[4]
         k, s, p = s0.kernel_size[1:], s0.stride[1:], s0.padding[1:]
-        y = F.conv_bn_act_raw(frames.view(N * T, 3, H, W), s0.weight, b0, (N * T, 3, H, W, True), k, s, p, relu=True, dtype=dt)
+        y = F.conv_bn_act_raw(frames.view(N * T, 3, H, W), s0.weight, b0, (N * T, 3, H, W, True), k, s, p, relu=True, dtype=dt,
+                              cpad=CPAD)
         H1, W1 = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
         fm = _temporal((y, N, T, H1, W1), s3, b3, True, dt)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -823,6 +823,27 @@ def conv_weight_unpack_grad_t(gt: Tensor, shape, *, out: Optional[Tensor] = None
     return out
 
 
+def pad3_f32(src: Tensor, A: int, B: int, K: int, Ap: int, Bp: int) -> Tensor:
+    """f32 [A, B, K] -> zero-extended [Ap, Bp, K]."""
+    _need_cuda(src)
+    src = src.detach().contiguous()
+    assert src.dtype == torch.float32 and src.numel() == A * B * K
+    dst = torch.empty((Ap, Bp, K), dtype=torch.float32, device=src.device)
+    L.check(L.load().dvt_pad3_f32(src.data_ptr(), dst.data_ptr(), A, B, K, Ap, Bp, _stream()), "dvt_pad3_f32")
+    return dst
+
+
+def unpad3_f32(src: Tensor, A: int, B: int, K: int, Bp: int, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """slice [:A, :B, :] of f32 [Ap, Bp, K] (+= into ``out`` when accumulate)."""
+    _need_cuda(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    if out is None:
+        assert not accumulate
+        out = torch.empty((A, B, K), dtype=torch.float32, device=src.device)
+    L.check(L.load().dvt_unpad3_f32(src.data_ptr(), out.data_ptr(), A, B, K, Bp, int(accumulate), _stream()), "dvt_unpad3_f32")
+    return out
+
+
 def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
     _need_cuda(w)
     w = w.detach().contiguous()

@@ -318,6 +318,12 @@ int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t
  * ld = kh*kw*C).  The data gradient of a stride-1 convolution is the same call on dz with the 180-degree-rotated,
  * channel-transposed weights and padding k-1-p.  16-bit dtypes, C % 64 == 0 (C % 32 == 0 when Cout <= 128),
  * Cout % 8 == 0; dvt_conv2d_implicit_supported tells (callers fall back to dvt_im2col + dvt_gemm otherwise). */
+/* Channel padding of f32 parameter arrays viewed as [A, B, K] (conv weights: A = Cout, B = Cin, K = kh*kw; BatchNorm
+ * vectors: B = K = 1): dst[Ap, Bp, K] = src zero-extended; dvt_unpad3_f32 is the adjoint slice (+= when accumulate).
+ * Lets layers whose channel counts are not multiples of 8 (R(2+1)D mid planes 45 / 230 / 460 / 921,
+ * frame_transformer.py:67) run on the MFMA kernels with exactly-zero padded channels. */
+int dvt_pad3_f32(const float* src, float* dst, int A, int B, int K, int Ap, int Bp, dvt_stream_t stream);
+int dvt_unpad3_f32(const float* src, float* dst, int A, int B, int K, int Bp, int accumulate, dvt_stream_t stream);
 /* w[Cout,Cin,kh,kw] f32 -> dst[Cin, (kh*kw)*Cout]: taps rotated by 180 degrees, channels transposed (the weight
  * operand of the data-gradient convolution, see dvt_conv2d_implicit). */
 int dvt_conv_weight_pack_dgrad(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw,
