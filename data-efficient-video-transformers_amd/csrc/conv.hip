@@ -5,9 +5,9 @@
 //     1x1 convolutions need no gather at all,
 //   * BatchNorm / ReLU / residual are column-statistics + row-streaming kernels,
 //   * global average pooling is the mean over rows of a [N, H*W, C] view.
-// The gather is explicit in this round (column order (ki, kj, c): contiguous C-runs);
-// fusing it into the GEMM's A-operand DMA (implicit GEMM) is the planned next step.
-// All kernels are HBM-bound streaming kernels.
+// Column order is (ki, kj, c): contiguous C-runs.  The explicit gather below serves the C = 3 stem, strided data
+// gradients and the fp32 parity mode; elsewhere the gather is fused into the GEMM's operand DMA (gemm256.hip,
+// dvt_conv2d_implicit*).  All kernels in this file are HBM-bound streaming kernels.
 #include "common.h"
 
 namespace {
