@@ -54,6 +54,7 @@ class AttnDesc(C.Structure):
         ("o_sb", c_i64), ("o_sh", c_i64), ("o_sl", c_i64),
         ("scale", c_f), ("dtype", C.c_int32),
         ("workspace", c_p),
+        ("dropout_p", c_f), ("rng_state", c_p), ("rng_offset", C.c_uint64),
     ]
 
 

@@ -46,7 +46,19 @@ struct AttnParams {
   float scale;
   int Lkp;  // Lk rounded up to 32
   int Lqp;  // Lq rounded up to 32
+  // attention-probability dropout (generic kernels only): keep iff Philox word >= drop_thr, survivors * drop_scale
+  uint32_t drop_thr;
+  float drop_scale;
+  const uint64_t* rng;
+  uint64_t rng_off;
 };
+
+// dropout multiplier of probability (b, h, i, j): 0 or 1 / (1 - p); 1 when dropout is off
+__device__ __forceinline__ float attn_drop(const AttnParams& p, int b, int h, int i, int j) {
+  if (p.drop_thr == 0u) return 1.0f;
+  const uint64_t idx = (((uint64_t)b * p.H + h) * p.Lq + i) * (uint64_t)p.Lk + j;
+  return dvt_dropout_keep(p.rng[0], p.rng[1] + p.rng_off, idx, p.drop_thr) ? p.drop_scale : 0.0f;
+}
 
 // ======================================================================= generic
 // forward: one wave per (b, h, i).  LDS per wave: q row [dh] + probabilities [Lk].
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const AttnParams 
   float l = 0.f;
   for (int j = lane; j < p.Lk; j += 64) {
     const float e = expf(ps[j] - m);
-    ps[j] = e;
+    ps[j] = e * attn_drop(p, b, h, i, j);          // dropped probabilities leave the normaliser untouched
     l += e;
   }
   l = wave_sum(l);
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_generic_kernel(const AttnPara
       dp = fmaf(gs[e], to_f32<T>(vj[e]), dp);
     }
     const float pr = expf(s * p.scale - lse);
-    ds[j] = pr * (dp - delta) * p.scale;
+    ds[j] = pr * (dp * attn_drop(p, b, h, i, j) - delta) * p.scale;
   }
   wave_lds_sync();
   for (int e = lane; e < p.dh; e += 64) {
@@ -195,8 +207,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic_kernel(const AttnPar
       dp = fmaf(to_f32<T>(gi[e]), vs[e], dp);
     }
     const float pr = expf(s * p.scale - lse[i]);
-    ps[i] = pr;
-    ds[i] = pr * (dp - delta[i]) * p.scale;
+    const float dm = attn_drop(p, b, h, i, j);
+    ps[i] = pr * dm;
+    ds[i] = pr * (dp * dm - delta[i]) * p.scale;
   }
   wave_lds_sync();
   for (int e = lane; e < p.dh; e += 64) {
@@ -563,6 +576,15 @@ int fill_params(const dvt_attn_desc* d, AttnParams& p, bool bwd, const char* nam
   p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_sl = d->v_sl;
   p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_sl = d->o_sl;
   p.scale = d->scale;
+  DVT_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout_p must be in [0, 1)", name);
+  DVT_REQUIRE(d->dropout_p == 0.f || d->rng_state, "%s: dropout needs rng_state", name);
+  p.drop_thr = 0u; p.drop_scale = 1.f; p.rng = d->rng_state; p.rng_off = d->rng_offset;
+  if (d->dropout_p > 0.f) {
+    const double th = (double)d->dropout_p * 4294967296.0;
+    p.drop_thr = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(th + 0.5);
+    if (p.drop_thr == 0u) p.drop_thr = 1u;
+    p.drop_scale = 1.0f / (1.0f - d->dropout_p);
+  }
   p.Lkp = (p.Lk + 31) & ~31;
   p.Lqp = (p.Lq + 31) & ~31;
   return DVT_OK;
@@ -577,7 +599,7 @@ bool strides_vec_ok(const dvt_attn_desc* d) {
 }
 
 bool mfma_fwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
-  return dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
+  return d->dropout_p == 0.f && dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
          dvt_aligned16(d->k) && dvt_aligned16(d->v) && dvt_aligned16(d->o) &&
          2 * p.Lkp * kRowBytes <= kMaxLds;
 }

@@ -161,6 +161,28 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   return fmaf(x, pdf, cdf);
 }
 
+// ---------------------------------------------------------------- device: counter-based RNG (dropout)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep-decision of dropout element `idx` under (seed, base): word (idx & 3) of Philox block base + idx / 4
+__device__ __forceinline__ bool dvt_dropout_keep(uint64_t seed, uint64_t base, uint64_t idx, uint32_t threshold) {
+  const uint64_t ctr = base + (idx >> 2);
+  uint32_t r[4];
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  return r[idx & 3] >= threshold;
+}
+
 // Dispatch a templated launcher on the activation dtype.
 #define DVT_DISPATCH_DTYPE(dtype, T, ...)                                   \
   do {                                                                      \

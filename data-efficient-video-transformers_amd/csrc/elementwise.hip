@@ -647,19 +647,6 @@ __global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 // Counter-based Philox4x32-10: element i draws word (i & 3) of block (offset + i / 4) under the key (seed).  No mask
 // is stored: backward re-draws the same words.  state[0] = seed, state[1] = per-step base offset live on the device
 // (advanced by dvt_rng_advance once per step), so a captured hipGraph draws fresh masks on every replay.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t threshold, float scale,
                                const uint64_t* __restrict__ state, uint64_t call_offset) {

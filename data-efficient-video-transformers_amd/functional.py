@@ -430,7 +430,7 @@ class _AttnBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv=None,
-                seq_first=False):
+                seq_first=False, attn_dropout=0.0):
         # seq_first: x is [L, B, E] (torch nn.MultiheadAttention layout, frame_transformer.py:204-207)
         shp = x.shape
         d = shp[-1]
@@ -455,7 +455,11 @@ class _AttnBlock(torch.autograd.Function):
         qkv = ops.linear_fwd(xn, wq, _f32(b_qkv))                      # [M, 3*inner]
         q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)          # [S,H,N,dh] views
         o_mem = torch.empty((N, S, heads, dh) if seq_first else (S, N, heads, dh), dtype=T, device=x.device)
-        lse = ops.attention_fwd(q, k, v, _heads_view(o_mem, seq_first), dh ** -0.5)
+        drop = None
+        if attn_dropout > 0.0:                        # nn.MultiheadAttention(dropout=p): Philox mask on the probabilities
+            drop = (attn_dropout, _rng.tensor(x.device), _rng.take(S * heads * N * N))
+        lse = ops.attention_fwd(q, k, v, _heads_view(o_mem, seq_first), dh ** -0.5, drop)
+        ctx.drop = drop
         o2 = o_mem.view(M, inner)
         if w_out is not None:
             wo = _wc(w_out, T)
@@ -492,7 +496,7 @@ class _AttnBlock(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = _split_qkv(dqkv, S, N, heads, dh, seq_first)
         ops.attention_bwd(q, k, v, _heads_view(o_mem, seq_first), lse,
-                          _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5)
+                          _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5, ctx.drop)
         dwq, dbq = _emit_wgrad_bias(ctx.sinks[2], ctx.sinks[5], dqkv, xn, has_qkv_bias)
         dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
         dg = db = None
@@ -501,12 +505,14 @@ class _AttnBlock(torch.autograd.Function):
                                  dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
-        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None, dbq, None
+        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None, dbq, None, None
 
 
 def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, residual=True, eps=1e-5,
-               b_qkv=None, seq_first=False):
-    return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first)
+               b_qkv=None, seq_first=False, attn_dropout=0.0):
+    """attn_dropout > 0: dropout on the attention probabilities (training mode of nn.MultiheadAttention)."""
+    return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first,
+                            float(attn_dropout))
 
 
 class _CrossAttnBlock(torch.autograd.Function):

@@ -91,12 +91,12 @@ class EncoderLayer(nn.Module):
     def forward(self, x):
         """x [L, B, E]:  x = LN1(x + drop(SA(x)));  x = LN2(x + drop(W2 drop(relu(W1 x)))).
         Training-mode dropout (p > 0) runs the unfused composition with the Philox dropout kernel at torch's
-        three hidden-state sites (dropout1, dropout, dropout2).  Deviation: torch additionally drops attention
-        probabilities inside ``MultiheadAttention(dropout=p)``; the fused attention kernel does not."""
+        three hidden-state sites (dropout1, dropout, dropout2) and on the attention probabilities
+        (``MultiheadAttention(dropout=p)``, inside the attention kernel)."""
         a = self.self_attn
         if self.training and self.p > 0.0:
             sa = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
-                              prenorm=False, residual=False, b_qkv=a.in_proj_bias, seq_first=True)
+                              prenorm=False, residual=False, b_qkv=a.in_proj_bias, seq_first=True, attn_dropout=self.p)
             x = F.layernorm(F.add(x, F.dropout(sa, self.p, True)), self.norm1.weight, self.norm1.bias, self.norm1.eps)
             h = F.dropout(F.relu(F.linear(x, self.linear1.weight, self.linear1.bias)), self.p, True)
             y = F.dropout(F.linear(h, self.linear2.weight, self.linear2.bias), self.p, True)

@@ -447,7 +447,7 @@ def colsum(x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False)
 
 
 # ------------------------------------------------------------------ attention
-def _attn_desc(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, scale: float) -> L.AttnDesc:
+def _attn_desc(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, scale: float, dropout=None) -> L.AttnDesc:
     """q,k,v,o are 4-D views [B, H, L, dh] with unit stride in the last dim."""
     for t in (q, k, v, o):
         assert t.dim() == 4 and t.stride(3) == 1, "attention operands must be [B,H,L,dh] views, dh contiguous"
@@ -463,15 +463,17 @@ def _attn_desc(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, scale: f
     d.o_sb, d.o_sh, d.o_sl = o.stride(0), o.stride(1), o.stride(2)
     d.scale = scale
     d.dtype = dt(q)
+    if dropout is not None:                      # (p, rng_state tensor, site offset): attention-probability dropout
+        d.dropout_p, d.rng_state, d.rng_offset = float(dropout[0]), dropout[1].data_ptr(), int(dropout[2])
     return d
 
 
-def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float) -> Tensor:
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float, dropout=None) -> Tensor:
     """Writes o (a [B,H,Lq,dh] view of caller-owned memory); returns lse [B,H,Lq] f32."""
     _need_cuda(q, k, v, o)
     B, H, Lq, _ = q.shape
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
-    d = _attn_desc(q, k, v, o, lse, scale)
+    d = _attn_desc(q, k, v, o, lse, scale, dropout)
     nb = (2 * q.numel() + k.numel() + v.numel()) * q.element_size()          # read q, k, v; write o
     with _timed(("hbm", "attention_fwd", q.numel()), nb):
         L.check(L.load().dvt_attention_fwd(C.byref(d), _stream()), "dvt_attention_fwd")
@@ -479,14 +481,14 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float) -> T
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: Tensor, dq: Tensor,
-                  dk: Tensor, dv: Tensor, scale: float) -> None:
+                  dk: Tensor, dv: Tensor, scale: float, dropout=None) -> None:
     """do must share o's strides; dq/dk/dv must share q/k/v's strides (views of
     caller-owned memory, fully overwritten)."""
     _need_cuda(q, k, v, o, do, dq, dk, dv)
     for a, b in ((do, o), (dq, q), (dk, k), (dv, v)):
         assert a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1), \
             "gradient views must share the layout of their primal"
-    d = _attn_desc(q, k, v, o, lse, scale)
+    d = _attn_desc(q, k, v, o, lse, scale, dropout)
     d.d_o, d.dq, d.dk, d.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     lib = L.load()
     ws = workspace(lib.dvt_attention_bwd_workspace_bytes(C.byref(d)), q.device)

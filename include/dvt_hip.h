@@ -245,6 +245,12 @@ typedef struct dvt_attn_desc {
   float scale;
   int32_t dtype;
   void* workspace; /* bwd only: >= dvt_attention_bwd_workspace_bytes(desc) bytes (may be NULL if 0) */
+  /* Attention-probability dropout, nn.MultiheadAttention(dropout=p) in training mode (frame_transformer.py:41-44):
+   * o = (softmax(s) * keep / (1 - p)) v, keep(b,h,i,j) drawn like dvt_dropout from rng_state (device {seed, base})
+   * at rng_offset + (((b*H + h)*Lq + i)*Lk + j) / 4.  0 = off.  Served by the generic (non-MFMA) kernels. */
+  float dropout_p;
+  const uint64_t* rng_state;
+  uint64_t rng_offset;
 } dvt_attn_desc;
 
 size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);

@@ -516,3 +516,39 @@ def test_dropout_training_step_and_checkpoint_consistency(dvt, device):
         assert torch.equal(res[False][1][k], res[True][1][k]), k
     ev = net.eval()(x)
     assert not torch.equal(ev, res[True][0])                               # dropout really was active
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_probability_dropout(dvt, device, dtype):
+    """nn.MultiheadAttention(dropout=p) in training mode: o = (softmax(s) * keep / (1-p)) v with a Philox mask that
+    forward and both backward kernels re-draw identically.  The mask is recovered from the kernel itself (v = identity
+    gives the dropped probabilities) and the outputs / gradients are then checked against autograd on that mask."""
+    ops, F = dvt.ops, dvt.functional
+    B, H, L, dh = 2, 2, 24, 32
+    g = torch.Generator().manual_seed(9)
+    F.manual_seed(5)
+    st = F._rng.tensor(torch.device("cuda"))
+    q, k = (torch.randn(B, H, L, dh, generator=g).to(dtype).cuda() for _ in range(2))
+    p = 0.4
+    # probabilities with dropout: use v = [I | 0] (dh >= L would be needed in general; L = 24 <= 32 here)
+    v_eye = torch.zeros(B, H, L, dh, dtype=dtype, device="cuda")
+    v_eye[:, :, torch.arange(L), torch.arange(L)] = 1
+    o = torch.empty(B, H, L, dh, dtype=dtype, device="cuda")
+    ops.attention_fwd(q, k, v_eye, o, dh ** -0.5, (p, st, 0))
+    pd = o[..., :L].float().cpu()                                        # dropped + rescaled probabilities
+    sm = torch.softmax((q.float() @ k.float().transpose(-1, -2)).cpu() * dh ** -0.5, -1)
+    mask = (pd > 0).float()
+    assert abs(float(mask.mean()) - (1 - p)) < 0.06
+    assert torch.allclose(pd, sm * mask / (1 - p), atol=2e-2 if dtype != torch.float32 else 1e-5)
+    # full forward / backward against autograd with that mask
+    v = torch.randn(B, H, L, dh, generator=g).to(dtype).cuda()
+    lse = ops.attention_fwd(q, k, v, o, dh ** -0.5, (p, st, 0))
+    qr, kr, vr = (t.float().cpu().requires_grad_(True) for t in (q, k, v))
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) * dh ** -0.5, -1) * mask / (1 - p)) @ vr
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_l2(o, ref) < tol
+    do = torch.randn(B, H, L, dh, generator=g).to(dtype)
+    ref.backward(do.float())
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    ops.attention_bwd(q, k, v, o, lse, do.cuda(), dq, dk, dv, dh ** -0.5, (p, st, 0))
+    assert rel_l2(dq, qr.grad) < 3 * tol and rel_l2(dk, kr.grad) < 3 * tol and rel_l2(dv, vr.grad) < 3 * tol
