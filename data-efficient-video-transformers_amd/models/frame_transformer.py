@@ -287,13 +287,13 @@ class FrameTransformer(LightningModule):
         emb = F.cast(emb, self.compute_dtype).reshape(B, -1, self.d_model)
         seq = F.to_seq_first(emb)                                       # [S, B, 896]
         mode = self.hparams.model
-        if mode in ("sum", "distil") and distil_inject is not None:
+        if mode in ("sum", "distil", "post_sum") and distil_inject is not None:
             # cross-modal injection: the video CLS embedding becomes one more token (:225-226)
             seq = F.concat_rows(seq, F.cast(distil_inject, self.compute_dtype).unsqueeze(0))
         seq = self.position_encoder(seq)
         seq = self.scene_transformer(seq)
         cls = F.select_seq_first_row(seq, 0)
-        if mode in ("distil", "sum"):
+        if mode in ("distil", "sum", "post_sum"):
             return cls, F.select_seq_first_row(seq, seq.shape[0] - 1)   # (:233-239)
         if mode == "sum_residual":
             return cls, seq
@@ -312,11 +312,26 @@ class FrameTransformer(LightningModule):
         if mode == "sum":
             img_cls, vid_tkn = self.distillation_step(img, vid)
             return self._head(F.add(img_cls, vid_tkn))
-        if mode == "frame":
+        if mode == "sum_residual":
+            # executed as written (:149-161): vid_cls is overwritten with normalize(img_cls), so the embedding is
+            # 2 * normalize(img_cls); the video branch still runs (its output feeds no loss term)
+            vid_cls = self.vid_step(vid)
+            img_cls, _seq = self.img_step(img, vid_cls)
+            n = F.l2_normalize(img_cls)
+            return self._head(F.add(n, n))
+        if mode == "post_sum":
+            # the reference unpacks three values from the two-value distillation_step (:163-164, TypeError); intended:
+            # image CLS + the video CLS *embedding* (before the joint encoder)
+            vid_cls = self.vid_step(vid)
+            img_cls, _vid_tkn = self.img_step(img, vid_cls)
+            return self._head(F.add(img_cls, F.cast(vid_cls, img_cls.dtype)))
+        if mode in ("frame", "pre_modal"):
+            # pre_modal passes the bound method ``self.vid_step`` as distil_inject (:188); img_step only reads it in
+            # "sum" mode, so the executed behaviour is the image-only path
             return self.img_step(img, None)
         if mode == "vid":
             return self._head(self.vid_step(vid))
-        raise NotImplementedError(f"model mode {mode!r} is not built (reference modes that execute: vid)")
+        raise ValueError(f"unknown model mode {mode!r}")
 
     # ------------------------------------------------------------------ steps (:246-366)
     def _loss(self, batch):
@@ -330,8 +345,10 @@ class FrameTransformer(LightningModule):
             self.log("train/distilloss", distil_loss)
             self.log("train/bass_loss", base_loss)
             return F.add(base_loss.reshape(1), distil_loss.reshape(1)).reshape(()), s
-        if mode in ("sum", "pre_modal", "sum_residual"):
+        if mode in ("sum", "sum_residual", "post_sum"):
             data = self(img, vid)
+        elif mode == "pre_modal":
+            data = self(img, None)
         elif mode == "frame":
             data = self(img, None)
         else:

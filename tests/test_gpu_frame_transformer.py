@@ -185,3 +185,39 @@ def test_simple_transformer_ptn(device, dtype, tol):
     for k in ("cls", "norm.weight", "transformer_encoder0.layers.1.linear1.weight",
               "transformer_encoder1.layers.0.self_attn.in_proj_bias", "mlp_head.1.weight"):
         assert rel_l2(dict(net.named_parameters())[k].grad, P[k].grad) < 3 * tol, k
+
+
+@pytest.mark.parametrize("mode", ["sum_residual", "post_sum", "pre_modal"])
+def test_frame_transformer_remaining_modes(device, mode):
+    """frame_transformer.py:149-175: sum_residual as executed (2 * normalize(img_cls)), post_sum as intended
+    (img CLS + video CLS embedding; the reference text raises), pre_modal as executed (image-only path)."""
+    net = _make_ft(mode, torch.float32)
+    g = torch.Generator().manual_seed(6)
+    vid = torch.randn(2, 4, 2, 3, 16, 16, generator=g)
+    img = torch.randn(2, 4, 3, 32, 32, generator=g)
+    P = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    B = 2
+    icls = P["img_cls"]
+    idata = torch.cat((icls.unsqueeze(0).expand(B, *icls.shape), img), dim=1).reshape(-1, 3, 32, 32)
+    iemb = _oracle_encoder(idata, P, "img_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    cls = P["vid_cls"]
+    vdata = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)
+    vdata = vdata.reshape(-1, *vdata.shape[2:]).permute(0, 2, 1, 3, 4)
+    vemb = _oracle_encoder(vdata, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    vcls = O.transformer_base(vemb + P["position_encoder.pe"][:5], P, "distil_transformer.", 4, 2)[0]
+    if mode == "post_sum":
+        joint = torch.cat((iemb, vcls.unsqueeze(0)), dim=0)
+        seq = O.transformer_base(joint + P["position_encoder.pe"][:6], P, "scene_transformer.", 4, 2)
+        ref = O.mlp_head3(seq[0] + vcls, P)
+    else:
+        seq = O.transformer_base(iemb + P["position_encoder.pe"][:5], P, "scene_transformer.", 4, 2)
+        if mode == "sum_residual":
+            n = seq[0] / seq[0].norm(dim=-1, keepdim=True).clamp_min(1e-12)
+            ref = O.mlp_head3(n + n, P)
+        else:
+            ref = O.mlp_head3(seq[0], P)
+    out = net(img.cuda(), vid.cuda())
+    assert rel_l2(out, ref) < 2e-4
+    target = (torch.rand(2, 19, generator=g) < 0.3).float()
+    loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
+    assert abs(float(loss.detach()) - float(O.bce_with_logits(ref, target))) < 1e-4
