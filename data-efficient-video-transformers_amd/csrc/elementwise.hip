@@ -496,9 +496,9 @@ extern "C" {
 
 int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
              dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(src && dst && n >= 0, "dvt_cast: null pointer or negative size");
   DVT_REQUIRE(dvt_aligned16(src) && dvt_aligned16(dst), "dvt_cast: buffers must be 16-byte aligned");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for((n >> 3) + 1);
 #define DVT_CAST_CASE(SD, S, DD, D)                                                        \
@@ -519,10 +519,10 @@ int dvt_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 }
 
 int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(a && b && out && n >= 0, "dvt_add: null pointer or negative size");
   DVT_REQUIRE(dvt_aligned16(a) && dvt_aligned16(b) && dvt_aligned16(out),
               "dvt_add: buffers must be 16-byte aligned");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for((n >> 3) + 1)), dim3(kBlock),
@@ -532,8 +532,8 @@ int dvt_add(const void* a, const void* b, void* out, int64_t n, int dtype, dvt_s
 }
 
 int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(x && y && n >= 0 && act >= 1 && act <= 3, "dvt_act_fwd: bad arguments");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL((act_kernel<T, true>), dim3(grid_for(n)), dim3(kBlock), 0, st,
@@ -544,8 +544,8 @@ int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_strea
 
 int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
                 dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(dy && x && dx && n >= 0 && act >= 1 && act <= 3, "dvt_act_bwd: bad arguments");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL((act_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0, st,
@@ -609,8 +609,8 @@ int dvt_permute_021(const void* src, void* dst, int64_t A, int64_t B, int64_t C,
 
 int dvt_axpby_f32(const void* src, int src_dtype, float alpha, float* dst, float beta, int64_t n,
                   dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(src && dst && n >= 0, "dvt_axpby_f32: null pointer or negative size");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   DVT_DISPATCH_DTYPE(src_dtype, T,
                      hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, st,
@@ -967,9 +967,9 @@ int dvt_ce_argmax_bwd(const void* student, const void* teacher, const float* glo
 int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1,
               "dvt_adamw_step: bad arguments");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -982,8 +982,8 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 
 int dvt_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* rng_state, uint64_t call_offset, int dtype,
                 dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(x && y && rng_state && n >= 0 && p >= 0.f && p < 1.f, "dvt_dropout: bad arguments (0 <= p < 1)");
-  if (n == 0) return DVT_OK;
   // keep iff word >= threshold, threshold = round(p * 2^32): P(drop) = p to 2^-32
   const double th = (double)p * 4294967296.0;
   const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(th + 0.5);
@@ -1024,8 +1024,8 @@ int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float
 
 int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                  float weight_decay, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && n >= 0 && (momentum == 0.f || momentum_buf), "dvt_sgd_step: bad arguments");
-  if (n == 0) return DVT_OK;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, momentum_buf,
                      n, lr, momentum, weight_decay);
   DVT_LAUNCH_CHECK("dvt_sgd_step");
@@ -1034,8 +1034,8 @@ int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n
 
 int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
                      float eps, float weight_decay, int64_t step, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && state_sum && n >= 0 && step >= 1, "dvt_adagrad_step: bad arguments");
-  if (n == 0) return DVT_OK;
   const float clr = (float)((double)lr / (1.0 + (double)(step - 1) * (double)lr_decay));
   hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, state_sum,
                      n, clr, eps, weight_decay);
@@ -1046,8 +1046,8 @@ int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_dev, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && n >= 0, "dvt_adamw_step_dev: bad arguments");
-  if (n == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg,
                      exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev);

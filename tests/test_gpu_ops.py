@@ -552,3 +552,40 @@ def test_attention_probability_dropout(dvt, device, dtype):
     dq, dk, dv = (torch.empty_like(q) for _ in range(3))
     ops.attention_bwd(q, k, v, o, lse, do.cuda(), dq, dk, dv, dh ** -0.5, (p, st, 0))
     assert rel_l2(dq, qr.grad) < 3 * tol and rel_l2(dk, kr.grad) < 3 * tol and rel_l2(dv, vr.grad) < 3 * tol
+
+
+def test_abi_error_reporting_and_edge_sizes(dvt, device):
+    """Every entry point returns a status and leaves a message in dvt_last_error(); nothing is launched on bad
+    arguments.  Also the degenerate sizes the reference can produce (empty batch, one row, one token)."""
+    import ctypes as C
+    L = dvt._lib
+    lib = L.load()
+    ops = dvt.ops
+    x = torch.randn(8, 16, device="cuda")
+    # null pointers / bad sizes straight through the C ABI
+    assert lib.dvt_cast(None, L.F32, x.data_ptr(), L.BF16, 8, None) != 0
+    assert b"dvt_cast" in lib.dvt_last_error()
+    assert lib.dvt_dropout(x.data_ptr(), x.data_ptr(), 8, C.c_float(1.5), x.data_ptr(), 0, L.F32, None) != 0
+    assert lib.dvt_layernorm_fwd(x.data_ptr(), None, None, x.data_ptr(), None, None, 8, 1, 16, 16, 0, 16, 0, C.c_float(1e-5),
+                                 L.F32, None) != 0
+    assert lib.dvt_adamw_step(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, C.c_float(1e-3), C.c_float(0.9),
+                              C.c_float(0.999), C.c_float(1e-8), C.c_float(0.0), 0, None) != 0      # step counts from 1
+    with pytest.raises(RuntimeError, match="dvt_"):
+        L.check(lib.dvt_frames_preprocess(x.data_ptr(), x.data_ptr(), L.F32, 1, 4, 4, 0, 2, x.data_ptr(), x.data_ptr(),
+                                          x.data_ptr(), None), "dvt_frames_preprocess")
+    # unsupported dtype code
+    assert lib.dvt_add(x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, 7, None) != 0
+    # degenerate sizes
+    assert ops.cast(torch.empty(0, device="cuda"), torch.bfloat16).numel() == 0
+    one = torch.randn(1, 16, device="cuda")
+    y, mean, rstd = ops.layernorm_fwd(one, torch.ones(16, device="cuda"), torch.zeros(16, device="cuda"))
+    assert torch.allclose(y.cpu(), torch.nn.functional.layer_norm(one.cpu(), (16,)), atol=1e-5)
+    w = torch.randn(3, 16, device="cuda")
+    assert rel_l2(ops.linear_fwd(one, w), one.cpu() @ w.cpu().t()) < 1e-5
+    q = torch.randn(1, 1, 1, 8, device="cuda")                       # one token attends to itself: o == v
+    o = torch.empty_like(q)
+    ops.attention_fwd(q, q, q, o, 1.0)
+    assert torch.allclose(o, q, atol=1e-6)
+    # wrong device is refused before anything is launched
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.layernorm_fwd(one.cpu(), torch.ones(16), torch.zeros(16))
