@@ -291,7 +291,7 @@ __device__ __forceinline__ void store4(E* p, const f32x4& v, float s) {
 
 // ---------------------------------------------------------------- forward
 template <typename E>
-__global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_mfma_kernel(const AttnParams 
 // ---------------------------------------------------------------- backward: dq
 // Query on the lane.  dQ^T[d][q] = sum_key K[key][d] * dS^T[key][q].
 template <typename E>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_mfma_kernel(const AttnPara
 // from LDS images, B = K / V rows straight from HBM);
 // dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key].
 template <typename E>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -609,9 +609,12 @@ bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
          dvt_aligned16(d->dv) && 2 * p.Lqp * kRowBytes + 2 * p.Lqp * 4 <= kMaxLds;
 }
 
-// waves per block so that the tile count splits evenly over as few rounds as possible
-int pick_waves(int tiles) {
-  const int rounds = (tiles + 7) / 8;
+// waves per block so that the tile count splits evenly over as few rounds as possible.  When the staged images
+// leave room for only one workgroup per CU (long sequences: > 80 KiB of LDS), that workgroup may use all 16 wave slots
+// (the kernels need <= 115 VGPRs, i.e. 4 waves per SIMD fit).
+int pick_waves(int tiles, size_t lds_bytes) {
+  const int maxw = lds_bytes > 80 * 1024 ? 16 : 8;
+  const int rounds = (tiles + maxw - 1) / maxw;
   int w = (tiles + rounds - 1) / rounds;
   return w < 1 ? 1 : w;
 }
@@ -640,7 +643,7 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (mfma_fwd_ok(d, p)) {
     const size_t lds = (size_t)2 * p.Lkp * kRowBytes;
-    const int W = pick_waves((p.Lq + 15) / 16);
+    const int W = pick_waves((p.Lq + 15) / 16, lds);
     DVT_DISPATCH_16BIT(d->dtype, E, {
       set_lds(attn_fwd_mfma_kernel<E>, lds);
       hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)), dim3(64 * W), lds, st, p);
@@ -681,9 +684,9 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
       set_lds(attn_bwd_dq_mfma_kernel<E>, lds_q);
       set_lds(attn_bwd_dkv_mfma_kernel<E>, lds_kv);
       hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
-                         dim3(64 * pick_waves((p.Lq + 15) / 16)), lds_q, st, p);
+                         dim3(64 * pick_waves((p.Lq + 15) / 16, lds_q)), lds_q, st, p);
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
-                         dim3(64 * pick_waves((p.Lk + 15) / 16)), lds_kv, st, p);
+                         dim3(64 * pick_waves((p.Lk + 15) / 16, lds_kv)), lds_kv, st, p);
     });
     DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
     return DVT_OK;

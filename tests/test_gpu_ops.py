@@ -265,6 +265,8 @@ ATTN_CASES = [
     # B, H, Lq, Lk, dh
     (2, 2, 17, 17, 64), (2, 3, 33, 33, 64), (1, 2, 197, 197, 64), (2, 2, 5, 40, 64),
     (1, 1, 64, 64, 64), (2, 2, 14, 14, 32), (1, 2, 15, 14, 448), (1, 4, 14, 15, 224),
+    (2, 2, 325, 325, 64),          # long-clip tokens per frame (288^2): > 80 KiB of LDS, one 11-wave workgroup per CU
+    (1, 2, 40, 600, 64),
 ]
 
 
