@@ -238,6 +238,37 @@ class FlatParameters:
         self.exp_avg_sq = torch.zeros_like(self.data)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.data.device)
 
+    # ------------------------------------------------------------------ checkpoint / resume of the optimizer side
+    _STATE_TENSORS = ("exp_avg", "exp_avg_sq", "step_dev", "momentum_buf", "state_sum", "scale_dev", "good_steps")
+
+    def state_dict(self) -> dict:
+        """Optimizer-side state of the flat buffers (the parameters themselves are saved through the module's own
+        ``state_dict``, whose tensors are views of ``self.data``).  Tensors are cloned to the host."""
+        sd = {"step_count": self.step_count, "total": self.total}
+        for k in self._STATE_TENSORS:
+            t = getattr(self, k, None)
+            if t is not None:
+                sd[k] = t.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd.get("total") != self.total:
+            raise ValueError(f"flat-buffer layout mismatch: checkpoint has {sd.get('total')} elements, model has {self.total}")
+        self.step_count = int(sd["step_count"])
+        dev = self.data.device
+        if "scale_dev" in sd and getattr(self, "scaler", None) is None:
+            self.enable_loss_scaling(float(sd["scale_dev"]))
+        for k in self._STATE_TENSORS:
+            if k in sd:
+                cur = getattr(self, k, None)
+                if cur is None:
+                    setattr(self, k, sd[k].to(dev).clone())
+                else:
+                    cur.copy_(sd[k].to(dev))
+        if getattr(self, "scaler", None) is not None:
+            self.loss_grad.copy_(self.scale_dev.reshape(()) * self.loss_scale)
+        self.invalidate_compute_copy()
+
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:
             dist.broadcast(self.data, src=src, group=self.group)

@@ -147,3 +147,26 @@ def test_eval_accumulators_gather_across_ranks():
     a = np.arange(12, dtype=np.float32).reshape(3, 4)
     b = np.arange(20, dtype=np.float32).reshape(5, 4) + 100
     assert np.array_equal(got, np.concatenate([a, b]))
+
+
+def test_flat_parameters_checkpoint_roundtrip():
+    """Resume: module state_dict (views of the flat buffer) + FlatParameters.state_dict (moments, step) restore a
+    second instance exactly (CPU plumbing; the kernels are not involved)."""
+    from dvt_amd.dp import FlatParameters
+    a = _model()
+    fa = FlatParameters(a, compute_dtype=None)
+    fa.init_optimizer_state()
+    fa.exp_avg.uniform_(-1, 1); fa.exp_avg_sq.uniform_(0, 1); fa.step_dev.fill_(7); fa.step_count = 7
+    with torch.no_grad():
+        fa.data.add_(0.25)
+    b = _model()
+    fb = FlatParameters(b, compute_dtype=None)
+    b.load_state_dict(a.state_dict())
+    fb.load_state_dict(fa.state_dict())
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):      # (alignment gaps of the flat buffer are not state)
+        assert torch.equal(p, q), k
+    assert torch.equal(fb.exp_avg, fa.exp_avg) and torch.equal(fb.exp_avg_sq, fa.exp_avg_sq)
+    assert int(fb.step_dev) == 7 and fb.step_count == 7
+    bad = fa.state_dict(); bad["total"] = 1
+    with pytest.raises(ValueError, match="layout"):
+        fb.load_state_dict(bad)
