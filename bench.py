@@ -236,9 +236,12 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (p10 / median / p90)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = run()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -248,6 +251,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.detach())
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+    # optimizer share of the step (SURVEY 8d asks for it separately): fused AdamW + bf16 weight mirror on the flat buffers
+    o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    o0.record()
+    for _ in range(5):
+        flat.adamw_step(lr=0.0, weight_decay=0.0)            # lr = 0: timing only, the weights stay put
+    o1.record()
+    torch.cuda.synchronize()
+    optimizer_ms = o0.elapsed_time(o1) / 5
 
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
@@ -328,6 +341,8 @@ def main():
             "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
             if args.workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
+            "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3)},
+            "optimizer_ms_per_step": round(optimizer_ms, 3),
             "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
         if cdt == torch.float16:
