@@ -294,9 +294,9 @@ def main():
                 continue
             f = fam.setdefault((ak, bk), [0.0, 0.0, 0])
             f[0] += ms; f[1] += fl; f[2] += cnt
-        names = {(1, 1): "gemm_mfma_kernel<k-major,k-major> (forward Linear)",
-                 (1, 0): "gemm_mfma_kernel<k-major,mn-major> (dgrad)",
-                 (0, 0): "gemm_mfma_kernel<mn-major,mn-major> (wgrad, split-K incl. reduce)"}
+        names = {(1, 1): "gemm_dma_kernel<A k-major, B k-major> (forward Linear)",
+                 (1, 0): "gemm_dma_kernel<A k-major, B mn-major> (data gradient)",
+                 (0, 0): "gemm_dma_kernel<A mn-major, B mn-major> (weight gradient, split-K incl. reduce)"}
         pmc = {}
         try:   # per-launch HBM bytes of each family from the committed PMC profile (rocprofv3 --pmc)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
