@@ -320,3 +320,40 @@ def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype,
     acc = torch.ones_like(dw)
     ops.conv_weight_unpack_grad_t(dwt, (Cout, Cin, kh, kw), out=acc, accumulate=True)
     assert rel_l2(acc - 1.0, dw) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_channel_padding_is_exact_zero_extension(dvt, device, dtype, tol):
+    """cpad: a 24 -> 45 convolution followed by a 45 -> 32 one, run at padded widths 64 (R(2+1)D mid planes): the
+    45 real channels, the running statistics and every parameter gradient equal the unpadded torch computation;
+    the padded channels are exactly zero."""
+    import torch.nn as nn
+    F = dvt.functional
+    torch.manual_seed(3)
+    c1, b1 = nn.Conv2d(24, 45, 3, 1, 1, bias=False), nn.BatchNorm2d(45)
+    c2, b2 = nn.Conv2d(45, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32)
+    with torch.no_grad():
+        for bn in (b1, b2):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
+    N, H, W = 4, 8, 8
+    x = torch.randn(N, 24, H, W)
+    ref_mods = [m for m in (c1, b1, c2, b2)]
+    import copy
+    r1, rb1, r2, rb2 = (copy.deepcopy(m) for m in ref_mods)
+    yr = torch.relu(rb2(r2(torch.relu(rb1(r1(x))))))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    for m in ref_mods:
+        m.cuda()
+    xm = x.permute(0, 2, 3, 1).reshape(-1, 24).to(dtype).cuda()
+    h = F.conv_bn_act_raw(xm, c1.weight, b1, (N, 24, H, W, False), 3, 1, 1, relu=True, dtype=dtype, cpad=64)
+    assert h.shape == (N * H * W, 64) and float(h.detach()[:, 45:].abs().max()) == 0.0
+    y = F.conv_bn_act_raw(h, c2.weight, b2, (N, 64, H, W, False), 3, 1, 1, relu=True, dtype=dtype, cpad=32)
+    assert y.shape == (N * H * W, 32)
+    ref = yr.permute(0, 2, 3, 1).reshape(-1, 32)
+    assert rel_l2(y, ref) < tol
+    y.backward(gy.permute(0, 2, 3, 1).reshape(-1, 32).to(dtype).cuda())
+    assert rel_l2(b1.running_mean, rb1.running_mean) < 5 * tol and rel_l2(b1.running_var, rb1.running_var) < 5 * tol
+    for got, want in ((c1.weight, r1.weight), (b1.weight, rb1.weight), (b1.bias, rb1.bias), (c2.weight, r2.weight),
+                      (b2.bias, rb2.bias)):
+        assert got.grad.shape == want.grad.shape and rel_l2(got.grad, want.grad) < 10 * tol
