@@ -464,7 +464,9 @@ constexpr int kColsumParts = 128;
 bool mfma_eligible(const dvt_gemm_desc* d) {
   if (!dvt_is_16bit(d->in_dtype)) return false;
   if (!(d->out_dtype == d->in_dtype || d->out_dtype == DVT_F32)) return false;
-  if (d->K % 8 || d->N % 8) return false;
+  // 16-byte operand loads run along k for k-major operands and along m / n for mn-major ones: K only has to be a
+  // multiple of 8 when some operand is k-major (the register-staged kernel zero-fills a ragged K tail).
+  if (d->N % 8 || ((d->a_kmajor || d->b_kmajor) && d->K % 8)) return false;
   if (d->lda % 8 || d->ldb % 8 || d->ldc % 8) return false;
   if (!d->a_kmajor && d->M % 8) return false;
   if (!dvt_aligned16(d->A) || !dvt_aligned16(d->B) || !dvt_aligned16(d->C)) return false;

@@ -236,6 +236,20 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     assert rel_l2(y2, x2 @ w2.t()) < BF16_TOL
 
 
+@pytest.mark.parametrize("rows", [28, 2, 13, 100])
+def test_wgrad_ragged_row_count_runs_on_mfma(dvt, device, rows):
+    """Weight gradients of the 14-token encoders (K = B * 14 = 28 rows, frame_transformer.py:204) -- K is not a multiple of 8
+    but both operands are mn-major, so the MFMA kernel (with its zero-filled K tail) serves them."""
+    g = torch.Generator().manual_seed(5)
+    dy_d, dy = _rnd((rows, 896), torch.bfloat16, g)
+    x_d, x = _rnd((rows, 512), torch.bfloat16, g)
+    dw = dvt.ops.linear_wgrad(dy_d, x_d)
+    assert dw.shape == (896, 512) and rel_l2(dw, dy.t() @ x) < 1e-5          # fp32 accumulation of bf16 products
+    bias = torch.zeros(896, device="cuda")
+    dvt.ops.linear_wgrad(dy_d, x_d, bias_out=bias)
+    assert rel_l2(bias, dy.sum(0)) < 1e-5
+
+
 def test_wgrad_split_k_reproducible(dvt, device):
     """Token-count reduction (K = rows) with few output tiles -> split-K slabs."""
     g = torch.Generator().manual_seed(8)
