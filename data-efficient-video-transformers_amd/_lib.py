@@ -101,7 +101,7 @@ SIGNATURES = {
     "dvt_bn_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_int, c_p]),
     "dvt_bn_eval_invstd": (c_int, [c_p, c_p, c_int, c_f, c_p]),
     "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
-    "dvt_bn_bwd": (c_int, [c_p] * 11 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_bn_bwd": (c_int, [c_p] * 12 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_maxpool_bwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_transpose_last2": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),

@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
                                                           const T* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int64_t rows, int C,
                                                           int rows_per_block, int relu, int vc_log2,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial,
+                                                          const float* __restrict__ gamma = nullptr,
+                                                          const float* __restrict__ beta = nullptr) {
   // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
   // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.
   __shared__ float red[2][256][8];
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
   const int64_t r1 = min(rows, r0 + rows_per_block);
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
-    float mu[8], is[8];
+    float mu[8], is[8], ga[8], be[8];
     if (MODE == 1) { load8<float>(mean + c, mu); load8<float>(invstd + c, is); }
+    const bool remask = MODE == 1 && relu && y == nullptr;      // no stored output: recompute the ReLU mask from x
+    if (remask) { load8<float>(gamma + c, ga); load8<float>(beta + c, be); }
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float xv[8];
       load8<T>(x + r * C + c, xv);
@@ -248,12 +252,14 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
       } else {
         float dv[8], yv[8];
         load8<T>(dy + r * C + c, dv);
-        if (relu) load8<T>(y + r * C + c, yv);
+        if (relu && !remask) load8<T>(y + r * C + c, yv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+          const float xh = (xv[k] - mu[k]) * is[k];
+          if (remask) yv[k] = fmaf(xh, ga[k], be[k]);
           const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
           a[k] += dz;
-          b[k] = fmaf(dz, (xv[k] - mu[k]) * is[k], b[k]);
+          b[k] = fmaf(dz, xh, b[k]);
         }
       }
     }
@@ -349,22 +355,26 @@ __global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
-                                    int64_t rows, int C, int relu, int training, float inv_rows) {
+                                    int64_t rows, int C, int relu, int training, float inv_rows,
+                                    const float* __restrict__ beta = nullptr) {
   const int cv = C >> 3;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
     const int c = (int)(it % cv) << 3;
     const int64_t off = (it / cv) * C + c;
-    float dv[8], xv[8], yv[8], mu[8], is[8], g[8], dg[8], db[8], o[8];
+    float dv[8], xv[8], yv[8], mu[8], is[8], g[8], dg[8], db[8], o[8], be[8];
     load8<T>(dy + off, dv); load8<T>(x + off, xv);
-    if (relu) load8<T>(y + off, yv);
+    const bool remask = relu && y == nullptr;
+    if (relu && !remask) load8<T>(y + off, yv);
+    if (remask) load8<float>(beta + c, be);
     load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g);
     load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      const float xh = (xv[k] - mu[k]) * is[k];
+      if (remask) yv[k] = fmaf(xh, g[k], be[k]);
       const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
       dv[k] = dz;
-      const float xh = (xv[k] - mu[k]) * is[k];
       o[k] = training ? g[k] * is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : g[k] * is[k] * dz;
     }
     store8<T>(dx + off, o);
@@ -378,7 +388,8 @@ template <typename T, int MODE>
 __global__ void bn_colstats_scalar_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                           int64_t rows, int C, int rows_per_block, int relu,
-                                          float* __restrict__ partial) {
+                                          float* __restrict__ partial, const float* __restrict__ gamma = nullptr,
+                                          const float* __restrict__ beta = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -389,7 +400,8 @@ __global__ void bn_colstats_scalar_kernel(const T* __restrict__ x, const T* __re
     if (MODE == 0) { a += xv; b = fmaf(xv, xv, b); }
     else {
       float dz = to_f32<T>(dy[r * C + c]);
-      if (relu && !(to_f32<T>(y[r * C + c]) > 0.f)) dz = 0.f;
+      const float yv = y ? to_f32<T>(y[r * C + c]) : (relu ? fmaf((xv - mu) * is, gamma[c], beta[c]) : 1.f);
+      if (relu && !(yv > 0.f)) dz = 0.f;
       a += dz;
       b = fmaf(dz, (xv - mu) * is, b);
     }
@@ -417,13 +429,15 @@ __global__ void bn_apply_bwd_scalar_kernel(const T* __restrict__ dy, const T* __
                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                            const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
-                                           int64_t rows, int C, int relu, int training, float inv_rows) {
+                                           int64_t rows, int C, int relu, int training, float inv_rows,
+                                           const float* __restrict__ beta = nullptr) {
   const int64_t total = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     float dz = to_f32<T>(dy[i]);
-    if (relu && !(to_f32<T>(y[i]) > 0.f)) dz = 0.f;
     const float xh = (to_f32<T>(x[i]) - mean[c]) * invstd[c];
+    const float yv = y ? to_f32<T>(y[i]) : (relu ? fmaf(xh, gamma[c], beta[c]) : 1.f);
+    if (relu && !(yv > 0.f)) dz = 0.f;
     const float o = training ? gamma[c] * invstd[c] * (dz - dbeta[c] * inv_rows - xh * dgamma[c] * inv_rows)
                              : gamma[c] * invstd[c] * dz;
     dx[i] = from_f32<T>(o);
@@ -845,14 +859,15 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 }
 
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
-               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, int64_t rows,
-               int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
+               const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
+               int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
   DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
               "dvt_bn_bwd: bad arguments");
   const bool cvec = C % 8 == 0 && dvt_aligned16(dy) && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(dx) &&
                     dvt_aligned16(dres) && dvt_aligned16(mean) && dvt_aligned16(invstd) && dvt_aligned16(gamma) &&
                     dvt_aligned16(workspace);
-  DVT_REQUIRE(!relu || y, "dvt_bn_bwd: relu needs the forward output");
+  DVT_REQUIRE(!relu || y || (beta && !dres),
+              "dvt_bn_bwd: relu needs the forward output y, or beta to recompute the mask (no residual branch)");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
@@ -863,10 +878,11 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   float* part = (float*)workspace;
   if (cvec) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part));
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma, beta));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid_s, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part));
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part,
+                                                    gamma, beta));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(stats)");
   // keep the local dgamma/dbeta 16-byte aligned behind the partials
@@ -878,12 +894,12 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
                                                     (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
                                                     loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
-                                                    1.0f / (float)rows));
+                                                    1.0f / (float)rows, beta));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
                                                     (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
                                                     loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
-                                                    1.0f / (float)rows));
+                                                    1.0f / (float)rows, beta));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(apply)");
   // publish dgamma / dbeta (overwrite or accumulate) from the local copy

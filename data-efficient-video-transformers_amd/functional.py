@@ -963,8 +963,10 @@ class _ConvBnAct(torch.autograd.Function):
         wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
                        ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad))
         keep_col = SAVE_CONV_COLUMNS and not direct and col is not None and not wg_implicit
-        ctx.save_for_backward(None if keep_col else xc, wp, z, y if relu else None, mean, invstd, g32,
-                              col if keep_col else None)
+        # a ReLU layer without a residual branch recomputes its mask from z in backward (saves two passes over y)
+        keep_y = relu and residual is not None
+        ctx.save_for_backward(None if keep_col else xc, wp, z, y if keep_y else None, mean, invstd, g32,
+                              col if keep_col else None, b32 if (relu and not keep_y) else None)
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -976,7 +978,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wp, z, y, mean, invstd, g32, col = ctx.saved_tensors
+        xc, wp, z, y, mean, invstd, g32, col, b32 = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l, padded = ctx.logical
@@ -984,11 +986,11 @@ class _ConvBnAct(torch.autograd.Function):
         dy = _as(dy.contiguous(), z.dtype)
         if sg is not None and sb is not None and Cout == Cout_l:
             dz, dres, _, _ = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res,
-                                        dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
+                                        dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh, beta=b32)
             sg.mark_written(); sb.mark_written()
             dgam = dbet = None
         else:
-            dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res)
+            dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32)
             if Cout != Cout_l:                                           # drop the padded channels
                 if sg is not None and sb is not None:
                     ops.unpad3_f32(dgam, Cout_l, 1, 1, 1, out=sg.buf.view(-1), accumulate=not sg.fresh)

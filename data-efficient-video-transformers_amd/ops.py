@@ -911,7 +911,8 @@ def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: T
 
 def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
            training: bool, want_dres: bool, *, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-           accumulate: bool = False):
+           accumulate: bool = False, beta: Optional[Tensor] = None):
+    """y may be None for a ReLU layer without a residual branch when ``beta`` is given (mask recomputed from z)."""
     rows, Cc = z.shape
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
@@ -922,7 +923,7 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
     lib = L.load()
     ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
     L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                           dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
+                           _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
                            int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
     return dz, dres, dgamma, dbeta
 

@@ -371,10 +371,11 @@ int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream);
 /* dz = dy*(y>0 if relu); dres = dz (if dres != NULL); dgamma/dbeta (+)=; dx by the batch-statistics
- * formula (training) or gamma*invstd*dz (eval). */
+ * formula (training) or gamma*invstd*dz (eval).  y may be NULL for a ReLU layer without a residual branch: the mask
+ * is then recomputed from x as (x - mean)*invstd*gamma + beta > 0 (beta required), which saves two passes over y. */
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
-               const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, int64_t rows,
-               int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
+               const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
+               int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC; idx: uint8 [N*Ho*Wo*C] window position of the (first) maximum. */
 int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, int W, int k, int stride, int pad,
                     int dtype, dvt_stream_t stream);
