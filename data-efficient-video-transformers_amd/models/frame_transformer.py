@@ -237,6 +237,17 @@ class FrameTransformer(LightningModule):
         for k in ("img_encoder", "vid_encoder"):       # modules are attributes, not hyper-parameters
             if k in hp:
                 delattr(hp, k)
+        # The members the reference leaves commented out (img_model / scene_transformer / img_cls, :94,98,104) exist here
+        # so that every mode can run; in the single-branch modes the other branch takes no part in the computation and
+        # must not be touched by the optimizer either (torch skips parameters without a gradient; a flat-buffer
+        # optimizer would still decay them), so it is frozen.  ``norm`` (:117) is unused by every forward path.
+        idle = {"vid": ("img_model", "scene_transformer", "img_cls"),
+                "frame": ("vid_model", "distil_transformer", "vid_cls"),
+                "pre_modal": ("vid_model", "distil_transformer", "vid_cls")}.get(hp.get("model", ""), ())
+        for name in idle + ("norm",):
+            m = getattr(self, name)
+            for p in ([m] if isinstance(m, nn.Parameter) else m.parameters()):
+                p.requires_grad_(False)
 
     # ------------------------------------------------------------------ optimizer (:123-134)
     def configure_optimizers(self):
