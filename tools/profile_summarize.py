@@ -81,6 +81,19 @@ def main():
                 fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
                          f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
             fh.write(f"\nTotal kernel time {tot/1e6:.2f} ms over 9 steps = {tot/9e6:.2f} ms/step.\n")
+    for wl in ("pyramid", "frametransformer", "longclip"):      # secondary workloads: eager, 1 warm-up + 3 timed steps
+        st2 = find(os.path.join(prof, f"stats_{wl}"), "*kernel_stats.csv")
+        if not st2:
+            continue
+        rows = list(csv.DictReader(open(st2)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        with open(os.path.join(outd, f"{tag}_{wl}_kernel_stats.md"), "w") as fh:
+            fh.write(f"# rocprofv3 --kernel-trace --stats, bench.py --workload {wl} ({tag})\n\n4 steps in the trace (eager launches); "
+                     "per-step columns = totals / 4.\n\n| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")
+            for r in rows[:28]:
+                fh.write(f"| `{short(r['Name'])}` | {int(r['Calls'])//4} | {float(r['TotalDurationNs'])/4e6:.3f} | "
+                         f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+            fh.write(f"\nTotal kernel time {tot/4e6:.2f} ms/step.\n")
     # ---- traffic
     fe, wr = load_counters(os.path.join(prof, "fetch")), load_counters(os.path.join(prof, "write"))
     if fe or wr:

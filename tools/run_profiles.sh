@@ -12,4 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/mfma" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/mfma.log" 2>&1
+# secondary workloads: kernel-time breakdown only
+for wl in pyramid frametransformer longclip; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- python3 "$BENCH" --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/stats_$wl.log" 2>&1
+done
 echo "profiles collected under $OUT"
