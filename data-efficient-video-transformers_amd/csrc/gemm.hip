@@ -501,8 +501,9 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
     int64_t s = 1;
     if (d->split_k > 0) s = d->split_k;
     else if (can_split && t256 < (cus * 3) / 4) {
-      s = dvt_cdiv(cus, t256);
-      const int64_t maxs = d->K / 1024;
+      s = cus / t256;                           // floor: tiles x slices must fit one round of workgroups (12 tiles x 22
+                                                // slices = 264 > 256 CUs ran a second, nearly empty round: 2x the time)
+      const int64_t maxs = d->K / 512;
       if (s > maxs) s = maxs;
       if (s > 256) s = 256;   // very deep K (convolution weight gradients over N*H*W rows): up to one slice per CU
       if (s < 1) s = 1;
