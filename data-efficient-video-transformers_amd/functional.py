@@ -915,7 +915,10 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
-                cpad=0):
+                cpad=0, dx_frames=None):
+        # dx_frames (NCHW stem only): [(first_frame, count), ...] -- the only input frames whose gradient is consumed (the
+        # learnable pixel-space CLS chunk of each sample, frame_transformer.py:105,195); other frames get zeros unseen.
+        ctx.dx_frames = dx_frames
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l = w.shape[0], w.shape[1]
         Cout = (Cout_l + cpad - 1) // cpad * cpad if cpad else Cout_l
@@ -1032,6 +1035,13 @@ class _ConvBnAct(torch.autograd.Function):
             pd = (kh - 1 - ph_, kw - 1 - pw_)
             if ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd)     # [N*H*W, Cin], no dcol / col2im
+        if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
+            dx = torch.zeros(ctx.x_shape, dtype=ctx.x_dtype, device=dz.device).view(N, Cin, H, W)
+            hw = Ho * Wo
+            for f0, cnt in ctx.dx_frames:                                # only the frames whose gradient is read
+                dcol = ops.linear_dgrad(dz[f0 * hw:(f0 + cnt) * hw], wp)
+                ops.copy_(dx[f0:f0 + cnt], ops.col2im_nchw(dcol, cnt, Cin, H, W, k, stride, pad, ctx.x_dtype))
+            dx = dx.view(ctx.x_shape)
         if ctx.x_needs and dx is None:
             dcol = ops.linear_dgrad(dz, wp)                              # [rows, ld]
             if direct:
@@ -1040,7 +1050,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
@@ -1053,7 +1063,7 @@ def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, rel
 
 
 def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16,
-                    cpad: int = 0):
+                    cpad: int = 0, dx_frames=None):
     """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
     Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
     (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
@@ -1061,7 +1071,7 @@ def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad)
+                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames)
 
 
 class _Subsample(torch.autograd.Function):

@@ -281,7 +281,14 @@ class FrameTransformer(LightningModule):
         data = self._with_cls(data, self.vid_cls)                       # [B, 14, 12, 3, 112, 112]
         data = data.reshape(-1, self.frame_len, 3, self.clip_size, self.clip_size)
         data = data.permute(0, 2, 1, 3, 4)                              # [B*14, 3, 12, 112, 112]
+        bb = getattr(self.vid_model, "backbone", None)
+        if bb is not None and getattr(self, "restrict_pixel_grad", True):
+            # only the CLS chunk (chunk 0 of every sample) carries a pixel gradient: tell the stem
+            S1 = data.shape[0] // B
+            bb.input_grad_clips = [b * S1 for b in range(B)]
         emb = self.vid_model(data)                                      # [B*14, 896]
+        if bb is not None:
+            bb.input_grad_clips = None
         if self.hparams.model == "pre-modal":
             return emb
         emb = F.cast(emb, self.compute_dtype).reshape(B, -1, self.d_model)

@@ -144,8 +144,12 @@ class VideoResNet(nn.Module):
             frames = frames.contiguous()
         s0, b0, s3, b3 = self.stem[0], self.stem[1], self.stem[3], self.stem[4]
         k, s, p = s0.kernel_size[1:], s0.stride[1:], s0.padding[1:]
+        # input_grad_clips: indices of the clips whose pixel gradient is consumed (None = all): the caller's hint that
+        # only the learnable CLS clip of each sample needs d(loss)/d(pixels)
+        hint = getattr(self, "input_grad_clips", None)
+        dx_frames = None if hint is None else [(int(c) * T, T) for c in hint]
         y = F.conv_bn_act_raw(frames.view(N * T, 3, H, W), s0.weight, b0, (N * T, 3, H, W, True), k, s, p, relu=True, dtype=dt,
-                              cpad=CPAD)
+                              cpad=CPAD, dx_frames=dx_frames)
         H1, W1 = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
         fm = _temporal((y, N, T, H1, W1), s3, b3, True, dt)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

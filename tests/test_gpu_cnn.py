@@ -246,6 +246,14 @@ def test_frame_transformer_with_reference_encoders(dvt, device):
     assert torch.isfinite(loss.detach()).item()
     assert net.vid_cls.grad is not None and torch.isfinite(net.vid_cls.grad).all()
     assert torch.isfinite(net.vid_model.backbone.stem[0].weight.grad).all()
+    # the stem computes the pixel gradient for the CLS chunks only; the full computation gives the same CLS gradient
+    g_restricted = net.vid_cls.grad.clone()
+    w_restricted = net.vid_model.backbone.stem[0].weight.grad.clone()
+    net.zero_grad()
+    net.restrict_pixel_grad = False
+    net.training_step((target, None, vid), 0).backward()
+    assert float(g_restricted.abs().max()) > 0
+    assert torch.equal(net.vid_cls.grad, g_restricted) and torch.equal(net.vid_model.backbone.stem[0].weight.grad, w_restricted)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
