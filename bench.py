@@ -137,6 +137,8 @@ def main():
                     "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
                     "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
                     "(config.yaml:2).  Secondary lines, same JSON contract.")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
+                    "one GPU to rehearse the data-parallel path on a single-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
                     "rank (rehearses the multi-GPU code path on a single GPU)")
     args = ap.parse_args()
@@ -146,12 +148,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import dvt_amd
     from dvt_amd import functional as F
