@@ -47,88 +47,88 @@ def _cba(fm: FMap, conv, bn, relu, residual=None, dtype=torch.bfloat16) -> FMap:
     return (y, N, Ho, Wo)
 
 
-class BasicBlock(nn.Module):
+class _ResidualBlock(nn.Module):
+    """conv{i} / bn{i} pairs (i = 1..len(spec)) + optional ``downsample``; the last pair takes the shortcut.
+    ``spec``: per convolution (kernel, out_planes, stride).  Attribute names are the torchvision ones, so the
+    state-dict keys match the reference's (custom_resnet.py:25-93)."""
+    expansion = 1
+
+    def _build(self, inplanes, spec, downsample, stride):
+        cin = inplanes
+        for i, (k, cout, s) in enumerate(spec, start=1):
+            conv = conv3x3(cin, cout, s) if k == 3 else nn.Conv2d(cin, cout, kernel_size=1, stride=s, bias=False)
+            setattr(self, f"conv{i}", conv)
+            setattr(self, f"bn{i}", nn.BatchNorm2d(cout))
+            cin = cout
+        self.depth = len(spec)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_nhwc(self, fm: FMap, dtype) -> FMap:
+        shortcut = fm[0]
+        if self.downsample is not None:
+            shortcut = _cba(fm, self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
+        out = fm
+        for i in range(1, self.depth):
+            out = _cba(out, getattr(self, f"conv{i}"), getattr(self, f"bn{i}"), True, dtype=dtype)
+        last = self.depth                                     # out += residual; relu  (fused into the BatchNorm pass)
+        return _cba(out, getattr(self, f"conv{last}"), getattr(self, f"bn{last}"), True, residual=shortcut, dtype=dtype)
+
+
+class BasicBlock(_ResidualBlock):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
-        super(BasicBlock, self).__init__()
-        self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.downsample = downsample
-        self.stride = stride
-
-    def forward_nhwc(self, fm: FMap, dtype) -> FMap:
-        residual = fm[0]
-        out = _cba(fm, self.conv1, self.bn1, True, dtype=dtype)
-        if self.downsample is not None:
-            residual = _cba(fm, self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
-        return _cba(out, self.conv2, self.bn2, True, residual=residual, dtype=dtype)   # out += residual; relu
+        super().__init__()
+        self._build(inplanes, [(3, planes, stride), (3, planes, 1)], downsample, stride)
 
 
-class Bottleneck(nn.Module):
+class Bottleneck(_ResidualBlock):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
-        super(Bottleneck, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.relu = nn.ReLU(inplace=True)
-        self.downsample = downsample
-        self.stride = stride
-
-    def forward_nhwc(self, fm: FMap, dtype) -> FMap:
-        residual = fm[0]
-        out = _cba(fm, self.conv1, self.bn1, True, dtype=dtype)
-        out = _cba(out, self.conv2, self.bn2, True, dtype=dtype)
-        if self.downsample is not None:
-            residual = _cba(fm, self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
-        return _cba(out, self.conv3, self.bn3, True, residual=residual, dtype=dtype)
+        super().__init__()
+        self._build(inplanes, [(1, planes, 1), (3, planes, stride), (1, planes * 4, 1)], downsample, stride)
 
 
 class ResNet(nn.Module):
+    _STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))          # (planes, stride of the first block) of layer1..4
 
     def __init__(self, block, layers, num_classes=1000, *, compute_dtype=torch.bfloat16):
+        super().__init__()
         self.inplanes = 64
-        super(ResNet, self).__init__()
+        self.compute_dtype = compute_dtype
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        self.avgpool = nn.AvgPool2d(7, stride=1)
+        for i, ((planes, stride), blocks) in enumerate(zip(self._STAGES, layers), start=1):
+            setattr(self, f"layer{i}", self._make_layer(block, planes, blocks, stride))
+        self.avgpool = nn.AvgPool2d(7, stride=1)                # kept for the state dict / attribute surface only
         self.fc = nn.Linear(512 * block.expansion, num_classes)
-        self.compute_dtype = compute_dtype
+        self._reset_parameters()
 
+    def _reset_parameters(self):
+        """He-normal convolutions (fan-out), unit BatchNorm (custom_resnet.py:113-119)."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
-                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
 
     def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion),
-            )
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for i in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        width = planes * block.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != width:
+            shortcut = nn.Sequential(nn.Conv2d(self.inplanes, width, kernel_size=1, stride=stride, bias=False),
+                                     nn.BatchNorm2d(width))
+        stage = [block(self.inplanes, planes, stride, shortcut)]
+        self.inplanes = width
+        stage += [block(width, planes) for _ in range(blocks - 1)]
+        return nn.Sequential(*stage)
 
     def forward_nhwc(self, x) -> List[FMap]:
         """x [N, 3, H, W] (NCHW frames) -> [(x2), (x3), (x4)] as NHWC matrices."""
@@ -143,48 +143,38 @@ class ResNet(nn.Module):
         H2 = (H1 + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
         W2 = (W1 + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
         fm: FMap = (y, N, H2, W2)
-        outs = []
-        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
-            for blk in layer:
+        pyramid = []
+        for i in range(1, 5):
+            for blk in getattr(self, f"layer{i}"):
                 fm = blk.forward_nhwc(fm, dt)
-            if li >= 1:
-                outs.append(fm)
-        return outs
+            if i >= 2:
+                pyramid.append(fm)
+        return pyramid
 
     def forward(self, x):
-        outs = []
+        maps = []
         for (y, N, H, W) in self.forward_nhwc(x):
             C = y.shape[1]
-            outs.append(F.transpose_last2(y.view(N, H * W, C)).view(N, C, H, W))     # NHWC -> NCHW
-        return tuple(outs)                                                           # (x2, x3, x4)
+            maps.append(F.transpose_last2(y.view(N, H * W, C)).view(N, C, H, W))     # NHWC -> NCHW
+        return tuple(maps)                                                           # (x2, x3, x4)
 
 
-def _no_pretrained(flag):
-    if flag:
-        raise RuntimeError("pretrained=True downloads ImageNet weights (model_zoo, custom_resnet.py:162-163); "
-                           "there is no network here -- load a state_dict explicitly")
+_DEPTHS = {"resnet18": (BasicBlock, (2, 2, 2, 2)), "resnet34": (BasicBlock, (3, 4, 6, 3)),
+           "resnet50": (Bottleneck, (3, 4, 6, 3)), "resnet101": (Bottleneck, (3, 4, 23, 3)),
+           "resnet152": (Bottleneck, (3, 8, 36, 3))}
 
 
-def resnet18(pretrained=False, **kwargs):
-    _no_pretrained(pretrained)
-    return ResNet(BasicBlock, [2, 2, 2, 2], **kwargs)
+def _factory(name):
+    block, layers = _DEPTHS[name]
+
+    def make(pretrained=False, **kwargs):
+        if pretrained:
+            raise RuntimeError("pretrained=True downloads ImageNet weights (model_zoo, custom_resnet.py:162-163); "
+                               "there is no network here -- load a state_dict explicitly")
+        return ResNet(block, list(layers), **kwargs)
+    make.__name__ = name
+    make.__doc__ = f"{name} returning the (x2, x3, x4) pyramid (custom_resnet.py:156-211)."
+    return make
 
 
-def resnet34(pretrained=False, **kwargs):
-    _no_pretrained(pretrained)
-    return ResNet(BasicBlock, [3, 4, 6, 3], **kwargs)
-
-
-def resnet50(pretrained=False, **kwargs):
-    _no_pretrained(pretrained)
-    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
-
-
-def resnet101(pretrained=False, **kwargs):
-    _no_pretrained(pretrained)
-    return ResNet(Bottleneck, [3, 4, 23, 3], **kwargs)
-
-
-def resnet152(pretrained=False, **kwargs):
-    _no_pretrained(pretrained)
-    return ResNet(Bottleneck, [3, 8, 36, 3], **kwargs)
+resnet18, resnet34, resnet50, resnet101, resnet152 = (_factory(n) for n in _DEPTHS)
