@@ -330,38 +330,42 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p)
           s[tt] = Elem16<E>::mma(
               img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt]);
       }
-      float mx = -INFINITY;
+      // softmax bookkeeping on the raw scores (c2 > 0: max and scaling commute); the key mask only exists in the
+      // last 32-key step; the accumulator rescale is skipped when no lane of the wave raised its running maximum
+      if (kp == nkp - 1) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = (2 * kp + tt) * 16 + 4 * g + r;
-          const float val = key < p.Lk ? s[tt][r] * c2 : -INFINITY;
-          s[tt][r] = val;
-          mx = fmaxf(mx, val);
-        }
+          for (int r = 0; r < 4; ++r)
+            if ((2 * kp + tt) * 16 + 4 * g + r >= p.Lk) s[tt][r] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      const float mn = fmaxf(m, mx * c2);
+      const bool raised = mn > m;
       float ps = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[tt][r] - mn);
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -mn));
           s[tt][r] = e;
           ps += e;
         }
-      l = fmaf(l, alpha, ps);
-      m = mn;
       const typename Elem16<E>::v8 pf = pack_pair<E>(s[0], s[1]);
+      if (__builtin_amdgcn_ballot_w64(raised) != 0) {       // wave-uniform branch
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        l *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        o[dt] *= alpha;
-        o[dt] = Elem16<E>::mma(
-            img_tr_frag<E>(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt]);
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
       }
+      l += ps;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = Elem16<E>::mma(img_tr_frag<E>(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt]);
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -599,7 +603,7 @@ bool strides_vec_ok(const dvt_attn_desc* d) {
 }
 
 bool mfma_fwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
-  return d->dropout_p == 0.f && dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
+  return d->dropout_p == 0.f && d->scale > 0.f && dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) && dvt_aligned16(d->q) &&
          dvt_aligned16(d->k) && dvt_aligned16(d->v) && dvt_aligned16(d->o) &&
          2 * p.Lkp * kRowBytes <= kMaxLds;
 }
