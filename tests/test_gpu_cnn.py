@@ -90,7 +90,8 @@ def test_maxpool_first_max_and_eval_bn(dvt, device):
 # bf16: 17 stacked conv+BN layers; the deepest scale (x4) accumulates ~4e-2 relative error
 # fp32 gradient bound 1e-2: one ReLU-mask flip of an activation that is 0 +- 1 ulp on the 98 x 512 layer-4 map moves
 # every upstream gradient by 1/sqrt(50176) = 4.5e-3 (seen after a change of the BatchNorm summation order); 1e-4 otherwise
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 1e-2), (torch.bfloat16, 7e-2, 5e-1)])
+@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 1e-2), (torch.bfloat16, 7e-2, 5e-1),
+                                                 (torch.float16, 1e-2, 2e-1)])
 def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, tol_g):
     """custom_resnet.resnet18 at 224x224, train mode, vs the imported reference."""
     from dvt_amd.models.custom_resnet import resnet18
@@ -107,8 +108,13 @@ def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, 
     assert max(errs) < tol_out
     gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (x2, x3, x4)]
     # the scalar of the fixture: sum_i <x_i, g_i> / 1000  -> gradient g_i / 1000 on each output
-    torch.autograd.backward([x2, x3, x4], [gg.to(t.dtype).cuda() / 1000.0 for t, gg in zip((x2, x3, x4), gs)])
+    # fp16: the fixture's 1e-3-scaled output gradients underflow half precision on the way down -> static loss scale
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    torch.autograd.backward([x2, x3, x4], [(gg * (ls / 1000.0)).to(t.dtype).cuda() for t, gg in zip((x2, x3, x4), gs)])
     P = dict(net.named_parameters())
+    for p_ in P.values():
+        if p_.grad is not None:
+            p_.grad.div_(ls)
     worst = 0.0
     for k in g.files:
         if k.startswith("g:"):

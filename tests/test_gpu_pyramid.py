@@ -54,7 +54,7 @@ def test_cross_attention_block(device, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,variant", [(torch.float32, "pyramid"), (torch.float32, "crossmodal"),
-                                           (torch.bfloat16, "crossmodal")])
+                                           (torch.bfloat16, "crossmodal"), (torch.float16, "pyramid")])
 def test_pyramid_vivit_matches_oracle(device, dtype, variant):
     from dvt_amd.models.pyramid_vivit import PyramidViViT
     audio_tokens = 32 if variant == "crossmodal" else 0
