@@ -378,15 +378,19 @@ class FrameTransformer(LightningModule):
         self.log("train/loss", loss, on_step=True, on_epoch=True)
         return loss
 
+    def _accumulate(self, data, target):
+        """:331-334 / :363-366: the callbacks consume sigmoid probabilities and integer labels."""
+        with torch.no_grad():
+            self.running_logits.append(F.sigmoid(data.detach()))
+        self.running_labels.append(target.int())
+
     def validation_step(self, batch, batch_idx):
         loss, data = self._loss(batch)
-        self.running_logits.append(data.detach())
-        self.running_labels.append(batch[0])
+        self._accumulate(data, batch[0])
         self.log("val/loss", loss, on_step=True, on_epoch=True)
         return loss
 
     def test_step(self, batch, batch_idx):
         loss, data = self._loss(batch)
-        self.running_logits.append(data.detach())
-        self.running_labels.append(batch[0])
+        self._accumulate(data, batch[0])
         return loss

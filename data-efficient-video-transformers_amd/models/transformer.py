@@ -93,6 +93,7 @@ class SimpleTransformer(LightningModule):
         data = self.shared_step(batch["experts"])
         loss = self.criterion(data, batch["label"].float())
         self.running_labels.append(batch["label"].int())
-        self.running_logits.append(data.detach())
+        with torch.no_grad():       # the reference appends sigmoid(data) AND data (:153-158: two entries per label batch,
+            self.running_logits.append(F.sigmoid(data.detach()))   # which breaks its own callback); the probabilities are kept
         self.log("val/loss", loss, on_step=False, on_epoch=True)
         return loss

@@ -109,6 +109,12 @@ def test_frame_transformer_vid_mode_fwd_bwd(device, dtype, tol):
     assert net.hparams.seq_len == 5 and isinstance(net.running_logits, list)
     net.validation_step((target.cuda(), img.cuda(), vid.cuda()), 0)
     assert len(net.running_logits) == 1 and net.running_logits[0].shape == (2, 19)
+    probs = net.running_logits[0].float().cpu()                       # sigmoid probabilities, integer labels (:331-334)
+    assert float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
+    assert rel_l2(probs, torch.sigmoid(ref_logits.detach())) < 5 * tol and net.running_labels[0].dtype == torch.int32
+    from dvt_amd.metrics import TransformerEval
+    scalars = TransformerEval().on_validation_epoch_end(None, net)     # the callback consumes exactly these accumulators
+    assert "sklearn apr" in scalars and net.running_logits == []
 
 
 @pytest.mark.parametrize("mode", ["sum", "distil", "frame"])
