@@ -118,6 +118,7 @@ SIGNATURES = {
     "dvt_average_precision": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
     "dvt_l2norm_rows_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_f, c_int, c_p]),
     "dvt_l2norm_rows_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_int, c_p]),
+    "dvt_cosine_rows": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_f, c_int, c_p]),
     "dvt_gate_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_gate_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_contrastive_fwd": (c_int, [c_p, c_int, c_f, c_p, c_p, c_p, c_p]),

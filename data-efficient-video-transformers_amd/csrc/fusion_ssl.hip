@@ -44,6 +44,22 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// out[r] = <a[r], b[r]> / max(||a[r]|| * ||b[r]||, eps)     (nn.CosineSimilarity(dim=1), frame_transformer.py:121,257)
+template <typename T>
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          float* __restrict__ out, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float ab = 0.f, aa = 0.f, bb = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float x = to_f32<T>(a[r * D + c]), y = to_f32<T>(b[r * D + c]);
+    ab = fmaf(x, y, ab); aa = fmaf(x, x, aa); bb = fmaf(y, y, bb);
+  }
+  ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+  if (lane == 0) out[r] = ab / fmaxf(sqrtf(aa) * sqrtf(bb), eps);
+}
+
 // y = a * sigmoid(b)
 template <typename T>
 __global__ void gate_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
@@ -143,6 +159,16 @@ int dvt_l2norm_rows_bwd(const void* dy, const void* y, const float* inv_norm, vo
                                                   (hipStream_t)stream, (const T*)dy, (const T*)y, inv_norm, (T*)dx, rows,
                                                   D, eps));
   DVT_LAUNCH_CHECK("dvt_l2norm_rows_bwd");
+  return DVT_OK;
+}
+
+int dvt_cosine_rows(const void* a, const void* b, float* out, int64_t rows, int D, float eps, int dtype,
+                    dvt_stream_t stream) {
+  DVT_REQUIRE(rows >= 0 && D > 0 && eps > 0.f && (rows == 0 || (a && b && out)), "dvt_cosine_rows: bad arguments");
+  if (rows == 0) return DVT_OK;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((cosine_rows_kernel<T>), dim3((unsigned)dvt_cdiv(rows, 4)), dim3(256), 0,
+                                                  (hipStream_t)stream, (const T*)a, (const T*)b, out, rows, D, eps));
+  DVT_LAUNCH_CHECK("dvt_cosine_rows");
   return DVT_OK;
 }
 

@@ -61,3 +61,47 @@ class TransformerEval:
         pl_module.running_labels = []
         pl_module.running_logits = []
         return scalars
+
+
+class AveragePrecision:
+    """Stand-in for ``torchmetrics.AveragePrecision(num_classes=C)`` (frame_transformer.py:114,118,277,335): calling the
+    object with ``(preds, target)`` accumulates a batch on the device, ``compute()`` returns the per-class average
+    precision (one-vs-rest, a list of C scalars like torchmetrics 0.6) and ``reset()`` clears it.  Average precision is
+    rank-based, so logits and probabilities give the same value."""
+
+    def __init__(self, num_classes: int):
+        self.num_classes = num_classes
+        self.preds: List[torch.Tensor] = []
+        self.target: List[torch.Tensor] = []
+
+    def __call__(self, preds: torch.Tensor, target: torch.Tensor) -> None:
+        self.update(preds, target)
+
+    def update(self, preds: torch.Tensor, target: torch.Tensor) -> None:
+        if preds.shape[-1] != self.num_classes:
+            raise ValueError(f"expected {self.num_classes} classes")
+        self.preds.append(preds.detach().reshape(-1, self.num_classes))
+        self.target.append(target.detach().reshape(-1, self.num_classes))
+
+    def compute(self, group: Optional[dist.ProcessGroup] = None) -> List[torch.Tensor]:
+        if not self.preds:
+            raise RuntimeError("AveragePrecision.compute() before any update")
+        p = gather_rows(torch.cat(self.preds), group)
+        t = gather_rows(torch.cat(self.target), group)
+        _, _, per_class = ops.average_precision(p.float() if p.dtype != torch.float32 else p, t)
+        return list(per_class.unbind(0))
+
+    def reset(self) -> None:
+        self.preds, self.target = [], []
+
+
+class CosineSimilarity:
+    """``nn.CosineSimilarity(dim=1)`` for logging (frame_transformer.py:121,257); no gradient."""
+
+    def __init__(self, dim: int = 1, eps: float = 1e-8):
+        if dim != 1:
+            raise ValueError("only dim=1 (rows of a [B, C] pair) is used by the reference")
+        self.eps = eps
+
+    def __call__(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return ops.cosine_rows(a, b, self.eps)

@@ -215,6 +215,10 @@ class FrameTransformer(LightningModule):
         self.img_size = hp.get("img_size", 224)
         self.n_out = hp.get("n_out", 19)
         self.compute_dtype = hp.get("compute_dtype", torch.bfloat16)
+        from .. import metrics as _metrics
+        self.train_aprc = _metrics.AveragePrecision(num_classes=self.n_out)     # :114
+        self.val_aprc = _metrics.AveragePrecision(num_classes=self.n_out)       # :118
+        self.cos = _metrics.CosineSimilarity(dim=1)                             # :121
         self.criterion = F.bce_with_logits                        # nn.BCEWithLogitsLoss()  :89
         self.distil_criterion = F.cross_entropy_argmax            # CE(student, argmax(teacher))  :90,250
         self.position_encoder = PositionalEncoding(d, drop, max_len=self.tokens + 1)      # :91-93 (+1: injected token)
@@ -362,6 +366,7 @@ class FrameTransformer(LightningModule):
             base_loss = self.criterion(s, target)
             self.log("train/distilloss", distil_loss)
             self.log("train/bass_loss", base_loss)
+            self.log("train/cossim", self.cos(s, t)[0])                        # :257
             return F.add(base_loss.reshape(1), distil_loss.reshape(1)).reshape(()), s
         if mode in ("sum", "sum_residual", "post_sum"):
             data = self(img, vid)
@@ -375,7 +380,9 @@ class FrameTransformer(LightningModule):
 
     def training_step(self, batch, batch_idx):
         loss, data = self._loss(batch)
-        self.log("train/loss", loss, on_step=True, on_epoch=True)
+        self.train_aprc(data, batch[0].int())                                  # :275-277
+        self.log("train/loss", loss, on_step=False, on_epoch=True)
+        self.log("train/aprc", self.train_aprc, on_step=False, on_epoch=True)
         return loss
 
     def _accumulate(self, data, target):
@@ -387,7 +394,9 @@ class FrameTransformer(LightningModule):
     def validation_step(self, batch, batch_idx):
         loss, data = self._loss(batch)
         self._accumulate(data, batch[0])
-        self.log("val/loss", loss, on_step=True, on_epoch=True)
+        self.val_aprc(data, batch[0].int())                                    # :335
+        self.log("val/loss", loss, on_epoch=True)
+        self.log("val/aprc", self.val_aprc, on_step=False, on_epoch=True)
         return loss
 
     def test_step(self, batch, batch_idx):

@@ -625,6 +625,17 @@ def l2norm_rows_bwd(dy: Tensor, y: Tensor, inv: Tensor, eps: float) -> Tensor:
     return dx
 
 
+def cosine_rows(a: Tensor, b: Tensor, eps: float = 1e-8) -> Tensor:
+    """nn.CosineSimilarity(dim=1): [rows, D] x [rows, D] -> f32 [rows] (no gradient)."""
+    _need_cuda(a, b)
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    assert a.shape == b.shape and a.dim() == 2 and a.dtype == b.dtype
+    out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    L.check(L.load().dvt_cosine_rows(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], eps, dt(a),
+                                     _stream()), "dvt_cosine_rows")
+    return out
+
+
 def gate_fwd(a: Tensor, b: Tensor) -> Tensor:
     _need_cuda(a, b)
     a, b = a.contiguous(), b.contiguous()

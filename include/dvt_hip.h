@@ -274,6 +274,9 @@ int dvt_l2norm_rows_fwd(const void* x, void* y, float* inv_norm, int64_t rows, i
                         dvt_stream_t stream);
 int dvt_l2norm_rows_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int D, float eps,
                         int dtype, dvt_stream_t stream);
+/* nn.CosineSimilarity(dim=1)(a, b) (frame_transformer.py:121, logged at :257): out[r] f32, no gradient. */
+int dvt_cosine_rows(const void* a, const void* b, float* out, int64_t rows, int D, float eps, int dtype,
+                    dvt_stream_t stream);
 /* ContextGating: F.glu(cat(x, x + x1), -1) = x * sigmoid(x + x1) (collabgating.py:83-86): y = a * sigmoid(b). */
 int dvt_gate_fwd(const void* a, const void* b, void* y, int64_t n, int dtype, dvt_stream_t stream);
 int dvt_gate_bwd(const void* dy, const void* a, const void* b, void* da, void* db, int64_t n, int dtype,

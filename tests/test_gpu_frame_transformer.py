@@ -112,6 +112,13 @@ def test_frame_transformer_vid_mode_fwd_bwd(device, dtype, tol):
     probs = net.running_logits[0].float().cpu()                       # sigmoid probabilities, integer labels (:331-334)
     assert float(probs.min()) >= 0.0 and float(probs.max()) <= 1.0
     assert rel_l2(probs, torch.sigmoid(ref_logits.detach())) < 5 * tol and net.running_labels[0].dtype == torch.int32
+    # torchmetrics-style accumulators of the reference surface (train_aprc / val_aprc / cos)
+    from oracle import eval_metrics as EM
+    ap = torch.stack(net.val_aprc.compute()).cpu().numpy()
+    want = EM.average_precision(ref_logits.detach().numpy(), target.numpy())[2]
+    assert ap.shape == (19,) and np.abs(ap - want).max() < (1e-6 if dtype == torch.float32 else 0.26)   # 2 samples: coarse ranks
+    c = net.cos(torch.randn(3, 19).cuda(), torch.randn(3, 19).cuda())
+    assert c.shape == (3,) and float(c.abs().max()) <= 1.0 + 1e-6
     from dvt_amd.metrics import TransformerEval
     scalars = TransformerEval().on_validation_epoch_end(None, net)     # the callback consumes exactly these accumulators
     assert "sklearn apr" in scalars and net.running_logits == []
