@@ -222,18 +222,25 @@ class FrameTransformer(LightningModule):
         self.criterion = F.bce_with_logits                        # nn.BCEWithLogitsLoss()  :89
         self.distil_criterion = F.cross_entropy_argmax            # CE(student, argmax(teacher))  :90,250
         self.position_encoder = PositionalEncoding(d, drop, max_len=self.tokens + 1)      # :91-93 (+1: injected token)
-        # default encoders = the reference's (random init: no pretrained download); injectable for other sizes
-        self.img_model = hp.get("img_encoder", None) or (ImgResNet(self.compute_dtype) if d == 896 else
-                                                         _MissingEncoder("img_encoder for d_model != 896"))   # :94
+        # default encoders = the reference's (random init: no pretrained download); injectable for other sizes.
+        # The image branch (img_model / scene_transformer / img_cls: commented out in the reference, :94,98,104) is
+        # only built for the modes that use it, so a "vid" model has exactly the reference's state-dict keys and loads
+        # its checkpoints with strict=True.
+        mode = hp.get("model", "vid")
+        self.has_img_branch = mode in ("distil", "sum", "sum_residual", "post_sum", "frame", "pre_modal")
+        if self.has_img_branch:
+            self.img_model = hp.get("img_encoder", None) or (ImgResNet(self.compute_dtype) if d == 896 else
+                                                             _MissingEncoder("img_encoder for d_model != 896"))   # :94
+            self.scene_transformer = TransformerBase(d, d, hp.get("scene_nhead", 4), hp.get("scene_nhid", 896), 4, drop)  # :98
         self.vid_model = hp.get("vid_encoder", None) or (VidResNet(self.compute_dtype) if d == 896 else
                                                          _MissingEncoder("vid_encoder for d_model != 896"))   # :95
-        self.scene_transformer = TransformerBase(d, d, hp.get("scene_nhead", 4), hp.get("scene_nhid", 896), 4, drop)  # :98
         self.distil_transformer = TransformerBase(d, 128, hp.get("vid_nhead", 2), hp.get("vid_nhid", 512), 4, drop)  # :99
         self.running_labels = []
         self.running_logits = []
         self.running_paths = []
         self.running_embeds = []
-        self.img_cls = nn.Parameter(torch.rand(1, 3, self.img_size, self.img_size))                       # :104
+        if self.has_img_branch:
+            self.img_cls = nn.Parameter(torch.rand(1, 3, self.img_size, self.img_size))                   # :104
         self.vid_cls = nn.Parameter(torch.rand(1, self.frame_len, 3, self.clip_size, self.clip_size))    # :105
         self.img_mlp_head = nn.Sequential(nn.Linear(d, 512), nn.GELU(), nn.Linear(512, 128), nn.GELU(),
                                           nn.Linear(128, self.n_out))                                     # :106
@@ -241,11 +248,10 @@ class FrameTransformer(LightningModule):
         for k in ("img_encoder", "vid_encoder"):       # modules are attributes, not hyper-parameters
             if k in hp:
                 delattr(hp, k)
-        # The members the reference leaves commented out (img_model / scene_transformer / img_cls, :94,98,104) exist here
-        # so that every mode can run; in the single-branch modes the other branch takes no part in the computation and
-        # must not be touched by the optimizer either (torch skips parameters without a gradient; a flat-buffer
+        # In the image-only modes the video branch (always constructed by the reference) takes no part in the computation
+        # and must not be touched by the optimizer either (torch skips parameters without a gradient; a flat-buffer
         # optimizer would still decay them), so it is frozen.  ``norm`` (:117) is unused by every forward path.
-        idle = {"vid": ("img_model", "scene_transformer", "img_cls"),
+        idle = {"vid": (),
                 "frame": ("vid_model", "distil_transformer", "vid_cls"),
                 "pre_modal": ("vid_model", "distil_transformer", "vid_cls")}.get(hp.get("model", ""), ())
         for name in idle + ("norm",):

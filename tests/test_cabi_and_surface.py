@@ -70,3 +70,28 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_frame_transformer_vid_mode_has_the_reference_state_dict_keys():
+    """frame_transformer.py:83-121 as executed (image branch commented out): a model="vid" mirror must expose exactly
+    position_encoder.pe, vid_model.backbone.* (torchvision R(2+1)D names, fc.0.*), distil_transformer.transformer.layers.*,
+    vid_cls, img_mlp_head.{0,2,4}.*, norm.* -- so reference checkpoints load with strict=True."""
+    import torch
+    from dvt_amd.models.frame_transformer import FrameTransformer
+    net = FrameTransformer(batch_size=2, seq_len=13, cls=1, model="vid", opt="adamW", learning_rate=5e-6, weight_decay=0.09,
+                           momentum=0.005)
+    keys = list(net.state_dict().keys())
+    tops = sorted({k.split(".")[0] for k in keys})
+    assert tops == ["distil_transformer", "img_mlp_head", "norm", "position_encoder", "vid_cls", "vid_model"], tops
+    sd = net.state_dict()
+    assert sd["vid_cls"].shape == (1, 12, 3, 112, 112) and sd["position_encoder.pe"].shape[2] == 896
+    assert sd["distil_transformer.transformer.layers.0.self_attn.in_proj_weight"].shape == (2688, 896)
+    assert sd["distil_transformer.transformer.layers.3.linear1.weight"].shape == (512, 896)
+    assert sd["vid_model.backbone.fc.0.weight"].shape == (896, 512)
+    assert sd["vid_model.backbone.stem.0.weight"].shape == (45, 3, 1, 7, 7)
+    assert sd["vid_model.backbone.layer2.0.conv1.0.0.weight"].shape == (230, 64, 1, 3, 3)
+    assert {k for k in keys if k.startswith("img_mlp_head")} == {f"img_mlp_head.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")}
+    # the image-branch modes add the members the reference left commented out
+    net2 = FrameTransformer(batch_size=2, seq_len=13, cls=1, model="sum", opt="adamW", learning_rate=5e-6, weight_decay=0.09,
+                            momentum=0.005)
+    assert {"img_model", "scene_transformer", "img_cls"} <= {k.split(".")[0] for k in net2.state_dict()}
