@@ -137,6 +137,8 @@ def main():
                     "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
                     "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
                     "(config.yaml:2).  Secondary lines, same JSON contract.")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="kernel element type of the vivit workload "
+                    "(fp16 adds the device-side dynamic loss scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
                     "one GPU to rehearse the data-parallel path on a single-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
@@ -165,6 +167,8 @@ def main():
     cdt = torch.bfloat16
     if args.workload == "longclip":
         cfg.update(image=288, T=64)
+        cdt = torch.float16
+    elif args.dtype == "fp16":
         cdt = torch.float16
     torch.manual_seed(1130)                                       # src/main.py:25
     if args.workload == "frametransformer":
@@ -328,7 +332,7 @@ def main():
         fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
                                               3 * cfg["patch"] ** 2, n_tok - 1)
         out = {
-            "metric": "clips/sec fwd+bwd, B=8 T=32 3x224x224 bf16" if args.workload == "vivit" else
+            "metric": f"clips/sec fwd+bwd, B=8 T=32 3x224x224 {args.dtype}" if args.workload == "vivit" else
                       ("samples/sec fwd+bwd [frametransformer workload], B=2 x 14 chunks x 12 x 3x112x112"
                        if args.workload == "frametransformer" else
                        f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}"),
