@@ -137,6 +137,8 @@ def main():
                     "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
                     "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
                     "(config.yaml:2).  Secondary lines, same JSON contract.")
+    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d secondary metric): the global batch stays "
+                    "--batch and each rank takes batch / world clips")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="kernel element type of the vivit workload "
                     "(fp16 adds the device-side dynamic loss scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
@@ -192,6 +194,10 @@ def main():
     flat.sync_compute_copy()
 
     gen = torch.Generator().manual_seed(1130 + rank)
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit(f"--strong: global batch {args.batch} is not divisible by {world} ranks")
+        args.batch //= world
     B = args.batch
     if args.workload == "frametransformer":
         x = torch.randn(B, 13, 12, 3, 112, 112, generator=gen).cuda()     # MMX_Light_dl.py:286 batch contract
@@ -338,7 +344,7 @@ def main():
                        f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}"),
             "value": round(clips, 2), "unit": "samples/s" if args.workload == "frametransformer" else "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
                        "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
             "launch": "hipGraph replay" if use_graph else "eager",
