@@ -159,6 +159,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit(f"--strong: global batch {args.batch} is not divisible by {world} ranks")
+        args.batch //= world
+
     import dvt_amd
     from dvt_amd import functional as F
     from dvt_amd import ops
@@ -194,10 +199,6 @@ def main():
     flat.sync_compute_copy()
 
     gen = torch.Generator().manual_seed(1130 + rank)
-    if args.strong:
-        if args.batch % world:
-            raise SystemExit(f"--strong: global batch {args.batch} is not divisible by {world} ranks")
-        args.batch //= world
     B = args.batch
     if args.workload == "frametransformer":
         x = torch.randn(B, 13, 12, 3, 112, 112, generator=gen).cuda()     # MMX_Light_dl.py:286 batch contract
