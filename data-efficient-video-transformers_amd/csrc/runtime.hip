@@ -40,7 +40,25 @@ int dvt_num_cus() {
   return g_cus;
 }
 
+namespace {
+// one lane spins on the 100 MHz wall clock for `ticks`; bounded (the loop also ends after a fixed number of polls)
+__global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 24); ++i) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int dvt_device_delay(uint64_t microseconds, dvt_stream_t stream) {
+  DVT_REQUIRE(microseconds <= 1000000, "dvt_device_delay: at most one second");
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  DVT_LAUNCH_CHECK("dvt_device_delay");
+  return DVT_OK;
+}
 
 int dvt_version(void) { return DVT_ABI_VERSION; }
 

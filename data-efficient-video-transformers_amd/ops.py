@@ -475,7 +475,7 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float, drop
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, lse, scale, dropout)
     nb = (2 * q.numel() + k.numel() + v.numel()) * q.element_size()          # read q, k, v; write o
-    with _timed(("hbm", "attention_fwd", q.numel()), nb):
+    with _timed(("hbm", "attention_fwd", q.numel(), 4.0 * q.numel() * k.shape[2]), nb):   # key carries the MFMA flops
         L.check(L.load().dvt_attention_fwd(C.byref(d), _stream()), "dvt_attention_fwd")
     return lse
 
@@ -495,7 +495,7 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: T
     d.workspace = _p(ws)
     # two kernels: dq reads q,k,v,o,dO writes dq; dkdv reads q,k,v,o,dO writes dk,dv
     nb = (7 * q.numel() + 3 * k.numel() + 3 * v.numel()) * q.element_size()
-    with _timed(("hbm", "attention_bwd", q.numel()), nb):
+    with _timed(("hbm", "attention_bwd", q.numel(), 10.0 * q.numel() * k.shape[2]), nb):  # 5 products of 2*L*L*dh
         L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
 
 
@@ -683,6 +683,11 @@ def adamw_step_scaled_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq:
                                            scale.data_ptr(), found_inf.data_ptr(), good_steps.data_ptr(), growth_interval,
                                            growth, backoff, loss_grad.data_ptr(), loss_grad_base, _stream()),
             "dvt_adamw_step_scaled")
+
+
+def device_delay(microseconds: int) -> None:
+    """Keep the current stream busy for a while (measurement aid, see dvt_device_delay)."""
+    L.check(L.load().dvt_device_delay(int(microseconds), _stream()), "dvt_device_delay")
 
 
 def dropout(x: Tensor, p: float, rng_state: Tensor, call_offset: int) -> Tensor:

@@ -85,6 +85,11 @@ int dvt_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dvt_strea
 int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype,
                 dvt_stream_t stream);
 
+/* Measurement aid: occupies the stream for `microseconds` (<= 1 s) with a single spinning lane, so that the host can
+ * enqueue a whole step behind it and HIP-event brackets around individual launches then measure device time only
+ * (bench.py's roofline pass). */
+int dvt_device_delay(uint64_t microseconds, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- dropout
  * nn.Dropout(p) in training mode (frame_transformer.py:22,41-44 p = 0.5; TPN.py:92,95; vit.py:23,25,43,104):
  * y[i] = keep_i ? x[i] / (1 - p) : 0.  keep_i comes from Philox4x32-10 word (i & 3) of counter
