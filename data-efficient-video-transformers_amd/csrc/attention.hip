@@ -21,6 +21,7 @@
 // per row (fp32 parity mode; dh = 448 / 224 / 256 / 32 heads of the reference's
 // 14-token encoders).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -46,6 +47,7 @@ struct AttnParams {
   float scale;
   int Lkp;  // Lk rounded up to 32
   int Lqp;  // Lq rounded up to 32
+  int patch_off;  // byte offset in LDS of the per-wave 2 KiB output patches (whole-row stores), -1: per-lane stores
   // attention-probability dropout (generic kernels only): keep iff Philox word >= drop_thr, survivors * drop_scale
   uint32_t drop_thr;
   float drop_scale;
@@ -232,15 +234,35 @@ __device__ __forceinline__ int img_off(int r, int c) {
   return r * kRowBytes + ((((c >> 1) ^ ((r >> 1) & 3)) << 5) | ((c & 1) << 4));
 }
 
-// stage rows [0, rows_pad) of a [L][64] bf16 matrix (row stride sl) into an image; rows >= L are 0
+// stage rows [0, rows_pad) of two [L][64] matrices (row strides sla / slb) into their images; rows >= L are 0.
+// All global loads of a batch (4 chunks per thread and image) are issued before the first LDS write, so a batch costs one
+// memory round trip (a load -> wait -> write loop costs one per 16-byte chunk).
 template <typename E>
-__device__ __forceinline__ void stage_image(char* img, const E* src, int64_t sl, int L,
-                                            int rows_pad) {
-  for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
-    const int r = idx >> 3, c = idx & 7;
-    typename Elem16<E>::v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < L) v = *reinterpret_cast<const typename Elem16<E>::v8*>(src + (int64_t)r * sl + c * 8);
-    *reinterpret_cast<typename Elem16<E>::v8*>(img + img_off(r, c)) = v;
+__device__ __forceinline__ void stage_images(char* imga, const E* srca, int64_t sla, char* imgb, const E* srcb,
+                                             int64_t slb, int L, int rows_pad) {
+  using V8 = typename Elem16<E>::v8;
+  constexpr int kBatch = 4;
+  const int total = rows_pad * 8, nt = blockDim.x;
+  for (int base = threadIdx.x; base < total; base += kBatch * nt) {
+    V8 va[kBatch], vb[kBatch];
+    // straight-line code: chunk indices past the end clamp to the last chunk (the same data written twice), rows >= L load
+    // a clamped row and are zeroed afterwards -- a branch around a load or a store makes the compiler wait per chunk
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int idx = min(base + u * nt, total - 1);
+      const int r = idx >> 3, c = idx & 7;
+      const int rr = r < L ? r : 0;
+      const V8 a = *reinterpret_cast<const V8*>(srca + (int64_t)rr * sla + c * 8);
+      const V8 b = *reinterpret_cast<const V8*>(srcb + (int64_t)rr * slb + c * 8);
+      va[u] = r < L ? a : V8{0, 0, 0, 0, 0, 0, 0, 0};
+      vb[u] = r < L ? b : V8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int idx = min(base + u * nt, total - 1);
+      *reinterpret_cast<V8*>(imga + img_off(idx >> 3, idx & 7)) = va[u];
+      *reinterpret_cast<V8*>(imgb + img_off(idx >> 3, idx & 7)) = vb[u];
+    }
   }
 }
 
@@ -289,6 +311,41 @@ __device__ __forceinline__ void store4(E* p, const f32x4& v, float s) {
   *reinterpret_cast<typename Elem16<E>::v4*>(p) = o;
 }
 
+// A wave's 16 x 64 output tile (lane (g, li): row li, columns dt*16 + 4g .. +3 of accumulator dt), scaled, as whole
+// 128-byte rows: transposed through a wave-private 2 KiB LDS patch (16-byte chunks XOR-swizzled by (row >> 1) & 7) and
+// written with two fully coalesced 16-byte-per-lane stores.  The per-lane form (8 bytes at a row stride: sixteen 32-byte
+// fragments per instruction) costs ~150 cycles of the CU's memory pipeline per instruction (tools/attn_persist_timing.py).
+template <typename E>
+__device__ __forceinline__ void store_tile(char* patch, E* dst, int64_t row_stride, int row0, int row_lim,
+                                           const f32x4* acc, float scale, int lane) {
+  using V4 = typename Elem16<E>::v4;
+  using V8 = typename Elem16<E>::v8;
+  const int g = lane >> 4, li = lane & 15;
+  if (patch == nullptr) {
+    if (row0 + li < row_lim) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4<E>(dst + (int64_t)(row0 + li) * row_stride + dt * 16 + 4 * g, acc[dt], scale);
+    }
+    return;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    V4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (E)(acc[dt][r] * scale);
+    const int chunk = (dt * 2 + (g >> 1)) ^ ((li >> 1) & 7);
+    *reinterpret_cast<V4*>(patch + li * 128 + chunk * 16 + (g & 1) * 8) = o;
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = ps * 8 + (lane >> 3), c = lane & 7;
+    const V8 v = *reinterpret_cast<const V8*>(patch + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+    if (row0 + r < row_lim) *reinterpret_cast<V8*>(dst + (int64_t)(row0 + r) * row_stride + c * 8) = v;
+  }
+  wave_lds_sync();
+}
+
 // ---------------------------------------------------------------- forward
 template <typename E>
 __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p) {
@@ -303,11 +360,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p)
   float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
   char* ks = smem;
   char* vs = smem + p.Lkp * kRowBytes;
-  stage_image<E>(ks, kb, p.k_sl, p.Lk, p.Lkp);
-  stage_image<E>(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  stage_images<E>(ks, kb, p.k_sl, vs, vb, p.v_sl, p.Lk, p.Lkp);
   __syncthreads();
 
   const float c2 = p.scale * kLog2e;
+  char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
   const int nqt = (p.Lq + 15) >> 4, nkp = p.Lkp >> 5;
   for (int qt = wid; qt < nqt; qt += W) {
     const int qi = qt * 16 + li;
@@ -370,19 +427,138 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p)
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (qi < p.Lq) {
+    store_tile<E>(patch, ob, p.o_sl, qt * 16, p.Lq, o, inv, lane);
+    if (qi < p.Lq && g == 0) lse[qi] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+  }
+}
+
+// ---------------------------------------------------------------- forward, scores resident in registers
+// Lk <= 32 * NKP <= 256: the 16 x Lkp score tile of a wave (8 * NKP floats per lane) stays in registers, so the row maximum
+// is taken once (no running maximum, no accumulator rescale, no per-step cross-lane exchange) and the three phases
+// (S^T = K Q^T; max / exp / pack; O^T += V^T P^T) are straight-line code the scheduler can overlap.  The next tile's
+// query rows are fetched while this tile computes.  Single-instruction max helpers: fmaxf() on MFMA results would add a
+// canonicalising v_max per operand.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// all-reduce over the four 16-lane rows of the wave (lanes li, li+16, li+32, li+48) without touching LDS
+template <bool kMax>
+__device__ __forceinline__ float rows_allreduce(float x) {
+  float a = x, b = x;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  x = kMax ? vmax2(a, b) : a + b;
+  a = x;
+  b = x;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return kMax ? vmax2(a, b) : a + b;
+}
+
+template <typename E, int NKP>
+__global__ __launch_bounds__(1024) void attn_fwd_mfma_res_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
+  const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+  const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+  E* ob = (E*)p.out + b * p.o_sb + h * p.o_sh;
+  float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  char* ks = smem;
+  char* vs = smem + NKP * 32 * kRowBytes;
+  const int nqt = (p.Lq + 15) >> 4;
+  auto load_q = [&](int qt, V8* qf) {
+    const int qi = qt * 16 + li;
+    const int qrow = qi < p.Lq ? qi : p.Lq - 1;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store4<E>(ob + (int64_t)qi * p.o_sl + dt * 16 + 4 * g, o[dt], inv);
-      if (g == 0) lse[qi] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const V8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+  };
+  V8 qf[2];
+  load_q(wid, qf);                                   // in flight while K / V are staged
+  stage_images<E>(ks, kb, p.k_sl, vs, vb, p.v_sl, p.Lk, NKP * 32);
+  __syncthreads();
+
+  const float c2 = p.scale * kLog2e;
+  char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
+  for (int qt = wid; qt < nqt; qt += W) {
+    asm volatile("" ::: "memory");                   // K fragments are loop-invariant: keep their LDS reads in the loop
+    f32x4 s[NKP][2];
+#pragma unroll
+    for (int kp = 0; kp < NKP; ++kp)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        s[kp][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          s[kp][tt] = Elem16<E>::mma(img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[kp][tt]);
+      }
+    load_q(qt + W, qf);                              // next tile's rows (clamped to Lq - 1: a harmless re-read at the end)
+    __builtin_amdgcn_sched_barrier(0);               // issue it here, a whole softmax + P V phase ahead of its use
+    // keys >= Lk only exist in the last 32-key step
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((2 * (NKP - 1) + tt) * 16 + 4 * g + r >= p.Lk) s[NKP - 1][tt][r] = -INFINITY;
+    float mx = vmax2(s[0][0][0], s[0][0][1]);
+#pragma unroll
+    for (int kp = 0; kp < NKP; ++kp)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        if (kp == 0 && tt == 0) {
+          mx = vmax3(mx, s[0][0][2], s[0][0][3]);
+        } else {
+          mx = vmax3(mx, s[kp][tt][0], s[kp][tt][1]);
+          mx = vmax3(mx, s[kp][tt][2], s[kp][tt][3]);
+        }
+      }
+    mx = rows_allreduce<true>(mx);
+    const float mn = mx * c2;                        // c2 > 0: max and scaling commute
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < NKP; ++kp) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[kp][tt][r], c2, -mn));
+          s[kp][tt][r] = e;
+          l += e;
+        }
+      const V8 pf = pack_pair<E>(s[kp][0], s[kp][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = Elem16<E>::mma(img_tr_frag<E>(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt]);
     }
+    l = rows_allreduce<false>(l);
+    const float inv = 1.0f / l;
+    const int qi = qt * 16 + li;
+    store_tile<E>(patch, ob, p.o_sl, qt * 16, p.Lq, o, inv, lane);
+    if (qi < p.Lq && g == 0) lse[qi] = (mn + __builtin_amdgcn_logf(l)) * kLn2;
   }
 }
 
 // ---------------------------------------------------------------- backward: dq
-// Query on the lane.  dQ^T[d][q] = sum_key K[key][d] * dS^T[key][q].
-template <typename E>
+// Query on the lane.  dQ^T[d][q] = scale * sum_key K[key][d] * (P (dP - delta))^T[key][q].
+// NKP > 0: the key loop has a compile-time trip count and is fully unrolled, so the LDS reads, MFMAs and the
+// exp / multiply work of different 32-key steps overlap (a rolled loop serialises read -> MFMA -> VALU -> MFMA per step
+// and two or three waves per SIMD cannot hide that chain); NKP == 0 keeps the rolled loop for any length.
+// Keys >= Lk only exist in the last step; their K rows are zero, the explicit zero keeps inf * 0 out of the MFMA.
+template <typename E, int NKP>
 __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -393,34 +569,46 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams
   const E* gb = (const E*)p.d_o + b * p.o_sb + h * p.o_sh;
   E* dqb = (E*)p.dq + b * p.q_sb + h * p.q_sh;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  float* delta = p.delta + ((int64_t)b * p.H + h) * p.Lq;
   char* ks = smem;
   char* vs = smem + p.Lkp * kRowBytes;
-  stage_image<E>(ks, kb, p.k_sl, p.Lk, p.Lkp);
-  stage_image<E>(vs, vb, p.v_sl, p.Lk, p.Lkp);
+  const int nqt = (p.Lq + 15) >> 4, nkp = NKP ? NKP : p.Lkp >> 5;
+  auto load_rows = [&](int qt, V8* qf, V8* gf, V8* of, float& l2) {
+    const int qi = qt * 16 + li;
+    const int qrow = qi < p.Lq ? qi : p.Lq - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = *reinterpret_cast<const V8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
+      gf[kk] = *reinterpret_cast<const V8*>(gb + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+      of[kk] = *reinterpret_cast<const V8*>(ob + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+    }
+    l2 = lse[qrow] * kLog2e;                         // lse in log2 units
+  };
+  V8 qf[2], gf[2], of[2];
+  float l2;
+  load_rows(wid, qf, gf, of, l2);                    // in flight while K / V are staged
+  stage_images<E>(ks, kb, p.k_sl, vs, vb, p.v_sl, p.Lk, p.Lkp);
   __syncthreads();
 
   const float c2 = p.scale * kLog2e;
-  const int nqt = (p.Lq + 15) >> 4, nkp = p.Lkp >> 5;
+  char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
   for (int qt = wid; qt < nqt; qt += W) {
-    const int qi = qt * 16 + li;
-    const int qrow = qi < p.Lq ? qi : p.Lq - 1;
-    typename Elem16<E>::v8 qf[2], gf[2];
+    asm volatile("" ::: "memory");                   // K / V fragments are loop-invariant: keep their LDS reads in the loop
     float dl = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      qf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
-      gf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(gb + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
-      const typename Elem16<E>::v8 of = *reinterpret_cast<const typename Elem16<E>::v8*>(ob + (int64_t)qrow * p.o_sl + kk * 32 + g * 8);
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dl = fmaf((float)gf[kk][j], (float)of[j], dl);
-    }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);          // delta of query li
-    const float l2 = lse[qrow] * kLog2e;   // lse in log2 units
+      for (int j = 0; j < 8; ++j) dl = fmaf((float)gf[kk][j], (float)of[kk][j], dl);
+    dl = rows_allreduce<false>(dl);                  // delta of query li
+    if (g == 0 && qt * 16 + li < p.Lq) delta[qt * 16 + li] = dl;   // the dk/dv kernel reads it instead of O
+    V8 qn[2], gn[2];
+    float l2n;
+    load_rows(qt + W, qn, gn, of, l2n);              // next tile (rows clamp to Lq - 1: a harmless re-read at the end)
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kp = 0; kp < nkp; ++kp) {
+    auto step = [&](int kp, bool last) {
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -428,95 +616,118 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams
         dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          s[tt] = Elem16<E>::mma(
-              img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt]);
-          dp[tt] = Elem16<E>::mma(
-              img_row_frag<E>(vs, (2 * kp + tt) * 16, kk, g, li), gf[kk], dp[tt]);
+          s[tt] = Elem16<E>::mma(img_row_frag<E>(ks, (2 * kp + tt) * 16, kk, g, li), qf[kk], s[tt]);
+          dp[tt] = Elem16<E>::mma(img_row_frag<E>(vs, (2 * kp + tt) * 16, kk, g, li), gf[kk], dp[tt]);
         }
       }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = (2 * kp + tt) * 16 + 4 * g + r;
           const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2));
-          s[tt][r] = key < p.Lk ? pr * (dp[tt][r] - dl) * p.scale : 0.f;
+          s[tt][r] = pr * (dp[tt][r] - dl);
+          if (last && (2 * kp + tt) * 16 + 4 * g + r >= p.Lk) s[tt][r] = 0.f;
         }
-      const typename Elem16<E>::v8 dsf = pack_pair<E>(s[0], s[1]);
+      const V8 dsf = pack_pair<E>(s[0], s[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        acc[dt] = Elem16<E>::mma(
-            img_tr_frag<E>(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li), dsf, acc[dt]);
-    }
-    if (qi < p.Lq) {
+        acc[dt] = Elem16<E>::mma(img_tr_frag<E>(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li), dsf, acc[dt]);
+    };
+    if constexpr (NKP > 0) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store4<E>(dqb + (int64_t)qi * p.q_sl + dt * 16 + 4 * g, acc[dt], 1.0f);
+      for (int kp = 0; kp < NKP; ++kp) step(kp, kp == NKP - 1);
+    } else {
+      for (int kp = 0; kp < nkp - 1; ++kp) step(kp, false);
+      step(nkp - 1, true);
     }
+    store_tile<E>(patch, dqb, p.q_sl, qt * 16, p.Lq, acc, p.scale, lane);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = qn[kk];
+      gf[kk] = gn[kk];
+    }
+    l2 = l2n;
   }
 }
 
 // ---------------------------------------------------------------- backward: dk, dv
 // Key on the lane.  S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO row fragments
 // from LDS images, B = K / V rows straight from HBM);
-// dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key].
-template <typename E>
+// dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = scale * sum_q Q[q][d] (P (dP - delta))[q][key].
+// Rows >= Lq of the Q / dO images are zero and their lse / delta entries are 0, so they contribute exact zeros without
+// a mask.  NQP as NKP above.
+template <typename E, int NQP>
 __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
   const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
   const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
-  const E* ob = (const E*)p.o + b * p.o_sb + h * p.o_sh;
   const E* gb = (const E*)p.d_o + b * p.o_sb + h * p.o_sh;
   E* dkb = (E*)p.dk + b * p.k_sb + h * p.k_sh;
   E* dvb = (E*)p.dv + b * p.v_sb + h * p.v_sh;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* delta = p.delta + ((int64_t)b * p.H + h) * p.Lq;
   char* qs = smem;
   char* gs = smem + p.Lqp * kRowBytes;
   float* l2s = reinterpret_cast<float*>(smem + 2 * p.Lqp * kRowBytes);  // lse * log2e, [Lqp]
   float* dls = l2s + p.Lqp;                                              // delta, [Lqp]
-  stage_image<E>(qs, qb, p.q_sl, p.Lq, p.Lqp);
-  stage_image<E>(gs, gb, p.o_sl, p.Lq, p.Lqp);
-  // per-row statistics: 8 consecutive threads share one query row
-  for (int idx = threadIdx.x; idx < p.Lqp * 8; idx += blockDim.x) {
-    const int r = idx >> 3, c = idx & 7;
-    float d = 0.f;
-    if (r < p.Lq) {
-      const typename Elem16<E>::v8 a = *reinterpret_cast<const typename Elem16<E>::v8*>(gb + (int64_t)r * p.o_sl + c * 8);
-      const typename Elem16<E>::v8 o = *reinterpret_cast<const typename Elem16<E>::v8*>(ob + (int64_t)r * p.o_sl + c * 8);
+  const int nkt = (p.Lk + 15) >> 4, nqp = NQP ? NQP : p.Lqp >> 5;
+  auto load_rows = [&](int kt, V8* kf, V8* vf) {
+    const int kj = kt * 16 + li;
+    const int krow = kj < p.Lk ? kj : p.Lk - 1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d = fmaf((float)a[j], (float)o[j], d);
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kk] = *reinterpret_cast<const V8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
+      vf[kk] = *reinterpret_cast<const V8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
     }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (c == 0) {
-      dls[r] = d;
-      l2s[r] = r < p.Lq ? lse[r] * kLog2e : 0.f;
-    }
+  };
+#ifdef DVT_ATTN_TIMING
+  long long* tbuf = reinterpret_cast<long long*>(p.delta + (((int64_t)p.B * p.H * p.Lq + 1) & ~1ll)) + (int64_t)blockIdx.x * 8;
+  if (threadIdx.x == 0) {
+    tbuf[0] = __builtin_amdgcn_s_memtime();
+    tbuf[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    tbuf[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  }
+#endif
+  V8 kf[2], vf[2];
+  load_rows(wid, kf, vf);                            // in flight while Q / dO are staged
+  // per-row statistics: lse in log2 units and delta = rowsum(dO * O) (written by the dq kernel); 0 for padding rows.
+  // The first blockDim rows are fetched before the images so that everything shares one memory round trip.
+  const int sr = (int)threadIdx.x < p.Lq ? (int)threadIdx.x : p.Lq - 1;
+  const float lse0 = lse[sr], dl0 = delta[sr];
+  stage_images<E>(qs, qb, p.q_sl, gs, gb, p.o_sl, p.Lq, p.Lqp);
+  if ((int)threadIdx.x < p.Lqp) {
+    l2s[threadIdx.x] = (int)threadIdx.x < p.Lq ? lse0 * kLog2e : 0.f;
+    dls[threadIdx.x] = (int)threadIdx.x < p.Lq ? dl0 : 0.f;
+  }
+  for (int r = threadIdx.x + blockDim.x; r < p.Lqp; r += blockDim.x) {
+    l2s[r] = r < p.Lq ? lse[r] * kLog2e : 0.f;
+    dls[r] = r < p.Lq ? delta[r] : 0.f;
   }
   __syncthreads();
 
+#ifdef DVT_ATTN_TIMING
+  if (threadIdx.x == 0) tbuf[1] = __builtin_amdgcn_s_memtime();
+#endif
   const float c2 = p.scale * kLog2e;
-  const int nkt = (p.Lk + 15) >> 4, nqp = p.Lqp >> 5;
+  char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
   for (int kt = wid; kt < nkt; kt += W) {
-    const int kj = kt * 16 + li;
-    const int krow = kj < p.Lk ? kj : p.Lk - 1;
-    typename Elem16<E>::v8 kf[2], vf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      kf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
-      vf[kk] = *reinterpret_cast<const typename Elem16<E>::v8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
-    }
+    asm volatile("" ::: "memory");                   // Q / dO fragments are loop-invariant: keep their LDS reads in the loop
+#ifdef DVT_ATTN_TIMING
+    if (threadIdx.x == 0) tbuf[kt == wid ? 2 : 4] = __builtin_amdgcn_s_memtime();
+#endif
+    if (kt != wid) load_rows(kt, kf, vf);
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int qp = 0; qp < nqp; ++qp) {
+    auto step = [&](int qp) {
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -525,10 +736,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           // D[row = query 4g+r][col = key li]:  A = Q / dO rows (image), B = K / V rows (regs)
-          s[tt] = Elem16<E>::mma(
-              img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt]);
-          dp[tt] = Elem16<E>::mma(
-              img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt]);
+          s[tt] = Elem16<E>::mma(img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt]);
+          dp[tt] = Elem16<E>::mma(img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt]);
         }
       }
 #pragma unroll
@@ -538,28 +747,209 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
         const f32x4 dl = *reinterpret_cast<const f32x4*>(dls + q0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = (q0 + r) < p.Lq ? __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r])) : 0.f;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r]));
           s[tt][r] = pr;
-          dp[tt][r] = pr * (dp[tt][r] - dl[r]) * p.scale;
+          dp[tt][r] = pr * (dp[tt][r] - dl[r]);
         }
       }
-      const typename Elem16<E>::v8 pf = pack_pair<E>(s[0], s[1]);
-      const typename Elem16<E>::v8 dsf = pack_pair<E>(dp[0], dp[1]);
+      const V8 pf = pack_pair<E>(s[0], s[1]);
+      const V8 dsf = pack_pair<E>(dp[0], dp[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = Elem16<E>::mma(
-            img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt]);
-        dk[dt] = Elem16<E>::mma(
-            img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt]);
+        dv[dt] = Elem16<E>::mma(img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt]);
+        dk[dt] = Elem16<E>::mma(img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt]);
       }
+    };
+    if constexpr (NQP > 0) {
+#pragma unroll
+      for (int qp = 0; qp < NQP; ++qp) step(qp);
+    } else {
+      for (int qp = 0; qp < nqp; ++qp) step(qp);
     }
-    if (kj < p.Lk) {
+    store_tile<E>(patch, dkb, p.k_sl, kt * 16, p.Lk, dk, p.scale, lane);
+    store_tile<E>(patch, dvb, p.v_sl, kt * 16, p.Lk, dv, 1.0f, lane);
+#ifdef DVT_ATTN_TIMING
+    if (threadIdx.x == 0) tbuf[kt == wid ? 3 : 5] = __builtin_amdgcn_s_memtime();
+#endif
+  }
+}
+
+// ======================================================================= persistent backward (one workgroup per CU)
+// The workgroup dispatcher keeps only ~1.5 of the 2 possible (head) workgroups resident per CU and every workgroup spends
+// a third of its life staging its images (tools/attn_timing_probe.py), so at >= 2 heads per CU the kernels below instead
+// run ONE workgroup per CU that walks heads blockIdx.x, blockIdx.x + gridDim.x, ...: the images of head i+1 arrive by
+// LDS-DMA (global_load_lds, 1 KiB pieces, swizzle on the source chunk, padding rows from a zero page) into the second LDS
+// buffer while head i computes; one barrier per head; each wave owns the same 16-row tile of every head, prefetches its
+// register operands of the next head a whole compute phase ahead.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __attribute__((aligned(16))) unsigned int attn_zero16[4] = {0u, 0u, 0u, 0u};
+
+// pieces (8 rows) of an image are dealt to the waves round-robin starting at wave `first`
+template <typename E>
+__device__ __forceinline__ void dma_image(char* img, const E* src, int64_t sl, int L, int rows_pad, int wid, int W,
+                                          int lane, int first) {
+  for (int pc = (wid - first % W + W) % W; pc < (rows_pad >> 3); pc += W) {
+    const int r = pc * 8 + (lane >> 3), slot = lane & 7;
+    const int c = (((slot >> 1) ^ ((r >> 1) & 3)) << 1) | (slot & 1);
+    const E* s = r < L ? src + (int64_t)r * sl + c * 8 : reinterpret_cast<const E*>(attn_zero16);
+    dvt_dma16(s, img + pc * 1024);
+  }
+}
+
+// lane id recomputed where it is needed: a lane-derived address kept live across the head loop gets spilled, and the
+// reload's compiler-inserted vmcnt(0) would serialise the DMA pieces behind the stores issued just before them
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// dk / dv: wave w owns key tile w of every head (blockDim = 64 * number of key tiles <= 1024, >= Lqp threads).
+// LDS: 2 x { Q image, dO image, lse * log2e [Lqp], delta [Lqp] }.
+template <typename E, int NQP>
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_persist_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  using V4 = typename Elem16<E>::v4;
+  constexpr int Lqp = NQP * 32, kImg = Lqp * kRowBytes, kBuf = 2 * kImg + 2 * Lqp * 4;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
+  const int nbh = p.B * p.H;
+  const float c2 = p.scale * kLog2e;
+
+  // The next head's traffic is issued in slices between the compute steps (a burst after the barrier would fill the CU's
+  // memory pipeline and hold every wave at its first load): slice j of a wave = its j-th 1 KiB DMA piece of the two
+  // images (56 pieces dealt round-robin), `live` false (no next head) points the DMA at the zero page.
+  constexpr int kPieces = 2 * (Lqp >> 3);
+  auto issue_piece = [&](int bh, int bi, int j, bool live) {
+    const int pc = wid + j * W;
+    if (pc >= kPieces) return;                       // wave-uniform
+    const int lane = fresh_lane();
+    const bool second = pc >= (Lqp >> 3);
+    const int pi = second ? pc - (Lqp >> 3) : pc;
+    const int b = bh / p.H, h = bh % p.H;
+    const E* src = second ? (const E*)p.d_o + b * p.o_sb + h * p.o_sh : (const E*)p.q + b * p.q_sb + h * p.q_sh;
+    const int64_t sl = second ? p.o_sl : p.q_sl;
+    const int r = pi * 8 + (lane >> 3), slot = lane & 7;
+    const int c = (((slot >> 1) ^ ((r >> 1) & 3)) << 1) | (slot & 1);
+    const E* sp = (live && r < p.Lq) ? src + (int64_t)r * sl + c * 8 : reinterpret_cast<const E*>(attn_zero16);
+    dvt_dma16(sp, smem + bi * kBuf + (second ? kImg : 0) + pi * 1024);
+  };
+  auto issue_rows = [&](int bh, V8* kn, V8* vn, float& lsn, float& dln) {
+    const int lane = fresh_lane();
+    const int g = lane >> 4, kj = wid * 16 + (lane & 15), tid = wid * 64 + lane;
+    const int krow = kj < p.Lk ? kj : p.Lk - 1;
+    const int sr = tid < p.Lq ? tid : p.Lq - 1;
+    const int b = bh / p.H, h = bh % p.H;
+    const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+    const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+    lsn = p.lse[(int64_t)bh * p.Lq + sr];
+    dln = p.delta[(int64_t)bh * p.Lq + sr];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kn[kk] = *reinterpret_cast<const V8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
+      vn[kk] = *reinterpret_cast<const V8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
+    }
+  };
+  auto put_stats = [&](int bi, float lsn, float dln) {
+    const int tid = wid * 64 + fresh_lane();
+    float* l2s = reinterpret_cast<float*>(smem + bi * kBuf + 2 * kImg);
+    if (tid < Lqp) {
+      l2s[tid] = tid < p.Lq ? lsn * kLog2e : 0.f;
+      l2s[Lqp + tid] = tid < p.Lq ? dln : 0.f;
+    }
+  };
+  char* patch = smem + 2 * kBuf + wid * 2048;
+  V8 kf[2], vf[2], kn[2], vn[2];
+  float lsn, dln;
+  int bh = blockIdx.x;
+  for (int j = 0; j * W < kPieces; ++j) issue_piece(bh, 0, j, true);
+  issue_rows(bh, kf, vf, lsn, dln);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  put_stats(0, lsn, dln);
+#ifdef DVT_ATTN_TIMING
+  long long* tb = reinterpret_cast<long long*>(p.delta + (((int64_t)p.B * p.H * p.Lq + 1) & ~1ll)) + (int64_t)blockIdx.x * 128;
+#define DVT_STAMP(i) if ((threadIdx.x & 63) == 0 && it == 3) tb[wid * 5 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define DVT_STAMP(i)
+#endif
+  for (int it = 0; bh < nbh; ++it, bh += gridDim.x) {
+    DVT_STAMP(0);
+    // every wave's pieces of this head have landed, its statistics are written, and everybody is done with the other buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    DVT_STAMP(1);
+    const int nx = bh + gridDim.x;
+    const bool more = nx < nbh;
+    const int nxc = more ? nx : bh;                  // no next head: the slices re-read this one's rows / the zero page
+    DVT_STAMP(2);
+    const int lane = fresh_lane();
+    const int g = lane >> 4, li = lane & 15;
+    const char* qs = smem + (it & 1) * kBuf;
+    const char* gs = qs + kImg;
+    const float* l2s = reinterpret_cast<const float*>(qs + 2 * kImg);
+    const float* dls = l2s + Lqp;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int qp = 0; qp < NQP; ++qp) {
+      // this step's slice of the next head: VMEM may not cross the fences (0x78f: everything else may)
+      __builtin_amdgcn_sched_barrier(0x78f);
+      for (int j = qp; j * W < kPieces; j += NQP) issue_piece(nxc, (it + 1) & 1, j, more);
+      if (qp == NQP / 2) issue_rows(nxc, kn, vn, lsn, dln);
+      __builtin_amdgcn_sched_barrier(0x78f);
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          s[tt] = Elem16<E>::mma(img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt]);
+          dp[tt] = Elem16<E>::mma(img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt]);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int q0 = (2 * qp + tt) * 16 + 4 * g;
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(l2s + q0);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(dls + q0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r]));
+          s[tt][r] = pr;
+          dp[tt][r] = pr * (dp[tt][r] - dl[r]);
+        }
+      }
+      const V8 pf = pack_pair<E>(s[0], s[1]);
+      const V8 dsf = pack_pair<E>(dp[0], dp[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store4<E>(dkb + (int64_t)kj * p.k_sl + dt * 16 + 4 * g, dk[dt], 1.0f);
-        store4<E>(dvb + (int64_t)kj * p.v_sl + dt * 16 + 4 * g, dv[dt], 1.0f);
+        dv[dt] = Elem16<E>::mma(img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt]);
+        dk[dt] = Elem16<E>::mma(img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt]);
       }
     }
+    {
+      const int b = bh / p.H, h = bh % p.H;
+      store_tile<E>(patch, (E*)p.dk + b * p.k_sb + h * p.k_sh, p.k_sl, wid * 16, p.Lk, dk, p.scale, lane);
+      store_tile<E>(patch, (E*)p.dv + b * p.v_sb + h * p.v_sh, p.v_sl, wid * 16, p.Lk, dv, 1.0f, lane);
+    }
+    DVT_STAMP(3);
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      put_stats((it + 1) & 1, lsn, dln);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        kf[kk] = kn[kk];
+        vf[kk] = vn[kk];
+      }
+    }
+    DVT_STAMP(4);
   }
 }
 
@@ -591,6 +981,7 @@ int fill_params(const dvt_attn_desc* d, AttnParams& p, bool bwd, const char* nam
   }
   p.Lkp = (p.Lk + 31) & ~31;
   p.Lqp = (p.Lq + 31) & ~31;
+  p.patch_off = -1;
   return DVT_OK;
 }
 
@@ -617,10 +1008,25 @@ bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
 // leave room for only one workgroup per CU (long sequences: > 80 KiB of LDS), that workgroup may use all 16 wave slots
 // (the kernels need <= 115 VGPRs, i.e. 4 waves per SIMD fit).
 int pick_waves(int tiles, size_t lds_bytes) {
+#ifdef DVT_ATTN_TIMING
+  if (const char* e = getenv("DVT_ATTN_W")) return atoi(e);
+#endif
   const int maxw = lds_bytes > 80 * 1024 ? 16 : 8;
   const int rounds = (tiles + maxw - 1) / maxw;
   int w = (tiles + rounds - 1) / rounds;
   return w < 1 ? 1 : w;
+}
+
+// LDS bytes including the per-wave 2 KiB output patches (store_tile) when they keep the occupancy the images allow
+// (two workgroups per CU up to 80 KiB); sets p.patch_off
+size_t with_patches(size_t lds, int waves, AttnParams& p) {
+  const size_t tot = lds + (size_t)waves * 2048;
+  bool ok = lds <= 80 * 1024 ? 2 * tot <= (size_t)kMaxLds : tot <= (size_t)kMaxLds;
+#ifdef DVT_ATTN_TIMING
+  if (getenv("DVT_ATTN_NOPATCH")) ok = false;
+#endif
+  p.patch_off = ok ? (int)lds : -1;
+  return ok ? tot : lds;
 }
 
 template <typename K>
@@ -636,6 +1042,9 @@ extern "C" {
 
 size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* d) {
   if (!d) return 0;
+#ifdef DVT_ATTN_TIMING
+  return ((size_t)d->B * (size_t)d->H * (size_t)d->Lq + 2) * sizeof(float) + (size_t)d->B * d->H * 64 + 256 * 128 * 8;
+#endif
   return (size_t)d->B * (size_t)d->H * (size_t)d->Lq * sizeof(float);
 }
 
@@ -646,12 +1055,25 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   if (p.B == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   if (mfma_fwd_ok(d, p)) {
-    const size_t lds = (size_t)2 * p.Lkp * kRowBytes;
-    const int W = pick_waves((p.Lq + 15) / 16, lds);
+    const size_t lds_img = (size_t)2 * p.Lkp * kRowBytes;
+    const int W = pick_waves((p.Lq + 15) / 16, lds_img);
+    const size_t lds = with_patches(lds_img, W, p);
+    const dim3 grid((unsigned)(p.B * p.H)), block(64 * W);
+#define DVT_ATTN_FWD_RES(NKP)                                                               \
+  case NKP:                                                                                 \
+    set_lds(attn_fwd_mfma_res_kernel<E, NKP>, lds);                                         \
+    hipLaunchKernelGGL((attn_fwd_mfma_res_kernel<E, NKP>), grid, block, lds, st, p);        \
+    break
     DVT_DISPATCH_16BIT(d->dtype, E, {
-      set_lds(attn_fwd_mfma_kernel<E>, lds);
-      hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)), dim3(64 * W), lds, st, p);
+      switch (p.Lkp >> 5) {                      // scores of up to 224 keys stay in registers (256 would spill)
+        DVT_ATTN_FWD_RES(1); DVT_ATTN_FWD_RES(2); DVT_ATTN_FWD_RES(3); DVT_ATTN_FWD_RES(4);
+        DVT_ATTN_FWD_RES(5); DVT_ATTN_FWD_RES(6); DVT_ATTN_FWD_RES(7);
+        default:
+          set_lds(attn_fwd_mfma_kernel<E>, lds);
+          hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), grid, block, lds, st, p);
+      }
     });
+#undef DVT_ATTN_FWD_RES
     DVT_LAUNCH_CHECK("dvt_attention_fwd(mfma)");
     return DVT_OK;
   }
@@ -682,16 +1104,63 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   if (p.B == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   if (mfma_bwd_ok(d, p)) {
-    const size_t lds_q = (size_t)2 * p.Lkp * kRowBytes;
-    const size_t lds_kv = (size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float);
+    DVT_REQUIRE(d->workspace, "dvt_attention_bwd: workspace (dvt_attention_bwd_workspace_bytes) required");
+    p.delta = (float*)d->workspace;             // dq kernel -> dk/dv kernel
+    const size_t img_q = (size_t)2 * p.Lkp * kRowBytes;
+    const size_t img_kv = (size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float);
+    const dim3 grid((unsigned)(p.B * p.H));
+    const int wq = pick_waves((p.Lq + 15) / 16, img_q), wkv = pick_waves((p.Lk + 15) / 16, img_kv);
+    const dim3 block_q(64 * wq), block_kv(64 * wkv);
+    AttnParams pq = p, pkv = p;
+    const size_t lds_q = with_patches(img_q, wq, pq), lds_kv = with_patches(img_kv, wkv, pkv);
+#define DVT_ATTN_BWD_DQ(NKP)                                                                \
+  case NKP:                                                                                 \
+    set_lds(attn_bwd_dq_mfma_kernel<E, NKP>, lds_q);                                        \
+    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, NKP>), grid, block_q, lds_q, st, pq);     \
+    break
+#define DVT_ATTN_BWD_DKV(NQP)                                                               \
+  case NQP:                                                                                 \
+    set_lds(attn_bwd_dkv_mfma_kernel<E, NQP>, lds_kv);                                      \
+    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, NQP>), grid, block_kv, lds_kv, st, pkv);  \
+    break
     DVT_DISPATCH_16BIT(d->dtype, E, {
-      set_lds(attn_bwd_dq_mfma_kernel<E>, lds_q);
-      set_lds(attn_bwd_dkv_mfma_kernel<E>, lds_kv);
-      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
-                         dim3(64 * pick_waves((p.Lq + 15) / 16, lds_q)), lds_q, st, p);
-      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E>), dim3((unsigned)(p.B * p.H)),
-                         dim3(64 * pick_waves((p.Lk + 15) / 16, lds_kv)), lds_kv, st, p);
+      switch (p.Lkp >> 5) {                      // unrolled key loop up to 256 keys
+        DVT_ATTN_BWD_DQ(1); DVT_ATTN_BWD_DQ(2); DVT_ATTN_BWD_DQ(3); DVT_ATTN_BWD_DQ(4);
+        DVT_ATTN_BWD_DQ(5); DVT_ATTN_BWD_DQ(6); DVT_ATTN_BWD_DQ(7); DVT_ATTN_BWD_DQ(8);
+        default:
+          set_lds(attn_bwd_dq_mfma_kernel<E, 0>, lds_q);
+          hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 0>), grid, block_q, lds_q, st, pq);
+      }
+      // >= 2 heads per CU: one persistent workgroup per CU (wave w = key tile w), double-buffered LDS-DMA
+      const int nkt = (p.Lk + 15) / 16, nqp = p.Lqp >> 5;
+      const size_t lds_p = 2 * ((size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float)) + (size_t)nkt * 2048;
+      bool persist_allowed = true;
+#ifdef DVT_ATTN_TIMING
+      if (getenv("DVT_ATTN_NOPERSIST")) persist_allowed = false;
+#endif
+      const bool persist = persist_allowed && nqp <= 8 && nkt >= 8 && nkt <= 16 && 64 * nkt >= p.Lqp && lds_p <= (size_t)kMaxLds &&
+                           (int64_t)p.B * p.H >= 2 * (int64_t)dvt_num_cus();
+      const dim3 grid_p((unsigned)dvt_num_cus()), block_p(64 * nkt);
+#define DVT_ATTN_BWD_DKV_P(NQP)                                                                        \
+  case NQP:                                                                                            \
+    set_lds(attn_bwd_dkv_persist_kernel<E, NQP>, lds_p);                                               \
+    hipLaunchKernelGGL((attn_bwd_dkv_persist_kernel<E, NQP>), grid_p, block_p, lds_p, st, p);          \
+    break
+      if (persist) switch (nqp) {
+        DVT_ATTN_BWD_DKV_P(1); DVT_ATTN_BWD_DKV_P(2); DVT_ATTN_BWD_DKV_P(3); DVT_ATTN_BWD_DKV_P(4);
+        DVT_ATTN_BWD_DKV_P(5); DVT_ATTN_BWD_DKV_P(6); DVT_ATTN_BWD_DKV_P(7); DVT_ATTN_BWD_DKV_P(8);
+      }
+      else switch (nqp) {                        // unrolled query loop up to 256 queries
+        DVT_ATTN_BWD_DKV(1); DVT_ATTN_BWD_DKV(2); DVT_ATTN_BWD_DKV(3); DVT_ATTN_BWD_DKV(4);
+        DVT_ATTN_BWD_DKV(5); DVT_ATTN_BWD_DKV(6); DVT_ATTN_BWD_DKV(7); DVT_ATTN_BWD_DKV(8);
+        default:
+          set_lds(attn_bwd_dkv_mfma_kernel<E, 0>, lds_kv);
+          hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, 0>), grid, block_kv, lds_kv, st, pkv);
+      }
     });
+#undef DVT_ATTN_BWD_DQ
+#undef DVT_ATTN_BWD_DKV
+#undef DVT_ATTN_BWD_DKV_P
     DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
     return DVT_OK;
   }

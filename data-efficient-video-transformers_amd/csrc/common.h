@@ -199,3 +199,16 @@ __device__ __forceinline__ bool dvt_dropout_keep(uint64_t seed, uint64_t base, u
     else if ((dtype) == DVT_F16) { typedef f16 E; __VA_ARGS__; }            \
     else DVT_UNSUPPORTED("dtype %d is not a 16-bit MFMA element type", (int)(dtype)); \
   } while (0)
+
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, LDS destination = wave-uniform base + 16 * lane), issued from inline
+// asm so that the compiler's wait-count pass does not see it: that pass models an LDS-DMA as a pending LDS write and, with
+// no alias scopes on dynamic LDS, waits vmcnt(0) before the next ds_read -- i.e. right after the issue, serialising the
+// very transfer the pipeline overlaps with compute.  Ordering is by the hand-placed s_waitcnt vmcnt(N) + s_barrier.
+// (The compiler's own vmcnt(N) for ordinary loads stays correct: uncounted younger operations only make it wait longer.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dvt_dma16(const void* src, const char* lds_dst) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);   // generic LDS address: low word = offset
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop

@@ -75,7 +75,7 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
       gmn = gmn < mn_lim ? gmn : mn_lim - 8;
       src = base + (int64_t)(k0 + k) * ld + gmn;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + piece * 1024), 16, 0, 0);
+    dvt_dma16(src, tile + piece * 1024);
   }
 }
 
@@ -113,7 +113,7 @@ struct ConvRows {
       const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
       const bf16* src = ok ? p.A + ((int64_t)(pix[i] + hi * p.cW + wi) * p.cC + c0 + coff[i])
                            : reinterpret_cast<const bf16*>(dvt_zero16);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wid * PPW + i) * 1024), 16, 0, 0);
+      dvt_dma16(src, tile + (wid * PPW + i) * 1024);
     }
   }
 };
@@ -151,7 +151,7 @@ struct ConvColsMN {
       const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
       const bf16* src = ok ? p.A + ((int64_t)((n * p.cH + hi) * p.cW + wi) * p.cC + ci[i])
                            : reinterpret_cast<const bf16*>(dvt_zero16);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wid * PPW + i) * 1024), 16, 0, 0);
+      dvt_dma16(src, tile + (wid * PPW + i) * 1024);
     }
   }
 };
