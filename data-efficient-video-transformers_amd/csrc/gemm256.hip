@@ -35,6 +35,7 @@ namespace {
 template <int CFG> struct Cfg;
 template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
+template <> struct Cfg<2> { enum { TM = 256, TN = 256, TK = 32, NW = 8, WN = 4, NSTG = 4 }; };   // 3 k-tiles (96 KiB) in flight
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
 constexpr int kEpiBytes = 32 * kEpiStride * 4;   // 8,704 B per wave
@@ -192,8 +193,10 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -271,11 +274,30 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
   for (int kt = 0; kt < nk; ++kt) {
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
-    if (NSTG == 3 && kt + 1 < nk) wait_vm<kPPT>();
-    else wait_vm<0>();
+    {
+      const int young = min(NSTG - 2, nk - 1 - kt);   // k-tiles issued after kt
+      if (NSTG >= 4 && young == 2) wait_vm<2 * kPPT>();
+      else if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
+      else wait_vm<0>();
+    }
     // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
     //     stage that the DMA below overwrites (it was consumed in iteration kt-1)
     __builtin_amdgcn_s_barrier();
+    const char* sa = smem + st_cur * kStage;
+    const char* sb = sa + kATile;
+    // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
+    // wave's 128 rows): the fragment reads of block b+1 are issued BEFORE the MFMAs of block b, into the other half of
+    // a double register buffer, so their LDS latency runs under 16 MFMAs instead of behind them.
+    constexpr int NB = DVT_ABL == 1 ? 0 : 2 * (TK / 32);
+    V8 bfr[2][4], af[2][4];
+    if (NB > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bfr[0][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, 0, g, li);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + t * 16, 0, g, li);
+    }
+    // the next k-tile's DMA is issued behind the first fragment reads: its address arithmetic runs under their latency
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
       if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
@@ -283,27 +305,30 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
     }
-    const char* sa = smem + st_cur * kStage;
-    const char* sb = sa + kATile;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < (DVT_ABL == 1 ? 0 : TK / 32); ++kk) {
-      V8 bfr[4];
+    for (int b = 0; b < NB; ++b) {
+      const int kk = b >> 1, th = b & 1;
+      if (b + 1 < NB) {
+        const int kk1 = (b + 1) >> 1, th1 = (b + 1) & 1;
+        if (th1 == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bfr[u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
+          for (int u = 0; u < 4; ++u) bfr[kk1 & 1][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk1, g, li);
+        }
 #pragma unroll
-      for (int th = 0; th < 2; ++th) {
-        V8 af[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (th * 4 + t) * 16, kk, g, li);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[u][th * 4 + t] = Elem16<E>::mma(bfr[u], af[t], acc[u][th * 4 + t]);
-        __builtin_amdgcn_s_setprio(0);
+        for (int t = 0; t < 4; ++t)
+          af[(b + 1) & 1][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (th1 * 4 + t) * 16, kk1, g, li);
       }
-      if (kCanColsum && do_cs) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[u][th * 4 + t] = Elem16<E>::mma(bfr[kk & 1][u], af[b & 1][t], acc[u][th * 4 + t]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kCanColsum && do_cs && th == 1) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
           csum[tt] = Elem16<E>::mma(ones, frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (2 * wn + tt) * 16, kk, g, li),
@@ -510,6 +535,7 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
   if (p.elem == DVT_F16)       // fp16: the 256x256x64 configuration only (cfg 1 is an experiment knob)
     return launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
+  if (cfg == 2) return launch_cfg<bf16, 2>(p, a_kmajor, b_kmajor, split, st);
   return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
                   : launch_cfg<bf16, 1>(p, a_kmajor, b_kmajor, split, st);
 }
