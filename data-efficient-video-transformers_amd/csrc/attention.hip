@@ -314,7 +314,7 @@ __device__ __forceinline__ void store4(E* p, const f32x4& v, float s) {
 // A wave's 16 x 64 output tile (lane (g, li): row li, columns dt*16 + 4g .. +3 of accumulator dt), scaled, as whole
 // 128-byte rows: transposed through a wave-private 2 KiB LDS patch (16-byte chunks XOR-swizzled by (row >> 1) & 7) and
 // written with two fully coalesced 16-byte-per-lane stores.  The per-lane form (8 bytes at a row stride: sixteen 32-byte
-// fragments per instruction) costs ~150 cycles of the CU's memory pipeline per instruction (tools/attn_persist_timing.py).
+// fragments per instruction) costs ~150 cycles of the CU's memory pipeline per instruction (measured with per-wave s_memtime stamps).
 template <typename E>
 __device__ __forceinline__ void store_tile(char* patch, E* dst, int64_t row_stride, int row0, int row_lim,
                                            const f32x4* acc, float scale, int lane) {
@@ -774,185 +774,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
   }
 }
 
-// ======================================================================= persistent backward (one workgroup per CU)
-// The workgroup dispatcher keeps only ~1.5 of the 2 possible (head) workgroups resident per CU and every workgroup spends
-// a third of its life staging its images (tools/attn_timing_probe.py), so at >= 2 heads per CU the kernels below instead
-// run ONE workgroup per CU that walks heads blockIdx.x, blockIdx.x + gridDim.x, ...: the images of head i+1 arrive by
-// LDS-DMA (global_load_lds, 1 KiB pieces, swizzle on the source chunk, padding rows from a zero page) into the second LDS
-// buffer while head i computes; one barrier per head; each wave owns the same 16-row tile of every head, prefetches its
-// register operands of the next head a whole compute phase ahead.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-__device__ __attribute__((aligned(16))) unsigned int attn_zero16[4] = {0u, 0u, 0u, 0u};
-
-// pieces (8 rows) of an image are dealt to the waves round-robin starting at wave `first`
-template <typename E>
-__device__ __forceinline__ void dma_image(char* img, const E* src, int64_t sl, int L, int rows_pad, int wid, int W,
-                                          int lane, int first) {
-  for (int pc = (wid - first % W + W) % W; pc < (rows_pad >> 3); pc += W) {
-    const int r = pc * 8 + (lane >> 3), slot = lane & 7;
-    const int c = (((slot >> 1) ^ ((r >> 1) & 3)) << 1) | (slot & 1);
-    const E* s = r < L ? src + (int64_t)r * sl + c * 8 : reinterpret_cast<const E*>(attn_zero16);
-    dvt_dma16(s, img + pc * 1024);
-  }
-}
-
-// lane id recomputed where it is needed: a lane-derived address kept live across the head loop gets spilled, and the
-// reload's compiler-inserted vmcnt(0) would serialise the DMA pieces behind the stores issued just before them
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-
-// dk / dv: wave w owns key tile w of every head (blockDim = 64 * number of key tiles <= 1024, >= Lqp threads).
-// LDS: 2 x { Q image, dO image, lse * log2e [Lqp], delta [Lqp] }.
-template <typename E, int NQP>
-__global__ __launch_bounds__(1024) void attn_bwd_dkv_persist_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using V8 = typename Elem16<E>::v8;
-  using V4 = typename Elem16<E>::v4;
-  constexpr int Lqp = NQP * 32, kImg = Lqp * kRowBytes, kBuf = 2 * kImg + 2 * Lqp * 4;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
-  const int nbh = p.B * p.H;
-  const float c2 = p.scale * kLog2e;
-
-  // The next head's traffic is issued in slices between the compute steps (a burst after the barrier would fill the CU's
-  // memory pipeline and hold every wave at its first load): slice j of a wave = its j-th 1 KiB DMA piece of the two
-  // images (56 pieces dealt round-robin), `live` false (no next head) points the DMA at the zero page.
-  constexpr int kPieces = 2 * (Lqp >> 3);
-  auto issue_piece = [&](int bh, int bi, int j, bool live) {
-    const int pc = wid + j * W;
-    if (pc >= kPieces) return;                       // wave-uniform
-    const int lane = fresh_lane();
-    const bool second = pc >= (Lqp >> 3);
-    const int pi = second ? pc - (Lqp >> 3) : pc;
-    const int b = bh / p.H, h = bh % p.H;
-    const E* src = second ? (const E*)p.d_o + b * p.o_sb + h * p.o_sh : (const E*)p.q + b * p.q_sb + h * p.q_sh;
-    const int64_t sl = second ? p.o_sl : p.q_sl;
-    const int r = pi * 8 + (lane >> 3), slot = lane & 7;
-    const int c = (((slot >> 1) ^ ((r >> 1) & 3)) << 1) | (slot & 1);
-    const E* sp = (live && r < p.Lq) ? src + (int64_t)r * sl + c * 8 : reinterpret_cast<const E*>(attn_zero16);
-    dvt_dma16(sp, smem + bi * kBuf + (second ? kImg : 0) + pi * 1024);
-  };
-  auto issue_rows = [&](int bh, V8* kn, V8* vn, float& lsn, float& dln) {
-    const int lane = fresh_lane();
-    const int g = lane >> 4, kj = wid * 16 + (lane & 15), tid = wid * 64 + lane;
-    const int krow = kj < p.Lk ? kj : p.Lk - 1;
-    const int sr = tid < p.Lq ? tid : p.Lq - 1;
-    const int b = bh / p.H, h = bh % p.H;
-    const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
-    const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
-    lsn = p.lse[(int64_t)bh * p.Lq + sr];
-    dln = p.delta[(int64_t)bh * p.Lq + sr];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      kn[kk] = *reinterpret_cast<const V8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
-      vn[kk] = *reinterpret_cast<const V8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
-    }
-  };
-  auto put_stats = [&](int bi, float lsn, float dln) {
-    const int tid = wid * 64 + fresh_lane();
-    float* l2s = reinterpret_cast<float*>(smem + bi * kBuf + 2 * kImg);
-    if (tid < Lqp) {
-      l2s[tid] = tid < p.Lq ? lsn * kLog2e : 0.f;
-      l2s[Lqp + tid] = tid < p.Lq ? dln : 0.f;
-    }
-  };
-  char* patch = smem + 2 * kBuf + wid * 2048;
-  V8 kf[2], vf[2], kn[2], vn[2];
-  float lsn, dln;
-  int bh = blockIdx.x;
-  for (int j = 0; j * W < kPieces; ++j) issue_piece(bh, 0, j, true);
-  issue_rows(bh, kf, vf, lsn, dln);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  put_stats(0, lsn, dln);
-#ifdef DVT_ATTN_TIMING
-  long long* tb = reinterpret_cast<long long*>(p.delta + (((int64_t)p.B * p.H * p.Lq + 1) & ~1ll)) + (int64_t)blockIdx.x * 128;
-#define DVT_STAMP(i) if ((threadIdx.x & 63) == 0 && it == 3) tb[wid * 5 + (i)] = __builtin_amdgcn_s_memtime()
-#else
-#define DVT_STAMP(i)
-#endif
-  for (int it = 0; bh < nbh; ++it, bh += gridDim.x) {
-    DVT_STAMP(0);
-    // every wave's pieces of this head have landed, its statistics are written, and everybody is done with the other buffer
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    DVT_STAMP(1);
-    const int nx = bh + gridDim.x;
-    const bool more = nx < nbh;
-    const int nxc = more ? nx : bh;                  // no next head: the slices re-read this one's rows / the zero page
-    DVT_STAMP(2);
-    const int lane = fresh_lane();
-    const int g = lane >> 4, li = lane & 15;
-    const char* qs = smem + (it & 1) * kBuf;
-    const char* gs = qs + kImg;
-    const float* l2s = reinterpret_cast<const float*>(qs + 2 * kImg);
-    const float* dls = l2s + Lqp;
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int qp = 0; qp < NQP; ++qp) {
-      // this step's slice of the next head: VMEM may not cross the fences (0x78f: everything else may)
-      __builtin_amdgcn_sched_barrier(0x78f);
-      for (int j = qp; j * W < kPieces; j += NQP) issue_piece(nxc, (it + 1) & 1, j, more);
-      if (qp == NQP / 2) issue_rows(nxc, kn, vn, lsn, dln);
-      __builtin_amdgcn_sched_barrier(0x78f);
-      f32x4 s[2], dp[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          s[tt] = Elem16<E>::mma(img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li), kf[kk], s[tt]);
-          dp[tt] = Elem16<E>::mma(img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li), vf[kk], dp[tt]);
-        }
-      }
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int q0 = (2 * qp + tt) * 16 + 4 * g;
-        const f32x4 l2 = *reinterpret_cast<const f32x4*>(l2s + q0);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(dls + q0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r]));
-          s[tt][r] = pr;
-          dp[tt][r] = pr * (dp[tt][r] - dl[r]);
-        }
-      }
-      const V8 pf = pack_pair<E>(s[0], s[1]);
-      const V8 dsf = pack_pair<E>(dp[0], dp[1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = Elem16<E>::mma(img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li), pf, dv[dt]);
-        dk[dt] = Elem16<E>::mma(img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li), dsf, dk[dt]);
-      }
-    }
-    {
-      const int b = bh / p.H, h = bh % p.H;
-      store_tile<E>(patch, (E*)p.dk + b * p.k_sb + h * p.k_sh, p.k_sl, wid * 16, p.Lk, dk, p.scale, lane);
-      store_tile<E>(patch, (E*)p.dv + b * p.v_sb + h * p.v_sh, p.v_sl, wid * 16, p.Lk, dv, 1.0f, lane);
-    }
-    DVT_STAMP(3);
-    if (more) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      put_stats((it + 1) & 1, lsn, dln);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        kf[kk] = kn[kk];
-        vf[kk] = vn[kk];
-      }
-    }
-    DVT_STAMP(4);
-  }
-}
-
 // ======================================================================= host
 constexpr int kMaxLds = 160 * 1024;
 
@@ -1131,26 +952,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
           set_lds(attn_bwd_dq_mfma_kernel<E, 0>, lds_q);
           hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 0>), grid, block_q, lds_q, st, pq);
       }
-      // >= 2 heads per CU: one persistent workgroup per CU (wave w = key tile w), double-buffered LDS-DMA
-      const int nkt = (p.Lk + 15) / 16, nqp = p.Lqp >> 5;
-      const size_t lds_p = 2 * ((size_t)2 * p.Lqp * kRowBytes + (size_t)2 * p.Lqp * sizeof(float)) + (size_t)nkt * 2048;
-      bool persist_allowed = true;
-#ifdef DVT_ATTN_TIMING
-      if (getenv("DVT_ATTN_NOPERSIST")) persist_allowed = false;
-#endif
-      const bool persist = persist_allowed && nqp <= 8 && nkt >= 8 && nkt <= 16 && 64 * nkt >= p.Lqp && lds_p <= (size_t)kMaxLds &&
-                           (int64_t)p.B * p.H >= 2 * (int64_t)dvt_num_cus();
-      const dim3 grid_p((unsigned)dvt_num_cus()), block_p(64 * nkt);
-#define DVT_ATTN_BWD_DKV_P(NQP)                                                                        \
-  case NQP:                                                                                            \
-    set_lds(attn_bwd_dkv_persist_kernel<E, NQP>, lds_p);                                               \
-    hipLaunchKernelGGL((attn_bwd_dkv_persist_kernel<E, NQP>), grid_p, block_p, lds_p, st, p);          \
-    break
-      if (persist) switch (nqp) {
-        DVT_ATTN_BWD_DKV_P(1); DVT_ATTN_BWD_DKV_P(2); DVT_ATTN_BWD_DKV_P(3); DVT_ATTN_BWD_DKV_P(4);
-        DVT_ATTN_BWD_DKV_P(5); DVT_ATTN_BWD_DKV_P(6); DVT_ATTN_BWD_DKV_P(7); DVT_ATTN_BWD_DKV_P(8);
-      }
-      else switch (nqp) {                        // unrolled query loop up to 256 queries
+      switch (p.Lqp >> 5) {                      // unrolled query loop up to 256 queries
         DVT_ATTN_BWD_DKV(1); DVT_ATTN_BWD_DKV(2); DVT_ATTN_BWD_DKV(3); DVT_ATTN_BWD_DKV(4);
         DVT_ATTN_BWD_DKV(5); DVT_ATTN_BWD_DKV(6); DVT_ATTN_BWD_DKV(7); DVT_ATTN_BWD_DKV(8);
         default:
@@ -1160,7 +962,6 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     });
 #undef DVT_ATTN_BWD_DQ
 #undef DVT_ATTN_BWD_DKV
-#undef DVT_ATTN_BWD_DKV_P
     DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
     return DVT_OK;
   }
