@@ -200,6 +200,14 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef DVT_GEMM_TIMING
+// dev instrumentation (tools/gemm_timing.sh): per-workgroup s_memtime stamps {start, prologue issued, main loop done, end}
+__device__ long long* g_gemm_tb = nullptr;
+#define DVT_GSTAMP(i) if (threadIdx.x == 0 && g_gemm_tb) g_gemm_tb[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define DVT_GSTAMP(i)
+#endif
+
 // OUT: 0 = C in bf16 with the fused epilogue EPI, 1 = C in fp32 (optionally accumulated),
 //      2 = raw fp32 split-K slab.  EPI and OUT are compile-time so that the unrolled
 //      epilogue stays a few hundred instructions (a runtime switch replicated over the
@@ -242,6 +250,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (DVT_ABL == 5 || DVT_ABL == 6) ? 0 : (kend - kbeg) / TK;   // ablations 5/6: epilogue only
 
+  DVT_GSTAMP(0);
   f32x4 acc[4][8];  // [u: n sub-tile][t: m sub-tile]
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -271,8 +280,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
     }
+  DVT_GSTAMP(1);
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef DVT_GEMM_TIMING
+    const long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
     {
       const int young = min(NSTG - 2, nk - 1 - kt);   // k-tiles issued after kt
@@ -282,7 +295,19 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     }
     // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
     //     stage that the DMA below overwrites (it was consumed in iteration kt-1)
+#ifdef DVT_GEMM_TIMING
+    const long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef DVT_GEMM_TIMING
+    if (threadIdx.x == 0 && g_gemm_tb) {
+      const long long tw2 = __builtin_amdgcn_s_memtime();
+      long long* w = g_gemm_tb + (1 << 19) + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 2;
+      if (kt == 0) { w[0] = 0; w[1] = 0; }
+      w[0] += tw1 - tw0;
+      w[1] += tw2 - tw1;
+    }
+#endif
     const char* sa = smem + st_cur * kStage;
     const char* sb = sa + kATile;
     // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
@@ -339,6 +364,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     st_nxt = st_nxt + 1 == NSTG ? 0 : st_nxt + 1;
   }
   __builtin_amdgcn_s_barrier();                // all LDS reads done before the staging overlay
+  DVT_GSTAMP(2);
   if (kCanColsum && do_cs && g == 0) {         // every row of the ones-product is the column sum: take row 0
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -362,12 +388,18 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   const int64_t ldl = EPI == DVT_EPI_RESIDUAL ? p.ldr : p.ldaux;
   float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (OUT != OUT_SLAB && p.bias && n_ok) load8<float>(p.bias + n, bias);
-  V8 nxt[4];
+  // all sixteen residual / aux rows of the wave's four passes are requested up front (the fragment registers are dead
+  // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
+  V8 rs[kNeedLd ? 4 : 1][4];
+  if (kNeedLd) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    nxt[j] = V8{0, 0, 0, 0, 0, 0, 0, 0};
-    const int m = wrow0 + (lane >> 3) + 8 * j;
-    if (kNeedLd && n_ok && m < p.M) nxt[j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + n);
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
+        m = m < p.M ? m : p.M - 1;                    // clamped row: loaded unconditionally, never stored
+        rs[ps][j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + (n_ok ? n : 0));
+      }
   }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
@@ -387,14 +419,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       const f32x4 b = *reinterpret_cast<const f32x4*>(es + row * kEpiStride + c + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v[j][k] = a[k]; v[j][4 + k] = b[k]; }
-      cur[j] = nxt[j];
-    }
-    if (kNeedLd && ps + 1 < 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = wrow0 + (ps + 1) * 32 + (lane >> 3) + 8 * j;
-        if (n_ok && m < p.M) nxt[j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + n);
-      }
+      cur[j] = kNeedLd ? rs[kNeedLd ? ps : 0][j] : V8{0, 0, 0, 0, 0, 0, 0, 0};
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -432,7 +457,14 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     }
     wave_lds_fence();
   }
+  DVT_GSTAMP(3);
 }
+
+#ifdef DVT_GEMM_TIMING
+extern "C" int dvt_debug_gemm_timing_buffer(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tb), &buf, sizeof(buf));
+}
+#endif
 
 // ---------------------------------------------------------------- host side
 template <typename E, bool AK, bool BK, int CFG, int EPI, int OUT>
