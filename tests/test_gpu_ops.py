@@ -281,6 +281,10 @@ ATTN_CASES = [
     (1, 1, 64, 64, 64), (2, 2, 14, 14, 32), (1, 2, 15, 14, 448), (1, 4, 14, 15, 224),
     (2, 2, 325, 325, 64),          # long-clip tokens per frame (288^2): > 80 KiB of LDS, one 11-wave workgroup per CU
     (1, 2, 40, 600, 64),
+    # every compile-time key / query count of the register-resident forward (<= 224 keys) and the unrolled backward
+    # (<= 256), incl. Lq != Lk and the 225..256 band (online-softmax forward, unrolled backward)
+    (1, 2, 90, 90, 64), (1, 2, 100, 128, 64), (1, 1, 150, 150, 64), (1, 2, 180, 190, 64), (1, 1, 250, 250, 64),
+    (1, 1, 224, 224, 64),
 ]
 
 
