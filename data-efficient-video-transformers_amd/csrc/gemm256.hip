@@ -36,6 +36,7 @@ template <int CFG> struct Cfg;
 template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
 template <> struct Cfg<2> { enum { TM = 256, TN = 256, TK = 32, NW = 8, WN = 4, NSTG = 4 }; };   // 3 k-tiles (96 KiB) in flight
+template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2 }; };  // 16 waves of 64 x 64: 4 per SIMD
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
 constexpr int kEpiBytes = 32 * kEpiStride * 4;   // 8,704 B per wave
@@ -215,18 +216,20 @@ __device__ long long* g_gemm_tb = nullptr;
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
 template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false>
-__global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW / 4) void gemm_dma_kernel(const GemmParams p) {
   // A_CONV: the A operand is gathered from an NHWC map (k-major: forward / data gradient; mn-major: weight gradient)
   typedef Cfg<CFG> C;
   typedef typename Elem16<E>::v8 V8;
   constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
   constexpr int kATile = TM * TK * 2, kBTile = TN * TK * 2, kStage = kATile + kBTile;
   constexpr int kPPT = (kATile + kBTile) / 1024 / NW;   // DMA instructions per thread per k-tile
+  constexpr int WROWS = TM / (NW / WN);                 // rows of the tile owned by one wave (x 64 columns)
+  constexpr int MT = WROWS / 16, NTH = MT / 4;          // m sub-tiles per wave, 64-row halves per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;      // every wave owns 128 x 64
+  const int wm = wid / WN, wn = wid % WN;      // every wave owns WROWS x 64
   const int g = lane >> 4, li = lane & 15;
 
   // XCD-aware order over the combined (K-slice, tile) space.  Blocks b and b+8 share an XCD
@@ -251,15 +254,16 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   const int nk = (DVT_ABL == 5 || DVT_ABL == 6) ? 0 : (kend - kbeg) / TK;   // ablations 5/6: epilogue only
 
   DVT_GSTAMP(0);
-  f32x4 acc[4][8];  // [u: n sub-tile][t: m sub-tile]
+  f32x4 acc[4][MT];  // [u: n sub-tile][t: m sub-tile]
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fused bias gradient (weight-gradient launches only): each wave of the n-tile-0 workgroups
   // also accumulates sum_k A(m,k) for two of its eight m sub-tiles (wave wn takes t = 2wn, 2wn+1)
-  constexpr bool kCanColsum = !A_KMAJOR && OUT == OUT_SLAB && WN == 4;
+  constexpr bool kCanColsum = !A_KMAJOR && OUT == OUT_SLAB && WN == 4 && MT == 8;   // (a 16-wave build spills with it)
+  constexpr int CS = MT / 4;                          // m sub-tiles per wave whose column sums this wave takes (wave wn: CS*wn ..)
   const bool do_cs = kCanColsum && p.colsum_slab != nullptr && n0 == 0;
   f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   V8 ones;
@@ -313,13 +317,14 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
     // wave's 128 rows): the fragment reads of block b+1 are issued BEFORE the MFMAs of block b, into the other half of
     // a double register buffer, so their LDS latency runs under 16 MFMAs instead of behind them.
-    constexpr int NB = DVT_ABL == 1 ? 0 : 2 * (TK / 32);
-    V8 bfr[2][4], af[2][4];
-    if (NB > 0) {
+    constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
+    constexpr bool kPipe = NW <= 8;              // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
+    V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
+    if (NB > 0 && kPipe) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) bfr[0][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, 0, g, li);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + t * 16, 0, g, li);
+      for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + t * 16, 0, g, li);
     }
     // the next k-tile's DMA is issued behind the first fragment reads: its address arithmetic runs under their latency
     __builtin_amdgcn_sched_barrier(0);
@@ -333,16 +338,24 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int kk = b >> 1, th = b & 1;
-      if (b + 1 < NB) {
-        const int kk1 = (b + 1) >> 1, th1 = (b + 1) & 1;
+      const int kk = b / NTH, th = b % NTH;
+      if (!kPipe) {
+        if (th == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bfr[0][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + (th * 4 + t) * 16, kk, g, li);
+      }
+      if (kPipe && b + 1 < NB) {
+        const int kk1 = (b + 1) / NTH, th1 = (b + 1) % NTH;
         if (th1 == 0) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) bfr[kk1 & 1][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk1, g, li);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          af[(b + 1) & 1][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (th1 * 4 + t) * 16, kk1, g, li);
+          af[(b + 1) & 1][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + (th1 * 4 + t) * 16, kk1, g, li);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -350,13 +363,13 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[u][th * 4 + t] = Elem16<E>::mma(bfr[kk & 1][u], af[b & 1][t], acc[u][th * 4 + t]);
+          acc[u][th * 4 + t] = Elem16<E>::mma(bfr[kPipe ? (kk & 1) : 0][u], af[kPipe ? (b & 1) : 0][t], acc[u][th * 4 + t]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (kCanColsum && do_cs && th == 1) {
+      if (kCanColsum && do_cs && th == NTH - 1) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-          csum[tt] = Elem16<E>::mma(ones, frag<E, A_KMAJOR, TM, TK>(sa, wm * 128 + (2 * wn + tt) * 16, kk, g, li),
+        for (int tt = 0; tt < CS; ++tt)
+          csum[tt] = Elem16<E>::mma(ones, frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + (CS * wn + tt) * 16, kk, g, li),
                                     csum[tt]);
       }
     }
@@ -367,8 +380,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   DVT_GSTAMP(2);
   if (kCanColsum && do_cs && g == 0) {         // every row of the ones-product is the column sum: take row 0
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int m = m0 + wm * 128 + (2 * wn + tt) * 16 + li;
+    for (int tt = 0; tt < CS; ++tt) {
+      const int m = m0 + wm * WROWS + (CS * wn + tt) * 16 + li;
       if (m < p.M) p.colsum_slab[(int64_t)zsl * p.M + m] = csum[tt][0];
     }
   }
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   // loaded once, and the residual / aux rows of pass ps+1 are requested BEFORE the
   // stores of pass ps (the compiler then waits with a counted vmcnt, not vmcnt(0)).
   float* es = reinterpret_cast<float*>(smem + wid * kEpiBytes);
-  const int wrow0 = m0 + wm * 128, wcol0 = n0 + wn * 64;
+  const int wrow0 = m0 + wm * WROWS, wcol0 = n0 + wn * 64;
   const int c = (lane & 7) << 3;
   const int n = wcol0 + c;
   const bool n_ok = n < p.N;
@@ -390,10 +403,11 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
   if (OUT != OUT_SLAB && p.bias && n_ok) load8<float>(p.bias + n, bias);
   // all sixteen residual / aux rows of the wave's four passes are requested up front (the fragment registers are dead
   // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
-  V8 rs[kNeedLd ? 4 : 1][4];
+  constexpr int NPS = WROWS / 32;                      // passes of 32 rows
+  V8 rs[kNeedLd ? NPS : 1][4];
   if (kNeedLd) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
+    for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, 2) void gemm_dma_kernel(const Ge
       }
   }
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -483,8 +497,9 @@ int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipSt
 template <typename E, int CFG>
 int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t st) {
   typedef Cfg<CFG> C;
-  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
-  static_assert(kSmem >= C::NW * kEpiBytes, "epilogue staging must fit in the stage buffers");
+  constexpr int kStages = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  constexpr int kSmem = kStages >= C::NW * kEpiBytes ? kStages : C::NW * kEpiBytes;   // the staging overlays the stages
+  static_assert(kSmem <= 160 * 1024, "LDS budget");
   GemmParams p = pin;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
@@ -568,6 +583,7 @@ int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int s
   if (p.elem == DVT_F16)       // fp16: the 256x256x64 configuration only (cfg 1 is an experiment knob)
     return launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 2) return launch_cfg<bf16, 2>(p, a_kmajor, b_kmajor, split, st);
+  if (cfg == 3) return launch_cfg<bf16, 3>(p, a_kmajor, b_kmajor, split, st);
   return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
                   : launch_cfg<bf16, 1>(p, a_kmajor, b_kmajor, split, st);
 }
