@@ -601,7 +601,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
       pl.kps = (int)(dvt_cdiv(d->K, BK) * BK);
     }
     int split = pl.split;
-    GemmParams p;
+    GemmParams p{};
     p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
     p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -711,7 +711,7 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
     DVT_UNSUPPORTED("dvt_conv2d_implicit: needs a 16-bit dtype, C %% 64 == 0 (C %% 32 for Cout <= 128), Cout %% 8 == 0 and "
                     "16-byte aligned buffers");
   const int Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
-  GemmParams p;
+  GemmParams p{};
   p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
   p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = d->kh * d->kw * d->C;
   p.lda = 0; p.ldb = p.K; p.ldc = d->Cout;
@@ -770,7 +770,7 @@ int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
                     "the k-tile (32 for Cout <= 128, else 64)");
   DVT_REQUIRE(d->workspace, "dvt_conv2d_implicit_wgrad: workspace (dvt_conv2d_implicit_wgrad_workspace_bytes) required");
   hipStream_t st = (hipStream_t)stream;
-  GemmParams p;
+  GemmParams p{};
   p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
   p.M = pl.K; p.N = d->Cout; p.K = (int)pl.rows;
   p.lda = 0; p.ldb = d->Cout; p.ldc = d->Cout;

@@ -216,7 +216,7 @@ __device__ long long* g_gemm_tb = nullptr;
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
 template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false>
-__global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW / 4) void gemm_dma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void gemm_dma_kernel(const GemmParams p) {
   // A_CONV: the A operand is gathered from an NHWC map (k-major: forward / data gradient; mn-major: weight gradient)
   typedef Cfg<CFG> C;
   typedef typename Elem16<E>::v8 V8;
@@ -481,6 +481,15 @@ extern "C" int dvt_debug_gemm_timing_buffer(void* buf) {
 #endif
 
 // ---------------------------------------------------------------- host side
+// dynamic LDS of a configuration: the stage ring, or the epilogue staging that overlays it
+template <int CFG> constexpr int smem_bytes() {
+  typedef Cfg<CFG> C;
+  constexpr int stages = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  constexpr int epi = C::NW * kEpiBytes;
+  static_assert((stages >= epi ? stages : epi) <= 160 * 1024, "LDS budget");
+  return stages >= epi ? stages : epi;
+}
+
 template <typename E, bool AK, bool BK, int CFG, int EPI, int OUT>
 int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipStream_t st) {
   static bool attr_set = false;
@@ -497,9 +506,7 @@ int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipSt
 template <typename E, int CFG>
 int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t st) {
   typedef Cfg<CFG> C;
-  constexpr int kStages = C::NSTG * (C::TM + C::TN) * C::TK * 2;
-  constexpr int kSmem = kStages >= C::NW * kEpiBytes ? kStages : C::NW * kEpiBytes;   // the staging overlays the stages
-  static_assert(kSmem <= 160 * 1024, "LDS budget");
+  constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
@@ -527,7 +534,7 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
 template <typename E, int CFG>
 int launch_conv(const GemmParams& pin, hipStream_t st) {
   typedef Cfg<CFG> C;
-  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
@@ -546,7 +553,7 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
 template <typename E, int CFG>
 int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
   typedef Cfg<CFG> C;
-  constexpr int kSmem = C::NSTG * (C::TM + C::TN) * C::TK * 2;
+  constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
