@@ -92,6 +92,16 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// streaming (non-temporal) 16-byte store of 8 converted values: written once, read by a later kernel -- keeps the GEMM's
+// output stream from evicting the operand panels its neighbours on the XCD are re-reading from L2
+template <typename T> __device__ __forceinline__ void store8_nt(T* p, const float (&o)[8]) {
+  typedef T v8t __attribute__((ext_vector_type(8)));
+  v8t v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
+  __builtin_nontemporal_store(v, reinterpret_cast<v8t*>(p));
+}
+
 // ---------------------------------------------------------------- device: 16-bit MFMA element traits
 // bf16 and fp16 share every data path (LDS images, DMA, swizzles); only the matrix instruction, the
 // transposing LDS read and the conversions differ.

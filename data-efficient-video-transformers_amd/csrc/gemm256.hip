@@ -209,6 +209,15 @@ __device__ long long* g_gemm_tb = nullptr;
 #define DVT_GSTAMP(i)
 #endif
 
+#ifndef DVT_GEMM_NT
+#define DVT_GEMM_NT 1
+#endif
+#if DVT_GEMM_NT
+#define DVT_C_STORE(ptr, vals) store8_nt<E>(ptr, vals)
+#else
+#define DVT_C_STORE(ptr, vals) store8<E>(ptr, vals)
+#endif
+
 // OUT: 0 = C in bf16 with the fused epilogue EPI, 1 = C in fp32 (optionally accumulated),
 //      2 = raw fp32 split-K slab.  EPI and OUT are compile-time so that the unrolled
 //      epilogue stays a few hundred instructions (a runtime switch replicated over the
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       const int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
       if (m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
         if (OUT == OUT_SLAB) {
-          store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);
+          store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);   // re-read from cache by the reduce: streaming stores cost 10 %
         } else if (OUT == OUT_F32) {
           float* o = (float*)p.C + (int64_t)m * p.ldc + n;
 #pragma unroll
@@ -459,12 +468,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             const float ld = (float)cur[j][k];
             v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
-          if (EPI == DVT_EPI_GELU && p.aux) store8<E>((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
+          if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
           if (DVT_ABL == 6) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(v[j][k]));
           } else {
-            store8<E>((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
+            DVT_C_STORE((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
           }
         }
       }
