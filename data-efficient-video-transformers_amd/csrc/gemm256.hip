@@ -295,13 +295,20 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     }
   DVT_GSTAMP(1);
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
+  // kCross (4-stage ring of 32-wide k-tiles): k-tile kt+1 is required landed at the barrier of kt, so the first fragment
+  // reads of kt+1 are issued under the last MFMA block of kt -- no LDS latency is exposed behind a barrier.
+  constexpr bool kCross = NSTG >= 4 && TK == 32 && NW <= 8;
+  constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
+  constexpr bool kPipe = NW <= 8;                // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
+  V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef DVT_GEMM_TIMING
     const long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
     {
-      const int young = min(NSTG - 2, nk - 1 - kt);   // k-tiles issued after kt
+      const int issued = min(nk - 1, kt + NSTG - 2);                 // youngest k-tile in flight
+      const int young = issued - (kCross ? min(kt + 1, nk - 1) : kt);   // k-tiles that may stay in flight
       if (NSTG >= 4 && young == 2) wait_vm<2 * kPPT>();
       else if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
       else wait_vm<0>();
@@ -326,10 +333,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
     // wave's 128 rows): the fragment reads of block b+1 are issued BEFORE the MFMAs of block b, into the other half of
     // a double register buffer, so their LDS latency runs under 16 MFMAs instead of behind them.
-    constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
-    constexpr bool kPipe = NW <= 8;              // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
-    V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
-    if (NB > 0 && kPipe) {
+    if (NB > 0 && kPipe && !(kCross && kt > 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) bfr[0][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, 0, g, li);
 #pragma unroll
@@ -356,6 +360,14 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
 #pragma unroll
         for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + (th * 4 + t) * 16, kk, g, li);
       }
+      const bool cross = kCross && b + 1 == NB && kt + 1 < nk;
+      if (cross) {                                 // first block of the next k-tile: B into the spare half, A into af[0]
+        const char* sa1 = smem + (st_cur + 1 == NSTG ? 0 : st_cur + 1) * kStage;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bfr[1][u] = frag<E, B_KMAJOR, TN, TK>(sa1 + kATile, wn * 64 + u * 16, 0, g, li);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa1, wm * WROWS + t * 16, 0, g, li);
+      }
       if (kPipe && b + 1 < NB) {
         const int kk1 = (b + 1) / NTH, th1 = (b + 1) % NTH;
         if (th1 == 0) {
@@ -375,6 +387,10 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
           acc[u][th * 4 + t] = Elem16<E>::mma(bfr[kPipe ? (kk & 1) : 0][u], af[kPipe ? (b & 1) : 0][t], acc[u][th * 4 + t]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (cross) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bfr[0][u] = bfr[1][u];
+      }
       if (kCanColsum && do_cs && th == NTH - 1) {
 #pragma unroll
         for (int tt = 0; tt < CS; ++tt)
