@@ -96,10 +96,12 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 // output stream from evicting the operand panels its neighbours on the XCD are re-reading from L2
 template <typename T> __device__ __forceinline__ void store8_nt(T* p, const float (&o)[8]) {
   typedef T v8t __attribute__((ext_vector_type(8)));
+  typedef int i4t __attribute__((ext_vector_type(4)));
   v8t v;
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
-  __builtin_nontemporal_store(v, reinterpret_cast<v8t*>(p));
+  // from asm: beside an ordinary store of the same value under a runtime flag the compiler merges the two and drops `nt`
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(__builtin_bit_cast(i4t, v)) : "memory");
 }
 
 // ---------------------------------------------------------------- device: 16-bit MFMA element traits

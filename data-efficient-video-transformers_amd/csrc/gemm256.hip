@@ -18,6 +18,7 @@
 // Requirements (else gemm.hip's 128x128 register-staged kernel is used):
 //   K and every split a multiple of 64, all leading dimensions multiples of 8.
 #include "gemm_common.h"
+#include <cstdlib>
 
 #ifndef DVT_ABL
 #define DVT_ABL 0   // dev ablations (tools/gemm_bench.hip); 0 = product kernel
@@ -213,7 +214,7 @@ __device__ long long* g_gemm_tb = nullptr;
 #define DVT_GEMM_NT 1
 #endif
 #if DVT_GEMM_NT
-#define DVT_C_STORE(ptr, vals) store8_nt<E>(ptr, vals)
+#define DVT_C_STORE(ptr, vals) do { if (p.stream_out) store8_nt<E>(ptr, vals); else store8<E>(ptr, vals); } while (0)
 #else
 #define DVT_C_STORE(ptr, vals) store8<E>(ptr, vals)
 #endif
@@ -533,6 +534,10 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   typedef Cfg<CFG> C;
   constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
+  // Outputs that the next kernel can still find in the 256 MB Infinity Cache stay cacheable; larger ones are streamed so
+  // that they do not evict the operand panels from L2 (threshold in MB, DVT_GEMM_STREAM_MB overrides)
+  static const int stream_mb = [] { const char* e = getenv("DVT_GEMM_STREAM_MB"); return e ? atoi(e) : 180; }();
+  p.stream_out = (int64_t)p.M * p.N * 2 * (p.epilogue == DVT_EPI_GELU && p.aux ? 2 : 1) >= (int64_t)stream_mb * 1000000;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);

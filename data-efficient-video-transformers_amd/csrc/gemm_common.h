@@ -18,6 +18,7 @@ struct GemmParams {
   int k_per_split;  // multiple of BK; == K rounded up when not splitting
   float* slab;      // != nullptr: write raw fp32 partials to slab[z][M][N]
   int tiles_n;
+  int stream_out;       // C (and the saved pre-activation) written with streaming stores: outputs too large to stay in the Infinity Cache
   int elem;             // DVT_BF16 or DVT_F16: element type of A, B (and of C / residual / aux when not f32)
   float* colsum_slab;
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
