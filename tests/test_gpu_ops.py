@@ -192,6 +192,23 @@ def test_gemm_epilogues(dvt, device, dtype, K):
     assert rel_l2(dr, (dy @ w) * (hpos > 0)) < tol
 
 
+def test_gemm256_streaming_store_path(dvt, device):
+    """The FF1 shape of the metric workload: its two outputs (414 MB) exceed the streaming threshold, so C and the saved
+    pre-activation are written with non-temporal stores; reference = fp32 matmul on the GPU."""
+    L = dvt._lib
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 50432, 2048, 512
+    x = (torch.randn(M, K, generator=g) * 1.0).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
+    bias = (0.5 * torch.randn(N, generator=g)).cuda()
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    y = dvt.ops.linear_fwd(x, w, bias, epilogue=L.EPI_GELU, aux=aux)
+    pre = x.float() @ w.float().t() + bias
+    assert float((aux.float() - pre).norm() / pre.norm()) < BF16_TOL
+    ref = torch.nn.functional.gelu(pre)
+    assert float((y.float() - ref).norm() / ref.norm()) < BF16_TOL
+
+
 @pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
 def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     """Shapes large enough for the 256x256 LDS-DMA kernel (>= 96 tiles), with ragged
