@@ -3,7 +3,7 @@ import os, sys, ctypes, torch
 sys.path.insert(0, "/root/repo")
 import dvt_amd  # noqa: F401
 from dvt_amd import ops, _lib as L
-L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libdvt_hip_gtiming.so")
+L.LIB_PATH = os.environ.get("DVT_PROBE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libdvt_hip_gtiming.so")
 import numpy as np
 lib = L.load()
 tb = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
