@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx,
                                                              int64_t M, int64_t N, int rows_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, float* __restrict__ out,
+                                                             int accumulate) {
   // thread handles 8 columns; blockDim.x = 256 threads = 32 column-chunks x 8 row lanes
   __shared__ float red[8][32][8];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -418,7 +419,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
       for (int r = 0; r < 8; ++r) t[k] += red[r][cl][k];
     }
-    store8<float>(partial + (int64_t)blockIdx.y * N + c, t);
+    if (out) {                                     // single row range (few rows): final result, no second pass
+      if (accumulate) {
+        float o[8];
+        load8<float>(out + c, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] += o[k];
+      }
+      store8<float>(out + c, t);
+    } else {
+      store8<float>(partial + (int64_t)blockIdx.y * N + c, t);
+    }
   }
 }
 
@@ -804,13 +815,15 @@ int dvt_colsum(const void* x, int64_t ldx, float* out, void* workspace, int64_t 
   const bool vec = workspace && N % 8 == 0 && ldx % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(workspace) && M >= 64;
   if (vec) {
     int parts = (int)(M / 64 < kColsumParts ? M / 64 : kColsumParts);
-    if (parts < 1) parts = 1;
+    if (parts < 1 || M <= 1024) parts = 1;       // few rows (33-token sequences): one launch writes the result directly
     const int rpb = (int)dvt_cdiv(M, parts);
     parts = (int)dvt_cdiv(M, rpb);
     const dim3 grid((unsigned)dvt_cdiv(N, 256), (unsigned)parts);
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, st,
-                                                    (const T*)x, ldx, M, N, rpb, (float*)workspace));
+                                                    (const T*)x, ldx, M, N, rpb, (float*)workspace,
+                                                    parts == 1 ? out : (float*)nullptr, accumulate));
     DVT_LAUNCH_CHECK("dvt_colsum(partial)");
+    if (parts == 1) return DVT_OK;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dvt_cdiv(N, 32)), dim3(256), 0, st,
                        (const float*)workspace, parts, N, out, accumulate);
     DVT_LAUNCH_CHECK("dvt_colsum(final)");

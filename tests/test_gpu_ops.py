@@ -137,6 +137,18 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("M,N", [(64, 256), (1024, 512), (1025, 512), (5000, 264), (264, 2048)])
+def test_colsum_row_counts(dvt, device, M, N):
+    """Both sides of the single-launch (<= 1024 rows) / two-pass switch, bf16 and f32, overwrite and accumulate."""
+    g = torch.Generator().manual_seed(12)
+    for dtype in (torch.bfloat16, torch.float32):
+        x_d, x = _rnd((M, N), dtype, g)
+        out = dvt.ops.colsum(x_d)
+        assert rel_l2(out, x.sum(0)) < 1e-5
+        dvt.ops.colsum(x_d, out=out, accumulate=True)
+        assert rel_l2(out, 2 * x.sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_linear_fwd_dgrad_wgrad(dvt, device, dtype, M, N, K):
@@ -155,6 +167,8 @@ def test_linear_fwd_dgrad_wgrad(dvt, device, dtype, M, N, K):
     assert rel_l2(dw, dy.t() @ x) < _tol(dtype)
     db = dvt.ops.colsum(dy_d)
     assert rel_l2(db, dy.sum(0)) < 1e-5
+    dvt.ops.colsum(dy_d, out=db, accumulate=True)       # accumulate form (single-launch path for <= 1024 rows)
+    assert rel_l2(db, 2 * dy.sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
