@@ -1,25 +1,32 @@
 // attention.hip -- fused softmax(q k^T * scale) v, forward and backward.
 // Scores are never written to HBM.
 //
-// bf16 fast path (dh == 64, Lk <= 608): one workgroup per (batch, head).
+// 16-bit fast path (bf16 / fp16, dh == 64, Lk <= 608): one workgroup per (batch, head).
 //   forward   K and V of the head are staged once in LDS as [key][64] images whose
 //             32-byte units are XOR-swizzled by (key>>1)&3 -- conflict-free both
 //             for ds_read_b128 row reads (K as the A operand of S^T = K Q^T) and
 //             for ds_read_b64_tr_b16 transposed reads (V^T as the A operand of
 //             O^T = V^T P^T).  Each wave owns 16-query tiles; the query sits on the
-//             MFMA *column* (lane & 15), so a lane owns one query: the softmax
-//             row-reduce is in-lane plus two wave shuffles (xor 16, 32), and the
-//             S^T accumulators are, converted to bf16, directly the B operand of
+//             MFMA *column* (lane & 15), so a lane owns one query, and the S^T
+//             accumulators are, converted to 16 bits, directly the B operand of
 //             the P V product (k order permuted identically on the V^T side).
-//             Online softmax over 32-key steps => any Lk that fits LDS.
+//             Lk <= 224: the whole 16 x Lk score tile stays in registers (one row
+//             maximum, no rescale, no per-step cross-lane exchange); longer: online
+//             softmax over 32-key steps.
 //   backward  two kernels with the same anatomy, no atomics, bitwise reproducible:
-//             dq   (query on the lane; recomputes S^T, dP^T; dQ^T = K^T dS^T)
-//             dkdv (key on the lane; recomputes S, dP; dV^T = dO^T P, dK^T = Q^T dS)
+//             dq   (query on the lane; recomputes S^T, dP^T; dQ^T = K^T dS^T; writes
+//                   delta = rowsum(dO * O) to the workspace)
+//             dkdv (key on the lane; recomputes S, dP; dV^T = dO^T P, dK^T = Q^T dS;
+//                   reads lse and delta)
 //             7 MFMA products instead of the minimal 5, in exchange for no
-//             cross-wave reduction of any gradient.
+//             cross-wave reduction of any gradient.  Key / query loops are unrolled at
+//             compile time up to 256 (template parameter), rolled beyond.
+//   staging   all loads of a batch before the first LDS write (one memory round trip);
+//   stores    output tiles transposed through a per-wave 2 KiB LDS patch and written as
+//             whole 128-byte rows.
 // generic path: any dtype / head dim / length that fits LDS, fp32 FMA, one wave
 // per row (fp32 parity mode; dh = 448 / 224 / 256 / 32 heads of the reference's
-// 14-token encoders).
+// 14-token encoders; attention-probability dropout).
 #include "common.h"
 #include <cstdlib>
 

@@ -249,7 +249,8 @@ typedef struct dvt_attn_desc {
   int64_t o_sb, o_sh, o_sl;
   float scale;
   int32_t dtype;
-  void* workspace; /* bwd only: >= dvt_attention_bwd_workspace_bytes(desc) bytes (may be NULL if 0) */
+  void* workspace; /* bwd only: >= dvt_attention_bwd_workspace_bytes(desc) bytes (may be NULL if 0): holds
+                    * delta = rowsum(dO * O), written by the dq pass and read by the dk/dv pass */
   /* Attention-probability dropout, nn.MultiheadAttention(dropout=p) in training mode (frame_transformer.py:41-44):
    * o = (softmax(s) * keep / (1 - p)) v, keep(b,h,i,j) drawn like dvt_dropout from rng_state (device {seed, base})
    * at rng_offset + (((b*H + h)*Lq + i)*Lk + j) / 4.  0 = off.  Served by the generic (non-MFMA) kernels. */
