@@ -4,16 +4,20 @@
 //   * both operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB
 //     per wave-instruction, no VGPR staging); LDS is lane-linear for the DMA, so
 //     the bank-conflict swizzles are applied on the per-lane SOURCE address and
-//     again on the fragment read (both are the same XOR involution);
+//     again on the fragment read (both are the same XOR involution).  The DMA is
+//     issued from inline asm (dvt_dma16): seen by the compiler it is a pending LDS
+//     write, and the wait-count pass then puts vmcnt(0) in front of the next ds_read,
+//     i.e. right behind the issue;
 //   * two 64 KiB stages: the DMA of k-tile t+1 is in flight during all 64 MFMAs
-//     per wave of k-tile t; counted s_waitcnt vmcnt(8) + raw s_barrier (never
-//     vmcnt(0) inside the loop);
+//     per wave of k-tile t; hand-placed s_waitcnt vmcnt + raw s_barrier, one per k-tile;
+//   * fragment reads software-pipelined one 16-MFMA block ahead (double register buffer);
 //   * each wave owns 128 x 64 of the tile (8 x 4 accumulators of
 //     v_mfma_f32_16x16x32_bf16); k-major operands are read with ds_read_b128,
 //     mn-major operands (dgrad's W, wgrad's dY and x) with ds_read_b64_tr_b16;
 //   * epilogue: every wave stages its own accumulators through a private LDS
 //     region (no workgroup barrier) and stores whole 128-byte row segments with
-//     bias / GELU / GELU' / ReLU / residual fused;
+//     bias / GELU / GELU' / ReLU / residual fused; outputs of >= 180 MB are written
+//     with streaming (nt) stores so that they do not evict the operand panels from L2;
 //   * split-K over blockIdx.z writes fp32 slabs (summed by splitk_reduce_kernel).
 // Requirements (else gemm.hip's 128x128 register-staged kernel is used):
 //   K and every split a multiple of 64, all leading dimensions multiples of 8.
@@ -26,13 +30,17 @@
 
 namespace {
 
-// Two configurations of one kernel:
+// Configurations of one kernel (0 is the product default; 1 serves narrow convolutions; 2 and 3 are measured
+// experiment knobs, DVT_GEMM_CFG):
 //   CFG 0  256x256 tile, BK=64, 2 LDS stages (128 KiB), 8 waves (2x4): 1 workgroup / CU.
 //          Highest arithmetic intensity per L2 byte; used when K is long enough that the
 //          un-overlapped epilogue burst does not matter.
 //   CFG 1  256x128 tile, BK=32, 3 LDS stages (72 KiB), 4 waves (2x2): 2 workgroups / CU,
 //          so one workgroup's epilogue (stores) overlaps the other's main loop.  Used for
-//          the short-K, write-heavy Linear layers of the d=512 model (K = 512).
+//          convolutions with <= 128 output channels (measured slower than CFG 0 on every Linear shape).
+//   CFG 2  256x256 tile, BK=32, 4 LDS stages, k-tile t+1 landed at the barrier of t (fragment prefetch across it).
+//   CFG 3  256x256 tile, BK=64, 16 waves of 64x64 (4 per SIMD, 128 VGPRs, no fragment double buffer): twice the
+//          memory-operation concurrency in the epilogue, a slower main loop.
 template <int CFG> struct Cfg;
 template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
