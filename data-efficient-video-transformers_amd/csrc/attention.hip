@@ -353,6 +353,14 @@ __device__ __forceinline__ void store_tile(char* patch, E* dst, int64_t row_stri
   wave_lds_sync();
 }
 
+// "Use" a prefetched register here: the wait-count pass then waits for its load at this point (long landed) instead
+// of at the first real use in the next iteration -- where the wait, vmcnt being one in-order counter and the number of
+// conditional stores in between unknown, would be vmcnt(0) and drain this tile's output stores as well.
+template <typename V>
+__device__ __forceinline__ void consume(V& v) {
+  asm volatile("" : "+v"(v));
+}
+
 // ---------------------------------------------------------------- forward
 template <typename E>
 __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(const AttnParams p) {
@@ -551,6 +559,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_res_kernel(const AttnParam
     l = rows_allreduce<false>(l);
     const float inv = 1.0f / l;
     const int qi = qt * 16 + li;
+    consume(qf[0]);
+    consume(qf[1]);
     store_tile<E>(patch, ob, p.o_sl, qt * 16, p.Lq, o, inv, lane);
     if (qi < p.Lq && g == 0) lse[qi] = (mn + __builtin_amdgcn_logf(l)) * kLn2;
   }
@@ -647,6 +657,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams
       for (int kp = 0; kp < nkp - 1; ++kp) step(kp, false);
       step(nkp - 1, true);
     }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      consume(qn[kk]);
+      consume(gn[kk]);
+      consume(of[kk]);
+    }
+    consume(l2n);
     store_tile<E>(patch, dqb, p.q_sl, qt * 16, p.Lq, acc, p.scale, lane);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {

@@ -435,6 +435,11 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   const int64_t ldl = EPI == DVT_EPI_RESIDUAL ? p.ldr : p.ldaux;
   float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (OUT != OUT_SLAB && p.bias && n_ok) load8<float>(p.bias + n, bias);
+  // Consume the bias registers once, here: the loads sit behind a branch, so the wait-count pass would otherwise keep them
+  // "possibly pending" through every row-bounds branch below and put vmcnt(0) -- which also drains every store issued so
+  // far -- in front of each group of stores.
+#pragma unroll
+  for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bias[k]));
   // all sixteen residual / aux rows of the wave's four passes are requested up front (the fragment registers are dead
   // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
   constexpr int NPS = WROWS / 32;                      // passes of 32 rows
