@@ -261,14 +261,17 @@ __device__ __forceinline__ void stage_images(char* imga, const E* srca, int64_t 
       const int rr = r < L ? r : 0;
       const V8 a = *reinterpret_cast<const V8*>(srca + (int64_t)rr * sla + c * 8);
       const V8 b = *reinterpret_cast<const V8*>(srcb + (int64_t)rr * slb + c * 8);
-      va[u] = r < L ? a : V8{0, 0, 0, 0, 0, 0, 0, 0};
-      vb[u] = r < L ? b : V8{0, 0, 0, 0, 0, 0, 0, 0};
+      va[u] = a;
+      vb[u] = b;
     }
+    __builtin_amdgcn_sched_barrier(0);               // all 2 * kBatch loads in flight before the first LDS write (under
+                                                     // register pressure the scheduler otherwise interleaves them in pairs)
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int idx = min(base + u * nt, total - 1);
-      *reinterpret_cast<V8*>(imga + img_off(idx >> 3, idx & 7)) = va[u];
-      *reinterpret_cast<V8*>(imgb + img_off(idx >> 3, idx & 7)) = vb[u];
+      const bool live = (idx >> 3) < L;
+      *reinterpret_cast<V8*>(imga + img_off(idx >> 3, idx & 7)) = live ? va[u] : V8{0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<V8*>(imgb + img_off(idx >> 3, idx & 7)) = live ? vb[u] : V8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
 }
