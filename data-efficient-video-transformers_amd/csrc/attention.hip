@@ -747,7 +747,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
 #ifdef DVT_ATTN_TIMING
     if (threadIdx.x == 0) tbuf[kt == wid ? 2 : 4] = __builtin_amdgcn_s_memtime();
 #endif
-    if (kt != wid) load_rows(kt, kf, vf);
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -793,6 +792,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
     } else {
       for (int qp = 0; qp < nqp; ++qp) step(qp);
     }
+    // the next tile's K / V rows are requested BEFORE this tile's stores: vmcnt is one in-order counter, so a load issued
+    // behind the stores would wait for them to drain AND for its own latency; in front of them the two overlap
+    if (kt + W < nkt) load_rows(kt + W, kf, vf);
     store_tile<E>(patch, dkb, p.k_sl, kt * 16, p.Lk, dk, p.scale, lane);
     store_tile<E>(patch, dvb, p.v_sl, kt * 16, p.Lk, dv, 1.0f, lane);
 #ifdef DVT_ATTN_TIMING
