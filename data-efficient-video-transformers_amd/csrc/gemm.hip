@@ -237,7 +237,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     const int64_t e = i * 8;
     const int m = (int)(e / N), n = (int)(e % N);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int z = 0; z < splits; ++z) {
+    // eight slices per round trip (a rolled loop waits for every slice before it requests the next: `splits` dependent
+    // memory latencies per output vector, 12 us for 21 slices); the additions keep the slice order => same bits
+    constexpr int ZB = 8;
+    int z = 0;
+    for (; z + ZB <= splits; z += ZB) {
+      float v[ZB][8];
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) load8<float>(slab + (int64_t)(z + u) * MN + e, v[u]);
+#pragma unroll
+      for (int u = 0; u < ZB; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[u][k];
+    }
+    for (; z < splits; ++z) {
       float v[8];
       load8<float>(slab + (int64_t)z * MN + e, v);
 #pragma unroll
@@ -265,18 +278,30 @@ __global__ void splitk_reduce_epi_kernel(const float* __restrict__ slab, int spl
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int64_t e = i * 8;
     const int m = (int)(e / p.N), n = (int)(e % p.N);
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int z = 0; z < splits; ++z) {
-      float t[8];
-      load8<float>(slab + (int64_t)z * MN + e, t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += t[k];
-    }
+    // epilogue operands first, then the slices four per round trip (a rolled loop costs one memory latency per slice)
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ld[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pre[8];
     if (p.bias) load8<float>(p.bias + n, bias);
     if (p.epilogue == DVT_EPI_RESIDUAL) load8<E>((const E*)p.residual + (int64_t)m * p.ldr + n, ld);
     if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
       load8<E>((const E*)p.aux + (int64_t)m * p.ldaux + n, ld);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int ZB = 4;
+    int z = 0;
+    for (; z + ZB <= splits; z += ZB) {
+      float t[ZB][8];
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) load8<float>(slab + (int64_t)(z + u) * MN + e, t[u]);
+#pragma unroll
+      for (int u = 0; u < ZB; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[u][k];
+    }
+    for (; z < splits; ++z) {
+      float t[8];
+      load8<float>(slab + (int64_t)z * MN + e, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
     // (the slabs already carry alpha)
     epi_apply8(p.epilogue, v, bias, ld, pre);
     if (p.epilogue == DVT_EPI_GELU && p.aux) store8<E>((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
