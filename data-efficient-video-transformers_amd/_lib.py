@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int64)] + \
                [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")] + \
-               [("workspace", C.c_void_p)]
+               [("workspace", C.c_void_p), ("stats_partial", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -133,6 +133,9 @@ SIGNATURES = {
     "dvt_unpad3_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv2d_implicit_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
+    "dvt_conv2d_implicit_stats_parts": (c_i64, [C.POINTER(ConvDesc)]),
+    "dvt_conv2d_implicit_stats_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "dvt_bn_stats_from_partials": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_p]),
     "dvt_conv2d_implicit_wgrad_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad": (c_int, [C.POINTER(ConvDesc), c_p]),

@@ -318,6 +318,39 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
 }
 
+// Fold many partial rows (one per 128 output rows of a convolution: thousands) into gridDim.y rows that bn_finalize can
+// sum: block = 32 columns x 32 part lanes over its contiguous range of parts, four loads in flight, fixed order.
+__global__ __launch_bounds__(1024) void bn_partial_fold_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                               int per_block, float* __restrict__ out) {
+  __shared__ float red[2][32][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int p0 = blockIdx.y * per_block, p1 = min(nparts, p0 + per_block);
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    int p = p0 + pl;
+    for (; p + 96 < p1; p += 128) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0[u] += partial[((int64_t)(p + 32 * u) * 2 + 0) * C + c];
+        s1[u] += partial[((int64_t)(p + 32 * u) * 2 + 1) * C + c];
+      }
+    }
+    for (; p < p1; p += 32) {
+      s0[0] += partial[((int64_t)p * 2 + 0) * C + c];
+      s1[0] += partial[((int64_t)p * 2 + 1) * C + c];
+    }
+  }
+  red[0][pl][cl] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+  red[1][pl][cl] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  float t0 = 0.f, t1 = 0.f;
+  for (int q = 0; q < 32; ++q) { t0 += red[0][q][cl]; t1 += red[1][q][cl]; }
+  out[((int64_t)blockIdx.y * 2 + 0) * C + c] = t0;
+  out[((int64_t)blockIdx.y * 2 + 1) * C + c] = t1;
+}
+
 __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restrict__ out, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) out[c] = rsqrtf(var[c] + eps);
@@ -828,6 +861,32 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
                      (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
                      running_var, momentum, unbias, 0);
   DVT_LAUNCH_CHECK("dvt_bn_stats(finalize)");
+  return DVT_OK;
+}
+
+int dvt_bn_stats_from_partials(const float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
+                               float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream) {
+  DVT_REQUIRE(partial && mean && invstd && parts > 0 && parts < (1ll << 31) && rows > 0 && C > 0,
+              "dvt_bn_stats_from_partials: bad arguments");
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = partial;
+  int np = (int)parts;
+  if (parts > 256) {
+    // fold in place is not possible (blocks read what others write): the folded rows go behind the partial rows, which the
+    // caller sized with dvt_conv2d_implicit_stats_bytes (parts + 64 rows)
+    const int folds = 64;
+    const int per_block = (int)dvt_cdiv(parts, folds);
+    float* folded = const_cast<float*>(partial) + (size_t)parts * 2 * C;
+    hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)dvt_cdiv(C, 32), (unsigned)folds), dim3(1024), 0, st, partial,
+                       (int)parts, C, per_block, folded);
+    DVT_LAUNCH_CHECK("dvt_bn_stats_from_partials(fold)");
+    src = folded;
+    np = folds;
+  }
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, src, np, C,
+                     1.0f / (float)rows, eps, mean, invstd, running_mean, running_var, momentum, unbias, 0);
+  DVT_LAUNCH_CHECK("dvt_bn_stats_from_partials");
   return DVT_OK;
 }
 

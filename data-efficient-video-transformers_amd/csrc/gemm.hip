@@ -756,7 +756,21 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = p.K; p.slab = nullptr; p.tiles_n = 0; p.colsum_slab = nullptr;
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
+  p.bn_partial = d->stats_partial;
   return dvt_conv_dma_launch(p, d->Cout <= 128 ? 1 : 0, (hipStream_t)stream);
+}
+
+// one partial row per 128 output rows (256-row tiles x 2 wave rows in both convolution configurations)
+int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
+  if (!d || d->sh <= 0 || d->sw <= 0) return 0;
+  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
+  return dvt_cdiv(d->N * Ho * Wo, 256) * 2;
+}
+
+size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* d) {
+  // + 64 rows: dvt_bn_stats_from_partials folds more than 256 partial rows into 64 behind them before it finalises
+  return (size_t)(dvt_conv2d_implicit_stats_parts(d) + 64) * 2 * (size_t)(d && d->Cout > 0 ? d->Cout : 0) * sizeof(float);
 }
 
 // ---- weight gradient: dWt[(ki,kj,c), co] = sum_rows col[row, (ki,kj,c)] * dz[row, co], col gathered on the fly

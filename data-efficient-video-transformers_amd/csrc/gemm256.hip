@@ -454,6 +454,10 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
         rs[ps][j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + (n_ok ? n : 0));
       }
   }
+  // fused BatchNorm statistics (convolution outputs): per-lane sums of its 8 columns over its rows of the tile
+  constexpr bool kCanBn = OUT == OUT_BF16 && EPI == DVT_EPI_NONE;
+  const bool do_bn = kCanBn && p.bn_partial != nullptr;
+  float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bsq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
 #pragma unroll
@@ -498,6 +502,13 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             const float ld = (float)cur[j][k];
             v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
+          if (kCanBn && do_bn) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              bsum[k] += v[j][k];
+              bsq[k] = fmaf(v[j][k], v[j][k], bsq[k]);
+            }
+          }
           if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
           if (DVT_ABL == 6) {
 #pragma unroll
@@ -509,6 +520,21 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       }
     }
     wave_lds_fence();
+  }
+  if (kCanBn && do_bn) {
+    // lanes with equal (lane & 7) hold the same 8 columns for different rows: fixed-order tree over the 8 row lanes
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bsum[k] += __shfl_xor(bsum[k], o, 64);
+        bsq[k] += __shfl_xor(bsq[k], o, 64);
+      }
+    if ((lane >> 3) == 0 && n_ok) {
+      const int part = (tile / p.tiles_n) * (NW / WN) + wm;
+      store8<float>(p.bn_partial + ((int64_t)part * 2 + 0) * p.N + n, bsum);
+      store8<float>(p.bn_partial + ((int64_t)part * 2 + 1) * p.N + n, bsq);
+    }
   }
   DVT_GSTAMP(3);
 }

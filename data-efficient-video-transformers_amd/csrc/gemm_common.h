@@ -21,6 +21,7 @@ struct GemmParams {
   int stream_out;       // C (and the saved pre-activation) written with streaming stores: outputs too large to stay in the Infinity Cache
   int elem;             // DVT_BF16 or DVT_F16: element type of A, B (and of C / residual / aux when not f32)
   float* colsum_slab;
+  float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
   int cH, cW, cC, cHo, cWo, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };

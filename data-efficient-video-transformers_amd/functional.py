@@ -902,6 +902,9 @@ SAVE_CONV_COLUMNS = True
 # Implicit-GEMM convolution (gather fused into the GEMM operand DMA) for the forward pass and, for stride-1
 # convolutions, the data gradient, wherever the geometry allows (16-bit dtype, Cin a multiple of 32/64).
 IMPLICIT_CONV = True
+# BatchNorm batch statistics from the implicit convolution's GEMM epilogue (fp32 accumulators) instead of a separate pass
+# over the stored output
+FUSE_BN_STATS = True
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -937,9 +940,13 @@ class _ConvBnAct(torch.autograd.Function):
         wp = ops.conv_weight_pack(w4, ld, dtype)
         implicit = (IMPLICIT_CONV and not direct and not nchw and ld == K and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
+        stats_partial = None
         if implicit:
             col = None
-            z = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad)
+            if training and FUSE_BN_STATS:       # column sums for the BatchNorm come out of the GEMM epilogue
+                z, stats_partial, stats_parts = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True)
+            else:
+                z = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad)
         else:
             col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
             z = ops.linear_fwd(col, wp)                                 # [N*Ho*Wo, Cout]
@@ -952,7 +959,10 @@ class _ConvBnAct(torch.autograd.Function):
                 rm = ops.pad3_f32(rm.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
                 rv = ops.pad3_f32(rv.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
         if training:
-            mean, invstd = ops.bn_stats(z, rm, rv, eps, momentum)
+            if stats_partial is not None:
+                mean, invstd = ops.bn_stats_from_partials(stats_partial, stats_parts, z.shape[0], Cout, rm, rv, eps, momentum)
+            else:
+                mean, invstd = ops.bn_stats(z, rm, rv, eps, momentum)
             if Cout != Cout_l and run_mean is not None:             # running statistics back into the module buffers
                 ops.unpad3_f32(rm, Cout_l, 1, 1, 1, out=run_mean)
                 ops.unpad3_f32(rv, Cout_l, 1, 1, 1, out=run_var)

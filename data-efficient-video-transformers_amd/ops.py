@@ -795,17 +795,36 @@ def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, strid
     return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad))))
 
 
-def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad) -> Tensor:
-    """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM."""
+def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
+                    want_stats: bool = False):
+    """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
+    want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
+    epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
     _need_cuda(x, wp)
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
     d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad)
-    prof = _profiler
+    lib = L.load()
+    partial, parts = None, 0
+    if want_stats:
+        parts = int(lib.dvt_conv2d_implicit_stats_parts(C.byref(d)))
+        partial = workspace(lib.dvt_conv2d_implicit_stats_bytes(C.byref(d)), x.device, slot="bn_partial")
+        d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
     with _timed(("gemm", 1, 1, N * Ho * Wo, Cout, kh * kw * Cc), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
-        L.check(L.load().dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
-    return y
+        L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
+    return (y, partial, parts) if want_stats else y
+
+
+def bn_stats_from_partials(partial: Tensor, parts: int, rows: int, Cc: int, running_mean: Optional[Tensor],
+                           running_var: Optional[Tensor], eps: float, momentum: float):
+    """mean / invstd (and the running statistics update) from the partial sums of conv2d_implicit(want_stats=True)."""
+    mean = torch.empty((Cc,), dtype=torch.float32, device=partial.device)
+    invstd = torch.empty((Cc,), dtype=torch.float32, device=partial.device)
+    L.check(L.load().dvt_bn_stats_from_partials(partial.data_ptr(), parts, mean.data_ptr(), invstd.data_ptr(),
+                                               _p(running_mean), _p(running_var), rows, Cc, eps, momentum, _stream()),
+            "dvt_bn_stats_from_partials")
+    return mean, invstd
 
 
 def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:

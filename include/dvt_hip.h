@@ -351,9 +351,17 @@ typedef struct dvt_conv_desc {
   int32_t H, W, C, Cout, kh, kw, sh, sw, ph, pw;
   int32_t dtype;
   void* workspace;   /* weight gradient only */
+  /* forward only, optional: the BatchNorm that follows the convolution (custom_resnet.py:30,33,104: conv -> bn) needs the
+   * column sums and sums of squares of y; when stats_partial != NULL (>= dvt_conv2d_implicit_stats_bytes(desc)) the GEMM
+   * epilogue leaves them here from its fp32 accumulators, per 128-row block: [parts][2][Cout] f32 with
+   * parts = dvt_conv2d_implicit_stats_parts(desc); dvt_bn_stats_from_partials turns them into mean / invstd.  Saves the
+   * separate statistics pass over y. */
+  float* stats_partial;
 } dvt_conv_desc;
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 int dvt_conv2d_implicit(const dvt_conv_desc* desc, dvt_stream_t stream);
+int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* desc);
+size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* desc);
 /* Weight gradient without a column matrix: with x = the layer input (NHWC), w = dz [N*Ho*Wo, Cout] and
  * y = dWt f32 [kh*kw*C, Cout] (overwritten): dWt[(ki*kw+kj)*C + c, co] = sum_rows gather(x)[row, .] * dz[row, co];
  * split-K over the rows with a fixed-order reduction (reproducible).  C % 8 == 0, Cout % 8 == 0, N*Ho*Wo a multiple
@@ -375,6 +383,10 @@ int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, in
 size_t dvt_bn_workspace_bytes(int64_t rows, int C);
 int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
                  void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream);
+/* Same result from the per-block partial sums a convolution left behind (dvt_conv_desc.stats_partial, a buffer of
+ * dvt_conv2d_implicit_stats_bytes: its tail is scratch for folding many partial rows). */
+int dvt_bn_stats_from_partials(const float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
+                               float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream);
 int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream);
 /* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52). */
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -371,3 +371,31 @@ def test_channel_padding_is_exact_zero_extension(dvt, device, dtype, tol):
     for got, want in ((c1.weight, r1.weight), (b1.weight, rb1.weight), (b1.bias, rb1.bias), (c2.weight, r2.weight),
                       (b2.bias, rb2.bias)):
         assert got.grad.shape == want.grad.shape and rel_l2(got.grad, want.grad) < 10 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W,Cout,k,stride,pad", [(6, 64, 28, 28, 64, 3, 1, 1), (3, 64, 30, 26, 128, 3, 2, 1),
+                                                        (40, 128, 14, 14, 256, 3, 1, 1), (5, 64, 56, 56, 64, (1, 3), 1, (0, 1))])
+def test_conv_epilogue_batchnorm_statistics(dvt, device, N, C, H, W, Cout, k, stride, pad):
+    """Column sums / sums of squares left by the implicit-convolution epilogue (incl. the > 256-part fold) against the
+    stand-alone statistics pass over the stored output: mean, invstd and the running-statistics update."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(3)
+    kh, kw = ops._pair(k)
+    x = torch.randn(N * H * W, C, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(Cout, C, kh, kw, generator=g) / (C * kh * kw) ** 0.5).cuda()
+    wp = ops.conv_weight_pack(w, kh * kw * C, torch.bfloat16)
+    if not ops.conv2d_implicit_supported(x, wp, N, C, H, W, Cout, k, stride, pad):
+        pytest.skip("geometry not served by the implicit kernel")
+    z, partial, parts = ops.conv2d_implicit(x, wp, N, C, H, W, Cout, k, stride, pad, want_stats=True)
+    z_plain = ops.conv2d_implicit(x, wp, N, C, H, W, Cout, k, stride, pad)
+    assert torch.equal(z, z_plain)
+    rm1, rv1 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, z.shape[0], Cout, rm1, rv1, 1e-5, 0.1)
+    mean_ref, invstd_ref = ops.bn_stats(z, rm2, rv2, 1e-5, 0.1)
+    zf = z.float()
+    # the epilogue sums the fp32 accumulators, the stand-alone pass the bf16-rounded output: equal to rounding noise
+    assert float((mean - mean_ref).abs().max()) < 2e-3 * float(zf.std()) + 1e-6
+    assert float((invstd / invstd_ref - 1).abs().max()) < 2e-3
+    assert float((rm1 - rm2).abs().max()) < 1e-3 and float((rv1 / rv2 - 1).abs().max()) < 1e-3
