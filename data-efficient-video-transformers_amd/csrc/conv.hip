@@ -292,7 +292,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const int c = blockIdx.x * 32 + cl;
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
-    for (int p = pl; p < nparts; p += 32) {
+    // four partial rows per round trip (a rolled loop waits for each before it requests the next); same order of additions
+    int p = pl;
+    for (; p + 96 < nparts; p += 128) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[((int64_t)(p + 32 * u) * 2 + 0) * C + c];
+        b[u] = partial[((int64_t)(p + 32 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; p < nparts; p += 32) {
       s0 += partial[((int64_t)p * 2 + 0) * C + c];
       s1 += partial[((int64_t)p * 2 + 1) * C + c];
     }
