@@ -560,7 +560,7 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       // (cfg 3) the epilogue's vector work of one wave overlaps the store latency of three others (FF1 206 -> 195 us).
       // cfg 1 (2 workgroups / CU) measured slower or equal on every metric shape.
       const bool heavy_epi = d->epilogue == DVT_EPI_GELU || d->epilogue == DVT_EPI_DGELU;
-      pl.cfg = force_cfg >= 0 ? force_cfg : (heavy_epi && d->in_dtype == DVT_BF16 && s == 1 ? 3 : 0);
+      pl.cfg = force_cfg >= 0 ? force_cfg : (heavy_epi && s == 1 ? 3 : 0);
       return pl;
     }
   }

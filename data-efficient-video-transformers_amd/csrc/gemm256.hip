@@ -656,8 +656,8 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
 // combination has no LDS-DMA instantiation.
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
-  if (p.elem == DVT_F16)       // fp16: the 256x256x64 configuration only (cfg 1 is an experiment knob)
-    return launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
+  if (p.elem == DVT_F16)       // fp16: the two product configurations (1 and 2 are bf16 experiment knobs)
+    return cfg == 3 ? launch_cfg<f16, 3>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 2) return launch_cfg<bf16, 2>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 3) return launch_cfg<bf16, 3>(p, a_kmajor, b_kmajor, split, st);
   return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
