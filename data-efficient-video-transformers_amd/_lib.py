@@ -124,7 +124,7 @@ SIGNATURES = {
     "dvt_contrastive_fwd": (c_int, [c_p, c_int, c_f, c_p, c_p, c_p, c_p]),
     "dvt_contrastive_bwd": (c_int, [c_p, c_p, c_int, c_f, c_p, c_p, c_p]),
     "dvt_adamw_step_scaled": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_int, c_f,
-                                      c_f, c_p, c_f, c_p]),
+                                      c_f, c_p, c_f, c_p, c_p]),
     "dvt_device_delay": (c_int, [C.c_uint64, c_p]),
     "dvt_dropout": (c_int, [c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_p]),
     "dvt_rng_advance": (c_int, [c_p, C.c_uint64, c_p]),
@@ -140,9 +140,9 @@ SIGNATURES = {
     "dvt_conv2d_implicit_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad": (c_int, [C.POINTER(ConvDesc), c_p]),
     "dvt_conv_weight_unpack_grad_t": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
-    "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
-    "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p]),
-    "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p, c_p]),
+    "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]),
+    "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -625,13 +625,14 @@ namespace {
 __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                  float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                  float b1, float b2, float eps, float wd,
-                                 const int64_t* __restrict__ step_dev) {
+                                 const int64_t* __restrict__ step_dev, const uint8_t* __restrict__ skip) {
   const float t = (float)(step_dev[0] + 1);
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (skip && skip[i >> 6]) continue;               // parameter without a gradient this step: untouched (torch: grad None)
     const float gi = g[i];
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
@@ -680,7 +681,7 @@ __global__ void check_finite_kernel(const float* __restrict__ g, int64_t n, int*
 __global__ void adamw_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                                     const int64_t* __restrict__ step_dev, const float* __restrict__ scale,
-                                    const int* __restrict__ found_inf) {
+                                    const int* __restrict__ found_inf, const uint8_t* __restrict__ skip) {
   if (found_inf[0]) return;                           // overflow: skip the whole update
   const float inv_scale = 1.0f / scale[0];
   const float t = (float)(step_dev[0] + 1);
@@ -688,6 +689,7 @@ __global__ void adamw_scaled_kernel(float* __restrict__ p, const float* __restri
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (skip && skip[i >> 6]) continue;
     const float gi = g[i] * inv_scale;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
@@ -715,9 +717,10 @@ __global__ void loss_scale_update_kernel(int64_t* step_dev, float* scale, int* f
 // torch.optim.SGD (dampening 0, no nesterov): d = g + wd p; buf = mu buf + d; p -= lr buf   (buf starts at 0,
 // which reproduces torch's "first step: buf = d" rule).  mu == 0: plain p -= lr d, buf untouched.
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                           int64_t n, float lr, float mu, float wd) {
+                           int64_t n, float lr, float mu, float wd, const uint8_t* __restrict__ skip) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (skip && skip[i >> 6]) continue;
     const float pi = p[i];
     float d = fmaf(wd, pi, g[i]);
     if (mu != 0.f) {
@@ -730,9 +733,10 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 // torch.optim.Adagrad: d = g + wd p; sum += d^2; p -= clr d / (sqrt(sum) + eps)
 __global__ void adagrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sum,
-                               int64_t n, float clr, float eps, float wd) {
+                               int64_t n, float clr, float eps, float wd, const uint8_t* __restrict__ skip) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (skip && skip[i >> 6]) continue;
     const float pi = p[i];
     const float d = fmaf(wd, pi, g[i]);
     const float si = fmaf(d, d, sum[i]);
@@ -1005,7 +1009,7 @@ int dvt_rng_advance(uint64_t* rng_state, uint64_t delta, dvt_stream_t stream) {
 int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float* scale,
                           int32_t* found_inf, int32_t* good_steps, int growth_interval, float growth, float backoff,
-                          float* loss_grad, float loss_grad_base, dvt_stream_t stream) {
+                          float* loss_grad, float loss_grad_base, const uint8_t* skip64, dvt_stream_t stream) {
   DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && scale && found_inf && good_steps && loss_grad &&
                   n >= 0 && growth_interval > 0 && growth >= 1.f && backoff > 0.f && backoff <= 1.f,
               "dvt_adamw_step_scaled: bad arguments");
@@ -1014,7 +1018,7 @@ int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float
     hipLaunchKernelGGL(check_finite_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, grad, n, (int*)found_inf);
     hipLaunchKernelGGL(adamw_scaled_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n,
                        lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev, (const float*)scale,
-                       (const int*)found_inf);
+                       (const int*)found_inf, skip64);
   }
   hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, st, step_dev, scale, (int*)found_inf,
                      (int*)good_steps, growth_interval, growth, backoff, loss_grad, loss_grad_base);
@@ -1023,34 +1027,34 @@ int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float
 }
 
 int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
-                 float weight_decay, dvt_stream_t stream) {
+                 float weight_decay, const uint8_t* skip64, dvt_stream_t stream) {
   if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && n >= 0 && (momentum == 0.f || momentum_buf), "dvt_sgd_step: bad arguments");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, momentum_buf,
-                     n, lr, momentum, weight_decay);
+                     n, lr, momentum, weight_decay, skip64);
   DVT_LAUNCH_CHECK("dvt_sgd_step");
   return DVT_OK;
 }
 
 int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
-                     float eps, float weight_decay, int64_t step, dvt_stream_t stream) {
+                     float eps, float weight_decay, int64_t step, const uint8_t* skip64, dvt_stream_t stream) {
   if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && state_sum && n >= 0 && step >= 1, "dvt_adagrad_step: bad arguments");
   const float clr = (float)((double)lr / (1.0 + (double)(step - 1) * (double)lr_decay));
   hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, state_sum,
-                     n, clr, eps, weight_decay);
+                     n, clr, eps, weight_decay, skip64);
   DVT_LAUNCH_CHECK("dvt_adagrad_step");
   return DVT_OK;
 }
 
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
-                       int64_t* step_dev, dvt_stream_t stream) {
+                       int64_t* step_dev, const uint8_t* skip64, dvt_stream_t stream) {
   if (n == 0) return DVT_OK;   // empty tensors carry null pointers: nothing to validate, nothing to launch
   DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && n >= 0, "dvt_adamw_step_dev: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, param, grad, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev);
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int64_t*)step_dev, skip64);
   hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
   DVT_LAUNCH_CHECK("dvt_adamw_step_dev");
   return DVT_OK;

@@ -612,16 +612,20 @@ extern "C" {
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // workspace = [split-K slabs][bias-gradient slabs or stand-alone colsum scratch]
+// The fused bias gradient writes one row of M floats per K slice (gemm256.hip: colsum_slab[slice * M + m]); the planner
+// allows up to 256 slices, so the scratch is sized from the plan, never from a fixed slice bound.
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
   if (!d) return 0;
+  const bool mfma = mfma_eligible(d) && d->K > 0;
+  GemmPlan pl{};
+  if (mfma) pl = plan_gemm(d);
   size_t cs = 0;
   if (d->colsum_out) {
-    const size_t fused = (size_t)64 * (size_t)d->M * sizeof(float);            // <= 64 K slices
+    const size_t fused = mfma ? (size_t)(pl.split > 1 ? pl.split : 1) * (size_t)d->M * sizeof(float) : 0;
     const size_t alone = dvt_colsum_workspace_bytes(d->K, d->M);
     cs = fused > alone ? fused : alone;
   }
-  if (!mfma_eligible(d) || d->K <= 0) return cs;
-  const GemmPlan pl = plan_gemm(d);
+  if (!mfma) return cs;
   const size_t slab = pl.split > 1 ? (size_t)pl.split * (size_t)d->M * (size_t)d->N * sizeof(float) : 0;
   return align256(slab) + cs;
 }

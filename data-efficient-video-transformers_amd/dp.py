@@ -37,20 +37,52 @@ _ALIGN = 64  # elements: every parameter slice starts 256-byte aligned
 
 
 class GradSink:
-    """Destination of one parameter's gradient inside the flat gradient buffer."""
+    """Destination of one parameter's gradient inside the flat gradient buffer.
 
-    __slots__ = ("buf", "fresh", "bucket", "owner", "index")
+    Writers (functional.py) follow one protocol: write into ``sink.buf`` with ``accumulate = not sink.fresh``, then
+    call ``sink.mark_written()``.  A parameter may be written more than once per step (a head used on two streams, a
+    shared encoder).  Under data parallelism its bucket's all-reduce may already be in flight when a later write
+    arrives: adding a local gradient to the (partly) reduced sum would be wrong on every rank and races with the
+    collective.  Such a *late* write is redirected transparently: ``buf`` / ``fresh`` then name a per-sink side buffer,
+    which ``FlatParameters.finish_backward`` all-reduces by itself and adds to the reduced gradient."""
+
+    __slots__ = ("_buf", "_fresh", "bucket", "owner", "index", "unwritten", "_late", "_late_fresh", "late_written")
 
     def __init__(self, buf: torch.Tensor, bucket: int, owner: "FlatParameters", index: int):
-        self.buf = buf          # view shaped like the parameter
-        self.fresh = True       # True until first written in the current step
+        self._buf = buf         # view shaped like the parameter
+        self._fresh = True      # True until first written in the current step
         self.bucket = bucket
         self.owner = owner
         self.index = index
+        self.unwritten = False  # nobody wrote it in the step that just finished (the optimizers skip it, like grad None)
+        self._late = None       # side buffer for writes that arrive after the bucket's all-reduce was launched
+        self._late_fresh = True
+        self.late_written = False
+
+    def _is_late(self) -> bool:
+        o = self.owner
+        return o.world > 1 and o._launched[self.bucket]
+
+    @property
+    def buf(self) -> torch.Tensor:
+        if self._is_late():
+            if self._late is None:
+                self._late = torch.zeros_like(self._buf)
+            return self._late
+        return self._buf
+
+    @property
+    def fresh(self) -> bool:
+        return self._late_fresh if self._is_late() else self._fresh
 
     def mark_written(self) -> None:
-        if self.fresh:
-            self.fresh = False
+        if self._is_late():
+            self._late_fresh = False
+            self.late_written = True
+            return
+        if self._fresh:
+            self._fresh = False
+            self.unwritten = False
             self.owner._on_first_write(self)
 
 
@@ -118,6 +150,11 @@ class FlatParameters:
         self.exp_avg = None
         self.exp_avg_sq = None
         self.step_count = 0
+        # Parameters nobody wrote a gradient for are left alone by the optimizers, as torch leaves parameters whose
+        # ``.grad`` is None (no weight decay, no moment update): one byte per 64-element block of the flat buffer
+        # (every parameter slice is 64-element aligned), rebuilt only when the set of unwritten parameters changes.
+        self.skip_mask = None
+        self._skip_sig = ()
 
     # ------------------------------------------------------------------ compute copy
     def _after_step(self) -> None:
@@ -139,7 +176,9 @@ class FlatParameters:
     def zero_grad(self) -> None:
         """Marks every sink fresh (first write overwrites): no memset pass."""
         for s in self.sinks:
-            s.fresh = True
+            s._fresh = True
+            s._late_fresh = True
+            s.late_written = False
         self._pending = list(self.bucket_size)
         self._launched = [False] * len(self.bucket_ranges)
         self._handles = []
@@ -150,8 +189,10 @@ class FlatParameters:
         self._launched[b] = True
         if self.world > 1:
             lo, hi = self.bucket_ranges[b]
-            self._handles.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True))
+            self._handles.append(self._all_reduce(self.grad[lo:hi]))
+
+    def _all_reduce(self, t: torch.Tensor):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_first_write(self, sink: GradSink) -> None:
         b = sink.bucket
@@ -160,17 +201,42 @@ class FlatParameters:
             self._launch_bucket(b)
 
     def finish_backward(self) -> None:
-        """Call after loss.backward(): zero gradients nobody wrote, flush remaining
-        buckets, wait for the collectives (on the compute stream, not the host)."""
+        """Call after loss.backward(): zero gradients nobody wrote (and exclude them from the optimizer step), flush
+        remaining buckets, wait for the collectives (on the compute stream, not the host), fold in late writes."""
+        unwritten = []
         for s in self.sinks:
-            if s.fresh:
-                s.buf.zero_()   # memset of a slice nobody wrote this step (rare)
-                s.fresh = False
+            if s._fresh:
+                s._buf.zero_()   # memset of a slice nobody wrote this step (rare)
+                s._fresh = False
+                s.unwritten = True
+                unwritten.append(s.index)
+        self._set_skip(tuple(unwritten))
         for b in range(len(self.bucket_ranges)):
             self._launch_bucket(b)
-        for h in self._handles:
+        late = [s for s in self.sinks if s.late_written]
+        late_handles = [self._all_reduce(s._late) for s in late]
+        for h in self._handles + late_handles:
             h.wait()
+        for s in late:                       # reduced late contribution joins the reduced bucket
+            s._buf.add_(s._late)
         self._handles = []
+
+    def _set_skip(self, sig) -> None:
+        if sig == self._skip_sig:
+            return
+        if self.data.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the set of parameters without a gradient changed inside a hipGraph capture; run the "
+                               "warm-up steps with the same model mode as the captured step")
+        self._skip_sig = sig
+        if not sig:
+            self.skip_mask = None
+            return
+        m = torch.zeros(self.total // _ALIGN, dtype=torch.uint8)
+        for i in sig:
+            lo = self.offsets[i] // _ALIGN
+            hi = (self.offsets[i] + self.params[i].numel() + _ALIGN - 1) // _ALIGN
+            m[lo:hi] = 1
+        self.skip_mask = m.to(self.data.device)
 
     @property
     def loss_scale(self) -> float:
@@ -209,7 +275,7 @@ class FlatParameters:
             return
         # step counter lives on the device so the launch can be captured in a hipGraph
         ops.adamw_step_dev_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
-                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
+                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, skip=self.skip_mask)
         self.sync_compute_copy()
         self._after_step()
 
@@ -219,7 +285,7 @@ class FlatParameters:
             self.momentum_buf = torch.zeros_like(self.data)
         self.step_count += 1
         ops.sgd_step_(self.data, self.grad, getattr(self, "momentum_buf", None), lr=lr, momentum=momentum,
-                      weight_decay=weight_decay)
+                      weight_decay=weight_decay, skip=self.skip_mask)
         self.sync_compute_copy()
         self._after_step()
 
@@ -229,7 +295,7 @@ class FlatParameters:
             self.state_sum = torch.zeros_like(self.data)
         self.step_count += 1
         ops.adagrad_step_(self.data, self.grad, self.state_sum, lr=lr, lr_decay=lr_decay, eps=eps,
-                          weight_decay=weight_decay, step=self.step_count)
+                          weight_decay=weight_decay, step=self.step_count, skip=self.skip_mask)
         self.sync_compute_copy()
         self._after_step()
 

@@ -8,8 +8,8 @@ Kept: class names, attribute names (state-dict keys ``net.*``, ``pyramid_{low,mi
 ``reason.relation.{0,1,2}.{1,4,7}.*``), constructor defaults.  The reference file has no import
 statements (NameError on import) and builds ``custom_resnet.resnet34(True)`` (pretrained download);
 here the backbone is ``resnet34(False)`` unless a state dict is loaded.  ``Feature_Pyramid_High`` keeps
-its unused 1x1 convolution (TPN.py:22) in the state dict.  Dropout (0.6 / 0.5, TPN.py:91,94) raises in
-training mode (no RNG-matching kernel); parity is defined in eval mode.
+its unused 1x1 convolution (TPN.py:22) in the state dict.  Dropout (0.6 / 0.5, TPN.py:91,94) draws its masks from
+the Philox dropout kernel in training mode (torch's generator stream cannot be reproduced); parity is defined in eval mode.
 
 On NHWC matrices a global AvgPool2d(k) over a k x k map is a mean over rows and a 1x1 convolution on
 the pooled vector is a Linear, so the pyramid head is two tiny GEMMs.

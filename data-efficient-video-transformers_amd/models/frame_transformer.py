@@ -20,15 +20,16 @@ the im2col + MFMA-GEMM + BatchNorm kernels (models/custom_resnet.py, models/vide
 torchvision's state-dict key layout; ``pretrained=True`` needs the network, so they start from random
 weights unless a state dict is loaded, and the R(2+1)D block is parity-UNPINNED (torchvision is not
 installed; checked against a torch-CPU conv3d restatement).  ``vid_encoder`` / ``img_encoder`` remain
-injectable; ``PatchLinearEncoder`` is a light build-defined stand-in used by the small tests.
+injectable (any module mapping frames / chunks to ``d_model`` vectors; the small tests inject a patch-linear
+stand-in of their own, tests/encoders.py).
 
 Deviations from the literal reference text, all where the reference does not execute
 (SURVEY section 8a notes): missing ``img_cls`` / ``img_model`` / ``scene_transformer``
 members are created; ``torch.cat((data, distil_inject))`` gets the missing
 ``unsqueeze(0)``; the positional table is sized to the sequence actually used;
 ``distil`` returns 19-d logits for both streams; ``view(batch_size, ...)`` uses the
-tensor's batch, not ``hparams.batch_size``; dropout p > 0 in training mode uses the Philox dropout kernel (was: raises
-(no RNG-matching kernel; parity is defined in eval mode).
+tensor's batch, not ``hparams.batch_size``; dropout p > 0 in training mode draws its masks from the Philox
+dropout kernel (torch's generator stream cannot be reproduced; parity is defined in eval mode).
 """
 from __future__ import annotations
 
@@ -131,28 +132,6 @@ class TransformerBase(LightningModule):
 
     def forward(self, x):
         return self.transformer(x)
-
-
-class PatchLinearEncoder(nn.Module):
-    """Build-defined stand-in for the CNN encoders: patchify -> Linear -> mean over
-    patches -> Linear(d_out).  Accepts [N, C, H, W] frames or [N, C, T, H, W] chunks."""
-
-    def __init__(self, in_channels=3, patch=16, width=256, d_out=896, compute_dtype=torch.bfloat16):
-        super().__init__()
-        self.patch = patch
-        self.embed = nn.Linear(in_channels * patch * patch, width)
-        self.fc = nn.Linear(width, d_out)
-        self.compute_dtype = compute_dtype
-
-    def forward(self, x):
-        if x.dim() == 5:                                  # [N, C, T, H, W] -> frames
-            n, c, t, h, w = x.shape
-            x = x.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w)
-        else:
-            n, t = x.shape[0], 1
-        emb = F.patch_embed(x, self.embed.weight, self.embed.bias, self.patch, self.compute_dtype)
-        tokens = emb.view(n, -1, emb.shape[-1])           # patches of all frames of a chunk
-        return F.linear(F.mean_rows(tokens), self.fc.weight, self.fc.bias)
 
 
 class ImgResNet(LightningModule):

@@ -674,14 +674,15 @@ def contrastive_bwd(sim: Tensor, row_lse: Tensor, temperature: float, gloss: Ten
 def adamw_step_scaled_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev: Tensor, scale: Tensor,
                        found_inf: Tensor, good_steps: Tensor, loss_grad: Tensor, *, lr: float, beta1: float, beta2: float,
                        eps: float, weight_decay: float, growth_interval: int, growth: float, backoff: float,
-                       loss_grad_base: float) -> None:
+                       loss_grad_base: float, skip: Optional[Tensor] = None) -> None:
     """AdamW under dynamic loss scaling, all scaler state on the device (hipGraph-capturable)."""
     _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev, scale, found_inf, good_steps, loss_grad)
     assert found_inf.dtype == torch.int32 and good_steps.dtype == torch.int32 and step_dev.dtype == torch.int64
     L.check(L.load().dvt_adamw_step_scaled(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                            param.numel(), lr, beta1, beta2, eps, weight_decay, step_dev.data_ptr(),
                                            scale.data_ptr(), found_inf.data_ptr(), good_steps.data_ptr(), growth_interval,
-                                           growth, backoff, loss_grad.data_ptr(), loss_grad_base, _stream()),
+                                           growth, backoff, loss_grad.data_ptr(), loss_grad_base, _skip(skip, param),
+                                           _stream()),
             "dvt_adamw_step_scaled")
 
 
@@ -704,24 +705,34 @@ def rng_advance_(rng_state: Tensor, delta: int) -> None:
     L.check(L.load().dvt_rng_advance(rng_state.data_ptr(), delta, _stream()), "dvt_rng_advance")
 
 
+def _skip(skip: Optional[Tensor], param: Tensor):
+    """Pointer of the optional 64-element-block skip mask of the flat-buffer optimizer steps."""
+    if skip is None:
+        return None
+    _need_cuda(skip)
+    assert skip.dtype == torch.uint8 and skip.is_contiguous() and skip.numel() * 64 >= param.numel()
+    return skip.data_ptr()
+
+
 def sgd_step_(param: Tensor, grad: Tensor, momentum_buf: Optional[Tensor], *, lr: float, momentum: float,
-              weight_decay: float) -> None:
+              weight_decay: float, skip: Optional[Tensor] = None) -> None:
     _need_cuda(param)
     assert param.dtype == grad.dtype == torch.float32 and param.is_contiguous() and grad.is_contiguous()
     L.check(L.load().dvt_sgd_step(param.data_ptr(), grad.data_ptr(), _p(momentum_buf), param.numel(), lr, momentum,
-                                  weight_decay, _stream()), "dvt_sgd_step")
+                                  weight_decay, _skip(skip, param), _stream()), "dvt_sgd_step")
 
 
 def adagrad_step_(param: Tensor, grad: Tensor, state_sum: Tensor, *, lr: float, lr_decay: float, eps: float,
-                  weight_decay: float, step: int) -> None:
+                  weight_decay: float, step: int, skip: Optional[Tensor] = None) -> None:
     _need_cuda(param)
     assert param.dtype == grad.dtype == torch.float32 and param.is_contiguous() and grad.is_contiguous()
     L.check(L.load().dvt_adagrad_step(param.data_ptr(), grad.data_ptr(), state_sum.data_ptr(), param.numel(), lr,
-                                      lr_decay, eps, weight_decay, step, _stream()), "dvt_adagrad_step")
+                                      lr_decay, eps, weight_decay, step, _skip(skip, param), _stream()), "dvt_adagrad_step")
 
 
 def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev: Tensor, *,
-                    lr: float, beta1: float, beta2: float, eps: float, weight_decay: float) -> None:
+                    lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+                    skip: Optional[Tensor] = None) -> None:
     """AdamW with the step counter on the device (hipGraph-capturable)."""
     _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev)
     for t in (param, grad, exp_avg, exp_avg_sq):
@@ -729,7 +740,8 @@ def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Te
     assert step_dev.dtype == torch.int64 and step_dev.numel() == 1
     L.check(L.load().dvt_adamw_step_dev(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                         exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps,
-                                        weight_decay, step_dev.data_ptr(), _stream()), "dvt_adamw_step_dev")
+                                        weight_decay, step_dev.data_ptr(), _skip(skip, param), _stream()),
+            "dvt_adamw_step_dev")
 
 
 # ------------------------------------------------------------------ per-frame CNN encoder (csrc/conv.hip)

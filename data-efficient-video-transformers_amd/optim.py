@@ -18,6 +18,9 @@ def _grad32(p):
     g = p.grad
     if g is None:
         return None
+    sink = getattr(p, "_dvt_sink", None)
+    if sink is not None and (sink.fresh or sink.unwritten):
+        return None        # a FlatParameters view nobody wrote a gradient into: torch would see grad None and skip it
     if g.dtype != torch.float32 or not g.is_contiguous():
         raise RuntimeError("optimizer expects contiguous fp32 gradients (master weights are fp32)")
     return g

@@ -427,10 +427,15 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    dvt_stream_t stream);
 /* Same update with the step counter in device memory (*step_dev is the number of steps
  * already taken; it is incremented by the call), so that the launch can be captured in
- * a hipGraph and replayed. */
+ * a hipGraph and replayed.
+ * skip64 (nullable; here and in the three flat-buffer forms below): one byte per 64-element block of the flat
+ * buffer; blocks whose byte is non-zero are left untouched -- parameter, moments and all.  torch's optimizers skip
+ * parameters whose .grad is None (frame_transformer.py:123-134 hands every parameter to the optimizer, and the frozen
+ * image encoder :59 / unused members never get a gradient): without the mask a flat-buffer step would still weight-
+ * decay them. */
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
-                       int64_t* step_dev, dvt_stream_t stream);
+                       int64_t* step_dev, const uint8_t* skip64, dvt_stream_t stream);
 /* AdamW under dynamic loss scaling (BASELINE configs[4]: fp16 + loss scaling; torch.cuda.amp.GradScaler rule).
  * grad holds the gradient of (scale * loss).  On the device, in stream order: found_inf |= any non-finite grad;
  * unless found_inf: the dvt_adamw_step_dev update with grad / scale and step_dev += 1; then
@@ -439,15 +444,15 @@ int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
 int dvt_adamw_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float* scale,
                           int32_t* found_inf, int32_t* good_steps, int growth_interval, float growth, float backoff,
-                          float* loss_grad, float loss_grad_base, dvt_stream_t stream);
+                          float* loss_grad, float loss_grad_base, const uint8_t* skip64, dvt_stream_t stream);
 /* torch.optim.SGD(lr, momentum, weight_decay) (frame_transformer.py:124-126; config.yaml momentum 0.005):
  * d = g + wd*p; buf = momentum*buf + d; p -= lr*buf.  momentum_buf starts zeroed (may be NULL when momentum == 0). */
 int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
-                 float weight_decay, dvt_stream_t stream);
+                 float weight_decay, const uint8_t* skip64, dvt_stream_t stream);
 /* torch.optim.Adagrad(lr, weight_decay) (frame_transformer.py:130-132): d = g + wd*p; sum += d*d;
  * p -= lr/(1+(step-1)*lr_decay) * d / (sqrt(sum) + eps); step counts from 1. */
 int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
-                     float eps, float weight_decay, int64_t step, dvt_stream_t stream);
+                     float eps, float weight_decay, int64_t step, const uint8_t* skip64, dvt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -95,3 +95,42 @@ def test_frame_transformer_vid_mode_has_the_reference_state_dict_keys():
     net2 = FrameTransformer(batch_size=2, seq_len=13, cls=1, model="sum", opt="adamW", learning_rate=5e-6, weight_decay=0.09,
                             momentum=0.005)
     assert {"img_model", "scene_transformer", "img_cls"} <= {k.split(".")[0] for k in net2.state_dict()}
+
+
+def test_src_layout_shim_resolves_the_drivers_imports(tmp_path):
+    """with ``shim/src`` on PYTHONPATH the driver's ``from models.frame_transformer import
+    FrameTransformer`` / ``from models.transformer import SimpleTransformer`` (main.py:14-15) resolve to the build's
+    classes from a ``src/``-style working directory whose own ``models/`` holds the modules the build does not
+    replace (``models.LSTM``, main.py:13) -- emulated in a temp directory; the reference tree is not read."""
+    import inspect
+    import subprocess
+    import sys
+    src = tmp_path / "src"
+    (src / "models").mkdir(parents=True)                       # like the reference: no __init__.py in src/models
+    (src / "models" / "LSTM.py").write_text("class LSTMRegressor:\n    origin = 'reference tree'\n")
+    (src / "models" / "vit.py").write_text("raise RuntimeError('the reference file must be shadowed by the shim')\n")
+    (src / "main.py").write_text(
+        "from models.LSTM import LSTMRegressor\n"
+        "from models.transformer import SimpleTransformer\n"
+        "from models.frame_transformer import FrameTransformer\n"
+        "from models.vit import ViViT\n"
+        "from models.custom_resnet import resnet18\n"
+        "from models.TPN import TPN, Reasoning\n"
+        "from models.losses.ntxent import ContrastiveLoss\n"
+        "import dvt_amd.models.frame_transformer as B, dvt_amd.models.transformer as Tm, dvt_amd.models.vit as V\n"
+        "assert FrameTransformer is B.FrameTransformer and SimpleTransformer is Tm.SimpleTransformer and ViViT is V.ViViT\n"
+        "assert LSTMRegressor.origin == 'reference tree'\n"
+        "print('SHIM-OK')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim", "src"))
+    r = subprocess.run([sys.executable, "main.py"], cwd=str(src), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SHIM-OK" in r.stdout, r.stderr[-2000:]
+    # constructor signatures the driver relies on: Model(**config) (main.py:38,44) and ViViT's positional order (vit.py:80-81)
+    from dvt_amd.models.frame_transformer import FrameTransformer
+    from dvt_amd.models.transformer import SimpleTransformer
+    from dvt_amd.models.vit import ViViT
+    for cls in (FrameTransformer, SimpleTransformer):
+        params = list(inspect.signature(cls.__init__).parameters.values())
+        assert params[-1].kind is inspect.Parameter.VAR_KEYWORD, cls
+    names = list(inspect.signature(ViViT.__init__).parameters)
+    assert names[1:14] == ["image_size", "patch_size", "num_classes", "num_frames", "dim", "depth", "heads", "pool",
+                           "in_channels", "dim_head", "dropout", "emb_dropout", "scale_dim"]

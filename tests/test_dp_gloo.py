@@ -46,7 +46,7 @@ def _oracle_grads(net, x, y, scale):
     return {k: v.grad for k, v in P.items()}
 
 
-def _worker(rank, world, port, bucket_mb, out):
+def _worker(rank, world, port, bucket_mb, out, twice=()):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,17 +64,30 @@ def _worker(rank, world, port, bucket_mb, out):
         flat.zero_grad()
         grads = _oracle_grads(net, xs, ys, flat.loss_scale)
         names = [k for k, _ in net.named_parameters()]
+        def write(k, part):
+            s = dict(net.named_parameters())[k]._dvt_sink
+            if s.fresh:                # the writer protocol of functional.py: buf / fresh, then mark_written
+                s.buf.copy_(part)
+            else:
+                s.buf.add_(part)
+            s.mark_written()
+
         for k in reversed(names):      # backward order
-            p = dict(net.named_parameters())[k]
-            s = p._dvt_sink
             if k == "temporal_token" and step == 0:
                 continue               # a parameter nobody writes: finish_backward zero-fills it
-            if s.fresh:
-                s.buf.copy_(grads[k])
-            else:
-                s.buf.add_(grads[k])
-            s.mark_written()
+            write(k, grads[k] * (0.25 if k in twice else 1.0))
+        for k in twice:                # a parameter used twice: its second contribution arrives when its bucket's
+            write(k, grads[k] * 0.75)  # all-reduce is long in flight (tiny buckets) -> the late-write path
         flat.finish_backward()
+        if step == 0:
+            i = names.index("temporal_token")
+            assert flat.sinks[i].unwritten and flat.skip_mask is not None
+            lo = flat.offsets[i] // 64
+            assert int(flat.skip_mask.sum()) == (flat.params[i].numel() + 63) // 64 and int(flat.skip_mask[lo]) == 1
+        else:
+            assert flat.skip_mask is None and not any(s.unwritten for s in flat.sinks)
+        if twice and bucket_mb < 1:
+            assert all(dict(net.named_parameters())[k]._dvt_sink.late_written for k in twice)
     if rank == 0:
         torch.save({"grad": flat.grad.clone(), "data": flat.data.clone(), "nb": len(flat.bucket_ranges),
                     "names": names, "offsets": flat.offsets}, out)
@@ -82,12 +95,17 @@ def _worker(rank, world, port, bucket_mb, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_mb", [32.0, 0.05])
-def test_two_rank_allreduce_equals_full_batch(tmp_path, bucket_mb):
+@pytest.mark.parametrize("bucket_mb,twice", [(32.0, ()), (0.05, ()),
+                                             (0.05, ("mlp_head.1.weight", "space_transformer.layers.0.1.fn.net.0.bias")),
+                                             (32.0, ("mlp_head.1.weight",))])
+def test_two_rank_allreduce_equals_full_batch(tmp_path, bucket_mb, twice):
+    """twice: parameters written a second time AFTER every other gradient (a shared head / an encoder called on two
+    streams).  With small buckets the second write finds its bucket already launched; it must neither be added on top
+    of the reduced sum nor race with the collective (dp.py) -- the result is still the full-batch gradient."""
     import dvt_amd  # noqa: F401  (registers the package alias before spawn pickles the worker)
     port = _free_port()
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, port, bucket_mb, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, bucket_mb, out, twice), nprocs=2, join=True)
     res = torch.load(out)
     net = _model()
     x, y = _data()

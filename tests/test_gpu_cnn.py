@@ -87,15 +87,22 @@ def test_maxpool_first_max_and_eval_bn(dvt, device):
     assert rel_l2(ye, refe.permute(0, 2, 3, 1).reshape(-1, 8)) < 1e-5
 
 
-# bf16: 17 stacked conv+BN layers; the deepest scale (x4) accumulates ~4e-2 relative error
 # fp32 gradient bound 1e-2: one ReLU-mask flip of an activation that is 0 +- 1 ulp on the 98 x 512 layer-4 map moves
-# every upstream gradient by 1/sqrt(50176) = 4.5e-3 (seen after a change of the BatchNorm summation order); 1e-4 otherwise
-@pytest.mark.parametrize("dtype,tol_out,tol_g", [(torch.float32, 2e-4, 1e-2), (torch.bfloat16, 7e-2, 5e-1),
-                                                 (torch.float16, 1e-2, 2e-1)])
-def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, tol_g):
+# every upstream gradient by 1/sqrt(50176) = 4.5e-3 (seen after a change of the BatchNorm summation order); 1e-4 otherwise.
+# 16-bit kernels: this fixture (17 BatchNorm'd ReLU layers on batch statistics, random output gradients) is
+# ill-conditioned in a short mantissa WHOEVER computes it -- the reference's own torch.autocast(bf16) CPU run deviates
+# from its fp32 run by 1.7e-2 / 2.9e-2 / 4.6e-2 on (x2, x3, x4) and by 0.10 .. 0.45 on the parameter gradients (cosines
+# down to 0.90), at batch 2 and at batch 16 alike; fp16: 6e-3 on x4, 0.03 .. 0.14 on gradients
+# (tests/golden/resnet18_lowprec.npz, written by tools/gen_golden.py from the imported reference).  The HIP path is
+# held to 1.5x the reference's own deviation, per output and per parameter.
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype):
     """custom_resnet.resnet18 at 224x224, train mode, vs the imported reference."""
     from dvt_amd.models.custom_resnet import resnet18
     g = golden("resnet18_pyramid.npz")
+    lp = golden("resnet18_lowprec.npz")
+    tag = {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(dtype)
+    lp_names = [str(n) for n in lp["names"]]
     net = resnet18(False, compute_dtype=dtype)
     rng = np.random.default_rng(int(g["seed"]))
     fill_resnet_from_numpy(net, rng)
@@ -104,8 +111,9 @@ def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, 
     x2, x3, x4 = net(x.cuda())
     assert x2.shape == (2, 128, 28, 28) and x3.shape == (2, 256, 14, 14) and x4.shape == (2, 512, 7, 7)
     errs = [rel_l2(t, T(g[k])) for t, k in ((x2, "x2"), (x3, "x3"), (x4, "x4"))]
-    print(f"[resnet18/{dtype}] pyramid rel errors {errs}")
-    assert max(errs) < tol_out
+    print(f"[resnet18/{dtype}] pyramid rel errors {errs}" + (f" (reference's own {list(lp[tag + ':out_err'])})" if tag else ""))
+    for i, e in enumerate(errs):
+        assert e < (2e-4 if tag is None else 1.5 * float(lp[tag + ":out_err"][i])), (i, e)
     gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (x2, x3, x4)]
     # the scalar of the fixture: sum_i <x_i, g_i> / 1000  -> gradient g_i / 1000 on each output
     # fp16: the fixture's 1e-3-scaled output gradients underflow half precision on the way down -> static loss scale
@@ -115,21 +123,28 @@ def test_resnet18_pyramid_matches_reference_golden(dvt, device, dtype, tol_out, 
     for p_ in P.values():
         if p_.grad is not None:
             p_.grad.div_(ls)
-    worst = 0.0
+    worst, worst_ratio = 0.0, 0.0
     for k in g.files:
         if k.startswith("g:"):
-            e = rel_l2(P[k[2:]].grad, T(g[k]))
+            name = k[2:]
+            e = rel_l2(P[name].grad, T(g[k]))
+            a, b = P[name].grad.double().cpu().reshape(-1), T(g[k]).double().reshape(-1)
+            cos = float(a @ b / (a.norm() * b.norm()))
             worst = max(worst, e)
-            assert e < tol_g, (k, e)
-            # direction of the gradient (bf16 storage of 17 BatchNorm'd layers with batch-of-2
-            # statistics is noisy in magnitude at the stem, not in direction)
-            a, b = P[k[2:]].grad.double().cpu().reshape(-1), T(g[k]).double().reshape(-1)
-            assert float(a @ b / (a.norm() * b.norm())) > (0.9998 if dtype == torch.float32 else 0.90), k
+            if tag is None:
+                assert e < 1e-2 and cos > 0.9998, (k, e, cos)
+            else:
+                i = lp_names.index(name)
+                ref_e, ref_cos = float(lp[tag + ":grad_err"][i]), float(lp[tag + ":grad_cos"][i])
+                worst_ratio = max(worst_ratio, e / ref_e)
+                assert e < 1.5 * ref_e, (k, e, ref_e)
+                assert 1.0 - cos < 2.0 * (1.0 - ref_cos), (k, cos, ref_cos)
     names, norms = list(g["grad_names"]), g["grad_norms"]
     for n, ref_norm in zip(names, norms):
         got = float(P[str(n)].grad.double().norm())
-        assert abs(got - ref_norm) <= (0.02 if dtype == torch.float32 else 0.25) * ref_norm + 1e-6, n
-    print(f"[resnet18/{dtype}] worst stored-grad rel {worst:.2e}")
+        slack = 0.02 if tag is None else max(0.05, 1.5 * float(lp[tag + ":grad_err"][lp_names.index(str(n))]))
+        assert abs(got - ref_norm) <= slack * ref_norm + 1e-6, (n, got, ref_norm)
+    print(f"[resnet18/{dtype}] worst stored-grad rel {worst:.2e}" + (f", worst ours/reference's-own ratio {worst_ratio:.2f}" if tag else ""))
     assert torch.allclose(net.bn1.running_mean.cpu(), T(g["rm:bn1"]), atol=1e-4 if dtype == torch.float32 else 2e-2)
     assert P["fc.weight"].grad is None          # the reference's avgpool+fc tail is dead code
 

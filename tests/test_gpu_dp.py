@@ -75,3 +75,52 @@ def test_two_ranks_on_hip_kernels_equal_full_batch(device, tmp_path):
     scale = ref_grad.abs().max()
     assert float((res["grad"] - ref_grad).abs().max() / scale) < 2e-5
     assert float((res["data"] - flat.data.cpu()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("opt", ["adamw", "sgd", "adagrad", "adamw_scaled"])
+def test_parameter_without_gradient_is_left_alone_by_the_flat_optimizers(device, opt):
+    """torch's optimizers (and the reference's configure_optimizers, frame_transformer.py:123-134) skip parameters
+    whose .grad is None.  FlatParameters gives every parameter a permanent gradient view and zero-fills the ones
+    nobody wrote, so the fused flat-buffer steps must exclude them explicitly: with weight decay 0.09 a frozen encoder
+    would otherwise drift towards zero.  Every ViViT parameter is used by its forward, so a registered but
+    unused probe parameter plays the frozen encoder."""
+    from dvt_amd.dp import FlatParameters
+    from dvt_amd import functional as F
+    net = _model().cuda()
+    extra = torch.nn.Parameter(torch.randn(300, device="cuda"))           # registered, never used by forward
+    net.register_parameter("unused_probe", extra)
+    flat = FlatParameters(net, compute_dtype=None)
+    if opt == "adamw_scaled":
+        seed = flat.enable_loss_scaling(init_scale=8.0, growth_interval=1000)
+    else:
+        seed = torch.ones((), device="cuda")
+    x, y = _data()
+    before = net.unused_probe.detach().clone()
+    used_before = net.mlp_head[1].weight.detach().clone()
+    for _ in range(3):
+        flat.zero_grad()
+        F.bce_with_logits(net(x.cuda()), y.cuda()).backward(seed)
+        flat.finish_backward()
+        if opt in ("adamw", "adamw_scaled"):
+            flat.adamw_step(lr=1e-2, weight_decay=0.09)
+        elif opt == "sgd":
+            flat.sgd_step(lr=1e-2, momentum=0.9, weight_decay=0.09)
+        else:
+            flat.adagrad_step(lr=1e-2, weight_decay=0.09)
+    assert flat.skip_mask is not None and int(flat.skip_mask.sum()) == (300 + 63) // 64
+    assert torch.equal(net.unused_probe.detach(), before)                 # bit-unchanged: no decay, no update
+    assert not torch.equal(net.mlp_head[1].weight.detach(), used_before)  # the others did move
+    i = [k for k, _ in net.named_parameters()].index("unused_probe")
+    lo, n = flat.offsets[i], 300
+    for name in ("exp_avg", "exp_avg_sq", "momentum_buf", "state_sum"):
+        st = getattr(flat, name, None)
+        if st is not None:
+            assert float(st[lo:lo + n].abs().max()) == 0.0, name
+    # the torch.optim-interface optimizers skip it as well (p.grad is a permanent view, never None)
+    from dvt_amd import optim
+    o = optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.09)
+    flat.zero_grad()
+    F.bce_with_logits(net(x.cuda()), y.cuda()).backward(seed)
+    flat.finish_backward()
+    o.step()
+    assert torch.equal(net.unused_probe.detach(), before) and net.unused_probe not in o.state

@@ -47,21 +47,11 @@ def test_positional_encoding_matches_reference(device):
     assert torch.allclose(out[kept], 2.0 * ev[kept], atol=1e-6)
 
 
-def _oracle_encoder(x, P, prefix, patch):
-    """Oracle counterpart of PatchLinearEncoder: patchify -> Linear -> mean -> Linear."""
-    if x.dim() == 5:
-        n, c, t, h, w = x.shape
-        x = x.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w)
-    else:
-        n = x.shape[0]
-    pt = O.patchify(x[None], patch)[0]                       # [frames, np, pd]
-    e = O.linear(pt, P[prefix + "embed.weight"], P[prefix + "embed.bias"])
-    e = e.reshape(n, -1, e.shape[-1]).mean(dim=1)
-    return O.linear(e, P[prefix + "fc.weight"], P[prefix + "fc.bias"])
+from tests.encoders import PatchLinearEncoder, oracle_patch_linear_encoder as _oracle_encoder
 
 
 def _make_ft(mode, dtype):
-    from dvt_amd.models.frame_transformer import FrameTransformer, PatchLinearEncoder
+    from dvt_amd.models.frame_transformer import FrameTransformer
     torch.manual_seed(1130)
     d = 64
     cfg = dict(batch_size=2, seq_len=4, cls=1, model=mode, opt="adamW", learning_rate=5e-6, weight_decay=0.09,
@@ -73,17 +63,57 @@ def _make_ft(mode, dtype):
     return net.cuda().eval()
 
 
-def _oracle_ft_vid(net, vid):
-    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()
-         if v.dtype.is_floating_point}
+def _oracle_params(net):
+    return {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()
+            if v.dtype.is_floating_point}
+
+
+def _oracle_vid_cls_embedding(P, vid):
+    """vid_step (frame_transformer.py:192-210): CLS chunk + chunks -> encoder -> pos-enc -> distil_transformer -> CLS."""
     B = vid.shape[0]
     cls = P["vid_cls"]                                                       # [1, T, 3, H, W]
     data = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)   # [B, 5, T, 3, H, W]
     data = data.reshape(-1, *data.shape[2:]).permute(0, 2, 1, 3, 4)
     emb = _oracle_encoder(data, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
     seq = emb + P["position_encoder.pe"][:5]
-    seq = O.transformer_base(seq, P, "distil_transformer.", 4, 2)
-    return O.mlp_head3(seq[0], P), P
+    return O.transformer_base(seq, P, "distil_transformer.", 4, 2)[0]
+
+
+def _oracle_ft_vid(net, vid):
+    P = _oracle_params(net)
+    return O.mlp_head3(_oracle_vid_cls_embedding(P, vid), P), P
+
+
+def _oracle_ft_forward(P, mode, img, vid):
+    """The intended semantics of FrameTransformer.forward per mode (frame_transformer.py:136-190, img_step :212-244;
+    the deviations from the non-executable text are the ones listed in the module docstring of the build)."""
+    B = img.shape[0]
+    icls = P["img_cls"]
+    idata = torch.cat((icls.unsqueeze(0).expand(B, *icls.shape), img), dim=1).reshape(-1, 3, 32, 32)
+    iemb = _oracle_encoder(idata, P, "img_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
+    if mode in ("frame", "pre_modal", "sum_residual"):
+        seq = O.transformer_base(iemb + P["position_encoder.pe"][:5], P, "scene_transformer.", 4, 2)
+        if mode == "sum_residual":                      # as executed (:149-161): 2 * normalize(img_cls)
+            n = seq[0] / seq[0].norm(dim=-1, keepdim=True).clamp_min(1e-12)
+            return O.mlp_head3(n + n, P)
+        return O.mlp_head3(seq[0], P)
+    vcls = _oracle_vid_cls_embedding(P, vid)
+    joint = torch.cat((iemb, vcls.unsqueeze(0)), dim=0)                      # 6 tokens: the injected video CLS (:225-226)
+    seq = O.transformer_base(joint + P["position_encoder.pe"][:6], P, "scene_transformer.", 4, 2)
+    img_cls, vid_tkn = seq[0], seq[-1]
+    if mode == "sum":
+        return O.mlp_head3(img_cls + vid_tkn, P)
+    if mode == "post_sum":
+        return O.mlp_head3(img_cls + vcls, P)
+    return O.mlp_head3(img_cls, P), O.mlp_head3(vid_tkn, P)                  # distil
+
+
+def _oracle_ft_loss(P, mode, img, vid, target):
+    out = _oracle_ft_forward(P, mode, img, vid)
+    if mode == "distil":                                                     # :250-252
+        s, t = out
+        return O.bce_with_logits(s, target) + O.cross_entropy_hard(s, t), out
+    return O.bce_with_logits(out, target), out
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
@@ -124,48 +154,63 @@ def test_frame_transformer_vid_mode_fwd_bwd(device, dtype, tol):
     assert "sklearn apr" in scalars and net.running_logits == []
 
 
-@pytest.mark.parametrize("mode", ["sum", "distil", "frame"])
-def test_frame_transformer_cross_modal_modes(device, mode):
-    """Cross-modal injection: the video CLS embedding is appended to the image tokens and
-    they self-attend jointly (frame_transformer.py:225-226), fp32 mode vs the oracle."""
-    net = _make_ft(mode, torch.float32)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["sum", "distil", "post_sum", "frame", "sum_residual", "pre_modal"])
+def test_frame_transformer_cross_modal_modes_fwd_bwd(device, mode, dtype):
+    """every image / cross-modal mode, forward AND backward.  ``sum`` / ``distil`` / ``post_sum``
+    inject the video CLS embedding as one more token of the image sequence, which then self-attends jointly
+    (frame_transformer.py:225-226), so the loss gradient reaches the video branch through the scene encoder's
+    attention: compared are the logits, the loss (BCE, + hard-label CE in ``distil``, :250-252) and the gradient of
+    EVERY parameter -- ``vid_cls``, ``img_cls``, both encoders, ``distil_transformer.*``, ``scene_transformer.*``, the
+    head -- against the CPU oracle.  fp32 kernels: 5e-4.  bf16 kernels: <= 2x the oracle's own bf16 deviation on the
+    same inputs (the oracle composition re-run under torch.autocast(bf16): the protocol of SURVEY section 7)."""
+    net = _make_ft(mode, dtype)
     g = torch.Generator().manual_seed(4)
     vid = torch.randn(2, 4, 2, 3, 16, 16, generator=g)
     img = torch.randn(2, 4, 3, 32, 32, generator=g)
-    P = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
-    B = 2
-    icls = P["img_cls"]
-    idata = torch.cat((icls.unsqueeze(0).expand(B, *icls.shape), img), dim=1).reshape(-1, 3, 32, 32)
-    iemb = _oracle_encoder(idata, P, "img_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
-    with torch.no_grad():
-        vlog, Pv = _oracle_ft_vid(net, vid)
-    if mode == "frame":
-        seq = O.transformer_base(iemb + P["position_encoder.pe"][:5], P, "scene_transformer.", 4, 2)
-        ref = O.mlp_head3(seq[0], P)
-        out = net(img.cuda(), None)
-        assert rel_l2(out, ref) < 2e-4
-        return
-    # video CLS embedding (before the head)
-    cls = P["vid_cls"]
-    vdata = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)
-    vdata = vdata.reshape(-1, *vdata.shape[2:]).permute(0, 2, 1, 3, 4)
-    vemb = _oracle_encoder(vdata, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
-    vseq = O.transformer_base(vemb + P["position_encoder.pe"][:5], P, "distil_transformer.", 4, 2)
-    joint = torch.cat((iemb, vseq[0].unsqueeze(0)), dim=0)                  # 6 tokens
-    seq = O.transformer_base(joint + P["position_encoder.pe"][:6], P, "scene_transformer.", 4, 2)
-    img_cls, vid_tkn = seq[0], seq[-1]
-    if mode == "sum":
-        ref = O.mlp_head3(img_cls + vid_tkn, P)
-        out = net(img.cuda(), vid.cuda())
-        assert rel_l2(out, ref) < 2e-4
+    target = (torch.rand(2, 19, generator=g) < 0.3).float()
+    P = _oracle_params(net)
+    ref_loss, ref_out = _oracle_ft_loss(P, mode, img, vid, target)
+    ref_loss.backward()
+    out = net(img.cuda(), vid.cuda())
+    loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
+    loss.backward()
+    named = dict(net.named_parameters())
+    if dtype == torch.float32:
+        tol_out, bound = 2e-4, {k: 5e-4 for k in P}
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4
     else:
-        s, t = net(img.cuda(), vid.cuda())
-        assert rel_l2(s, O.mlp_head3(img_cls, P)) < 2e-4 and rel_l2(t, O.mlp_head3(vid_tkn, P)) < 2e-4
-        target = (torch.rand(2, 19, generator=g) < 0.3).float()
-        loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
-        ref_loss = O.bce_with_logits(O.mlp_head3(img_cls, P), target) + \
-            O.cross_entropy_hard(O.mlp_head3(img_cls, P), O.mlp_head3(vid_tkn, P))
-        assert abs(float(loss.detach()) - float(ref_loss)) < 1e-4
+        Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lp_loss, lp_out = _oracle_ft_loss(Q, mode, img, vid, target)
+        lp_loss.float().backward()
+        first = lambda o: (o[0] if isinstance(o, tuple) else o).detach().float()
+        tol_out = 2 * rel_l2(first(lp_out), first(ref_out)) + 2e-3
+        bound = {k: 2 * rel_l2(Q[k].grad, P[k].grad) + 5e-3 for k in P if P[k].grad is not None}
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) < 5e-3
+    outs, refs = (out if isinstance(out, tuple) else (out,)), (ref_out if isinstance(ref_out, tuple) else (ref_out,))
+    for a, b in zip(outs, refs):
+        assert rel_l2(a, b) < tol_out, (mode, rel_l2(a, b), tol_out)
+    checked, worst = 0, ("", 0.0)
+    for k, p in P.items():
+        if k not in named:
+            continue                                     # buffers (positional table)
+        got = named[k].grad
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            assert got is None or float(got.abs().max()) == 0.0, (mode, k, "gradient where the oracle has none")
+            continue
+        assert got is not None, (mode, k)
+        e = rel_l2(got, p.grad)
+        worst = max(worst, (k, e / bound[k]), key=lambda t: t[1])
+        assert e < bound[k], (mode, k, e, bound[k])
+        checked += 1
+    print(f"[ft/{mode}/{dtype}] {checked} parameter gradients checked; worst error/bound {worst[1]:.2f} ({worst[0]})")
+    expect = {"frame": ("img_cls", "scene_transformer", "img_model"), "pre_modal": ("img_cls", "scene_transformer"),
+              "sum_residual": ("img_cls", "scene_transformer")}.get(mode, ("img_cls", "vid_cls", "scene_transformer",
+                                                                            "distil_transformer", "vid_model", "img_model"))
+    for pre in expect + ("img_mlp_head",):
+        assert any(k.startswith(pre) and P[k].grad is not None and float(P[k].grad.abs().max()) > 0 for k in P), pre
+    assert checked >= (20 if mode in ("frame", "pre_modal", "sum_residual") else 40)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
@@ -198,39 +243,3 @@ def test_simple_transformer_ptn(device, dtype, tol):
     for k in ("cls", "norm.weight", "transformer_encoder0.layers.1.linear1.weight",
               "transformer_encoder1.layers.0.self_attn.in_proj_bias", "mlp_head.1.weight"):
         assert rel_l2(dict(net.named_parameters())[k].grad, P[k].grad) < 3 * tol, k
-
-
-@pytest.mark.parametrize("mode", ["sum_residual", "post_sum", "pre_modal"])
-def test_frame_transformer_remaining_modes(device, mode):
-    """frame_transformer.py:149-175: sum_residual as executed (2 * normalize(img_cls)), post_sum as intended
-    (img CLS + video CLS embedding; the reference text raises), pre_modal as executed (image-only path)."""
-    net = _make_ft(mode, torch.float32)
-    g = torch.Generator().manual_seed(6)
-    vid = torch.randn(2, 4, 2, 3, 16, 16, generator=g)
-    img = torch.randn(2, 4, 3, 32, 32, generator=g)
-    P = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
-    B = 2
-    icls = P["img_cls"]
-    idata = torch.cat((icls.unsqueeze(0).expand(B, *icls.shape), img), dim=1).reshape(-1, 3, 32, 32)
-    iemb = _oracle_encoder(idata, P, "img_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
-    cls = P["vid_cls"]
-    vdata = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)
-    vdata = vdata.reshape(-1, *vdata.shape[2:]).permute(0, 2, 1, 3, 4)
-    vemb = _oracle_encoder(vdata, P, "vid_model.", 8).reshape(B, 5, -1).permute(1, 0, 2)
-    vcls = O.transformer_base(vemb + P["position_encoder.pe"][:5], P, "distil_transformer.", 4, 2)[0]
-    if mode == "post_sum":
-        joint = torch.cat((iemb, vcls.unsqueeze(0)), dim=0)
-        seq = O.transformer_base(joint + P["position_encoder.pe"][:6], P, "scene_transformer.", 4, 2)
-        ref = O.mlp_head3(seq[0] + vcls, P)
-    else:
-        seq = O.transformer_base(iemb + P["position_encoder.pe"][:5], P, "scene_transformer.", 4, 2)
-        if mode == "sum_residual":
-            n = seq[0] / seq[0].norm(dim=-1, keepdim=True).clamp_min(1e-12)
-            ref = O.mlp_head3(n + n, P)
-        else:
-            ref = O.mlp_head3(seq[0], P)
-    out = net(img.cuda(), vid.cuda())
-    assert rel_l2(out, ref) < 2e-4
-    target = (torch.rand(2, 19, generator=g) < 0.3).float()
-    loss = net.training_step((target.cuda(), img.cuda(), vid.cuda()), 0)
-    assert abs(float(loss.detach()) - float(O.bce_with_logits(ref, target))) < 1e-4

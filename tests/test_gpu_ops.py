@@ -296,6 +296,39 @@ def test_wgrad_split_k_reproducible(dvt, device):
     assert rel_l2(acc, dy.t() @ x + 1) < BF16_TOL
 
 
+def test_wgrad_deep_k_fused_bias_with_exact_workspace(dvt, device):
+    """Reference-default ViViT (dim 192) at batch 32: the to_out weight gradient is M = N = 192 with K = 100,864 token
+    rows -> one 256x256 tile, 197 K slices, bias gradient fused (one scratch row of M floats per slice).  A C-ABI caller
+    allocates exactly ``dvt_gemm_workspace_bytes``: the scratch must fit (it was sized for 128 slices), checked with a
+    guard region behind the workspace."""
+    import ctypes as C
+    from dvt_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(18)
+    rows, N, K = 100864, 192, 192
+    dy_d, dy = _rnd((rows, N), torch.bfloat16, g)
+    x_d, x = _rnd((rows, K), torch.bfloat16, g)
+    dw = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    db = torch.empty((N,), dtype=torch.float32, device="cuda")
+    d = L.GemmDesc()
+    d.A, d.B, d.C = dy_d.data_ptr(), x_d.data_ptr(), dw.data_ptr()
+    d.M, d.N, d.K = N, K, rows
+    d.lda, d.ldb, d.ldc = N, K, K
+    d.a_kmajor, d.b_kmajor = 0, 0
+    d.in_dtype, d.out_dtype = L.BF16, L.F32
+    d.epilogue, d.accumulate, d.alpha, d.split_k = L.EPI_NONE, 0, 1.0, 0
+    d.colsum_out, d.colsum_accumulate = db.data_ptr(), 0
+    need = lib.dvt_gemm_workspace_bytes(C.byref(d))
+    guard = 1 << 20
+    buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    d.workspace = buf.data_ptr()
+    L.check(lib.dvt_gemm(C.byref(d), dvt.ops._stream()), "dvt_gemm")
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0x5A).all()), "dvt_gemm wrote past the workspace size it reported"
+    assert rel_l2(dw, dy.t() @ x) < BF16_TOL and rel_l2(db, dy.sum(0)) < 1e-5
+    assert need >= 197 * N * 4                      # one scratch row per K slice actually planned
+
+
 def test_gemm_rejects_bad_arguments(dvt, device):
     x = torch.randn(4, 8, device="cuda")
     w = torch.randn(6, 8, device="cuda")

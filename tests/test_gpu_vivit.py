@@ -3,16 +3,22 @@ vectors (generated from the imported reference, tools/gen_golden.py) and
 against the CPU oracle.
 
 fp32 mode: logits / loss / every parameter gradient within 1e-3 rel (north_star)
--- asserted at 2e-4.  bf16 mode: <= 1e-2 (logits) and <= 3e-2 (gradients)
-rel-L2, i.e. within 2-3x of the reference's own bf16-vs-fp32 deviation at this
-config (4.6e-3 / 1e-2).
+-- asserted at 2e-4.  bf16 / fp16 modes follow the protocol of SURVEY section 7 and
+BASELINE.md section 2: logits <= 1e-2 rel-L2, and logits and EVERY parameter
+gradient <= 2x the reference's own low-precision deviation on the same inputs.
+That deviation is not quoted from prose: tools/gen_golden.py runs the imported
+reference under torch.autocast(bf16 / fp16) on the CPU and stores the digests
+(tests/golden/vivit_*_lowprec.npz); at configs[0] it reproduces BASELINE.md's
+4.6e-3 / 1e-2, at the metric shape it is 6.8e-3 (logits) and 3.5e-3 .. 1.7e-2
+(gradients, per parameter).
 """
 import numpy as np
 import pytest
 import torch
 
 from oracle import clip_path as O
-from tests.util import golden, rel_l2, fill_state_from_numpy, digest_inputs, check_grad_digest
+from tests.util import (golden, rel_l2, fill_state_from_numpy, digest_inputs, check_grad_digest, grad_digest_errors,
+                        reference_lowprec_errors, assert_within_reference_lowprec)
 
 pytestmark = pytest.mark.gpu
 
@@ -48,16 +54,21 @@ def test_vivit_matches_reference_golden(device, mode, case):
     else:
         fill_state_from_numpy(net.named_parameters(), int(g["fill_seed"]))
     logits, loss, grads = _run(net, g, 1024.0 if mode == "fp16" else 1.0)
-    tol_out, tol_g = {"fp32": (2e-4, 2e-4), "bf16": (1e-2, 3e-2), "fp16": (2e-3, 6e-3)}[mode]   # fp16: 3 more mantissa bits
     e_out = rel_l2(logits, torch.from_numpy(g["logits"]))
     e_loss = abs(float(loss) - float(g["loss"][0]))
     errs = {k: rel_l2(v, torch.from_numpy(g["g:" + k])) for k, v in grads.items()}
     worst = max(errs, key=errs.get)
     print(f"[{case}/{mode}] logits rel {e_out:.2e} loss abs {e_loss:.2e} worst grad {worst} {errs[worst]:.2e}")
-    assert e_out < tol_out
     assert e_loss < (1e-5 if mode == "fp32" else 5e-3)
-    for k, e in errs.items():
-        assert e < tol_g, (k, e)
+    if mode == "fp32":
+        assert e_out < 2e-4
+        for k, e in errs.items():
+            assert e < 2e-4, (k, e)
+        return
+    ref_out, ref_errs = reference_lowprec_errors(g, golden(f"vivit_{case}_lowprec.npz"), "amp_" + mode)
+    w = assert_within_reference_lowprec(f"{case}/{mode}", e_out, grad_digest_errors(g, grads), ref_out, ref_errs,
+                                        out_cap=1e-2)
+    print(f"[{case}/{mode}] reference's own {mode}: logits {ref_out:.2e}; worst ratio ours/reference {w[1]:.2f} ({w[0]})")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
@@ -81,11 +92,61 @@ def test_vivit_large_configs_match_reference_digest(device, tag, mode):
         p.grad.div_(scale)
     e_out = rel_l2(logits, torch.from_numpy(g["logits"]))
     e_loss = abs(float(loss) - float(g["loss"][0]))
-    worst = check_grad_digest(g, {k: p.grad for k, p in net.named_parameters()},
-                              {"fp32": 1e-3, "bf16": 6e-2, "fp16": 1e-2}[mode], tag)
-    print(f"[{tag}/{mode}] logits rel {e_out:.2e} loss abs {e_loss:.2e} worst grad digest {worst[0]} {worst[1]:.2e}")
-    assert e_out < {"fp32": 1e-3, "bf16": 3e-2, "fp16": 4e-3}[mode]
+    grads = {k: p.grad for k, p in net.named_parameters()}
     assert e_loss < {"fp32": 1e-5, "bf16": 5e-3, "fp16": 1e-3}[mode]
+    if mode == "fp32":
+        worst = check_grad_digest(g, grads, 1e-3, tag)
+        print(f"[{tag}/{mode}] logits rel {e_out:.2e} loss abs {e_loss:.2e} worst grad digest {worst[0]} {worst[1]:.2e}")
+        assert e_out < 1e-3
+        return
+    errs = grad_digest_errors(g, grads)
+    ref_out, ref_errs = reference_lowprec_errors(g, golden(f"vivit_{tag.split('_')[0]}_lowprec.npz"), "amp_" + mode)
+    wk = max(errs, key=errs.get)
+    print(f"[{tag}/{mode}] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} worst grad digest "
+          f"{wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
+    w = assert_within_reference_lowprec(f"{tag}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=1e-2)
+    print(f"[{tag}/{mode}] worst ratio ours/reference {w[1]:.2f} ({w[0]})")
+
+
+def test_longclip_config_composed_matches_reference_digest(device):
+    """BASELINE configs[4] as ONE workload: T=64, 288^2 (N = 325 tokens per frame), fp16 kernels, device-side dynamic
+    loss scaling (``FlatParameters.enable_loss_scaling``), activation checkpointing -- the step bench.py's ``longclip``
+    workload times -- at one clip, against the digest the executed reference wrote (vit.py:109-128 at 288^2) and the
+    reference's own autocast-fp16 deviation on the same clip."""
+    from dvt_amd.models.vit import ViViT
+    from dvt_amd.dp import FlatParameters
+    from dvt_amd import functional as F
+    g = golden("vivit_longclip_digest.npz")
+    cfg, x, y = digest_inputs(g)
+    assert (cfg["frames"], cfg["image"]) == (64, 288)
+    net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["frames"], dim=cfg["dim"], depth=cfg["depth"],
+                heads=cfg["heads"], dim_head=cfg["dim_head"], compute_dtype=torch.float16, activation_checkpointing=True)
+    fill_state_from_numpy(net.named_parameters(), int(g["fill_seed"]))
+    net = net.cuda().train()
+    flat = FlatParameters(net, compute_dtype=torch.float16)
+    flat.sync_compute_copy()
+    seed = flat.enable_loss_scaling(init_scale=1024.0, growth_interval=1000)
+    flat.zero_grad()
+    logits = net(x.cuda())
+    loss = F.bce_with_logits(logits, y.cuda())
+    loss.backward(seed)
+    flat.finish_backward()
+    scale = float(flat.scale_dev)
+    grads = {k: p.grad / scale for k, p in net.named_parameters()}
+    e_out = rel_l2(logits, torch.from_numpy(g["logits"]))
+    e_loss = abs(float(loss) - float(g["loss"][0]))
+    errs = grad_digest_errors(g, grads)
+    ref_out, ref_errs = reference_lowprec_errors(g, golden("vivit_longclip_lowprec.npz"), "amp_fp16")
+    wk = max(errs, key=errs.get)
+    print(f"[longclip/fp16+scaling+ckpt] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} "
+          f"worst grad digest {wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
+    assert e_loss < 1e-3
+    w = assert_within_reference_lowprec("longclip/fp16", e_out, errs, ref_out, ref_errs, out_cap=4e-3)
+    print(f"[longclip/fp16+scaling+ckpt] worst ratio ours/reference {w[1]:.2f} ({w[0]})")
+    # the optimizer consumes the scaled gradients: one AdamW step must not overflow-skip and must move the weights
+    before = flat.data.clone()
+    flat.adamw_step(lr=1e-3, weight_decay=0.0)
+    assert int(flat.found_inf) == 0 and not torch.equal(before, flat.data)
 
 
 def test_vivit_state_dict_roundtrip_and_eval_determinism(device):

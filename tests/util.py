@@ -87,3 +87,58 @@ def check_grad_digest(npz, grads, tol, label=""):
             worst = (k, e)
         assert e < tol, (label, k, e_s, e_n)
     return worst
+
+
+def _digest_idx(n):
+    return np.linspace(0, n - 1, num=min(256, n)).astype(np.int64)
+
+
+def grad_digest_errors(npz, grads, prefix=""):
+    """name -> max(rel-L2 error on the 256 digest entries, rel error of the L2 norm) of ``grads`` (name -> tensor or
+    flat numpy array of the digest entries when ``prefix`` names a low-precision run stored in digest form) against the
+    fp32 digest / full gradients held by ``npz``."""
+    out = {}
+    names = [f[3:] for f in npz.files if f.startswith("gs:")] or [f[2:] for f in npz.files if f.startswith("g:")]
+    for k in names:
+        if "gs:" + k in npz.files:
+            ref_s, ref_n = torch.from_numpy(npz["gs:" + k]).double(), float(npz["gn:" + k])
+        else:
+            full = torch.from_numpy(npz["g:" + k]).double().reshape(-1)
+            ref_s, ref_n = full[torch.from_numpy(_digest_idx(full.numel()))], float(full.norm())
+        got = grads[k]
+        if isinstance(got, tuple):                       # (digest entries, norm) of a stored low-precision run
+            g_s, g_n = torch.from_numpy(got[0]).double(), float(got[1])
+        else:
+            g = got.detach().double().cpu().reshape(-1)
+            g_s, g_n = g[torch.from_numpy(_digest_idx(g.numel()))], float(g.norm())
+        e_s = float((g_s - ref_s).norm() / (ref_s.norm() + 1e-30))
+        e_n = abs(g_n - ref_n) / (ref_n + 1e-30)
+        out[k] = max(e_s, e_n)
+    return out
+
+
+def reference_lowprec_errors(npz, lp, mode):
+    """(logits rel-L2, {name: gradient digest error}) of the reference's OWN low-precision run ``mode`` (``amp_bf16`` /
+    ``amp_fp16`` / ``pure_bf16`` in a ``vivit_*_lowprec.npz`` fixture) against its fp32 run ``npz`` -- measured exactly
+    like ``grad_digest_errors`` measures the HIP path."""
+    ref_logits = torch.from_numpy(npz["logits"]).double()
+    e_out = float((torch.from_numpy(lp[f"{mode}:logits"]).double() - ref_logits).norm() / ref_logits.norm())
+    pre = f"{mode}:gs:"
+    stored = {k[len(pre):]: (lp[k], lp[f"{mode}:gn:" + k[len(pre):]]) for k in lp.files if k.startswith(pre)}
+    return e_out, grad_digest_errors(npz, stored)
+
+
+def assert_within_reference_lowprec(tag, e_out, errs, ref_out, ref_errs, factor=2.0, out_cap=None, floor=2e-4):
+    """The parity protocol of SURVEY section 7 / BASELINE.md section 2 for the 16-bit kernels: every error must stay
+    within ``factor`` x the reference's own low-precision deviation on the same inputs (and the logits under
+    ``out_cap``).  Returns the worst ratio for the log line."""
+    assert e_out <= factor * ref_out + floor, (tag, "logits", e_out, ref_out)
+    if out_cap is not None:
+        assert e_out <= out_cap, (tag, "logits", e_out)
+    worst = ("", 0.0)
+    for k, e in errs.items():
+        r = e / (ref_errs[k] + 1e-30)
+        if r > worst[1]:
+            worst = (k, r)
+        assert e <= factor * ref_errs[k] + floor, (tag, k, e, ref_errs[k])
+    return worst

@@ -205,6 +205,47 @@ def resnet_case():
     print("resnet18_pyramid: x2", tuple(x2.shape), "x3", tuple(x3.shape), "x4", tuple(x4.shape), "loss", float(loss))
 
 
+def resnet_lowprec_case():
+    """The reference ResNet-18's OWN low-precision deviation on the ``resnet18_pyramid`` fixture inputs (torch.autocast on
+    the CPU, train-mode BatchNorm): relative L2 error of (x2, x3, x4) and of every parameter gradient against the
+    reference's fp32 run, plus the gradient cosines.  Stored as scalars; the GPU test holds the bf16 / fp16 kernels to
+    a multiple of these.  (Measured here: the reference's own bf16 gradients deviate by 0.24-0.45 with cosines down to
+    0.90 on this fixture, at batch 2 and at batch 16 alike -- 17 BatchNorm'd ReLU layers under a random output
+    gradient are ill-conditioned in 8-bit mantissas whoever computes them.)"""
+    cr = _load("ref_custom_resnet3", os.path.join(REF, "custom_resnet.py"))
+
+    def run(dt):
+        net = cr.resnet18(False)
+        rng = np.random.default_rng(SEED + 20)
+        fill_resnet_from_numpy(net, rng)
+        net.train()
+        x = torch.from_numpy(rng.standard_normal((2, 3, 224, 224)).astype(np.float32))
+        if dt is None:
+            outs = net(x)
+        else:
+            with torch.autocast("cpu", dtype=dt):
+                outs = net(x)
+        gs = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in outs]
+        scale = 1024.0 if dt == torch.float16 else 1.0
+        loss = sum((t.float() * g).sum() for t, g in zip(outs, gs)) / 1000.0
+        (loss * scale).backward()
+        return ([o.detach().double() for o in outs],
+                {k: p.grad.double() / scale for k, p in net.named_parameters() if p.grad is not None})
+
+    ref_o, ref_g = run(None)
+    out = {"names": np.array(list(ref_g))}
+    for tag, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        o, g = run(dt)
+        out[f"{tag}:out_err"] = np.array([float((a - b).norm() / b.norm()) for a, b in zip(o, ref_o)])
+        out[f"{tag}:grad_err"] = np.array([float((g[k] - ref_g[k]).norm() / ref_g[k].norm()) for k in ref_g])
+        out[f"{tag}:grad_cos"] = np.array([float(g[k].flatten() @ ref_g[k].flatten() / (g[k].norm() * ref_g[k].norm()))
+                                           for k in ref_g])
+        print(f"resnet18_lowprec[{tag}]: out err {out[tag + ':out_err']}, grad err median "
+              f"{np.median(out[tag + ':grad_err']):.3f} max {out[tag + ':grad_err'].max():.3f}, "
+              f"min cos {out[tag + ':grad_cos'].min():.4f}")
+    np.savez_compressed(os.path.join(OUT, "resnet18_lowprec.npz"), **out)
+
+
 def tpn_case():
     """src/models/TPN.py has no import statements (NameError on import).  Its source is executed here
     with the missing names supplied (torch, nn, a LightningModule stand-in, the reference's own
@@ -262,6 +303,52 @@ def vivit_digest_case(vit, tag, cfg, batch, seed):
         out["gs:" + name] = g[torch.from_numpy(idx)].numpy()
     np.savez_compressed(os.path.join(OUT, f"vivit_{tag}.npz"), **out)
     print(f"vivit_{tag}: logits {tuple(logits.shape)} loss {loss.item():.6f}")
+
+
+def _lowprec_run(vit, cfg, batch, seed, mode):
+    """The reference's OWN low-precision CPU run on the digest inputs: ``amp_*`` = torch.autocast on the CPU (what
+    Lightning's ``precision=16`` in the comment at src/main.py:85 would do; reproduces BASELINE.md section 2's
+    4.6e-3 / 1e-2 at configs[0]); ``pure_*`` = module and clip cast to the 16-bit type.  fp16 runs use a static loss
+    scale of 1024 (activation gradients underflow without one), removed from the gradients afterwards."""
+    torch.manual_seed(seed)
+    net = vit.ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["frames"], dim=cfg["dim"],
+                    depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"])
+    fill_from_numpy(net, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    x = torch.from_numpy(rng.standard_normal(
+        (batch, cfg["frames"], 3, cfg["image"], cfg["image"])).astype(np.float32))
+    y = torch.from_numpy((rng.random((batch, cfg["classes"])) < 0.2).astype(np.float32))
+    y[:, 0] = 1.0
+    kind, prec = mode.split("_")
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    scale = 1024.0 if prec == "fp16" else 1.0
+    if kind == "amp":
+        with torch.autocast("cpu", dtype=dt):
+            logits = net(x)
+    else:
+        net = net.to(dt)
+        logits = net(x.to(dt))
+    loss = torch.nn.BCEWithLogitsLoss()(logits.float(), y)
+    (loss * scale).backward()
+    return logits.detach().float(), loss.detach(), {k: p.grad.detach().float() / scale for k, p in net.named_parameters()}
+
+
+def vivit_lowprec_case(vit, tag, cfg, batch, seed, modes):
+    """``vivit_<tag>_lowprec.npz``: digests (logits, loss, per-gradient norm + the same 256 evenly spaced entries as
+    the fp32 digest) of the reference's own low-precision runs, so that the GPU tests can hold the bf16 / fp16 kernels
+    to "<= 2x the reference's own low-precision deviation on the same inputs" (BASELINE.md section 2)."""
+    out = {"modes": np.array(modes), "batch": np.array(batch), "fill_seed": np.array(seed + 1), "x_seed": np.array(seed + 2)}
+    for mode in modes:
+        logits, loss, grads = _lowprec_run(vit, cfg, batch, seed, mode)
+        out[f"{mode}:logits"] = logits.numpy()
+        out[f"{mode}:loss"] = loss.numpy()[None]
+        for name, g in grads.items():
+            g = g.reshape(-1)
+            idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
+            out[f"{mode}:gn:{name}"] = np.array(float(g.double().norm()))
+            out[f"{mode}:gs:{name}"] = g[torch.from_numpy(idx)].numpy()
+        print(f"vivit_{tag}_lowprec[{mode}]: loss {float(loss):.6f}")
+    np.savez_compressed(os.path.join(OUT, f"vivit_{tag}_lowprec.npz"), **out)
 
 
 def input_stage_case():
@@ -375,25 +462,38 @@ def fusion_case():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])                 # e.g. ``gen_golden.py lowprec longclip`` regenerates just those groups
+
+    def want(group):
+        return not only or group in only
+
     vit = _load("ref_vit", os.path.join(REF, "vit.py"))
     tiny = dict(image=32, patch=8, classes=19, frames=3, dim=64, depth=2, heads=2, dim_head=32)
-    vivit_case(vit, "tiny", tiny, batch=2, store_weights=True, seed=SEED)
     # BASELINE.json configs[0]: T=4, 64x64, d=128, 2 layers (plumbing config)
     c1 = dict(image=64, patch=16, classes=19, frames=4, dim=128, depth=2, heads=2, dim_head=64)
-    vivit_case(vit, "c1", c1, batch=2, store_weights=False, seed=SEED + 10)
     # BASELINE.json configs[1]: single-modal video path d=384, T=16, 224^2 (one clip); and the metric shape
     c2 = dict(image=224, patch=16, classes=19, frames=16, dim=384, depth=4, heads=6, dim_head=64)
-    vivit_digest_case(vit, "c2_digest", c2, batch=1, seed=SEED + 20)
     cm = dict(image=224, patch=16, classes=19, frames=32, dim=512, depth=4, heads=8, dim_head=64)
-    vivit_digest_case(vit, "metric_digest", cm, batch=1, seed=SEED + 30)
-    block_cases(vit)
-    encoder_layer_case()
-    posenc_case()
-    resnet_case()
-    tpn_case()
-    input_stage_case()
-    eval_metrics_case()
-    fusion_case()
+    # BASELINE.json configs[4]: long clip, T=64, 288^2 (N = 325 tokens per frame), one clip
+    c5 = dict(image=288, patch=16, classes=19, frames=64, dim=512, depth=4, heads=8, dim_head=64)
+    if want("vivit"):
+        vivit_case(vit, "tiny", tiny, batch=2, store_weights=True, seed=SEED)
+        vivit_case(vit, "c1", c1, batch=2, store_weights=False, seed=SEED + 10)
+        vivit_digest_case(vit, "c2_digest", c2, batch=1, seed=SEED + 20)
+        vivit_digest_case(vit, "metric_digest", cm, batch=1, seed=SEED + 30)
+    if want("longclip"):
+        vivit_digest_case(vit, "longclip_digest", c5, batch=1, seed=SEED + 70)
+    if want("lowprec"):
+        vivit_lowprec_case(vit, "tiny", tiny, 2, SEED, ["amp_bf16", "pure_bf16", "amp_fp16"])
+        vivit_lowprec_case(vit, "c1", c1, 2, SEED + 10, ["amp_bf16", "pure_bf16", "amp_fp16"])
+        vivit_lowprec_case(vit, "c2", c2, 1, SEED + 20, ["amp_bf16", "pure_bf16", "amp_fp16"])
+        vivit_lowprec_case(vit, "metric", cm, 1, SEED + 30, ["amp_bf16", "pure_bf16", "amp_fp16"])
+        vivit_lowprec_case(vit, "longclip", c5, 1, SEED + 70, ["amp_fp16", "amp_bf16"])
+    for group, fn in (("blocks", lambda: block_cases(vit)), ("encoder", encoder_layer_case), ("posenc", posenc_case),
+                      ("resnet", resnet_case), ("resnet_lowprec", resnet_lowprec_case), ("tpn", tpn_case), ("input_stage", input_stage_case),
+                      ("eval_metrics", eval_metrics_case), ("fusion", fusion_case)):
+        if want(group):
+            fn()
 
 
 if __name__ == "__main__":
