@@ -527,12 +527,8 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
   const bool plain = d->epilogue == DVT_EPI_NONE && !d->bias && d->alpha == 1.0f;
   const bool can_split = plain;   // LDS-DMA path: slabs are summed without an epilogue
   const int64_t cus = dvt_num_cus();
-  static const bool allow256 = [] {
-    const char* e = getenv("DVT_GEMM256");
-    return !(e && e[0] == '0');
-  }();
   // --- 256x256 LDS-DMA kernel
-  if (allow256 && d->K % 64 == 0) {
+  if (d->K % 64 == 0) {
     const int64_t t256 = dvt_cdiv(d->M, 256) * dvt_cdiv(d->N, 256);
     int64_t s = 1;
     if (d->split_k > 0) s = d->split_k;
@@ -551,16 +547,11 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       pl.use256 = true;
       pl.split = (int)s;
       pl.kps = (int)kps;
-      // short K: the epilogue burst is a large share of a tile's life -> two workgroups per CU
-      static const int force_cfg = [] {
-        const char* e = getenv("DVT_GEMM_CFG");
-        return e ? atoi(e) : -1;
-      }();
       // cfg 0 (8 waves of 128 x 64) except for the arithmetic-heavy GELU / GELU' epilogues: with 16 waves of 64 x 64
       // (cfg 3) the epilogue's vector work of one wave overlaps the store latency of three others (FF1 206 -> 195 us).
-      // cfg 1 (2 workgroups / CU) measured slower or equal on every metric shape.
+      // cfg 1 (2 workgroups / CU) measured slower or equal on every Linear shape.
       const bool heavy_epi = d->epilogue == DVT_EPI_GELU || d->epilogue == DVT_EPI_DGELU;
-      pl.cfg = force_cfg >= 0 ? force_cfg : (heavy_epi && s == 1 ? 3 : 0);
+      pl.cfg = heavy_epi && s == 1 ? 3 : 0;
       return pl;
     }
   }

@@ -30,21 +30,18 @@
 
 namespace {
 
-// Configurations of one kernel (0 is the product default; 1 serves narrow convolutions; 2 and 3 are measured
-// experiment knobs, DVT_GEMM_CFG):
+// Configurations of one kernel (0 is the default; 1 serves narrow convolutions; 3 the GELU / GELU' epilogues):
 //   CFG 0  256x256 tile, BK=64, 2 LDS stages (128 KiB), 8 waves (2x4): 1 workgroup / CU.
 //          Highest arithmetic intensity per L2 byte; used when K is long enough that the
 //          un-overlapped epilogue burst does not matter.
 //   CFG 1  256x128 tile, BK=32, 3 LDS stages (72 KiB), 4 waves (2x2): 2 workgroups / CU,
 //          so one workgroup's epilogue (stores) overlaps the other's main loop.  Used for
 //          convolutions with <= 128 output channels (measured slower than CFG 0 on every Linear shape).
-//   CFG 2  256x256 tile, BK=32, 4 LDS stages, k-tile t+1 landed at the barrier of t (fragment prefetch across it).
 //   CFG 3  256x256 tile, BK=64, 16 waves of 64x64 (4 per SIMD, 128 VGPRs, no fragment double buffer): twice the
 //          memory-operation concurrency in the epilogue, a slower main loop.
 template <int CFG> struct Cfg;
 template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
-template <> struct Cfg<2> { enum { TM = 256, TN = 256, TK = 32, NW = 8, WN = 4, NSTG = 4 }; };   // 3 k-tiles (96 KiB) in flight
 template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2 }; };  // 16 waves of 64 x 64: 4 per SIMD
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
@@ -304,9 +301,6 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     }
   DVT_GSTAMP(1);
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
-  // kCross (4-stage ring of 32-wide k-tiles): k-tile kt+1 is required landed at the barrier of kt, so the first fragment
-  // reads of kt+1 are issued under the last MFMA block of kt -- no LDS latency is exposed behind a barrier.
-  constexpr bool kCross = NSTG >= 4 && TK == 32 && NW <= 8;
   constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
   constexpr bool kPipe = NW <= 8;                // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
   V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
@@ -317,9 +311,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
     {
       const int issued = min(nk - 1, kt + NSTG - 2);                 // youngest k-tile in flight
-      const int young = issued - (kCross ? min(kt + 1, nk - 1) : kt);   // k-tiles that may stay in flight
-      if (NSTG >= 4 && young == 2) wait_vm<2 * kPPT>();
-      else if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
+      const int young = issued - kt;                                 // k-tiles that may stay in flight
+      if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
       else wait_vm<0>();
     }
     // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
@@ -342,7 +335,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
     // wave's 128 rows): the fragment reads of block b+1 are issued BEFORE the MFMAs of block b, into the other half of
     // a double register buffer, so their LDS latency runs under 16 MFMAs instead of behind them.
-    if (NB > 0 && kPipe && !(kCross && kt > 0)) {
+    if (NB > 0 && kPipe) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) bfr[0][u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, 0, g, li);
 #pragma unroll
@@ -369,14 +362,6 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
 #pragma unroll
         for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + (th * 4 + t) * 16, kk, g, li);
       }
-      const bool cross = kCross && b + 1 == NB && kt + 1 < nk;
-      if (cross) {                                 // first block of the next k-tile: B into the spare half, A into af[0]
-        const char* sa1 = smem + (st_cur + 1 == NSTG ? 0 : st_cur + 1) * kStage;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bfr[1][u] = frag<E, B_KMAJOR, TN, TK>(sa1 + kATile, wn * 64 + u * 16, 0, g, li);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[0][t] = frag<E, A_KMAJOR, TM, TK>(sa1, wm * WROWS + t * 16, 0, g, li);
-      }
       if (kPipe && b + 1 < NB) {
         const int kk1 = (b + 1) / NTH, th1 = (b + 1) % NTH;
         if (th1 == 0) {
@@ -396,10 +381,6 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
           acc[u][th * 4 + t] = Elem16<E>::mma(bfr[kPipe ? (kk & 1) : 0][u], af[kPipe ? (b & 1) : 0][t], acc[u][th * 4 + t]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (cross) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bfr[0][u] = bfr[1][u];
-      }
       if (kCanColsum && do_cs && th == NTH - 1) {
 #pragma unroll
         for (int tt = 0; tt < CS; ++tt)
@@ -573,10 +554,9 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   typedef Cfg<CFG> C;
   constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
-  // Outputs that the next kernel can still find in the 256 MB Infinity Cache stay cacheable; larger ones are streamed so
-  // that they do not evict the operand panels from L2 (threshold in MB, DVT_GEMM_STREAM_MB overrides)
-  static const int stream_mb = [] { const char* e = getenv("DVT_GEMM_STREAM_MB"); return e ? atoi(e) : 180; }();
-  p.stream_out = (int64_t)p.M * p.N * 2 * (p.epilogue == DVT_EPI_GELU && p.aux ? 2 : 1) >= (int64_t)stream_mb * 1000000;
+  // Outputs that the next kernel can still find in the 256 MB Infinity Cache stay cacheable; larger ones (>= 180 MB) are
+  // streamed so that they do not evict the operand panels from L2
+  p.stream_out = (int64_t)p.M * p.N * 2 * (p.epilogue == DVT_EPI_GELU && p.aux ? 2 : 1) >= (int64_t)180 * 1000000;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
@@ -656,9 +636,8 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
 // combination has no LDS-DMA instantiation.
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
-  if (p.elem == DVT_F16)       // fp16: the two product configurations (1 and 2 are bf16 experiment knobs)
+  if (p.elem == DVT_F16)
     return cfg == 3 ? launch_cfg<f16, 3>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
-  if (cfg == 2) return launch_cfg<bf16, 2>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 3) return launch_cfg<bf16, 3>(p, a_kmajor, b_kmajor, split, st);
   return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
                   : launch_cfg<bf16, 1>(p, a_kmajor, b_kmajor, split, st);

@@ -269,7 +269,7 @@ class FlatParameters:
             ops.adamw_step_scaled_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.scale_dev,
                                    self.found_inf, self.good_steps, self.loss_grad, lr=lr, beta1=betas[0],
                                    beta2=betas[1], eps=eps, weight_decay=weight_decay, loss_grad_base=self.loss_scale,
-                                   **self.scaler)
+                                   skip=self.skip_mask, **self.scaler)
             self.sync_compute_copy()
             self._after_step()
             return

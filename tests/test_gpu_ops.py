@@ -267,6 +267,51 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     assert rel_l2(y2, x2 @ w2.t()) < BF16_TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(50432, 512, 512), (50432, 2048, 512), (12345 * 8, 1536, 256), (23000, 1000, 192),
+                                   (50432, 512, 2048), (3000 * 8, 256, 64)])
+def test_gemm_large_m_every_row_written_exactly_once(dvt, device, M, N, K):
+    """The metric workload's token counts (M = 50,432 and ragged variants) through the LDS-DMA kernel's XCD-aware tile
+    remap: every output row must be written exactly once -- ragged M (not a multiple of the tile), ragged N, 1 / 2 / 4 / 6
+    / 8 column panels, forward and data-gradient layouts, every fused epilogue.  The outputs start as NaN and are checked
+    per element (max error), not only in norm: one misplaced 64-row block is 0.1 % of the rows."""
+    L = dvt._lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x_d = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w_d = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
+    bias = (0.5 * torch.randn(N, generator=g)).cuda()
+    pre = x_d.float() @ w_d.float().t() + bias                     # fp32 reference on the same rounded operands
+    scale = float(pre.abs().max())
+
+    def check(got, want, what):
+        err = float((got.float() - want).abs().max())
+        assert err < 2e-2 * max(scale, float(want.abs().max())), (what, err)
+        assert rel_l2(got, want) < BF16_TOL, what
+
+    poison = lambda *shape: torch.full(shape, float("nan"), dtype=torch.bfloat16, device="cuda")
+    y = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias, out=poison(M, N))
+    check(y, pre, "plain")                                          # NaN anywhere = a row nobody wrote
+    aux = poison(M, N)
+    h = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias, epilogue=L.EPI_GELU, aux=aux,
+                     out=poison(M, N))
+    check(aux, pre, "gelu pre-activation")
+    check(h, torch.nn.functional.gelu(pre), "gelu")
+    res_d = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    yr = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias, epilogue=L.EPI_RESIDUAL,
+                      residual=res_d, out=poison(M, N))
+    check(yr, pre + res_d.float(), "residual")
+    # data gradient layout: dx[M, N] = dy[M, K] @ W[K, N] (mn-major B), plain and with GELU'
+    wt_d = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
+    dx_ref = x_d.float() @ wt_d.float()
+    dx = dvt.ops.gemm(x_d, wt_d, M, N, K, a_kmajor=True, b_kmajor=False, lda=K, ldb=N, out=poison(M, N))
+    check(dx, dx_ref, "dgrad")
+    u_d = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    uu = u_d.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).backward(dx_ref)
+    du = dvt.ops.gemm(x_d, wt_d, M, N, K, a_kmajor=True, b_kmajor=False, lda=K, ldb=N, epilogue=L.EPI_DGELU, aux=u_d,
+                      out=poison(M, N))
+    check(du, uu.grad, "dgrad + gelu'")
+
+
 @pytest.mark.parametrize("rows", [28, 2, 13, 100])
 def test_wgrad_ragged_row_count_runs_on_mfma(dvt, device, rows):
     """Weight gradients of the 14-token encoders (K = B * 14 = 28 rows, frame_transformer.py:204) -- K is not a multiple of 8

@@ -5,7 +5,8 @@ against the CPU oracle.
 fp32 mode: logits / loss / every parameter gradient within 1e-3 rel (north_star)
 -- asserted at 2e-4.  bf16 / fp16 modes follow the protocol of SURVEY section 7 and
 BASELINE.md section 2: logits <= 1e-2 rel-L2, and logits and EVERY parameter
-gradient <= 2x the reference's own low-precision deviation on the same inputs.
+gradient <= 2x the reference's own low-precision deviation on the same inputs
+(per parameter, floored at the reference's median: tests/util.py).
 That deviation is not quoted from prose: tools/gen_golden.py runs the imported
 reference under torch.autocast(bf16 / fp16) on the CPU and stores the digests
 (tests/golden/vivit_*_lowprec.npz); at configs[0] it reproduces BASELINE.md's
@@ -68,7 +69,8 @@ def test_vivit_matches_reference_golden(device, mode, case):
     ref_out, ref_errs = reference_lowprec_errors(g, golden(f"vivit_{case}_lowprec.npz"), "amp_" + mode)
     w = assert_within_reference_lowprec(f"{case}/{mode}", e_out, grad_digest_errors(g, grads), ref_out, ref_errs,
                                         out_cap=1e-2)
-    print(f"[{case}/{mode}] reference's own {mode}: logits {ref_out:.2e}; worst ratio ours/reference {w[1]:.2f} ({w[0]})")
+    print(f"[{case}/{mode}] reference's own {mode}: logits {ref_out:.2e}; worst gradient ratio ours/reference {w[0][1]:.2f} "
+          f"({w[0][0]}); against the raw per-parameter deviation {w[1][1]:.2f} ({w[1][0]})")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
@@ -86,7 +88,8 @@ def test_vivit_large_configs_match_reference_digest(device, tag, mode):
     net = net.cuda()
     logits = net(x.cuda())
     loss = F.bce_with_logits(logits, y.cuda())
-    scale = 256.0 if mode == "fp16" else 1.0            # static loss scale: fp16 activation gradients underflow at 1.0
+    scale = 8192.0 if mode == "fp16" else 1.0           # static loss scale: fp16 activation gradients underflow at 1.0, and
+    # at 256 the smallest pos_embedding entries of a one-clip gradient still sit in fp16's subnormal range
     loss.backward(torch.tensor(scale, device="cuda"))
     for p in net.parameters():
         p.grad.div_(scale)
@@ -105,7 +108,8 @@ def test_vivit_large_configs_match_reference_digest(device, tag, mode):
     print(f"[{tag}/{mode}] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} worst grad digest "
           f"{wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
     w = assert_within_reference_lowprec(f"{tag}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=1e-2)
-    print(f"[{tag}/{mode}] worst ratio ours/reference {w[1]:.2f} ({w[0]})")
+    print(f"[{tag}/{mode}] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); against the raw per-parameter "
+          f"deviation {w[1][1]:.2f} ({w[1][0]})")
 
 
 def test_longclip_config_composed_matches_reference_digest(device):
@@ -142,7 +146,8 @@ def test_longclip_config_composed_matches_reference_digest(device):
           f"worst grad digest {wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
     assert e_loss < 1e-3
     w = assert_within_reference_lowprec("longclip/fp16", e_out, errs, ref_out, ref_errs, out_cap=4e-3)
-    print(f"[longclip/fp16+scaling+ckpt] worst ratio ours/reference {w[1]:.2f} ({w[0]})")
+    print(f"[longclip/fp16+scaling+ckpt] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); against the raw "
+          f"per-parameter deviation {w[1][1]:.2f} ({w[1][0]})")
     # the optimizer consumes the scaled gradients: one AdamW step must not overflow-skip and must move the weights
     before = flat.data.clone()
     flat.adamw_step(lr=1e-3, weight_decay=0.0)
@@ -184,13 +189,13 @@ def test_metric_shape_bf16_tracks_fp32_mode(device):
     e_out = rel_l2(outs[1][0], outs[0][0])
     print(f"[metric-shape] bf16 vs fp32-mode logits rel {e_out:.2e} loss {float(outs[0][1]):.5f} / {float(outs[1][1]):.5f}")
     assert torch.isfinite(outs[1][0]).all()
-    assert e_out < 3e-2
+    assert e_out < 1e-2
     worst = 0.0
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert torch.isfinite(p.grad).all(), k
         worst = max(worst, rel_l2(p.grad, q.grad))
     print(f"[metric-shape] worst grad rel {worst:.2e}")
-    assert worst < 6e-2
+    assert worst < 2.5e-2
 
 
 def test_activation_checkpointing_same_gradients_less_memory(device):

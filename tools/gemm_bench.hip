@@ -20,7 +20,7 @@ static void fill(bf16* d, size_t n, float scale) {
 
 int main(int argc, char** argv) {
   struct Shape { const char* name; int M, N, K; bool ak, bk; int epi; int split; };
-  const int Mt = 50432;
+  const int Mt = argc > 1 ? atoi(argv[1]) : 50432;
   Shape shapes[] = {
     {"qkv_fwd   [M,512]x[1536,512]^T", Mt, 1536, 512, true, true, DVT_EPI_NONE, 1},
     {"ff1_fwd   [M,512]x[2048,512]^T gelu", Mt, 2048, 512, true, true, DVT_EPI_GELU, 1},
@@ -28,12 +28,14 @@ int main(int argc, char** argv) {
     {"proj_fwd  [M,512]x[512,512]^T res", Mt, 512, 512, true, true, DVT_EPI_RESIDUAL, 1},
     {"ff2_dgrad [M,512]x[512,2048] dgelu", Mt, 2048, 512, true, false, DVT_EPI_DGELU, 1},
     {"ff1_dgrad [M,2048]x[2048,512]", Mt, 512, 2048, true, false, DVT_EPI_NONE, 1},
+    {"qkv_dgrad [M,1536]x[1536,512]", Mt, 512, 1536, true, false, DVT_EPI_NONE, 1},
+    {"proj_dgrad [M,512]x[512,512]", Mt, 512, 512, true, false, DVT_EPI_NONE, 1},
     {"ff1_wgrad [2048,M]x[M,512] split16", 2048, 512, Mt, false, false, DVT_EPI_NONE, 16},
     {"square 4096^3 k,k", 4096, 4096, 4096, true, true, DVT_EPI_NONE, 1},
     {"square 4096^3 k,mn", 4096, 4096, 4096, true, false, DVT_EPI_NONE, 1},
     {"square 4096^3 mn,mn", 4096, 4096, 4096, false, false, DVT_EPI_NONE, 1},
   };
-  size_t maxA = (size_t)Mt * 2048, maxB = (size_t)Mt * 2048, maxC = (size_t)Mt * 2048;
+  size_t maxA = (size_t)(Mt > 4096 ? Mt : 4096) * 2048, maxB = (size_t)Mt * 2048, maxC = (size_t)Mt * 2048;
   bf16 *A, *B, *C, *AUX, *RES; float* bias; float* slab;
   hipMalloc(&A, maxA * 2); hipMalloc(&B, maxB * 2); hipMalloc(&C, maxC * 2);
   hipMalloc(&AUX, maxC * 2); hipMalloc(&RES, maxC * 2); hipMalloc(&bias, 4096 * 4);
@@ -51,7 +53,7 @@ int main(int argc, char** argv) {
     int split = (int)dvt_cdiv(s.K, kps);
     p.k_per_split = kps; p.slab = split > 1 ? slab : nullptr;
     if (split > 1) { p.bias = nullptr; }
-    for (int cfg = 0; cfg < 2; ++cfg) {
+    for (int cfg = 0; cfg < 1; ++cfg) {
     for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfg, 0);
     hipDeviceSynchronize();
     const int reps = 20;
