@@ -91,30 +91,54 @@ class EventProfiler:
         return out
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
-    """Oracle fwd+bwd on host cores, bounded sample of the same workload."""
+def cpu_baseline(cfg, batch=8, timed_steps=3):
+    """The oracle (the reference's arithmetic restated, pinned to the reference by tests/golden) timed on this host:
+    forward + BCE + backward of the metric workload at B = 8, 1 warm-up + ``timed_steps`` timed
+    steps, at the best thread count of an ascending sweep (8, 16, 32, 64, cores/4, cores/2, cores; capped at 64 and stopped
+    once more threads are slower) -- the sweep itself runs on one clip to stay bounded."""
     from oracle import clip_path as O
-    torch.manual_seed(1130)
     from dvt_amd.models.vit import ViViT
+    torch.manual_seed(1130)
     net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
                 heads=cfg["heads"], dim_head=cfg["dh"])
     P = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    bs = 1
-    x = torch.randn(bs, cfg["T"], 3, cfg["image"], cfg["image"])
-    y = (torch.rand(bs, cfg["classes"]) < 0.2).float()
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    O.vivit_step_fwd_bwd(x, y, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])   # warm-up
-    warm = time.perf_counter() - t0
-    steps = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.vivit_step_fwd_bwd(x, y, P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(bs / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (pure-torch fp32 restatement) fwd+bwd on {bs} clip of the metric shape "
-                      f"(T={cfg['T']}, {cfg['image']}^2, d={cfg['d']}), 1 warm-up + {steps} timed steps, "
-                      f"{dt:.2f} s/step"}
+    gen = torch.Generator().manual_seed(1130)
+    x = torch.randn(batch, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen)
+    y = (torch.rand(batch, cfg["classes"], generator=gen) < 0.2).float()
+    y[:, 0] = 1.0
+
+    def step(n):
+        t0 = time.perf_counter()
+        O.vivit_step_fwd_bwd(x[:n], y[:n], P, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"])
+        return time.perf_counter() - t0
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    # Thread counts in ascending order, stopping once more threads stop paying: on a shared 256-thread host the full count
+    # is oversubscribed by an order of magnitude (measured: 2.9 / 5.8 / 106 s per clip at 64 / 128 / 256 threads).
+    cands = sorted({c for c in (8, 16, 32, 64, cores // 4, cores // 2, cores) if 1 <= c <= min(cores, 64)} or {1})
+    sweep = {}
+    for th in cands:                       # one clip per setting: warm-up + one timed step
+        torch.set_num_threads(th)
+        step(1)
+        sweep[th] = step(1)
+        if sweep[th] > 1.1 * min(sweep.values()):
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    step(batch)                             # warm-up at the full batch
+    ts = sorted(step(batch) for _ in range(timed_steps))
+    dt = ts[len(ts) // 2]
+    return {"value": round(batch / dt, 4), "unit": "clips/s", "cores": best, "kind": "port",
+            "sample": f"oracle (pure-torch fp32 restatement of src/models/vit.py) fwd+BCE+bwd at the metric shape, B={batch} "
+                      f"(T={cfg['T']}, {cfg['image']}^2, d={cfg['d']}), 1 warm-up + {timed_steps} timed steps, median "
+                      f"{dt:.2f} s/step at {best} threads",
+            "host_logical_cpus": cores,
+            "thread_sweep_s_per_clip": {str(k): round(v, 2) for k, v in sweep.items()},
+            "survey_cross_check": "the imported reference itself: 0.69 clips/s at B=8 on 8 cores, fp32 (BASELINE.md section 2)"}
 
 
 WORKLOADS = {
@@ -134,89 +158,60 @@ WORKLOADS = {
 }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=32.0)
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
-                    "replaying one captured hipGraph per step (single-GPU only)")
-    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal", "longclip", "frametransformer"], default="vivit",
-                    help="vivit = the metric workload (default); pyramid = BASELINE configs[2] (ResNet-18 3-scale "
-                    "pyramid front-end -> the same transformer); crossmodal = configs[3] (+ 32 audio tokens, "
-                    "cross-attention block, distillation head); longclip = configs[4] (T=64, 288^2, fp16 + dynamic loss "
-                    "scaling, activation checkpointing; reports HBM GB/s of the streaming kernels and the activation "
-                    "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
-                    "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
-                    "(config.yaml:2).  Secondary lines, same JSON contract.")
-    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d secondary metric): the global batch stays "
-                    "--batch and each rank takes batch / world clips")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="kernel element type of the vivit workload "
-                    "(fp16 adds the device-side dynamic loss scaling)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
-                    "one GPU to rehearse the data-parallel path on a single-GPU box)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one "
-                    "rank (rehearses the multi-GPU code path on a single GPU)")
-    args = ap.parse_args()
+def newest_pmc_traffic():
+    """Per-launch HBM bytes of the GEMM families from the newest committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes cannot run inside this process; tools/run_profiles.sh collects them with this same command)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc_traffic", f).group(1)))
+    if not files:
+        return {}, None
+    try:
+        with open(files[-1]) as fh:
+            return json.load(fh)["families"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return {}, None
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    if args.strong:
-        if args.batch % world:
-            raise SystemExit(f"--strong: global batch {args.batch} is not divisible by {world} ranks")
-        args.batch //= world
-
-    import dvt_amd
+def build_workload(args, workload, rank, comm):
+    """Model, flat parameter store, synthetic batch and the step closure of one workload."""
     from dvt_amd import functional as F
-    from dvt_amd import ops
     from dvt_amd.dp import FlatParameters
     from dvt_amd.models.vit import ViViT
 
     cfg = dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64)
     cdt = torch.bfloat16
-    if args.workload == "longclip":
+    if workload == "longclip":
         cfg.update(image=288, T=64)
         cdt = torch.float16
     elif args.dtype == "fp16":
         cdt = torch.float16
+    B = args.batch
     torch.manual_seed(1130)                                       # src/main.py:25
-    if args.workload == "frametransformer":
+    if workload == "frametransformer":
         from dvt_amd.models.frame_transformer import FrameTransformer
-        if args.batch == 8:
-            args.batch = 2                                     # config.yaml:2
-        net = FrameTransformer(batch_size=args.batch, seq_len=13, cls=1, model="vid", opt="adamW", learning_rate=5e-6,
+        if B == 8:
+            B = 2                                              # config.yaml:2
+        net = FrameTransformer(batch_size=B, seq_len=13, cls=1, model="vid", opt="adamW", learning_rate=5e-6,
                                weight_decay=0.09, momentum=0.005).cuda().train()
-    elif args.workload in ("vivit", "longclip"):
+    elif workload in ("vivit", "longclip"):
         net = ViViT(cfg["image"], cfg["patch"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"],
                     heads=cfg["heads"], dim_head=cfg["dh"], compute_dtype=cdt,
-                    activation_checkpointing=args.workload == "longclip").cuda().train()
+                    activation_checkpointing=workload == "longclip").cuda().train()
     else:
         from dvt_amd.models.pyramid_vivit import PyramidViViT
-        cm = args.workload == "crossmodal"
+        cm = workload == "crossmodal"
         net = PyramidViViT(cfg["image"], cfg["classes"], cfg["T"], dim=cfg["d"], depth=cfg["depth"], heads=cfg["heads"],
                            dim_head=cfg["dh"], audio_tokens=32 if cm else 0, audio_dim=128, distill=cm,
                            compute_dtype=torch.bfloat16).cuda().train()
-    flat = FlatParameters(net, bucket_mb=args.bucket_mb, compute_dtype=cdt)
+    rdt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.grad_dtype] if comm is not None else None
+    flat = FlatParameters(net, bucket_mb=args.bucket_mb, compute_dtype=cdt, comm=comm, grad_reduce_dtype=rdt)
     flat.broadcast_parameters(0)
     flat.sync_compute_copy()
 
     gen = torch.Generator().manual_seed(1130 + rank)
-    B = args.batch
-    if args.workload == "frametransformer":
+    if workload == "frametransformer":
         x = torch.randn(B, 13, 12, 3, 112, 112, generator=gen).cuda()     # MMX_Light_dl.py:286 batch contract
     else:
         x = torch.randn(B, cfg["T"], 3, cfg["image"], cfg["image"], generator=gen).to(cdt).cuda()
@@ -227,61 +222,154 @@ def main():
     if cdt == torch.float16:
         gloss = flat.enable_loss_scaling(init_scale=4096.0, growth_interval=1000)     # device-resident seed
     audio = None
-    if args.workload == "crossmodal":       # one 128-d VGGish-style vector per 1-s chunk (SURVEY 8d synthetic inputs)
+    if workload == "crossmodal":       # one 128-d VGGish-style vector per 1-s chunk (SURVEY 8d synthetic inputs)
         audio = torch.randn(B, 32, 128, generator=gen).to(torch.bfloat16).cuda()
 
-    def step():
+    def fwd_bwd():
         flat.zero_grad()
-        if args.workload in ("vivit", "longclip"):
+        if workload in ("vivit", "longclip"):
             loss = F.bce_with_logits(net(x), y)
-        elif args.workload == "frametransformer":
+        elif workload == "frametransformer":
             loss = net.training_step((y, None, x), 0)
         else:
             loss = net.training_step((y, x, audio) if audio is not None else (y, x))
         loss.backward(gloss)
-        flat.finish_backward()
-        flat.adamw_step(lr=5e-6, weight_decay=0.09)              # config.yaml:3,12
         return loss
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
+    def update():
+        flat.adamw_step(lr=5e-6, weight_decay=0.09)              # config.yaml:3,12
 
-    # Single GPU: the whole step (fwd + loss + bwd + AdamW + weight cast) is captured once as a
-    # hipGraph and replayed.  Multi GPU: eager launches, so that the bucketed RCCL all-reduces
-    # stay ordinary asynchronous collectives overlapped with backward.
-    use_graph = not use_dist and not args.no_graph
-    run = step
-    if use_graph:
-        from dvt_amd.graph import capture_step
-        replay, static_loss = capture_step(step, warmup=2)
+    def step():
+        loss = fwd_bwd()
+        flat.finish_backward()
+        update()
+        return loss
 
-        def run():
-            replay()
-            return static_loss
+    return dict(cfg=cfg, cdt=cdt, B=B, net=net, flat=flat, step=step, fwd_bwd=fwd_bwd, update=update)
 
-    for _ in range(args.warmup):
-        run()
+
+def collective_capture_ok(comm):
+    """Can this RCCL build's all-reduce be recorded in a hipGraph and replayed with the right result?  (Checked on a small
+    buffer on every rank before the step is captured; a refusal or a wrong sum selects the segmented form.)"""
+    try:
+        world, rank = comm.world, comm.rank
+        t = torch.full((4096,), float(rank + 1), device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            comm.all_reduce_async(t).wait()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        want = world * (world + 1) / 2.0
+        if float(t[0]) != want:
+            return False, f"eager all-reduce returned {float(t[0])}, expected {want}"
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            comm.all_reduce_async(t).wait()
+        for _ in range(2):
+            t.fill_(float(rank + 1))
+            g.replay()
+            torch.cuda.synchronize()
+            if float(t[0]) != want or float(t[-1]) != want:
+                return False, f"replayed all-reduce returned {float(t[0])}, expected {want}"
+        return True, ""
+    except Exception as e:      # capture refused
+        return False, f"{type(e).__name__}: {e}"[:200]
+
+
+def timed_steps(run, steps, barrier):
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (p10 / median / p90)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # per-step spread (p10 / median / p90)
     t0 = time.perf_counter()
     evs[0].record()
-    for i in range(args.steps):
+    loss = None
+    for i in range(steps):
         loss = run()
         evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    return elapsed, per_step, loss
+
+
+def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, roofline, secondary=False):
+    """One workload, timed per the driver's contract.  Returns the JSON dict (rank 0) or None."""
+    from dvt_amd import ops
+    from dvt_amd.graph import capture_step, capture_step_segments
+    W = build_workload(args, workload, rank, comm)
+    cfg, cdt, B, flat, step = W["cfg"], W["cdt"], W["B"], W["flat"], W["step"]
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    # Launch form.  One GPU: the whole step (fwd + loss + bwd + AdamW + weight cast) is one captured hipGraph.  Data
+    # parallel: the SAME single graph, with the bucketed RCCL all-reduces (dvt_comm_allreduce on a side stream, forked
+    # and joined through events) recorded inside it -- the host launches one graph per step whatever N is.  If this RCCL
+    # build cannot be captured: two graphs around one eagerly launched all-reduce; last resort: eager launches.
+    launch, note = "eager", ""
+    run = step
+    if not args.no_graph:
+        if not use_dist:
+            replay, static_loss = capture_step(step, warmup=2)
+            launch = "hipGraph replay"
+        else:
+            ok, why = (True, "") if comm is None else collective_capture_ok(comm)
+            if comm is not None and ok:
+                replay, static_loss = capture_step(step, warmup=2)
+                launch = "hipGraph replay (bucketed RCCL all-reduce captured inside the step graph)"
+            elif comm is not None:
+                flat.defer_exchange = True
+
+                def fwd_bwd_local():
+                    loss = W["fwd_bwd"]()
+                    flat.finish_backward(exchange=False)
+                    return loss
+
+                replay, static_loss = capture_step_segments(fwd_bwd_local, flat.exchange_all, W["update"], warmup=2)
+                launch, note = "two hipGraphs around one eager RCCL all-reduce", why
+            else:
+                replay = None            # torch.distributed collectives of a non-RCCL backend: eager
+        if launch != "eager":
+            def run():
+                replay()
+                return static_loss
+
+    for _ in range(warmup):
+        run()
+    elapsed, per_step, loss = timed_steps(run, steps, barrier)
     if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.detach())
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+
+    extra = {}
+    if use_dist and not secondary:
+        # the same step launched kernel by kernel from the host (what round 1 did under data parallelism)
+        k = max(3, min(10, steps))
+        for _ in range(2):
+            step()
+        e_elapsed, _, _ = timed_steps(step, k, barrier)
+        extra["eager_ms_per_step"] = round(e_elapsed / k * 1e3, 3)
+        extra["graph_ms_per_step"] = round(elapsed / steps * 1e3, 3)
+        if comm is not None and launch.startswith("hipGraph replay"):
+            # exposed (un-overlapped) exchange time: the captured step with and without its collectives
+            flat.exchange_enabled = False
+            replay0, _ = capture_step(step, warmup=1)
+            for _ in range(2):
+                replay0()
+            n_elapsed, _, _ = timed_steps(lambda: replay0(), k, barrier)
+            flat.exchange_enabled = True
+            extra["graph_ms_per_step_without_exchange"] = round(n_elapsed / k * 1e3, 3)
+            extra["exposed_allreduce_ms_per_step"] = round(max(0.0, elapsed / steps - n_elapsed / k) * 1e3, 3)
+            extra["allreduce_bytes_per_step"] = int(flat.total * (2 if flat.grad16 is not None else 4))
+
     # optimizer share of the step (SURVEY 8d asks for it separately): fused AdamW + bf16 weight mirror on the flat buffers
     o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     o0.record()
@@ -294,13 +382,13 @@ def main():
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
     roof = None
-    if not args.no_roofline:
+    if roofline:
         prof = EventProfiler()
         ops.set_profiler(prof)
-        nprof = max(1, min(3, args.steps))
+        nprof = max(1, min(3, steps))
         # The host needs longer to issue a step than the GPU to run it when every launch is bracketed by events; a
         # device-side delay in front of each profiled step lets the host run ahead, so the brackets see device time only.
-        host_ms = max(20.0, 4.0 * elapsed / args.steps * 1e3)
+        host_ms = max(20.0, 4.0 * elapsed / steps * 1e3)
         ops.device_delay(20000)
         bracket_us = prof.calibrate(lambda: ops.device_delay(0)) * 1e3
         for _ in range(nprof):
@@ -310,9 +398,7 @@ def main():
         torch.cuda.synchronize()
         ops.set_profiler(None)
         summ = prof.summary()
-        fam = {}
-        hbm = {}
-        big = {}
+        fam, hbm, big = {}, {}, {}
         for key in summ:                       # per kernel: its largest launch shape (the space-transformer one)
             if key[0] == "hbm" and (key[1] not in big or key[2] > big[key[1]][2]):
                 big[key[1]] = key
@@ -326,75 +412,173 @@ def main():
                 tf = key[3] * cnt / (ms * 1e-3) / 1e12
                 hbm[name]["mfma_TFLOPs"] = round(tf, 1)
                 hbm[name]["frac_of_mfma_peak"] = round(tf / MFMA_PEAK_TFLOPS, 3)
+                hbm[name]["mfma_ceiling_note"] = ("fused attention moves 4 N dh 2 B per (frame, head) for 4 N^2 dh flop: N/2 flop/B "
+                                                  "= 98.5 at N=197 against a machine balance of 312, i.e. at most 31 % of the MFMA "
+                                                  "peak at the HBM roofline (north_star asks 40 %)")
         for key, (ms, fl, cnt) in summ.items():
             if key[0] != "gemm":
                 continue
-            tag, ak, bk, M, N, K = key
+            tag, ak, bk, M, N, K, epi, nbytes = key
             if M * N * K < (1 << 30):      # launch-bound temporal/head GEMMs: not this kernel's regime
                 continue
-            f = fam.setdefault((ak, bk), [0.0, 0.0, 0])
-            f[0] += ms; f[1] += fl; f[2] += cnt
+            f = fam.setdefault((ak, bk), [0.0, 0.0, 0, 0.0])
+            f[0] += ms; f[1] += fl; f[2] += cnt; f[3] += float(nbytes) * cnt
         names = {(1, 1): "gemm_dma_kernel<A k-major, B k-major> (forward Linear)",
                  (1, 0): "gemm_dma_kernel<A k-major, B mn-major> (data gradient)",
                  (0, 0): "gemm_dma_kernel<A mn-major, B mn-major> (weight gradient, split-K incl. reduce)"}
-        pmc = {}
-        try:   # per-launch HBM bytes of each family from the committed PMC profile (rocprofv3 --pmc)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)["families"]
-        except Exception:
-            pmc = {}
+        pmc, pmc_file = newest_pmc_traffic()
         pmc_key = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}
         if fam:
             dom = max(fam, key=lambda k: fam[k][0])
-            ms, fl, cnt = fam[dom]
+            ms, fl, cnt, nb = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = (pmc.get(pmc_key.get(dom, ""), {}) or {}).get("hbm_bytes_corrected")
+            alg = nb / cnt
             roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(ach, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": (pmc.get(pmc_key.get(dom, ""), {}) or {}).get("hbm_bytes_corrected"),
-                    "traffic_note": "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/r01_pmc_traffic.json; "
-                                    "FETCH_SIZE includes Infinity-Cache hits (upper bound of HBM reads)",
-                    "algorithmic_bytes_per_launch": None, "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
+                    "traffic": traffic,
+                    "traffic_source": f"committed profile {pmc_file} (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE per launch; "
+                                      "FETCH_SIZE includes Infinity-Cache hits: an upper bound of the HBM reads)" if pmc_file else None,
+                    "algorithmic_bytes_per_launch": int(alg),
+                    "traffic_ratio": round(traffic / alg, 3) if traffic else None,
+                    "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
                     "families": {names.get(k, str(k)): {"ms_per_step": round(v[0] / nprof, 3),
-                                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                                        "algorithmic_MB_per_launch": round(v[3] / v[2] / 1e6, 1)}
                                  for k, v in fam.items()},
                     "hbm_kernels": hbm,
                     "event_bracket_overhead_us": round(bracket_us, 1),
                     "timing_note": "HIP-event pair per launch on the launch stream, behind a device-side delay so that the host "
                                    "runs ahead; the measured cost of an empty bracket is subtracted from every record"}
 
+    out = None
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        clips = B * world * args.steps / elapsed
+        ms_step = elapsed / steps * 1e3
+        clips = B * world * steps / elapsed
         n_tok = (cfg["image"] // cfg["patch"]) ** 2 + 1
         fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
                                               3 * cfg["patch"] ** 2, n_tok - 1)
+        is_ft = workload == "frametransformer"
         out = {
-            "metric": f"clips/sec fwd+bwd, B=8 T=32 3x224x224 {args.dtype}" if args.workload == "vivit" else
-                      ("samples/sec fwd+bwd [frametransformer workload], B=2 x 14 chunks x 12 x 3x112x112"
-                       if args.workload == "frametransformer" else
-                       f"clips/sec fwd+bwd [{args.workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}"),
-            "value": round(clips, 2), "unit": "samples/s" if args.workload == "frametransformer" else "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload],
+            "metric": f"clips/sec fwd+bwd, B=8 T=32 3x224x224 {args.dtype}" if workload == "vivit" else
+                      ("samples/sec fwd+bwd [frametransformer workload], B=2 x 14 chunks x 12 x 3x112x112" if is_ft else
+                       f"clips/sec fwd+bwd [{workload} workload], B={B} T={cfg['T']} 3x{cfg['image']}x{cfg['image']}"),
+            "value": round(clips, 2), "unit": "samples/s" if is_ft else "clips/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "fp16" if cdt == torch.float16 else "bf16", "data": "synthetic",
+            "config": {"workload": WORKLOADS[workload],
                        "global_batch": B * world, "parallelism": f"dp{world}", "params_M": round(flat.total / 1e6, 2)},
-            "launch": "hipGraph replay" if use_graph else "eager",
-            "model_tflops": round(tot * B * world / (elapsed / args.steps) / 1e12, 1)
-            if args.workload in ("vivit", "longclip") else None,
-            "model_mfma_frac": round(tot * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
-            if args.workload in ("vivit", "longclip") else None,
+            "launch": launch,
+            "model_tflops": round(tot * B * world / (elapsed / steps) / 1e12, 1)
+            if workload in ("vivit", "longclip") else None,
+            "model_mfma_frac": round(tot * B / (elapsed / steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+            if workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
             "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3)},
             "optimizer_ms_per_step": round(optimizer_ms, 3),
             "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
+        if note:
+            out["launch_note"] = note
+        if use_dist:
+            out["gradient_exchange"] = {"dtype": args.grad_dtype if comm is not None else "fp32", "bucket_mb": args.bucket_mb,
+                                        "through": "dvt_comm_allreduce (RCCL behind the C ABI)" if comm is not None
+                                        else f"torch.distributed ({args.backend})", **extra}
         if cdt == torch.float16:
             out["loss_scale"] = float(flat.scale_dev)
         if roof is not None:
             out["roofline"] = roof
+    return out
+
+
+def release_gpu_memory():
+    """Between workloads: the previous one's graphs, activations and flat buffers are garbage once run_workload returned."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bounded secondary workloads (pyramid, crossmodal, "
+                    "longclip: 3 timed steps each) that the default single-GPU run appends under \"secondary\"")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--grad-dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="element type of the gradient buckets on "
+                    "the wire (bf16: 57.7 MB instead of 115 MB per step for the d=512 model; the sum stays fp32 on either side)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of "
+                    "replaying one captured hipGraph per step")
+    ap.add_argument("--workload", choices=["vivit", "pyramid", "crossmodal", "longclip", "frametransformer"], default="vivit",
+                    help="vivit = the metric workload (default); pyramid = BASELINE configs[2] (ResNet-18 3-scale "
+                    "pyramid front-end -> the same transformer); crossmodal = configs[3] (+ 32 audio tokens, "
+                    "cross-attention block, distillation head); longclip = configs[4] (T=64, 288^2, fp16 + dynamic loss "
+                    "scaling, activation checkpointing; reports HBM GB/s of the streaming kernels and the activation "
+                    "peak); frametransformer = the reference's default FrameTransformer(model='vid'): R(2+1)D-18 on 14 chunks "
+                    "of 12 x 112^2 frames per sample, post-norm encoder with dropout 0.5, 2 samples per GPU "
+                    "(config.yaml:2).  Secondary lines, same JSON contract.")
+    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d secondary metric): the global batch stays "
+                    "--batch and each rank takes batch / world clips")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="kernel element type of the vivit workload "
+                    "(fp16 adds the device-side dynamic loss scaling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend used for bootstrap, barriers and the timing "
+                    "reduction (nccl = RCCL; gloo lets several ranks share one GPU to rehearse the data-parallel path on a "
+                    "single-GPU box -- the gradient exchange then goes through torch.distributed as well)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and the RCCL communicator even "
+                    "with one rank (rehearses the multi-GPU code path on a single GPU)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    use_dist = world > 1 or args.force_dist
+    comm = None
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit(f"--strong: global batch {args.batch} is not divisible by {world} ranks")
+        args.batch //= world
+
+    import dvt_amd  # noqa: F401
+    if use_dist and args.backend == "nccl":
+        from dvt_amd.dp import Communicator
+        comm = Communicator.from_torch_distributed()
+
+    out = run_workload(args, args.workload, rank, world, use_dist, comm, steps=args.steps, warmup=args.warmup,
+                       roofline=not args.no_roofline)
+    if world == 1 and not use_dist and args.workload == "vivit" and not args.no_secondary:
+        # BASELINE configs[2..4] -- the per-frame CNN encoder + pyramid, the cross-modal attention + distillation head, the
+        # long-clip stress -- timed in the same driver-visible line, bounded (3 timed steps each, no roofline pass)
+        sec = {}
+        for wl in ("pyramid", "crossmodal", "longclip"):
+            release_gpu_memory()
+            try:
+                r = run_workload(args, wl, rank, world, False, None, steps=3, warmup=1, roofline=False, secondary=True)
+                sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "launch", "peak_hbm_GiB",
+                                             "final_loss")}
+                sec[wl]["workload"] = r["config"]["workload"]
+            except Exception as e:   # a secondary line must never take the headline down with it
+                sec[wl] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if out is not None:
+            out["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64))
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     if use_dist:
         dist.destroy_process_group()
 

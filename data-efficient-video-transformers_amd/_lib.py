@@ -142,6 +142,11 @@ SIGNATURES = {
     "dvt_conv_weight_unpack_grad_t": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_sgd_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p, c_p]),
     "dvt_adagrad_step": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_i64, c_p, c_p]),
+    "dvt_comm_unique_id": (c_int, [c_p]),
+    "dvt_comm_init": (c_int, [C.POINTER(c_p), c_p, c_int, c_int]),
+    "dvt_comm_allreduce": (c_int, [c_p, c_p, c_i64, c_int, c_p]),
+    "dvt_comm_broadcast": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p]),
+    "dvt_comm_destroy": (c_int, [c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
 }
 

@@ -390,7 +390,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
     d.workspace = _p(ws)
     prof = _profiler
     if prof is not None:
-        key = ("gemm", int(a_kmajor), int(b_kmajor), M, N, K)
+        # algorithmic bytes of the launch: both operands once, every output once, every extra epilogue operand once
+        esz, osz = A.element_size(), out.element_size()
+        nbytes = esz * (M * K + N * K) + osz * M * N * (2 if accumulate else 1)
+        nbytes += esz * M * N * ((residual is not None) + (aux is not None))
+        key = ("gemm", int(a_kmajor), int(b_kmajor), M, N, K, epilogue, nbytes)
         prof.begin(key, 2.0 * M * N * K)
         L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
         prof.end(key)

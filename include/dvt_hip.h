@@ -454,6 +454,24 @@ int dvt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n
 int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t n, float lr, float lr_decay,
                      float eps, float weight_decay, int64_t step, const uint8_t* skip64, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- data-parallel gradient exchange
+ * The reference is single-GPU (pl.Trainer(gpus=1), src/main.py:87); north_star partitions the clips of the global
+ * batch over the 8 GPUs of a node, and the only exchange of the path is the SUM of the parameter gradients.  RCCL over
+ * xGMI behind the ABI, one process per GPU:
+ *   rank 0 calls dvt_comm_unique_id and hands the 128 bytes to every rank (any side channel: torch.distributed's
+ *   store, MPI, a file); every rank calls dvt_comm_init (a collective: ncclCommInitRank on the calling thread's current
+ *   device); dvt_comm_allreduce / dvt_comm_broadcast ENQUEUE an in-place collective on `stream` (no host sync: they may
+ *   be captured in a hipGraph next to the backward kernels they overlap with); dvt_comm_destroy frees the communicator.
+ * dtype: DVT_F32, or DVT_BF16 / DVT_F16 for half-width gradient buckets.  RCCL is bound at run time (the instance the
+ * process has already loaded, e.g. PyTorch's, else the ROCm installation's); DVT_ERR_UNSUPPORTED when none is found. */
+#define DVT_COMM_ID_BYTES 128
+typedef void* dvt_comm_t;
+int dvt_comm_unique_id(void* id_out /* DVT_COMM_ID_BYTES */);
+int dvt_comm_init(dvt_comm_t* comm_out, const void* unique_id, int world, int rank);
+int dvt_comm_allreduce(dvt_comm_t comm, void* buf, int64_t count, int dtype, dvt_stream_t stream);
+int dvt_comm_broadcast(dvt_comm_t comm, void* buf, int64_t count, int dtype, int root, dvt_stream_t stream);
+int dvt_comm_destroy(dvt_comm_t comm);
+
 #ifdef __cplusplus
 }
 #endif

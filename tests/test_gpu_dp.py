@@ -124,3 +124,136 @@ def test_parameter_without_gradient_is_left_alone_by_the_flat_optimizers(device,
     flat.finish_backward()
     o.step()
     assert torch.equal(net.unused_probe.detach(), before) and net.unused_probe not in o.state
+
+
+def _make_step(net, flat, x, y):
+    from dvt_amd import functional as F
+    seed = torch.full((), flat.loss_scale, device="cuda")
+
+    def fwd_bwd():
+        flat.zero_grad()
+        loss = F.bce_with_logits(net(x), y)
+        loss.backward(seed)
+        return loss
+
+    def update():
+        flat.adamw_step(lr=1e-3, weight_decay=0.09)
+
+    def step():
+        loss = fwd_bwd()
+        flat.finish_backward()
+        update()
+        return loss
+
+    return fwd_bwd, update, step
+
+
+@pytest.mark.parametrize("grad_dtype", [None, torch.bfloat16])
+def test_rccl_communicator_behind_the_c_abi_and_graph_captured_dp_step(device, grad_dtype):
+    """dvt_comm_* (RCCL behind the C ABI) on the one GPU of the test box: a single-rank communicator runs the same
+    enqueue / side-stream / event-join sequence as N ranks do.  (1) all-reduce and broadcast leave the data intact at
+    world 1, in fp32 and through the half-width wire format; (2) the data-parallel step with its bucketed all-reduces
+    captured INSIDE the hipGraph replays to the eager step's weights bit for bit; (3) so does the two-graph form around
+    an eagerly launched exchange."""
+    import os
+    import torch.distributed as dist
+    from dvt_amd.dp import Communicator, FlatParameters
+    from dvt_amd.graph import capture_step, capture_step_segments
+    comm = Communicator(1, 0, Communicator.unique_id())
+    try:
+        t = torch.randn(100003, device="cuda")
+        ref = t.clone()
+        comm.all_reduce_async(t).wait()
+        comm.broadcast(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+        half = torch.empty(100003, dtype=torch.bfloat16, device="cuda")
+        comm.all_reduce_async(t, half).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref.bfloat16().float())              # the wire format is bf16: one rounding, nothing else
+        x, y = _data()
+        x, y = x.cuda(), y.cuda()
+        results = {}
+        for mode in ("eager", "graph", "segments"):
+            net = _model().cuda()
+            flat = FlatParameters(net, bucket_mb=0.1, compute_dtype=None, comm=comm, grad_reduce_dtype=grad_dtype)
+            assert len(flat.bucket_ranges) >= 2
+            fwd_bwd, update, step = _make_step(net, flat, x, y)
+            losses = []
+            if mode == "eager":
+                for i in range(2 + 3):
+                    l = step()
+                    if i >= 2:
+                        losses.append(float(l.detach()))
+            elif mode == "graph":
+                replay, out = capture_step(step, warmup=2)
+                for _ in range(3):
+                    replay()
+                    losses.append(float(out.detach()))
+            else:
+                flat.defer_exchange = True
+
+                def local():
+                    l = fwd_bwd()
+                    flat.finish_backward(exchange=False)
+                    return l
+
+                replay, out = capture_step_segments(local, flat.exchange_all, update, warmup=2)
+                for _ in range(3):
+                    replay()
+                    losses.append(float(out.detach()))
+            results[mode] = (losses, flat.data.clone(), flat.grad.clone())
+        assert results["graph"][0] == results["eager"][0] and torch.equal(results["graph"][1], results["eager"][1])
+        assert results["segments"][0] == results["eager"][0] and torch.equal(results["segments"][1], results["eager"][1])
+        if grad_dtype is not None:                                   # the gradients really went through the half-width format
+            assert torch.equal(results["eager"][2], results["eager"][2].bfloat16().float())
+    finally:
+        comm.destroy()
+
+
+def _graph_worker(rank, world, port, out):
+    """Two gloo ranks on one GPU: gloo cannot be captured, so the graph form is the two-graph one around the exchange."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvt_amd.dp import FlatParameters
+    from dvt_amd.graph import capture_step_segments
+    x, y = _data()
+    xs, ys = x[rank * 2:(rank + 1) * 2].cuda(), y[rank * 2:(rank + 1) * 2].cuda()
+    res = {}
+    for mode in ("eager", "segments"):
+        net = _model().cuda()
+        flat = FlatParameters(net, bucket_mb=0.1, compute_dtype=None)
+        flat.broadcast_parameters(0)
+        fwd_bwd, update, step = _make_step(net, flat, xs, ys)
+        if mode == "eager":
+            for _ in range(2 + 3):
+                step()
+        else:
+            flat.defer_exchange = True
+
+            def local():
+                l = fwd_bwd()
+                flat.finish_backward(exchange=False)
+                return l
+
+            replay, _ = capture_step_segments(local, flat.exchange_all, update, warmup=2)
+            for _ in range(3):
+                replay()
+        torch.cuda.synchronize()
+        res[mode] = flat.data.cpu()
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_graph_segments_equal_eager_bit_for_bit(device, tmp_path):
+    """the graph-replayed data-parallel step on 2 ranks == the eager one, bit for bit (deferred exchange:
+    one all-reduce over the flat gradient between the fwd+bwd graph and the optimizer graph)."""
+    import dvt_amd  # noqa: F401
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_graph_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["eager"], res["segments"])
