@@ -478,8 +478,11 @@ __device__ __forceinline__ float rows_allreduce(float x) {
   return kMax ? vmax2(a, b) : a + b;
 }
 
+// NKP 8 .. 11 (225 .. 352 keys: the 325-token frames of BASELINE configs[4]) hold up to 88 score registers per lane and
+// are built for at most 12 waves per workgroup (3 per SIMD, 168 registers); the images of such sequences exceed 80 KiB,
+// so one workgroup per CU is resident either way.
 template <typename E, int NKP>
-__global__ __launch_bounds__(1024) void attn_fwd_mfma_res_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using V8 = typename Elem16<E>::v8;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -857,11 +860,9 @@ bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
 // waves per block so that the tile count splits evenly over as few rounds as possible.  When the staged images
 // leave room for only one workgroup per CU (long sequences: > 80 KiB of LDS), that workgroup may use all 16 wave slots
 // (the kernels need <= 115 VGPRs, i.e. 4 waves per SIMD fit).
-int pick_waves(int tiles, size_t lds_bytes) {
-#ifdef DVT_ATTN_TIMING
-  if (const char* e = getenv("DVT_ATTN_W")) return atoi(e);
-#endif
-  const int maxw = lds_bytes > 80 * 1024 ? 16 : 8;
+int pick_waves(int tiles, size_t lds_bytes, int cap = 16) {
+  int maxw = lds_bytes > 80 * 1024 ? 16 : 8;
+  if (maxw > cap) maxw = cap;
   const int rounds = (tiles + maxw - 1) / maxw;
   int w = (tiles + rounds - 1) / rounds;
   return w < 1 ? 1 : w;
@@ -871,10 +872,7 @@ int pick_waves(int tiles, size_t lds_bytes) {
 // (two workgroups per CU up to 80 KiB); sets p.patch_off
 size_t with_patches(size_t lds, int waves, AttnParams& p) {
   const size_t tot = lds + (size_t)waves * 2048;
-  bool ok = lds <= 80 * 1024 ? 2 * tot <= (size_t)kMaxLds : tot <= (size_t)kMaxLds;
-#ifdef DVT_ATTN_TIMING
-  if (getenv("DVT_ATTN_NOPATCH")) ok = false;
-#endif
+  const bool ok = lds <= 80 * 1024 ? 2 * tot <= (size_t)kMaxLds : tot <= (size_t)kMaxLds;
   p.patch_off = ok ? (int)lds : -1;
   return ok ? tot : lds;
 }
@@ -906,7 +904,8 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (mfma_fwd_ok(d, p)) {
     const size_t lds_img = (size_t)2 * p.Lkp * kRowBytes;
-    const int W = pick_waves((p.Lq + 15) / 16, lds_img);
+    const int nkp = p.Lkp >> 5;
+    const int W = pick_waves((p.Lq + 15) / 16, lds_img, nkp > 7 && nkp <= 11 ? 12 : 16);
     const size_t lds = with_patches(lds_img, W, p);
     const dim3 grid((unsigned)(p.B * p.H)), block(64 * W);
 #define DVT_ATTN_FWD_RES(NKP)                                                               \
@@ -915,9 +914,10 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     hipLaunchKernelGGL((attn_fwd_mfma_res_kernel<E, NKP>), grid, block, lds, st, p);        \
     break
     DVT_DISPATCH_16BIT(d->dtype, E, {
-      switch (p.Lkp >> 5) {                      // scores of up to 224 keys stay in registers (256 would spill)
+      switch (nkp) {                             // scores of up to 352 keys stay in registers
         DVT_ATTN_FWD_RES(1); DVT_ATTN_FWD_RES(2); DVT_ATTN_FWD_RES(3); DVT_ATTN_FWD_RES(4);
-        DVT_ATTN_FWD_RES(5); DVT_ATTN_FWD_RES(6); DVT_ATTN_FWD_RES(7);
+        DVT_ATTN_FWD_RES(5); DVT_ATTN_FWD_RES(6); DVT_ATTN_FWD_RES(7); DVT_ATTN_FWD_RES(8);
+        DVT_ATTN_FWD_RES(9); DVT_ATTN_FWD_RES(10); DVT_ATTN_FWD_RES(11);
         default:
           set_lds(attn_fwd_mfma_kernel<E>, lds);
           hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), grid, block, lds, st, p);
@@ -974,16 +974,18 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, NQP>), grid, block_kv, lds_kv, st, pkv);  \
     break
     DVT_DISPATCH_16BIT(d->dtype, E, {
-      switch (p.Lkp >> 5) {                      // unrolled key loop up to 256 keys
+      switch (p.Lkp >> 5) {                      // unrolled key loop up to 352 keys
         DVT_ATTN_BWD_DQ(1); DVT_ATTN_BWD_DQ(2); DVT_ATTN_BWD_DQ(3); DVT_ATTN_BWD_DQ(4);
         DVT_ATTN_BWD_DQ(5); DVT_ATTN_BWD_DQ(6); DVT_ATTN_BWD_DQ(7); DVT_ATTN_BWD_DQ(8);
+        DVT_ATTN_BWD_DQ(9); DVT_ATTN_BWD_DQ(10); DVT_ATTN_BWD_DQ(11);
         default:
           set_lds(attn_bwd_dq_mfma_kernel<E, 0>, lds_q);
           hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 0>), grid, block_q, lds_q, st, pq);
       }
-      switch (p.Lqp >> 5) {                      // unrolled query loop up to 256 queries
+      switch (p.Lqp >> 5) {                      // unrolled query loop up to 352 queries
         DVT_ATTN_BWD_DKV(1); DVT_ATTN_BWD_DKV(2); DVT_ATTN_BWD_DKV(3); DVT_ATTN_BWD_DKV(4);
         DVT_ATTN_BWD_DKV(5); DVT_ATTN_BWD_DKV(6); DVT_ATTN_BWD_DKV(7); DVT_ATTN_BWD_DKV(8);
+        DVT_ATTN_BWD_DKV(9); DVT_ATTN_BWD_DKV(10); DVT_ATTN_BWD_DKV(11);
         default:
           set_lds(attn_bwd_dkv_mfma_kernel<E, 0>, lds_kv);
           hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, 0>), grid, block_kv, lds_kv, st, pkv);

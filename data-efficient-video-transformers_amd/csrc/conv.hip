@@ -287,10 +287,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ run_var, float momentum, float unbias,
                                                            int accumulate) {
   // block = 32 columns x 32 part lanes; fixed summation order (lane-strided partial sums, then a lane tree)
-  __shared__ float red[2][32][33];
+  // The partial sums are added in double and the variance is formed in double: the one-pass form E[x^2] - mu^2 in fp32
+  // loses the variance of channels whose |mean| is large against their spread to the rounding of sums over 10^5..10^7
+  // rows; with double accumulation of the (fp32, <= 128-row) partials what is left is the rounding inside one partial.
+  __shared__ double red[2][32][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
   if (c < C) {
     // four partial rows per round trip (a rolled loop waits for each before it requests the next); same order of additions
     int p = pl;
@@ -302,22 +305,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         b[u] = partial[((int64_t)(p + 32 * u) * 2 + 1) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+      for (int u = 0; u < 4; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
     }
     for (; p < nparts; p += 32) {
-      s0 += partial[((int64_t)p * 2 + 0) * C + c];
-      s1 += partial[((int64_t)p * 2 + 1) * C + c];
+      s0 += (double)partial[((int64_t)p * 2 + 0) * C + c];
+      s1 += (double)partial[((int64_t)p * 2 + 1) * C + c];
     }
   }
   red[0][pl][cl] = s0;
   red[1][pl][cl] = s1;
   __syncthreads();
   if (pl != 0 || c >= C) return;
-  s0 = 0.f; s1 = 0.f;
+  s0 = 0.0; s1 = 0.0;
   for (int p = 0; p < 32; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
   if (MODE == 0) {
-    const float mu = s0 * inv_rows;
-    const float var = fmaxf(s1 * inv_rows - mu * mu, 0.f);
+    const double mud = s0 * (double)inv_rows;
+    const double vard = s1 * (double)inv_rows - mud * mud;
+    const float mu = (float)mud;
+    const float var = vard > 0.0 ? (float)vard : 0.f;
     o0[c] = mu;
     o1[c] = rsqrtf(var + eps);
     if (run_mean) {
@@ -325,8 +330,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
     }
   } else {
-    o0[c] = accumulate ? o0[c] + s1 : s1;   // dgamma
-    o1[c] = accumulate ? o1[c] + s0 : s0;   // dbeta
+    const float d0 = (float)s0, d1 = (float)s1;
+    o0[c] = accumulate ? o0[c] + d1 : d1;   // dgamma
+    o1[c] = accumulate ? o1[c] + d0 : d0;   // dbeta
   }
 }
 
@@ -334,11 +340,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 // sum: block = 32 columns x 32 part lanes over its contiguous range of parts, four loads in flight, fixed order.
 __global__ __launch_bounds__(1024) void bn_partial_fold_kernel(const float* __restrict__ partial, int nparts, int C,
                                                                int per_block, float* __restrict__ out) {
-  __shared__ float red[2][32][33];
+  __shared__ double red[2][32][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int p0 = blockIdx.y * per_block, p1 = min(nparts, p0 + per_block);
-  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < C) {
     int p = p0 + pl;
     for (; p + 96 < p1; p += 128) {
@@ -357,10 +363,10 @@ __global__ __launch_bounds__(1024) void bn_partial_fold_kernel(const float* __re
   red[1][pl][cl] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
   __syncthreads();
   if (pl != 0 || c >= C) return;
-  float t0 = 0.f, t1 = 0.f;
+  double t0 = 0.0, t1 = 0.0;
   for (int q = 0; q < 32; ++q) { t0 += red[0][q][cl]; t1 += red[1][q][cl]; }
-  out[((int64_t)blockIdx.y * 2 + 0) * C + c] = t0;
-  out[((int64_t)blockIdx.y * 2 + 1) * C + c] = t1;
+  out[((int64_t)blockIdx.y * 2 + 0) * C + c] = (float)t0;
+  out[((int64_t)blockIdx.y * 2 + 1) * C + c] = (float)t1;
 }
 
 __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restrict__ out, int C, float eps) {
@@ -876,7 +882,7 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
   return DVT_OK;
 }
 
-int dvt_bn_stats_from_partials(const float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
+int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
                                float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream) {
   DVT_REQUIRE(partial && mean && invstd && parts > 0 && parts < (1ll << 31) && rows > 0 && C > 0,
               "dvt_bn_stats_from_partials: bad arguments");
@@ -884,12 +890,12 @@ int dvt_bn_stats_from_partials(const float* partial, int64_t parts, float* mean,
   hipStream_t st = (hipStream_t)stream;
   const float* src = partial;
   int np = (int)parts;
-  if (parts > 256) {
+  if (parts > 256) {   // (this is why `partial` is not const: its 64-row tail is written)
     // fold in place is not possible (blocks read what others write): the folded rows go behind the partial rows, which the
     // caller sized with dvt_conv2d_implicit_stats_bytes (parts + 64 rows)
     const int folds = 64;
     const int per_block = (int)dvt_cdiv(parts, folds);
-    float* folded = const_cast<float*>(partial) + (size_t)parts * 2 * C;
+    float* folded = partial + (size_t)parts * 2 * C;
     hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)dvt_cdiv(C, 32), (unsigned)folds), dim3(1024), 0, st, partial,
                        (int)parts, C, per_block, folded);
     DVT_LAUNCH_CHECK("dvt_bn_stats_from_partials(fold)");

@@ -384,8 +384,9 @@ size_t dvt_bn_workspace_bytes(int64_t rows, int C);
 int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
                  void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream);
 /* Same result from the per-block partial sums a convolution left behind (dvt_conv_desc.stats_partial, a buffer of
- * dvt_conv2d_implicit_stats_bytes: its tail is scratch for folding many partial rows). */
-int dvt_bn_stats_from_partials(const float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
+ * dvt_conv2d_implicit_stats_bytes = parts + 64 rows of 2 * C floats: with more than 256 partial rows the call WRITES
+ * the 64-row tail -- it folds the partial rows into it before the final sum, hence the non-const pointer). */
+int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
                                float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream);
 int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream);
 /* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52). */
