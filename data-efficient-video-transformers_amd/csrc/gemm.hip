@@ -513,6 +513,14 @@ bool mfma_eligible(const dvt_gemm_desc* d) {
   return true;
 }
 
+// Launch-bound regime (the 33-token temporal encoder, the heads): gemm_small.hip's panel-streaming kernel, no split-K.
+bool small_regime(const dvt_gemm_desc* d) {
+  if (d->split_k != 0 || d->K <= 0) return false;
+  if ((double)d->M * (double)d->N * (double)d->K > 2147483648.0) return false;
+  if (dvt_cdiv(d->M, 32) * dvt_cdiv(d->N, 64) > 4096) return false;
+  return dvt_gemm_small_tile(d->M, d->N, d->a_kmajor != 0, d->b_kmajor != 0) != 0;
+}
+
 struct GemmPlan {
   bool use256;
   int cfg;   // LDS-DMA kernel configuration (gemm256.hip)
@@ -608,6 +616,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
   if (!d) return 0;
   const bool mfma = mfma_eligible(d) && d->K > 0;
+  if (mfma && small_regime(d)) return 0;          // no slabs, the bias gradient comes out of the same launch
   GemmPlan pl{};
   if (mfma) pl = plan_gemm(d);
   size_t cs = 0;
@@ -626,8 +635,21 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   if (rc) return rc;
   if (d->M == 0 || d->N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
-  DVT_REQUIRE(!d->colsum_out || (!d->a_kmajor && d->workspace), "dvt_gemm: colsum_out needs an mn-major A and a workspace");
+  DVT_REQUIRE(!d->colsum_out || !d->a_kmajor, "dvt_gemm: colsum_out needs an mn-major A");
 
+  if (mfma_eligible(d) && d->K > 0 && small_regime(d)) {
+    GemmParams p{};
+    p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+    p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
+    p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
+    p.alpha = d->alpha; p.elem = d->in_dtype; p.k_per_split = (int)d->K; p.slab = nullptr;
+    p.colsum_slab = d->colsum_out; p.accumulate_colsum = d->colsum_accumulate;
+    rc = dvt_gemm_small_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, st);
+    if (rc <= 0) return rc;                       // launched (or failed); 1 = no instantiation: fall through
+  }
+  DVT_REQUIRE(!d->colsum_out || d->workspace, "dvt_gemm: colsum_out needs a workspace (dvt_gemm_workspace_bytes)");
   if (mfma_eligible(d) && d->K > 0) {
     GemmPlan pl = plan_gemm(d);
     if (pl.split > 1 && !d->workspace) {   // no scratch: fall back to an unsplit 128x128 launch

@@ -21,6 +21,7 @@ struct GemmParams {
   int stream_out;       // C (and the saved pre-activation) written with streaming stores: outputs too large to stay in the Infinity Cache
   int elem;             // DVT_BF16 or DVT_F16: element type of A, B (and of C / residual / aux when not f32)
   float* colsum_slab;
+  int accumulate_colsum;   // gemm_small.hip only: colsum_slab is the final bias-gradient vector; += when set
   float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
   int cH, cW, cC, cHo, cWo, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
@@ -80,3 +81,6 @@ __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st);
 int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st);
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st);
+// launch-bound shapes (gemm_small.hip): tile height (0 = shape / layout not taken), launch (1 = no instantiation)
+int dvt_gemm_small_tile(int64_t M, int64_t N, bool a_kmajor, bool b_kmajor);
+int dvt_gemm_small_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, hipStream_t st);

@@ -1,0 +1,243 @@
+// gemm_small.hip -- MFMA GEMM for launch-bound shapes: a few hundred rows (the 33-token temporal encoder of
+// vit.py:122-128 at B = 8 is 264 rows; the heads are 8), where the whole launch lives for a few microseconds.
+//
+// The 128x128 register-staged kernel (gemm.hip) runs such a GEMM as one latency-bound k loop per tile (a global
+// load -> LDS write -> barrier round trip per 64 of K) and fills the chip by splitting K over workgroups, which costs a
+// second launch for the slab reduce: ~10 + 5 us per Linear.  Here a workgroup owns a TM x 64 output tile (TM = 32 or 64)
+// and streams its two operand panels through LDS in 256-deep k chunks by LDS-DMA (global_load_lds_dwordx4, no VGPR
+// staging), two chunks in flight: for K = 512 both chunks are requested before the first MFMA and the second lands
+// under the first one's MFMAs.  No split-K, no second launch; the fused epilogues of the family (bias, GELU + saved
+// pre-activation, ReLU, residual, GELU', ReLU', fp32 accumulate) and the fused bias gradient of the weight-gradient
+// form run on the accumulators.
+//
+// Layouts as in the rest of the family (no operand is transposed through HBM):
+//   k-major  operand [rows][256 k]: 512-byte rows; 16-byte chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128
+//   mn-major operand [256 k][64 mn]: 128-byte rows; 32-byte units XOR-swizzled by f(k) = (k>>1 & 1) | (k>>3 & 1) << 1,
+//            read with ds_read_b64_tr_b16 (hardware transpose); an mn-major A needs TM = 64.
+// LDS is lane-linear for the DMA, so both swizzles sit on the per-lane SOURCE address and again on the fragment read.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int SK = 256;                      // k chunk
+constexpr int STN = 64;                      // tile columns
+
+__device__ __attribute__((aligned(16))) unsigned int dvt_small_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int swz_mn64(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+
+// DMA one operand chunk (ROWS x 256 k) into LDS, 1 KiB per wave-instruction; k >= k_lim and rows >= mn_lim read zeros
+// (a clamped row would do for rows -- they are never stored -- but zeros keep the bias-gradient sums exact).
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void dma_chunk(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim, int k0, int k_lim,
+                                          char* img, int wid, int lane) {
+  constexpr int PIECES = ROWS * SK * 2 / 1024;
+  constexpr int PPW = PIECES / 4;
+  const bf16* zero = reinterpret_cast<const bf16*>(dvt_small_zero16);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wid * PPW + i;
+    const bf16* src;
+    if (KMAJOR) {
+      const int row = piece * 2 + (lane >> 5);            // 512-byte rows: two per piece
+      const int c = (lane & 31) ^ (row & 15);
+      const int gk = k0 + c * 8, gmn = mn0 + row;
+      src = (gmn < mn_lim && gk < k_lim) ? base + (int64_t)gmn * ld + gk : zero;
+    } else {
+      const int k = piece * 8 + (lane >> 3);              // 128-byte rows: eight per piece
+      const int cp = lane & 7;
+      const int c = ((((cp >> 1) ^ swz_mn64(k)) << 1) | (cp & 1));
+      const int gk = k0 + k, gmn = mn0 + c * 8;
+      src = (gk < k_lim && gmn < mn_lim) ? base + (int64_t)gk * ld + gmn : zero;
+    }
+    dvt_dma16(src, img + piece * 1024);
+  }
+}
+
+// MFMA operand fragment of 16 rows (k-major) / 16 columns (mn-major) starting at `base`, k-step kk (32 k each) of the
+// chunk: lane (g, li) gets element j <-> (base + li, kk*32 + 8g + j).
+template <typename E, bool KMAJOR>
+__device__ __forceinline__ typename Elem16<E>::v8 sfrag(const char* img, int base, int kk, int g, int li) {
+  typedef typename Elem16<E>::v8 V8;
+  if (KMAJOR) {
+    const int row = base + li;
+    const int c = kk * 4 + g;
+    return *reinterpret_cast<const V8*>(img + row * (SK * 2) + ((c ^ (row & 15)) << 4));
+  } else {
+    const int q = li >> 2, pp = li & 3;
+    const int u = base >> 4;
+    typename Elem16<E>::v4 half[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = kk * 32 + 8 * g + 4 * hf + q;
+      half[hf] = Elem16<E>::tr_read(img + k * 128 + ((u ^ swz_mn64(k)) << 5) + 8 * pp);
+    }
+    return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <int N> __device__ __forceinline__ void swait_vm() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// TM = 64: waves 2 x 2, each 32 x 32;  TM = 32: waves 1 x 4, each 32 x 16.
+template <typename E, bool A_KMAJOR, bool B_KMAJOR, int TM>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
+  static_assert(A_KMAJOR || TM == 64, "an mn-major A panel is 64 wide");
+  typedef typename Elem16<E>::v8 V8;
+  constexpr int WM = TM / 32, WNC = 4 / WM, WCOLS = STN / WNC, NU = WCOLS / 16;
+  constexpr int kA = TM * SK * 2, kB = STN * SK * 2, kStage = kA + kB;
+  constexpr int kPPC = (kA + kB) / 1024 / 4;           // DMA instructions per wave per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WNC, wn = wid % WNC;
+  const int g = lane >> 4, li = lane & 15;
+  const int m0 = (blockIdx.x / p.tiles_n) * TM, n0 = (blockIdx.x % p.tiles_n) * STN;
+  const int nch = (p.K + SK - 1) / SK;
+
+  f32x4 acc[NU][2];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int ch) {
+    char* st = smem + (ch & 1) * kStage;
+    dma_chunk<A_KMAJOR, TM>(p.A, p.lda, m0, p.M, ch * SK, p.K, st, wid, lane);
+    dma_chunk<B_KMAJOR, STN>(p.B, p.ldb, n0, p.N, ch * SK, p.K, st + kA, wid, lane);
+  };
+  issue(0);
+  if (nch > 1) issue(1);
+
+  // fused bias gradient (weight-gradient form): colsum[m] = sum_k A(m, k) for the tiles of the first tile column
+  const bool do_cs = !A_KMAJOR && p.colsum_slab != nullptr && n0 == 0;
+  float cs = 0.f;
+
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) swait_vm<kPPC>(); else swait_vm<0>();   // chunk ch landed (ch + 1 may stay in flight)
+    __builtin_amdgcn_s_barrier();
+    const char* sa = smem + (ch & 1) * kStage;
+    const char* sb = sa + kA;
+#pragma unroll
+    for (int kk = 0; kk < SK / 32; ++kk) {
+      V8 af[2], bfr[NU];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) af[t] = sfrag<E, A_KMAJOR>(sa, wm * 32 + t * 16, kk, g, li);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) bfr[u] = sfrag<E, B_KMAJOR>(sb, wn * WCOLS + u * 16, kk, g, li);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[u][t] = Elem16<E>::mma(bfr[u], af[t], acc[u][t]);
+    }
+    if (do_cs && tid < TM) {                               // thread = one column m of the [k][64] image
+#pragma unroll 8
+      for (int k = 0; k < SK; ++k)
+        cs += (float)*reinterpret_cast<const E*>(sa + k * 128 + (((tid >> 4) ^ swz_mn64(k)) << 5) + (tid & 15) * 2);
+    }
+    if (ch + 2 < nch) {
+      __builtin_amdgcn_s_barrier();                        // everybody finished reading this stage
+      issue(ch + 2);
+    }
+  }
+  if (do_cs && tid < TM && m0 + tid < p.M) {
+    float* o = p.colsum_slab + m0 + tid;                   // (here: the final bias gradient, not a slab)
+    *o = p.accumulate_colsum ? *o + cs : cs;
+  }
+
+  // ---- epilogue on the accumulators: lane (g, li) holds C[row = .. + li][col = .. + 4g .. 4g+3]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int m = m0 + wm * 32 + t * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int n = n0 + wn * WCOLS + u * 16 + 4 * g;
+      if (n >= p.N) continue;                              // N % 8 == 0: a group of four is inside or outside
+      float v[4];
+      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = b[r];
+      }
+      float ld[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.epilogue == DVT_EPI_RESIDUAL || p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU) {
+        const E* src = p.epilogue == DVT_EPI_RESIDUAL ? (const E*)p.residual + (int64_t)m * p.ldr + n
+                                                      : (const E*)p.aux + (int64_t)m * p.ldaux + n;
+        const typename Elem16<E>::v4 x = *reinterpret_cast<const typename Elem16<E>::v4*>(src);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ld[r] = (float)x[r];
+      }
+      float pre[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = epi_apply(p.epilogue, acc[u][t][r] * p.alpha, bias[r], ld[r], ld[r], pre[r]);
+      if (p.epilogue == DVT_EPI_GELU && p.aux) {
+        typename Elem16<E>::v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (E)pre[r];
+        *reinterpret_cast<typename Elem16<E>::v4*>((E*)p.aux + (int64_t)m * p.ldaux + n) = o;
+      }
+      if (p.out_f32) {
+        float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+        f32x4 w = {v[0], v[1], v[2], v[3]};
+        if (p.accumulate) w += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = w;
+      } else {
+        typename Elem16<E>::v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (E)v[r];
+        *reinterpret_cast<typename Elem16<E>::v4*>((E*)p.C + (int64_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <typename E, bool AK, bool BK, int TM>
+int launch_small(const GemmParams& pin, hipStream_t st) {
+  constexpr int kSmem = 2 * (TM + STN) * SK * 2;
+  static_assert(kSmem <= 160 * 1024, "LDS budget");
+  GemmParams p = pin;
+  p.tiles_n = (int)dvt_cdiv(p.N, STN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_small_kernel<E, AK, BK, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(dvt_cdiv(p.M, TM) * p.tiles_n)), block(256);
+  hipLaunchKernelGGL((gemm_small_kernel<E, AK, BK, TM>), grid, block, kSmem, st, p);
+  DVT_LAUNCH_CHECK("dvt_gemm(small)");
+  return DVT_OK;
+}
+
+template <typename E>
+int launch_small_any(const GemmParams& p, bool ak, bool bk, int tm, hipStream_t st) {
+  if (ak && bk) return tm == 32 ? launch_small<E, true, true, 32>(p, st) : launch_small<E, true, true, 64>(p, st);
+  if (ak && !bk) return tm == 32 ? launch_small<E, true, false, 32>(p, st) : launch_small<E, true, false, 64>(p, st);
+  if (!ak && !bk) return launch_small<E, false, false, 64>(p, st);
+  return 1;
+}
+
+}  // namespace
+
+// Tile height for a launch-bound shape: 32-row tiles when 64-row ones would leave most CUs without a workgroup.
+// Returns 0 when this kernel does not take the shape (layouts: A k-major with either B, or both mn-major).
+int dvt_gemm_small_tile(int64_t M, int64_t N, bool a_kmajor, bool b_kmajor) {
+  if (!a_kmajor && b_kmajor) return 0;
+  const int64_t t64 = dvt_cdiv(M, 64) * dvt_cdiv(N, STN);
+  if (!a_kmajor) return 64;
+  return t64 >= 128 ? 64 : 32;
+}
+
+// p.colsum_slab (weight-gradient form): the FINAL bias gradient vector here (this kernel does not split K);
+// p.accumulate_colsum selects += .  Returns DVT_OK, a negative status, or 1 when there is no instantiation.
+int dvt_gemm_small_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, hipStream_t st) {
+  const int tm = dvt_gemm_small_tile(p.M, p.N, a_kmajor, b_kmajor);
+  if (tm == 0) return 1;
+  if (p.elem == DVT_F16) return launch_small_any<f16>(p, a_kmajor, b_kmajor, tm, st);
+  return launch_small_any<bf16>(p, a_kmajor, b_kmajor, tm, st);
+}

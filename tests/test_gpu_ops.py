@@ -312,6 +312,54 @@ def test_gemm_large_m_every_row_written_exactly_once(dvt, device, M, N, K):
     check(du, uu.grad, "dgrad + gelu'")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(264, 1536, 512), (264, 512, 2048), (264, 2048, 512), (8, 512, 512), (33, 64, 200),
+                                   (528, 1000, 520)])
+def test_gemm_launch_bound_shapes_panel_streaming_kernel(dvt, device, dtype, M, N, K):
+    """The 33-token temporal encoder at B = 8 (264 rows; vit.py:122-128) and the heads: gemm_small.hip streams whole
+    operand panels through LDS (no split-K, one launch per Linear).  Forward with every epilogue, data gradient with
+    GELU', weight gradient with the fused bias gradient (overwrite and accumulate) and fp32 accumulation -- per element."""
+    L = dvt._lib
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    tol = _tol(dtype)
+    x_d, x = _rnd((M, K), dtype, g)
+    w_d, w = _rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias = 0.5 * torch.randn(N, generator=g)
+    pre = x @ w.t() + bias
+
+    def check(got, want, what):
+        assert torch.isfinite(got.float()).all(), what
+        assert float((got.float().cpu() - want).abs().max()) < 4 * tol * float(want.abs().max()), what
+        assert rel_l2(got, want) < tol, what
+
+    nan16 = lambda *shape: torch.full(shape, float("nan"), dtype=dtype, device="cuda")
+    check(dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias.cuda(), out=nan16(M, N)), pre,
+          "plain")
+    aux = nan16(M, N)
+    h = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias.cuda(), epilogue=L.EPI_GELU,
+                     aux=aux, out=nan16(M, N))
+    check(aux, pre, "pre-activation")
+    check(h, O.gelu_erf(pre), "gelu")
+    res_d, res = _rnd((M, N), dtype, g)
+    check(dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d), pre + res, "residual")
+    check(dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RELU), torch.relu(pre), "relu")
+    dy_d, dy = _rnd((M, N), dtype, g)
+    check(dvt.ops.linear_dgrad(dy_d, w_d), dy @ w, "dgrad")
+    u_d, u = _rnd((M, K), dtype, g)
+    uu = u.clone().requires_grad_(True)
+    O.gelu_erf(uu).backward(dy @ w)
+    check(dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d), uu.grad, "dgrad gelu'")
+    dw_ref = dy.t() @ x
+    db = torch.full((N,), float("nan"), device="cuda")
+    dw = dvt.ops.linear_wgrad(dy_d, x_d, bias_out=db)
+    check(dw, dw_ref, "wgrad")
+    assert rel_l2(db, dy.sum(0)) < 1e-5
+    dvt.ops.linear_wgrad(dy_d, x_d, out=dw, accumulate=True, bias_out=db, bias_accumulate=True)
+    check(dw, 2 * dw_ref, "wgrad accumulate")
+    assert rel_l2(db, 2 * dy.sum(0)) < 1e-5
+    assert torch.equal(dvt.ops.linear_wgrad(dy_d, x_d), dvt.ops.linear_wgrad(dy_d, x_d))      # no atomics: reproducible
+
+
 @pytest.mark.parametrize("rows", [28, 2, 13, 100])
 def test_wgrad_ragged_row_count_runs_on_mfma(dvt, device, rows):
     """Weight gradients of the 14-token encoders (K = B * 14 = 28 rows, frame_transformer.py:204) -- K is not a multiple of 8
