@@ -746,13 +746,19 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 }
 
 // ---------------------------------------------------------------- implicit-GEMM convolution
+// LDS-DMA configuration of a convolution by its output width (gemm256.hip): 256x64x32 tiles up to 64 channels,
+// 256x128x32 up to 128, 256x256x64 beyond.
+static int conv_cfg(int cout) { return cout <= 64 ? 4 : cout <= 128 ? 1 : 0; }
+
 static bool conv_implicit_ok(const dvt_conv_desc* d) {
   if (!d || !d->x || !d->w || !d->y) return false;
   if (!dvt_is_16bit(d->dtype)) return false;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->kh <= 0 || d->kw <= 0 || d->sh <= 0 || d->sw <= 0 || d->ph < 0 || d->pw < 0)
     return false;
   const int tk = d->Cout <= 128 ? 32 : 64;
-  if (d->C % tk || d->Cout % 8) return false;
+  // C % k-tile == 0 (a k-tile inside one filter tap), or C == 8: the stem, its 3 channels zero-extended to one 16-byte
+  // chunk per (pixel, tap) by dvt_nchw_to_nhwc_pad
+  if ((d->C % tk && d->C != 8) || d->Cout % 8) return false;
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0) return false;
   if (d->N * Ho * Wo >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
@@ -762,6 +768,14 @@ static bool conv_implicit_ok(const dvt_conv_desc* d) {
 
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* d) { return conv_implicit_ok(d) ? 1 : 0; }
 
+// Row length of the packed weights [Cout][K]: kh*kw*C, rounded up to the k-tile in the C == 8 (stem) form.
+int64_t dvt_conv2d_implicit_k(const dvt_conv_desc* d) {
+  if (!d || d->C <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+  const int64_t K = (int64_t)d->kh * d->kw * d->C;
+  const int tk = d->Cout <= 128 ? 32 : 64;
+  return d->C % tk ? dvt_cdiv(K, tk) * tk : K;
+}
+
 int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(d, "dvt_conv2d_implicit: null descriptor");
   if (!conv_implicit_ok(d))
@@ -770,23 +784,23 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   const int Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   GemmParams p{};
   p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
-  p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = d->kh * d->kw * d->C;
+  p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = (int)dvt_conv2d_implicit_k(d);
   p.lda = 0; p.ldb = p.K; p.ldc = d->Cout;
   p.epilogue = DVT_EPI_NONE; p.out_f32 = 0; p.accumulate = 0;
   p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0;
   p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = p.K; p.slab = nullptr; p.tiles_n = 0; p.colsum_slab = nullptr;
-  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckw = d->kw;
+  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   p.bn_partial = d->stats_partial;
-  return dvt_conv_dma_launch(p, d->Cout <= 128 ? 1 : 0, (hipStream_t)stream);
+  return dvt_conv_dma_launch(p, conv_cfg(d->Cout), (hipStream_t)stream);
 }
 
-// one partial row per 128 output rows (256-row tiles x 2 wave rows in both convolution configurations)
+// one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4
 int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   if (!d || d->sh <= 0 || d->sw <= 0) return 0;
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
-  return dvt_cdiv(d->N * Ho * Wo, 256) * 2;
+  return dvt_cdiv(d->N * Ho * Wo, 256) * (conv_cfg(d->Cout) == 4 ? 4 : 2);
 }
 
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* d) {
@@ -805,12 +819,12 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0) return false;
   const int64_t rows = d->N * Ho * Wo;
-  pl->cfg = d->Cout <= 128 ? 1 : 0;
+  pl->cfg = conv_cfg(d->Cout);
   pl->tk = pl->cfg ? 32 : 64;
   if (rows % pl->tk || rows >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
   pl->K = d->kh * d->kw * d->C;
   pl->rows = rows; pl->Ho = (int)Ho; pl->Wo = (int)Wo;
-  const int tn = pl->cfg ? 128 : 256;
+  const int tn = pl->cfg == 4 ? 64 : pl->cfg ? 128 : 256;
   const int64_t tiles = dvt_cdiv(pl->K, 256) * dvt_cdiv(d->Cout, tn);
   const int64_t target = (int64_t)dvt_num_cus() * (pl->cfg ? 2 : 1);       // cfg 1 runs two workgroups per CU
   int64_t split = target / tiles;
@@ -849,7 +863,7 @@ int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0;
   p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = pl.kps; p.slab = (float*)d->workspace; p.tiles_n = 0;
   p.colsum_slab = nullptr;
-  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = pl.Ho; p.cWo = pl.Wo; p.ckw = d->kw;
+  p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = pl.Ho; p.cWo = pl.Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   int rc = dvt_conv_wgrad_dma_launch(p, pl.split, pl.cfg, st);
   if (rc) return rc;

@@ -39,10 +39,13 @@ namespace {
 //          convolutions with <= 128 output channels (measured slower than CFG 0 on every Linear shape).
 //   CFG 3  256x256 tile, BK=64, 16 waves of 64x64 (4 per SIMD, 128 VGPRs, no fragment double buffer): twice the
 //          memory-operation concurrency in the epilogue, a slower main loop.
+//   CFG 4  256x64 tile, BK=32, 3 LDS stages (60 KiB), 4 waves (4x1) of 64x64: convolutions with <= 64 output channels
+//          (the stem and layer 1 of the ResNets: a 128-wide tile would spend half its MFMAs on padding columns).
 template <int CFG> struct Cfg;
 template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
 template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2 }; };  // 16 waves of 64 x 64: 4 per SIMD
+template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, NSTG = 3 }; };    // 4 waves of 64 x 64, 60 KiB: 2 workgroups / CU
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
 constexpr int kEpiBytes = 32 * kEpiStride * 4;   // 8,704 B per wave
@@ -78,7 +81,7 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
       constexpr int RPP = 64 / CPR;
       const int k = piece * RPP + lane / CPR;
       const int cp = lane % CPR;
-      const int c = ((((cp >> 1) ^ swz_mn(k)) << 1) | (cp & 1));
+      const int c = ((((cp >> 1) ^ swz_mn_r<ROWS>(k)) << 1) | (cp & 1));
       int gmn = mn0 + c * 8;
       gmn = gmn < mn_lim ? gmn : mn_lim - 8;
       src = base + (int64_t)(k0 + k) * ld + gmn;
@@ -113,6 +116,22 @@ struct ConvRows {
     }
   }
   __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) const {
+    if (p.cC == 8) {
+      // Stem form (the 3 image channels zero-extended to 8, custom_resnet.py:100): a 16-byte chunk is one (pixel, tap), so
+      // the chunks of a k-tile are consecutive taps and every lane derives its own tap; k >= kh*kw*8 (K is rounded up
+      // to the k-tile) and padded taps read the zero page.  tap / kw by multiplication (taps < 2^10, kw < 2^6).
+      const int ntap = p.ckh * p.ckw, magic = (65536 + p.ckw - 1) / p.ckw;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int tap = (k0 + coff[i]) >> 3;
+        const int ki = (tap * magic) >> 16, kj = tap - ki * p.ckw;
+        const int hi = h0[i] + ki, wi = w0[i] + kj;
+        const bool ok = tap < ntap && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+        const bf16* src = ok ? p.A + (int64_t)(pix[i] + hi * p.cW + wi) * 8 : reinterpret_cast<const bf16*>(dvt_zero16);
+        dvt_dma16(src, tile + (wid * PPW + i) * 1024);
+      }
+      return;
+    }
     const int tap = k0 / p.cC, c0 = k0 - tap * p.cC;
     const int ki = tap / p.ckw, kj = tap - ki * p.ckw;
 #pragma unroll
@@ -138,7 +157,7 @@ struct ConvColsMN {
     for (int i = 0; i < PPW; ++i) {
       const int k = (wid * PPW + i) * RPP + lane / CPR;
       const int cp = lane % CPR;
-      const int c = ((((cp >> 1) ^ swz_mn(k)) << 1) | (cp & 1));
+      const int c = ((((cp >> 1) ^ swz_mn_r<ROWS>(k)) << 1) | (cp & 1));
       int gmn = m0 + c * 8;
       gmn = gmn < p.M ? gmn : p.M - 8;
       const int tap = gmn / p.cC;
@@ -180,7 +199,7 @@ __device__ __forceinline__ typename Elem16<E>::v8 frag(const char* tile, int bas
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int k = kk * 32 + 8 * g + 4 * hf + q;
-      const char* a = tile + k * (ROWS * 2) + ((u ^ swz_mn(k)) << 5) + 8 * pp;
+      const char* a = tile + k * (ROWS * 2) + ((u ^ swz_mn_r<ROWS>(k)) << 5) + 8 * pp;
       half[hf] = Elem16<E>::tr_read(a);
     }
     // concatenation, not element inserts: the two 64-bit reads land in adjacent VGPR pairs
@@ -622,15 +641,16 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
 
 // Weight gradient with the column matrix gathered on the fly: slab[z][M = kh*kw*C][N = Cout] partial sums.
 int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st) {
-  if (p.elem == DVT_F16) return cfg == 0 ? launch_conv_wgrad<f16, 0>(p, split, st) : launch_conv_wgrad<f16, 1>(p, split, st);
-  return cfg == 0 ? launch_conv_wgrad<bf16, 0>(p, split, st) : launch_conv_wgrad<bf16, 1>(p, split, st);
+  if (p.elem == DVT_F16)
+    return cfg == 0 ? launch_conv_wgrad<f16, 0>(p, split, st) : cfg == 4 ? launch_conv_wgrad<f16, 4>(p, split, st) : launch_conv_wgrad<f16, 1>(p, split, st);
+  return cfg == 0 ? launch_conv_wgrad<bf16, 0>(p, split, st) : cfg == 4 ? launch_conv_wgrad<bf16, 4>(p, split, st) : launch_conv_wgrad<bf16, 1>(p, split, st);
 }
 
 // Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
-// fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32.
+// fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32, cfg 4 = 256x64x32 (Cout <= 64).
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
-  if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : launch_conv<f16, 1>(p, st);
-  return cfg == 0 ? launch_conv<bf16, 0>(p, st) : launch_conv<bf16, 1>(p, st);
+  if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : cfg == 4 ? launch_conv<f16, 4>(p, st) : launch_conv<f16, 1>(p, st);
+  return cfg == 0 ? launch_conv<bf16, 0>(p, st) : cfg == 4 ? launch_conv<bf16, 4>(p, st) : launch_conv<bf16, 1>(p, st);
 }
 
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)

@@ -24,10 +24,16 @@ struct GemmParams {
   int accumulate_colsum;   // gemm_small.hip only: colsum_slab is the final bias-gradient vector; += when set
   float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
-  int cH, cW, cC, cHo, cWo, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
+  int cH, cW, cC, cHo, cWo, ckh, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };
 
 __device__ __forceinline__ int swz_mn(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// 32-byte-unit swizzle of an mn-major image row by its k index.  Rows of >= 256 bytes have eight units to permute
+// (swz_mn); a 64-wide image (128-byte rows: four units; rows k and k+2 alias on the 256-byte bank row) uses two bits
+// chosen so that the eight k rows a 32-lane half of ds_read_b64_tr_b16 touches ({q, 8+q} + 4 hf) hit eight bank groups.
+template <int ROWS> __device__ __forceinline__ int swz_mn_r(int k) {
+  return ROWS >= 128 ? swz_mn(k) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+}
 
 __device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float res, float aux_in,
                                            float& aux_out) {

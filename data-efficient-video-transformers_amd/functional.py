@@ -925,20 +925,31 @@ class _ConvBnAct(torch.autograd.Function):
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l = w.shape[0], w.shape[1]
         Cout = (Cout_l + cpad - 1) // cpad * cpad if cpad else Cout_l
+        (kh, kw), (sh, sw) = ops._pair(k), ops._pair(stride)
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        xc = x.contiguous()
+        stem8 = (IMPLICIT_CONV and nchw and Cin <= 8 and not x.requires_grad and dtype in (torch.bfloat16, torch.float16)
+                 and Cout % 8 == 0 and (N * Ho * Wo) % 32 == 0)
+        if stem8:
+            # The stem (custom_resnet.py:100: 7x7 / 2 on the 3-channel frames) as an implicit GEMM: the frames become an
+            # NHWC map with the channels zero-extended to 8 (one 16-byte chunk per pixel and tap), the weights carry the
+            # matching zero planes, and from here on it is an ordinary NHWC convolution with Cin = 8 -- no column matrix
+            # (0.94 GB at 256 frames of 224^2) in forward or in the weight gradient.  Not taken when the frames need a
+            # gradient (the pixel-space CLS clip of FrameTransformer): that path keeps the explicit gather.
+            xc = ops.nchw_to_nhwc_pad8(xc.view(N, Cin, H, W), dtype)
+            Cin, nchw = 8, False
+            geom = (N, Cin, H, W, k, stride, pad, nchw)
         padded = Cout != Cout_l or Cin != Cin_l
         if Cin < Cin_l:
             raise ValueError("input has fewer channels than the convolution weight")
-        (kh, kw), (sh, sw) = ops._pair(k), ops._pair(stride)
-        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         K = kh * kw * Cin
         direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
-        ld = K if direct else _kpad(K, dtype)
-        xc = x.contiguous()
+        ld = K if direct else (ops.conv2d_implicit_k(Cin, Cout, k) if stem8 else _kpad(K, dtype))
         w4 = w.reshape(Cout_l, Cin_l, kh, kw)
         if padded:
             w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
         wp = ops.conv_weight_pack(w4, ld, dtype)
-        implicit = (IMPLICIT_CONV and not direct and not nchw and ld == K and xc.dtype == dtype and
+        implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8) and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
         stats_partial = None
         if implicit:

@@ -802,13 +802,31 @@ def _conv_desc(x: Tensor, wp: Tensor, y, N, Cc, H, W, Cout, k, stride, pad):
     return d
 
 
+def conv2d_implicit_k(Cc: int, Cout: int, k) -> int:
+    """Row length of the packed weights the implicit forward expects (kh*kw*C; rounded up to the k-tile for C == 8)."""
+    (kh, kw) = _pair(k)
+    d = L.ConvDesc()
+    d.C, d.Cout, d.kh, d.kw = Cc, Cout, kh, kw
+    return int(L.load().dvt_conv2d_implicit_k(C.byref(d)))
+
+
 def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
         return False
-    (kh, kw) = _pair(k)
-    if not (x.is_contiguous() and wp.is_contiguous() and wp.shape == (Cout, kh * kw * Cc)):
+    if not (x.is_contiguous() and wp.is_contiguous() and wp.shape == (Cout, conv2d_implicit_k(Cc, Cout, k))):
         return False
     return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad))))
+
+
+def nchw_to_nhwc_pad8(x: Tensor, dtype: torch.dtype) -> Tensor:
+    """Raw frames [N, C <= 8, H, W] -> NHWC matrix [N*H*W, 8] in ``dtype`` (channels C.. zero): the stem's input form."""
+    _need_cuda(x)
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    y = torch.empty((N * H * W, 8), dtype=dtype, device=x.device)
+    L.check(L.load().dvt_nchw_to_nhwc_pad(x.data_ptr(), dt(x), y.data_ptr(), _DT[dtype], N, Cc, H, W, 8, _stream()),
+            "dvt_nchw_to_nhwc_pad")
+    return y
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,

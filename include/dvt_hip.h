@@ -320,6 +320,11 @@ int dvt_average_precision(const float* probs, const unsigned char* labels, int64
  * the [T, H*W] view of each clip. */
 int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
                int W, int kh, int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream);
+/* Raw NCHW frames x[N, C, H, W] (custom_resnet.py:138: the stem reads the clip frames) -> NHWC matrix y[N*H*W, Cpad] with
+ * the channels C .. Cpad-1 zero (Cpad = 8: one 16-byte chunk per pixel, the input form of the implicit stem
+ * convolution; C <= Cpad, Cpad % 8 == 0). */
+int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64_t N, int C, int H, int W, int Cpad,
+                         dvt_stream_t stream);
 /* Adjoint gather (data gradient of the convolution), NHWC, C % 8 == 0. */
 int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
                int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream);
@@ -359,6 +364,9 @@ typedef struct dvt_conv_desc {
   float* stats_partial;
 } dvt_conv_desc;
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
+/* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
+ * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */
+int64_t dvt_conv2d_implicit_k(const dvt_conv_desc* desc);
 int dvt_conv2d_implicit(const dvt_conv_desc* desc, dvt_stream_t stream);
 int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* desc);
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* desc);

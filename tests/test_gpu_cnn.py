@@ -63,6 +63,68 @@ def test_conv_bn_relu_block(dvt, device, dtype, tol, k, stride, pad, Cin, Cout, 
         assert rel_l2(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)) < 2 * tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cout,H,W", [(64, 32, 32), (16, 64, 48)])
+def test_stem_as_implicit_gemm_matches_conv2d(dvt, device, dtype, Cout, H, W):
+    """The 7x7 / 2 stem on raw NCHW frames (custom_resnet.py:100) through the implicit-GEMM form -- frames zero-extended to
+    8 channels (dvt_nchw_to_nhwc_pad), K rounded up to the k-tile, no column matrix -- against torch's conv2d + batch_norm
+    on the same rounded operands: output, running statistics, weight / BatchNorm gradients; and against the explicit
+    im2col path of the same library."""
+    from dvt_amd import functional as F
+    g = torch.Generator().manual_seed(41)
+    N = 2
+    x = torch.randn(N, 3, H, W, generator=g)
+    conv = torch.nn.Conv2d(3, Cout, 7, 2, 3, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / 147) ** 0.5)
+        bn.weight.copy_(1 + 0.1 * torch.randn(Cout, generator=g)); bn.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+    wr = conv.weight.detach().to(dtype).float().clone().requires_grad_(True)
+    gr, br = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    z = TF.conv2d(x.to(dtype).float(), wr, None, 2, 3)
+    ref = torch.relu(TF.batch_norm(z, rm, rv, gr, br, True, 0.1, 1e-5))
+    gy = torch.randn(ref.shape, generator=g).to(dtype)
+    ref.backward(gy.float())
+    outs = {}
+    for implicit in (True, False):
+        F.IMPLICIT_CONV = implicit
+        try:
+            c2, b2 = torch.nn.Conv2d(3, Cout, 7, 2, 3, bias=False), torch.nn.BatchNorm2d(Cout)
+            c2.load_state_dict(conv.state_dict()); b2.load_state_dict(bn.state_dict())
+            c2, b2 = c2.cuda(), b2.cuda().train()
+            y = F.conv_bn_act(x.to(dtype).cuda(), c2, b2, (N, 3, H, W, True), relu=True, dtype=dtype)
+            y.backward(gy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda())
+            outs[implicit] = (y.detach(), c2.weight.grad.clone(), b2.weight.grad.clone(), b2.bias.grad.clone(), b2.running_var.clone())
+        finally:
+            F.IMPLICIT_CONV = True
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 3e-3
+    y, dw, dg, db, rvar = outs[True]
+    assert rel_l2(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout)) < tol
+    assert rel_l2(dw, wr.grad) < 2 * tol and rel_l2(dg, gr.grad) < 2 * tol and rel_l2(db, br.grad) < 2 * tol
+    assert torch.allclose(rvar.cpu(), rv, atol=2e-2)
+    for a, b in zip(outs[True], outs[False]):          # the two forms agree to rounding of the 16-bit conv output
+        assert rel_l2(a, b) < tol
+
+
+@pytest.mark.parametrize("H,W,k,stride,pad", [(9, 11, 3, 2, 1), (12, 16, 3, 2, 1), (10, 10, 2, 2, 0), (7, 9, 3, 1, 1)])
+def test_maxpool_fwd_bwd_matches_torch(dvt, device, H, W, k, stride, pad):
+    """nn.MaxPool2d (custom_resnet.py:107 uses 3 / 2 / 1: the specialised backward; other geometries: the generic one),
+    first-max tie rule, odd and even map sizes."""
+    g = torch.Generator().manual_seed(33)
+    N, C = 2, 16
+    x = torch.relu(torch.randn(N, C, H, W, generator=g))          # many exact zeros -> ties
+    xr = x.clone().requires_grad_(True)
+    ref = TF.max_pool2d(xr, k, stride, pad)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda().requires_grad_(True)
+    y = dvt.functional.maxpool_nhwc(xd, N, C, H, W, k, stride, pad)
+    assert torch.equal(y.cpu(), ref.permute(0, 2, 3, 1).reshape(-1, C))
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    y.backward(gy.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda())
+    assert torch.allclose(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, C), atol=1e-6)
+
+
 def test_maxpool_first_max_and_eval_bn(dvt, device):
     g = torch.Generator().manual_seed(32)
     N, C, H, W = 2, 8, 9, 11

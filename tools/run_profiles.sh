@@ -1,6 +1,6 @@
 #!/bin/bash
-# Reproduces profiles/r01_* on an MI355X box (run from the repo root through gpurun):
-#   bash tools/run_profiles.sh && python3 tools/profile_summarize.py gpurun_out/prof profiles r01
+# Reproduces profiles/rNN_* on an MI355X box (run from the repo root through gpurun):
+#   bash tools/run_profiles.sh && python3 tools/profile_summarize.py gpurun_out/prof profiles r02
 # One rocprofv3 run per counter group (--pmc never together with other trace domains); the program itself follows `--`.
 set -e
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
@@ -8,12 +8,12 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$BENCH" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/write.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/mfma" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/mfma.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$BENCH" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/mfma" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/mfma.log" 2>&1
 # secondary workloads: kernel-time breakdown only
 for wl in pyramid frametransformer longclip; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- python3 "$BENCH" --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > "$OUT/stats_$wl.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- python3 "$BENCH" --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/stats_$wl.log" 2>&1
 done
 echo "profiles collected under $OUT"
