@@ -411,6 +411,41 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p
   }
 }
 
+// Tiny outputs (the 19-class heads: [8, 512] x [19, 512]^T and its two gradients): the 64x64-tile kernel above runs
+// them as ONE workgroup looping over K (24 us for 78 kFLOP).  Here every output element has its own wave (long K: the
+// lanes stride over k, then a wave reduction) or its own thread (short K).  fp32 accumulation in a fixed order.
+template <typename T, bool WAVE>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(const GenericParams p) {
+  const T* A = (const T*)p.A;
+  const T* B = (const T*)p.B;
+  const int64_t total = (int64_t)p.M * p.N;
+  const int64_t o = WAVE ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= total) return;
+  const int m = (int)(o / p.N), n = (int)(o % p.N);
+  float acc = 0.f;
+  if (WAVE) {
+    for (int k = threadIdx.x & 63; k < p.K; k += 64)
+      acc = fmaf(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc);
+    acc = wave_sum(acc);
+    if (threadIdx.x & 63) return;
+  } else {
+    for (int k = 0; k < p.K; ++k)
+      acc = fmaf(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc);
+  }
+  const float bias = p.bias ? p.bias[n] : 0.f;
+  float res = 0.f, aux = 0.f, pre = 0.f;
+  if (p.epilogue == DVT_EPI_RESIDUAL) res = to_f32<T>(((const T*)p.residual)[(int64_t)m * p.ldr + n]);
+  if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU) aux = to_f32<T>(((const T*)p.aux)[(int64_t)m * p.ldaux + n]);
+  const float v = epi_apply(p.epilogue, acc * p.alpha, bias, res, aux, pre);
+  if (p.epilogue == DVT_EPI_GELU && p.aux) ((T*)p.aux)[(int64_t)m * p.ldaux + n] = from_f32<T>(pre);
+  if (p.out_f32) {
+    float* out = (float*)p.C + (int64_t)m * p.ldc + n;
+    *out = p.accumulate ? *out + v : v;
+  } else {
+    ((T*)p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+  }
+}
+
 // ---------------------------------------------------------------- colsum (bias gradients)
 // partial[b][n] = sum over this block's row range; then a second pass sums partials.
 template <typename T>
@@ -739,6 +774,17 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   g.ldc = d->ldc; g.epilogue = d->epilogue; g.out_f32 = d->out_dtype == DVT_F32;
   g.accumulate = d->accumulate; g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
   g.aux = d->aux; g.ldaux = d->ldaux; g.alpha = d->alpha;
+  const int64_t outs = d->M * d->N;
+  if (outs <= 16384 && d->K >= 128) {            // one wave per output element
+    DVT_DISPATCH_DTYPE(d->in_dtype, T, hipLaunchKernelGGL((gemm_tiny_kernel<T, true>), dim3((unsigned)dvt_cdiv(outs, 4)), dim3(256), 0, st, g));
+    DVT_LAUNCH_CHECK("dvt_gemm(tiny)");
+    return DVT_OK;
+  }
+  if (outs <= 65536 && d->K <= 32) {             // one thread per output element
+    DVT_DISPATCH_DTYPE(d->in_dtype, T, hipLaunchKernelGGL((gemm_tiny_kernel<T, false>), dim3((unsigned)dvt_cdiv(outs, 256)), dim3(256), 0, st, g));
+    DVT_LAUNCH_CHECK("dvt_gemm(tiny)");
+    return DVT_OK;
+  }
   const dim3 grid((unsigned)dvt_cdiv(d->N, 64), (unsigned)dvt_cdiv(d->M, 64)), block(256);
   DVT_DISPATCH_DTYPE(d->in_dtype, T, hipLaunchKernelGGL((gemm_generic_kernel<T>), grid, block, 0, st, g));
   DVT_LAUNCH_CHECK("dvt_gemm(generic)");

@@ -28,15 +28,15 @@ __device__ __forceinline__ int swz_mn64(int k) { return ((k >> 1) & 1) | (((k >>
 
 // DMA one operand chunk (ROWS x 256 k) into LDS, 1 KiB per wave-instruction; k >= k_lim and rows >= mn_lim read zeros
 // (a clamped row would do for rows -- they are never stored -- but zeros keep the bias-gradient sums exact).
+// ck = k length of the chunk: SK, or (mn-major images only: their rows are k) any multiple of 32 up to 512.
 template <bool KMAJOR, int ROWS>
 __device__ __forceinline__ void dma_chunk(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim, int k0, int k_lim,
-                                          char* img, int wid, int lane) {
-  constexpr int PIECES = ROWS * SK * 2 / 1024;
-  constexpr int PPW = PIECES / 4;
+                                          char* img, int wid, int lane, int ck = SK) {
+  const int ppw = KMAJOR ? ROWS * SK * 2 / 1024 / 4 : ck * ROWS * 2 / 1024 / 4;
   const bf16* zero = reinterpret_cast<const bf16*>(dvt_small_zero16);
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int piece = wid * PPW + i;
+#pragma unroll 4
+  for (int i = 0; i < ppw; ++i) {
+    const int piece = wid * ppw + i;
     const bf16* src;
     if (KMAJOR) {
       const int row = piece * 2 + (lane >> 5);            // 512-byte rows: two per piece
@@ -97,7 +97,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   const int wm = wid / WNC, wn = wid % WNC;
   const int g = lane >> 4, li = lane & 15;
   const int m0 = (blockIdx.x / p.tiles_n) * TM, n0 = (blockIdx.x % p.tiles_n) * STN;
-  const int nch = (p.K + SK - 1) / SK;
+  // Weight-gradient form with K <= 512 (the temporal encoder: K = 264 rows): ONE chunk of K rounded up to 32 rows --
+  // two 256-row chunks would spend half their DMA instructions and MFMA steps on zero rows.
+  const int ck = (!A_KMAJOR && !B_KMAJOR && p.K <= 512) ? ((p.K + 31) & ~31) : SK;
+  const int nch = (p.K + ck - 1) / ck;
+  const int boff = (!A_KMAJOR && !B_KMAJOR) ? ck * 128 : kA;      // B image behind the A image of the same stage
 
   f32x4 acc[NU][2];
 #pragma unroll
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
 
   auto issue = [&](int ch) {
     char* st = smem + (ch & 1) * kStage;
-    dma_chunk<A_KMAJOR, TM>(p.A, p.lda, m0, p.M, ch * SK, p.K, st, wid, lane);
-    dma_chunk<B_KMAJOR, STN>(p.B, p.ldb, n0, p.N, ch * SK, p.K, st + kA, wid, lane);
+    dma_chunk<A_KMAJOR, TM>(p.A, p.lda, m0, p.M, ch * ck, p.K, st, wid, lane, ck);
+    dma_chunk<B_KMAJOR, STN>(p.B, p.ldb, n0, p.N, ch * ck, p.K, st + boff, wid, lane, ck);
   };
   issue(0);
   if (nch > 1) issue(1);
@@ -118,12 +122,12 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   float cs = 0.f;
 
   for (int ch = 0; ch < nch; ++ch) {
-    if (ch + 1 < nch) swait_vm<kPPC>(); else swait_vm<0>();   // chunk ch landed (ch + 1 may stay in flight)
+    if (ch + 1 < nch) swait_vm<kPPC>(); else swait_vm<0>();   // chunk ch landed (ch + 1 may stay in flight; then ck == SK)
     __builtin_amdgcn_s_barrier();
     const char* sa = smem + (ch & 1) * kStage;
-    const char* sb = sa + kA;
-#pragma unroll
-    for (int kk = 0; kk < SK / 32; ++kk) {
+    const char* sb = sa + boff;
+#pragma unroll 4
+    for (int kk = 0; kk < ck / 32; ++kk) {
       V8 af[2], bfr[NU];
 #pragma unroll
       for (int t = 0; t < 2; ++t) af[t] = sfrag<E, A_KMAJOR>(sa, wm * 32 + t * 16, kk, g, li);
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     }
     if (do_cs && tid < TM) {                               // thread = one column m of the [k][64] image
 #pragma unroll 8
-      for (int k = 0; k < SK; ++k)
+      for (int k = 0; k < ck; ++k)
         cs += (float)*reinterpret_cast<const E*>(sa + k * 128 + (((tid >> 4) ^ swz_mn64(k)) << 5) + (tid & 15) * 2);
     }
     if (ch + 2 < nch) {
