@@ -553,7 +553,12 @@ bool small_regime(const dvt_gemm_desc* d) {
   if (d->split_k != 0 || d->K <= 0) return false;
   if ((double)d->M * (double)d->N * (double)d->K > 2147483648.0) return false;
   if (dvt_cdiv(d->M, 32) * dvt_cdiv(d->N, 64) > 4096) return false;
-  return dvt_gemm_small_tile(d->M, d->N, d->a_kmajor != 0, d->b_kmajor != 0) != 0;
+  const int tm = dvt_gemm_small_tile(d->M, d->N, d->a_kmajor != 0, d->b_kmajor != 0);
+  if (tm == 0) return false;
+  // The panel kernel never splits K: a deep product on a handful of tiles (the weight gradient of a narrow
+  // convolution, K = output pixels) belongs to the split-K path.
+  if (d->K > 2048 && dvt_cdiv(d->M, tm) * dvt_cdiv(d->N, 64) < 96) return false;
+  return true;
 }
 
 struct GemmPlan {

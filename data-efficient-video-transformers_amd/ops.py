@@ -845,7 +845,8 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         partial = workspace(lib.dvt_conv2d_implicit_stats_bytes(C.byref(d)), x.device, slot="bn_partial")
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
-    with _timed(("gemm", 1, 1, N * Ho * Wo, Cout, kh * kw * Cc), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
+    nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
+    with _timed(("gemm", 1, 1, N * Ho * Wo, Cout, kh * kw * Cc, 0, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
     return (y, partial, parts) if want_stats else y
 
@@ -879,7 +880,8 @@ def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int
     ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device)
     d.workspace = _p(ws)
     rows = dz.shape[0]
-    with _timed(("gemm", 0, 0, kh * kw * Cc, Cout, rows), 2.0 * rows * Cout * kh * kw * Cc):
+    nb = (x.numel() + dz.numel()) * x.element_size() + out.numel() * out.element_size()
+    with _timed(("gemm", 0, 0, kh * kw * Cc, Cout, rows, 0, nb), 2.0 * rows * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit_wgrad(C.byref(d), _stream()), "dvt_conv2d_implicit_wgrad")
     return out
 
