@@ -554,7 +554,12 @@ def main():
     import dvt_amd  # noqa: F401
     if use_dist and args.backend == "nccl":
         from dvt_amd.dp import Communicator
-        comm = Communicator.from_torch_distributed()
+        try:
+            comm = Communicator.from_torch_distributed()
+        except Exception as e:      # the exchange then goes through torch.distributed's own RCCL group (launched eagerly)
+            if rank == 0:
+                print(f"[bench] dvt_comm_init failed ({type(e).__name__}: {e}); falling back to torch.distributed", file=sys.stderr)
+            comm = None
 
     out = run_workload(args, args.workload, rank, world, use_dist, comm, steps=args.steps, warmup=args.warmup,
                        roofline=not args.no_roofline)

@@ -801,6 +801,14 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 // 256x128x32 up to 128, 256x256x64 beyond.
 static int conv_cfg(int cout) { return cout <= 64 ? 4 : cout <= 128 ? 1 : 0; }
 
+// Forward / data-gradient launches with few output rows (layer 4 of a ResNet-18 on 224^2 frames: 49 pixels per frame)
+// leave most CUs without a 256x256 tile: the 256x128 configuration doubles the tile count (and runs two per CU).
+static int conv_fwd_cfg(int64_t rows, int cout) {
+  const int cfg = conv_cfg(cout);
+  if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < (int64_t)dvt_num_cus() * 3) return 1;
+  return cfg;
+}
+
 static bool conv_implicit_ok(const dvt_conv_desc* d) {
   if (!d || !d->x || !d->w || !d->y) return false;
   if (!dvt_is_16bit(d->dtype)) return false;
@@ -843,7 +851,7 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   p.bn_partial = d->stats_partial;
-  return dvt_conv_dma_launch(p, conv_cfg(d->Cout), (hipStream_t)stream);
+  return dvt_conv_dma_launch(p, conv_fwd_cfg(p.M, d->Cout), (hipStream_t)stream);
 }
 
 // one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4

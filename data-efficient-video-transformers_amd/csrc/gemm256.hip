@@ -147,12 +147,21 @@ struct ConvRows {
 
 // Implicit-GEMM mn-major operand (weight gradient): image [TK k-rows][ROWS m-columns], k = output pixel row of the
 // layer, m = (ki, kj, c) column of the never-materialised column matrix.  A lane's 16-byte chunk is 8 channels of one
-// tap of one pixel; its (tap, channel) is fixed for the whole K loop, only the pixel changes per k-tile.
+// tap of one pixel; its (tap, channel) is fixed for the whole K loop, only the pixel changes per k-tile.  The k-tiles of
+// a workgroup are requested in order, TK pixels apart, so the pixel coordinates (image, ho, wo) are carried and advanced
+// by TK = (dqq * Ho + dqr) * Wo + dr per request instead of being divided out of the row index every time (two integer
+// divisions per chunk and k-tile were more vector work than the k-tile's MFMAs at 64 output channels).
 template <int ROWS, int TK, int NW>
 struct ConvColsMN {
   enum { PIECES = ROWS * TK * 2 / 1024, PPW = PIECES / NW, CPR = ROWS / 8, RPP = 64 / CPR };
-  int kin[PPW], ki[PPW], kj[PPW], ci[PPW];
-  __device__ __forceinline__ void init(const GemmParams& p, int m0, int wid, int lane) {
+  int wo[PPW], ho[PPW], nb[PPW], tc[PPW];   // tc = channel | kj << 16 | ki << 24
+  int dr, dqr, dqq;
+  __device__ __forceinline__ void init(const GemmParams& p, int m0, int kbeg, int wid, int lane) {
+    const int dq = TK / p.cWo;
+    dr = TK - dq * p.cWo;
+    dqq = dq / p.cHo;
+    dqr = dq - dqq * p.cHo;
+    const int hw = p.cHo * p.cWo;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int k = (wid * PPW + i) * RPP + lane / CPR;
@@ -161,24 +170,29 @@ struct ConvColsMN {
       int gmn = m0 + c * 8;
       gmn = gmn < p.M ? gmn : p.M - 8;
       const int tap = gmn / p.cC;
-      kin[i] = k;
-      ci[i] = gmn - tap * p.cC;
-      ki[i] = tap / p.ckw;
-      kj[i] = tap - ki[i] * p.ckw;
+      const int ki = tap / p.ckw, kj = tap - ki * p.ckw;
+      tc[i] = (gmn - tap * p.cC) | (kj << 16) | (ki << 24);
+      const int row = kbeg + k;
+      const int n = row / hw, r = row - n * hw;
+      ho[i] = r / p.cWo;
+      wo[i] = r - ho[i] * p.cWo;
+      nb[i] = n * p.cH * p.cW;
     }
   }
-  __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) const {
-    const int hw = p.cHo * p.cWo;
+  // the NEXT k-tile of this workgroup (call order = k order)
+  __device__ __forceinline__ void dma(const GemmParams& p, char* tile, int wid) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int row = k0 + kin[i];
-      const int n = row / hw, r = row - n * hw;
-      const int ho = r / p.cWo, wo = r - ho * p.cWo;
-      const int hi = ho * p.csh - p.cph + ki[i], wi = wo * p.csw - p.cpw + kj[i];
+      const int hi = ho[i] * p.csh - p.cph + (tc[i] >> 24), wi = wo[i] * p.csw - p.cpw + ((tc[i] >> 16) & 0xff);
       const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
-      const bf16* src = ok ? p.A + ((int64_t)((n * p.cH + hi) * p.cW + wi) * p.cC + ci[i])
+      const bf16* src = ok ? p.A + ((int64_t)(nb[i] + hi * p.cW + wi) * p.cC + (tc[i] & 0xffff))
                            : reinterpret_cast<const bf16*>(dvt_zero16);
       dvt_dma16(src, tile + (wid * PPW + i) * 1024);
+      wo[i] += dr;
+      ho[i] += dqr;
+      nb[i] += dqq * p.cH * p.cW;
+      if (wo[i] >= p.cWo) { wo[i] -= p.cWo; ho[i] += 1; }
+      if (ho[i] >= p.cHo) { ho[i] -= p.cHo; nb[i] += p.cH * p.cW; }
     }
   }
 };
@@ -307,14 +321,14 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   ConvRows<TM, TK, NW> cv;
   ConvColsMN<TM, TK, NW> cvm;
   if (A_CONV && A_KMAJOR) cv.init(p, m0, wid, lane);
-  if (A_CONV && !A_KMAJOR) cvm.init(p, m0, wid, lane);
+  if (A_CONV && !A_KMAJOR) cvm.init(p, m0, kbeg, wid, lane);
 
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s)
     if (s < nk) {
       if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
-      else if (A_CONV) cvm.dma(p, kbeg + s * TK, smem + s * kStage, wid);
+      else if (A_CONV) cvm.dma(p, smem + s * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
     }
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
       if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
-      else if (A_CONV) cvm.dma(p, k0, smem + st_nxt * kStage, wid);
+      else if (A_CONV) cvm.dma(p, smem + st_nxt * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
     }
