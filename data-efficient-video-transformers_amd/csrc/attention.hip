@@ -546,23 +546,33 @@ __global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float l = 0.f;
+    // The kernel is bound by vector issue beside the MFMAs, so the row sum is taken by the matrix pipe:
+    // a fifth "V^T" fragment of ones makes every row of ol the sum over the keys of the 16-bit probabilities that also
+    // enter P V (numerator and normaliser see the same rounding; no per-element add, no cross-lane reduction), and the
+    // scale / subtract-maximum step runs as packed f32 pairs.
+    f32x4 ol = f32x4{0.f, 0.f, 0.f, 0.f};
+    V8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (E)1.0f;
+    const f32x2 c2v = {c2, c2}, mnv = {-mn, -mn};
 #pragma unroll
     for (int kp = 0; kp < NKP; ++kp) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[kp][tt][r], c2, -mn));
-          s[kp][tt][r] = e;
-          l += e;
-        }
+      for (int tt = 0; tt < 2; ++tt) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{s[kp][tt][0], s[kp][tt][1]}, c2v, mnv);
+        const f32x2 c = __builtin_elementwise_fma(f32x2{s[kp][tt][2], s[kp][tt][3]}, c2v, mnv);
+        s[kp][tt][0] = __builtin_amdgcn_exp2f(a[0]);
+        s[kp][tt][1] = __builtin_amdgcn_exp2f(a[1]);
+        s[kp][tt][2] = __builtin_amdgcn_exp2f(c[0]);
+        s[kp][tt][3] = __builtin_amdgcn_exp2f(c[1]);
+      }
       const V8 pf = pack_pair<E>(s[kp][0], s[kp][1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         o[dt] = Elem16<E>::mma(img_tr_frag<E>(vs, 2 * kp, 2 * kp + 1, dt * 16, g, li), pf, o[dt]);
+      ol = Elem16<E>::mma(ones, pf, ol);
     }
-    l = rows_allreduce<false>(l);
+    const float l = ol[0];                           // rows 4g .. 4g+3 of ol all hold query li's sum
     const float inv = 1.0f / l;
     const int qi = qt * 16 + li;
     consume(qf[0]);
@@ -631,6 +641,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x2 c2v = {c2, c2}, l2v = {-l2, -l2}, dlv = {-dl, -dl};
     auto step = [&](int kp, bool last) {
       f32x4 s[2], dp[2];
 #pragma unroll
@@ -646,10 +657,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(const AttnParams
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2));
-          s[tt][r] = pr * (dp[tt][r] - dl);
+        for (int r = 0; r < 4; r += 2) {             // packed f32 pairs: the kernel is bound by vector issue
+          const f32x2 x = __builtin_elementwise_fma(f32x2{s[tt][r], s[tt][r + 1]}, c2v, l2v);
+          const f32x2 d = f32x2{dp[tt][r], dp[tt][r + 1]} + dlv;
+          const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          const f32x2 ds = pr * d;
+          s[tt][r] = ds[0];
+          s[tt][r + 1] = ds[1];
           if (last && (2 * kp + tt) * 16 + 4 * g + r >= p.Lk) s[tt][r] = 0.f;
+          if (last && (2 * kp + tt) * 16 + 4 * g + r + 1 >= p.Lk) s[tt][r + 1] = 0.f;
         }
       const V8 dsf = pack_pair<E>(s[0], s[1]);
 #pragma unroll
@@ -703,8 +719,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
   const float* delta = p.delta + ((int64_t)b * p.H + h) * p.Lq;
   char* qs = smem;
   char* gs = smem + p.Lqp * kRowBytes;
-  float* l2s = reinterpret_cast<float*>(smem + 2 * p.Lqp * kRowBytes);  // lse * log2e, [Lqp]
-  float* dls = l2s + p.Lqp;                                              // delta, [Lqp]
+  float* l2s = reinterpret_cast<float*>(smem + 2 * p.Lqp * kRowBytes);  // -lse * log2e, [Lqp]
+  float* dls = l2s + p.Lqp;                                              // -delta, [Lqp]
   const int nkt = (p.Lk + 15) >> 4, nqp = NQP ? NQP : p.Lqp >> 5;
   auto load_rows = [&](int kt, V8* kf, V8* vf) {
     const int kj = kt * 16 + li;
@@ -730,13 +746,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
   const int sr = (int)threadIdx.x < p.Lq ? (int)threadIdx.x : p.Lq - 1;
   const float lse0 = lse[sr], dl0 = delta[sr];
   stage_images<E>(qs, qb, p.q_sl, gs, gb, p.o_sl, p.Lq, p.Lqp);
-  if ((int)threadIdx.x < p.Lqp) {
-    l2s[threadIdx.x] = (int)threadIdx.x < p.Lq ? lse0 * kLog2e : 0.f;
-    dls[threadIdx.x] = (int)threadIdx.x < p.Lq ? dl0 : 0.f;
+  if ((int)threadIdx.x < p.Lqp) {                  // both negated: the step adds them (packed f32 add / fma, no sign flips)
+    l2s[threadIdx.x] = (int)threadIdx.x < p.Lq ? -lse0 * kLog2e : 0.f;
+    dls[threadIdx.x] = (int)threadIdx.x < p.Lq ? -dl0 : 0.f;
   }
   for (int r = threadIdx.x + blockDim.x; r < p.Lqp; r += blockDim.x) {
-    l2s[r] = r < p.Lq ? lse[r] * kLog2e : 0.f;
-    dls[r] = r < p.Lq ? delta[r] : 0.f;
+    l2s[r] = r < p.Lq ? -lse[r] * kLog2e : 0.f;
+    dls[r] = r < p.Lq ? -delta[r] : 0.f;
   }
   __syncthreads();
 
@@ -756,6 +772,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const f32x2 c2v = {c2, c2};
     auto step = [&](int qp) {
       f32x4 s[2], dp[2];
 #pragma unroll
@@ -775,10 +792,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
         const f32x4 l2 = *reinterpret_cast<const f32x4*>(l2s + q0);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(dls + q0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c2, -l2[r]));
-          s[tt][r] = pr;
-          dp[tt][r] = pr * (dp[tt][r] - dl[r]);
+        for (int r = 0; r < 4; r += 2) {             // packed f32 pairs (vector-issue-bound)
+          const f32x2 x = __builtin_elementwise_fma(f32x2{s[tt][r], s[tt][r + 1]}, c2v, f32x2{l2[r], l2[r + 1]});
+          const f32x2 d = f32x2{dp[tt][r], dp[tt][r + 1]} + f32x2{dl[r], dl[r + 1]};
+          const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          const f32x2 ds = pr * d;
+          s[tt][r] = pr[0];
+          s[tt][r + 1] = pr[1];
+          dp[tt][r] = ds[0];
+          dp[tt][r + 1] = ds[1];
         }
       }
       const V8 pf = pack_pair<E>(s[0], s[1]);
