@@ -47,7 +47,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm)
+        dep = max(os.path.getmtime(src), hm)
+        if os.path.basename(src) == "gemm256_pp.hip":        # includes gemm256.hip (the same kernel, configuration 5 only)
+            dep = max(dep, os.path.getmtime(os.path.join(CSRC, "gemm256.hip")))
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < dep
         if stale:
             jobs.append((src, obj))
 

@@ -598,8 +598,11 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       // cfg 0 (8 waves of 128 x 64) except for the arithmetic-heavy GELU / GELU' epilogues: with 16 waves of 64 x 64
       // (cfg 3) the epilogue's vector work of one wave overlaps the store latency of three others (FF1 206 -> 195 us).
       // cfg 1 (2 workgroups / CU) measured slower or equal on every Linear shape.
+      // cfg 5 (cfg 0's tile, wave rows in antiphase) elsewhere: +3..6 % (4096^3: 1,263 -> 1,343 TF/s), except a plain
+      // forward product of <= 8 k-tiles (QKV: 99 vs 105-111 us), which keeps the in-phase loop.
       const bool heavy_epi = d->epilogue == DVT_EPI_GELU || d->epilogue == DVT_EPI_DGELU;
-      pl.cfg = heavy_epi && s == 1 ? 3 : 0;
+      const bool short_plain_fwd = d->a_kmajor && d->b_kmajor && d->epilogue == DVT_EPI_NONE && s == 1 && d->K <= 512;
+      pl.cfg = heavy_epi && s == 1 ? 3 : short_plain_fwd ? 0 : 5;
       return pl;
     }
   }
@@ -712,7 +715,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     // bias gradient fused into the LDS-DMA weight-gradient kernel (split-K slab path, cfg 0)
     const size_t slab_bytes = split > 1 ? align256((size_t)split * (size_t)d->M * (size_t)d->N * sizeof(float)) : 0;
     float* cs_scratch = d->colsum_out ? (float*)((char*)d->workspace + slab_bytes) : nullptr;
-    const bool cs_fused = d->colsum_out && pl.use256 && pl.cfg == 0 && split > 1 && !d->a_kmajor && !d->b_kmajor &&
+    const bool cs_fused = d->colsum_out && pl.use256 && (pl.cfg == 0 || pl.cfg == 5) && split > 1 && !d->a_kmajor && !d->b_kmajor &&
                           d->epilogue == DVT_EPI_NONE && p.out_f32;
     p.colsum_slab = cs_fused ? cs_scratch : nullptr;
     if (d->colsum_out && !cs_fused) {   // same semantics through the stand-alone reduction

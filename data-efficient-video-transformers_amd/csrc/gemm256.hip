@@ -27,6 +27,12 @@
 #ifndef DVT_ABL
 #define DVT_ABL 0   // dev ablations (tools/gemm_bench.hip); 0 = product kernel
 #endif
+// Translation units of this file: 0 (gemm256.hip itself) = configurations 0, 1, 3, 4 and every entry point; 1
+// (gemm256_pp.hip includes this file) = the antiphase configuration 5 alone.  Instantiated beside the others it changed
+// THEIR register allocation (spills in the 16-wave and implicit weight-gradient kernels), so it gets its own module.
+#ifndef DVT_GEMM256_UNIT
+#define DVT_GEMM256_UNIT 0
+#endif
 
 namespace {
 
@@ -39,13 +45,16 @@ namespace {
 //          convolutions with <= 128 output channels (measured slower than CFG 0 on every Linear shape).
 //   CFG 3  256x256 tile, BK=64, 16 waves of 64x64 (4 per SIMD, 128 VGPRs, no fragment double buffer): twice the
 //          memory-operation concurrency in the epilogue, a slower main loop.
+//   CFG 5  CFG 0's tile with the two wave rows in antiphase (one reads a 32-deep slice's fragments while its SIMD partner
+//          runs the previous slice's MFMAs out of registers; four phase barriers per k-tile): +3..6 % on most shapes.
 //   CFG 4  256x64 tile, BK=32, 3 LDS stages (60 KiB), 4 waves (4x1) of 64x64: convolutions with <= 64 output channels
 //          (the stem and layer 1 of the ResNets: a 128-wide tile would spend half its MFMAs on padding columns).
 template <int CFG> struct Cfg;
-template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2 }; };
-template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3 }; };
-template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2 }; };  // 16 waves of 64 x 64: 4 per SIMD
-template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, NSTG = 3 }; };    // 4 waves of 64 x 64, 60 KiB: 2 workgroups / CU
+template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 0 }; };
+template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3, PP = 0 }; };
+template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2, PP = 0 }; };  // 16 waves of 64 x 64: 4 per SIMD
+template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, NSTG = 3, PP = 0 }; };    // 4 waves of 64 x 64, 60 KiB: 2 workgroups / CU
+template <> struct Cfg<5> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 0 with the two wave rows in antiphase
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
 constexpr int kEpiBytes = 32 * kEpiStride * 4;   // 8,704 B per wave
@@ -91,7 +100,7 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
 }
 
 // 16 zero bytes in global memory: the DMA source of every padded (out-of-image) tap of the implicit convolution
-__device__ __attribute__((aligned(16))) unsigned int dvt_zero16[4] = {0u, 0u, 0u, 0u};
+static __device__ __attribute__((aligned(16))) unsigned int dvt_zero16[4] = {0u, 0u, 0u, 0u};
 
 // Implicit-GEMM A operand: row = output pixel (n, ho, wo), k = (ki, kj, c) of an NHWC map x[N, H, W, C].
 // C % TK == 0, so a whole k-tile lies inside one filter tap: per k-tile a lane only adds the tap's (ki, kj) to the
@@ -323,10 +332,89 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   if (A_CONV && A_KMAJOR) cv.init(p, m0, wid, lane);
   if (A_CONV && !A_KMAJOR) cvm.init(p, m0, kbeg, wid, lane);
 
+  if constexpr (C::PP) {
+    // ---- antiphase main loop ("ping-pong").  Waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs
+    // cyclically), i.e. wave row 0 and wave row 1.  Each wave alternates a READ phase (the 12 fragments of one 32-deep
+    // slice into registers, plus its share of the DMA for the k-tile after next) and an MFMA phase (the slice's 32 MFMAs,
+    // operands already in registers), one phase out of step with its SIMD partner: after every phase barrier one of the two
+    // waves of a SIMD starts MFMAs whose operands are there, so the matrix pipe does not wait for a barrier plus an LDS
+    // round trip per k-tile as it does when both waves reach the k-tile barrier together.  Phase ph (4 per k-tile):
+    //   row 0:  R(kt,0) M(kt,0) R(kt,1) M(kt,1)           row 1:  M(kt-1,1) R(kt,0) M(kt,0) R(kt,1)   [+ M(nk-1,1) at the end]
+    // k-tile kt+1 is requested at the start of the wave's R(kt,0) (kt >= 1; k-tiles 0 and 1 in the prologue) into the stage
+    // that held kt-1 (last read in phase 4kt-1), and must have landed by the barrier that ends phase 4kt+3.
+    static_assert(NSTG == 2 && TK == 64 && NW == 8 && MT == 8, "antiphase loop: 256x256x64, 8 waves");
+    auto issue = [&](int kt) {
+      char* st = smem + (kt & 1) * kStage;
+      if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + kt * TK, st, wid);
+      else if (A_CONV) cvm.dma(p, st, wid);
+      else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + kt * TK, st, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + kt * TK, st + kATile, wid, lane);
+    };
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    DVT_GSTAMP(1);
+    if (nk > 1) wait_vm<kPPT>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    V8 fa[MT], fb[4];
+    auto rd = [&](int kt, int kk) {
+      const char* sa = smem + (kt & 1) * kStage;
+      const char* sb = sa + kATile;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fb[u] = frag<E, B_KMAJOR, TN, TK>(sb, wn * 64 + u * 16, kk, g, li);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t] = frag<E, A_KMAJOR, TM, TK>(sa, wm * WROWS + t * 16, kk, g, li);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto mm = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[u][t] = Elem16<E>::mma(fb[u], fa[t], acc[u][t]);
+      if (kCanColsum && do_cs) {                     // static fragment indices (a runtime index would move fa to scratch)
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4)
+          if (wn == w4) {
+#pragma unroll
+            for (int tt = 0; tt < CS; ++tt) csum[tt] = Elem16<E>::mma(ones, fa[CS * w4 + tt], csum[tt]);
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (wm == 0) {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt >= 1 && kt + 1 < nk) issue(kt + 1);
+        rd(kt, 0); bar();
+        mm(); bar();
+        rd(kt, 1); bar();
+        mm(); wait_vm<0>(); bar();
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt >= 1) mm();
+        bar();
+        if (kt >= 1 && kt + 1 < nk) issue(kt + 1);
+        rd(kt, 0); bar();
+        mm(); bar();
+        rd(kt, 1); wait_vm<0>(); bar();
+      }
+      if (nk > 0) mm();
+    }
+    // no barrier here: the last LDS read (row 1's R(nk-1,1)) completed before the last phase barrier, so row 0 starts its
+    // epilogue (per-wave staging over the stage ring) while row 1 still runs its last 32 MFMAs out of registers
+  }
+  const int nko = C::PP ? 0 : nk;                 // the in-phase loop below (dead code in the antiphase build)
   // prologue: NSTG-1 k-tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s)
-    if (s < nk) {
+    if (s < nko) {
       if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
       else if (A_CONV) cvm.dma(p, smem + s * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
@@ -337,13 +425,13 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
   constexpr bool kPipe = NW <= 8;                // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
   V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nko; ++kt) {
 #ifdef DVT_GEMM_TIMING
     const long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
     {
-      const int issued = min(nk - 1, kt + NSTG - 2);                 // youngest k-tile in flight
+      const int issued = min(nko - 1, kt + NSTG - 2);                 // youngest k-tile in flight
       const int young = issued - kt;                                 // k-tiles that may stay in flight
       if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
       else wait_vm<0>();
@@ -376,7 +464,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     }
     // the next k-tile's DMA is issued behind the first fragment reads: its address arithmetic runs under their latency
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + NSTG - 1 < nk && DVT_ABL != 2) {
+    if (kt + NSTG - 1 < nko && DVT_ABL != 2) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
       if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
       else if (A_CONV) cvm.dma(p, smem + st_nxt * kStage, wid);
@@ -424,7 +512,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     st_cur = st_cur + 1 == NSTG ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == NSTG ? 0 : st_nxt + 1;
   }
-  __builtin_amdgcn_s_barrier();                // all LDS reads done before the staging overlay
+  if (!C::PP) __builtin_amdgcn_s_barrier();    // all LDS reads done before the staging overlay
   DVT_GSTAMP(2);
   if (kCanColsum && do_cs && g == 0) {         // every row of the ones-product is the column sum: take row 0
 #pragma unroll
@@ -613,6 +701,7 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   return 1;   // combination not instantiated: caller falls back to the 128x128 kernel
 }
 
+#if DVT_GEMM256_UNIT == 0
 template <typename E, int CFG>
 int launch_conv(const GemmParams& pin, hipStream_t st) {
   typedef Cfg<CFG> C;
@@ -651,8 +740,16 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
   return DVT_OK;
 }
 
+#endif
 }  // namespace
 
+#if DVT_GEMM256_UNIT == 1
+// configuration 5 (antiphase main loop), compiled as a module of its own
+int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, hipStream_t st) {
+  if (p.elem == DVT_F16) return launch_cfg<f16, 5>(p, a_kmajor, b_kmajor, split, st);
+  return launch_cfg<bf16, 5>(p, a_kmajor, b_kmajor, split, st);
+}
+#else
 // Weight gradient with the column matrix gathered on the fly: slab[z][M = kh*kw*C][N = Cout] partial sums.
 int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st) {
   if (p.elem == DVT_F16)
@@ -670,9 +767,11 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
 // Returns DVT_OK, a negative dvt_status, or 1 when this (layout, epilogue, output)
 // combination has no LDS-DMA instantiation.
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
+  if (cfg == 5) return dvt_gemm_dma_launch_pp(p, a_kmajor, b_kmajor, split, st);
   if (p.elem == DVT_F16)
     return cfg == 3 ? launch_cfg<f16, 3>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 3) return launch_cfg<bf16, 3>(p, a_kmajor, b_kmajor, split, st);
   return cfg == 0 ? launch_cfg<bf16, 0>(p, a_kmajor, b_kmajor, split, st)
                   : launch_cfg<bf16, 1>(p, a_kmajor, b_kmajor, split, st);
 }
+#endif  // DVT_GEMM256_UNIT

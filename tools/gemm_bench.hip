@@ -1,5 +1,5 @@
 // Dev tool (not shipped): times gemm256_kernel variants on the metric shapes.
-//   hipcc --offload-arch=gfx950 -O3 -DDVT_ABL=<n> tools/gemm_bench.hip <csrc>/runtime.hip -o gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -DDVT_ABL=<n> -I include tools/gemm_bench.hip <csrc>/gemm256_pp.hip <csrc>/runtime.hip -o gemm_bench
 // DVT_ABL: 0 full, 1 no MFMA/ds_read, 2 no DMA inside the loop, 3 no epilogue stores
 #include "../data-efficient-video-transformers_amd/csrc/gemm256.hip"
 #include <vector>
@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     int split = (int)dvt_cdiv(s.K, kps);
     p.k_per_split = kps; p.slab = split > 1 ? slab : nullptr;
     if (split > 1) { p.bias = nullptr; }
-    for (int cfg = 0; cfg < 1; ++cfg) {
+    for (int cfg : {0, 3, 5}) {
     for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfg, 0);
     hipDeviceSynchronize();
     const int reps = 20;
