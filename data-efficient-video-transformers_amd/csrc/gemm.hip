@@ -598,11 +598,10 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       // cfg 0 (8 waves of 128 x 64) except for the arithmetic-heavy GELU / GELU' epilogues: with 16 waves of 64 x 64
       // (cfg 3) the epilogue's vector work of one wave overlaps the store latency of three others (FF1 206 -> 195 us).
       // cfg 1 (2 workgroups / CU) measured slower or equal on every Linear shape.
-      // cfg 5 (cfg 0's tile, wave rows in antiphase) elsewhere: +3..6 % (4096^3: 1,263 -> 1,343 TF/s), except a plain
-      // forward product of <= 8 k-tiles (QKV: 99 vs 105-111 us), which keeps the in-phase loop.
+      // cfg 5 (cfg 0's tile, wave rows in antiphase) elsewhere: 0..5 % faster than cfg 0 on every metric shape
+      // (interleaved medians, tools/gemm_bench.hip; 4096^3: 1,316 -> 1,358 TF/s).
       const bool heavy_epi = d->epilogue == DVT_EPI_GELU || d->epilogue == DVT_EPI_DGELU;
-      const bool short_plain_fwd = d->a_kmajor && d->b_kmajor && d->epilogue == DVT_EPI_NONE && s == 1 && d->K <= 512;
-      pl.cfg = heavy_epi && s == 1 ? 3 : short_plain_fwd ? 0 : 5;
+      pl.cfg = heavy_epi && s == 1 ? 3 : 5;
       return pl;
     }
   }

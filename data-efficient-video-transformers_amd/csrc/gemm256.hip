@@ -340,8 +340,9 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     // waves of a SIMD starts MFMAs whose operands are there, so the matrix pipe does not wait for a barrier plus an LDS
     // round trip per k-tile as it does when both waves reach the k-tile barrier together.  Phase ph (4 per k-tile):
     //   row 0:  R(kt,0) M(kt,0) R(kt,1) M(kt,1)           row 1:  M(kt-1,1) R(kt,0) M(kt,0) R(kt,1)   [+ M(nk-1,1) at the end]
-    // k-tile kt+1 is requested at the start of the wave's R(kt,0) (kt >= 1; k-tiles 0 and 1 in the prologue) into the stage
-    // that held kt-1 (last read in phase 4kt-1), and must have landed by the barrier that ends phase 4kt+3.
+    // k-tile kt+1 is requested at the start of the wave's R(kt,0) (row 1 requests k-tile 1 in its idle phase 0; k-tile 0 is the
+    // prologue) into the stage that held kt-1 (last read in phase 4kt-1), and must have landed by the barrier that ends
+    // phase 4kt+3.
     static_assert(NSTG == 2 && TK == 64 && NW == 8 && MT == 8, "antiphase loop: 256x256x64, 8 waves");
     auto issue = [&](int kt) {
       char* st = smem + (kt & 1) * kStage;
@@ -351,9 +352,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + kt * TK, st + kATile, wid, lane);
     };
     if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
     DVT_GSTAMP(1);
-    if (nk > 1) wait_vm<kPPT>(); else wait_vm<0>();
+    wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     V8 fa[MT], fb[4];
     auto rd = [&](int kt, int kk) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     };
     if (wm == 0) {
       for (int kt = 0; kt < nk; ++kt) {
-        if (kt >= 1 && kt + 1 < nk) issue(kt + 1);
+        if (kt + 1 < nk) issue(kt + 1);
         rd(kt, 0); bar();
         mm(); bar();
         rd(kt, 1); bar();
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     } else {
       for (int kt = 0; kt < nk; ++kt) {
         if (kt >= 1) mm();
+        else if (nk > 1) issue(1);                   // phase 0 has no MFMAs for this row: its share of k-tile 1 goes out now
         bar();
         if (kt >= 1 && kt + 1 < nk) issue(kt + 1);
         rd(kt, 0); bar();

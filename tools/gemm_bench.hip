@@ -3,6 +3,7 @@
 // DVT_ABL: 0 full, 1 no MFMA/ds_read, 2 no DMA inside the loop, 3 no epilogue stores
 #include "../data-efficient-video-transformers_amd/csrc/gemm256.hip"
 #include <vector>
+#include <algorithm>
 #include <string.h>
 #include <random>
 
@@ -53,17 +54,28 @@ int main(int argc, char** argv) {
     int split = (int)dvt_cdiv(s.K, kps);
     p.k_per_split = kps; p.slab = split > 1 ? slab : nullptr;
     if (split > 1) { p.bias = nullptr; }
-    for (int cfg : {0, 3, 5}) {
-    for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfg, 0);
+    // configurations interleaved over several rounds, median per configuration: the clock the chip holds drifts by a few
+    // per cent within seconds, which is the size of the differences being measured
+    const int cfgs[3] = {0, 3, 5};
+    std::vector<double> t[3];
+    for (int c = 0; c < 3; ++c) { for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfgs[c], 0); }
     hipDeviceSynchronize();
-    const int reps = 20;
-    hipEventRecord(e0, 0);
-    for (int it = 0; it < reps; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfg, 0);
-    hipEventRecord(e1, 0); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double us = ms * 1e3 / reps, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
-    printf("ABL=%d cfg%d %-40s %8.1f us  %7.1f TF/s\n", DVT_ABL, cfg, s.name, us, tf);
+    for (int round = 0; round < 7; ++round)
+      for (int c = 0; c < 3; ++c) {
+        const int reps = 10;
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < reps; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfgs[c], 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        t[c].push_back(ms * 1e3 / reps);
+      }
+    printf("ABL=%d %-40s", DVT_ABL, s.name);
+    for (int c = 0; c < 3; ++c) {
+      std::sort(t[c].begin(), t[c].end());
+      const double us = t[c][t[c].size() / 2];
+      printf("  cfg%d %7.1f us %7.1f TF/s", cfgs[c], us, 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12);
     }
+    printf("\n");
   }
   return 0;
 }
