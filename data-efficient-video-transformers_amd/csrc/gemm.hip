@@ -801,12 +801,15 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 // ---------------------------------------------------------------- implicit-GEMM convolution
 // LDS-DMA configuration of a convolution by its output width (gemm256.hip): 256x64x32 tiles up to 64 channels,
 // 256x128x32 up to 128, 256x256x64 beyond.
-static int conv_cfg(int cout) { return cout <= 64 ? 4 : cout <= 128 ? 1 : 0; }
+// Up to 64 output channels: 64-deep k-tiles (cfg 6) when a k-tile can stay inside one filter tap (C % 64 == 0: a pixel's
+// channels of the tap are then one whole 128-byte line per gather), else 32-deep (cfg 4: the stem's C = 8 form, C = 32).
+static int conv_cfg(int cout, int c) { return cout <= 64 ? (c % 64 == 0 ? 6 : 4) : cout <= 128 ? 1 : 0; }
+static int conv_tk(int cfg) { return cfg == 0 || cfg == 6 ? 64 : 32; }
 
 // Forward / data-gradient launches with few output rows (layer 4 of a ResNet-18 on 224^2 frames: 49 pixels per frame)
 // leave most CUs without a 256x256 tile: the 256x128 configuration doubles the tile count (and runs two per CU).
-static int conv_fwd_cfg(int64_t rows, int cout) {
-  const int cfg = conv_cfg(cout);
+static int conv_fwd_cfg(int64_t rows, int cout, int c) {
+  const int cfg = conv_cfg(cout, c);
   if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < (int64_t)dvt_num_cus() * 3) return 1;
   return cfg;
 }
@@ -853,7 +856,7 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   p.bn_partial = d->stats_partial;
-  return dvt_conv_dma_launch(p, conv_fwd_cfg(p.M, d->Cout), (hipStream_t)stream);
+  return dvt_conv_dma_launch(p, conv_fwd_cfg(p.M, d->Cout, d->C), (hipStream_t)stream);
 }
 
 // one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4
@@ -861,7 +864,7 @@ int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   if (!d || d->sh <= 0 || d->sw <= 0) return 0;
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
-  return dvt_cdiv(d->N * Ho * Wo, 256) * (conv_cfg(d->Cout) == 4 ? 4 : 2);
+  return dvt_cdiv(d->N * Ho * Wo, 256) * (d->Cout <= 64 ? 4 : 2);
 }
 
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* d) {
@@ -880,12 +883,13 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0) return false;
   const int64_t rows = d->N * Ho * Wo;
-  pl->cfg = conv_cfg(d->Cout);
-  pl->tk = pl->cfg ? 32 : 64;
+  pl->cfg = conv_cfg(d->Cout, d->C);
+  if (pl->cfg == 6 && rows % 64) pl->cfg = 4;
+  pl->tk = conv_tk(pl->cfg);
   if (rows % pl->tk || rows >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
   pl->K = d->kh * d->kw * d->C;
   pl->rows = rows; pl->Ho = (int)Ho; pl->Wo = (int)Wo;
-  const int tn = pl->cfg == 4 ? 64 : pl->cfg ? 128 : 256;
+  const int tn = pl->cfg == 4 || pl->cfg == 6 ? 64 : pl->cfg ? 128 : 256;
   const int64_t tiles = dvt_cdiv(pl->K, 256) * dvt_cdiv(d->Cout, tn);
   const int64_t target = (int64_t)dvt_num_cus() * (pl->cfg ? 2 : 1);       // cfg 1 runs two workgroups per CU
   int64_t split = target / tiles;

@@ -45,6 +45,8 @@ namespace {
 //          convolutions with <= 128 output channels (measured slower than CFG 0 on every Linear shape).
 //   CFG 3  256x256 tile, BK=64, 16 waves of 64x64 (4 per SIMD, 128 VGPRs, no fragment double buffer): twice the
 //          memory-operation concurrency in the epilogue, a slower main loop.
+//   CFG 6  CFG 4's tile with BK=64 and 2 stages (80 KiB): a pixel's 64 channels of one filter tap are one 128-byte line per
+//          gather instead of two half lines (convolutions with <= 64 output channels and C % 64 == 0).
 //   CFG 5  CFG 0's tile with the two wave rows in antiphase (one reads a 32-deep slice's fragments while its SIMD partner
 //          runs the previous slice's MFMAs out of registers; four phase barriers per k-tile): +3..6 % on most shapes.
 //   CFG 4  256x64 tile, BK=32, 3 LDS stages (60 KiB), 4 waves (4x1) of 64x64: convolutions with <= 64 output channels
@@ -54,6 +56,7 @@ template <> struct Cfg<0> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, 
 template <> struct Cfg<1> { enum { TM = 256, TN = 128, TK = 32, NW = 4, WN = 2, NSTG = 3, PP = 0 }; };
 template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4, NSTG = 2, PP = 0 }; };  // 16 waves of 64 x 64: 4 per SIMD
 template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, NSTG = 3, PP = 0 }; };    // 4 waves of 64 x 64, 60 KiB: 2 workgroups / CU
+template <> struct Cfg<6> { enum { TM = 256, TN = 64, TK = 64, NW = 4, WN = 1, NSTG = 2, PP = 0 }; };    // CFG 4 with 64-deep k-tiles, 2 x 40 KiB: 2 workgroups / CU
 template <> struct Cfg<5> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 0 with the two wave rows in antiphase
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
@@ -702,7 +705,6 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   return 1;   // combination not instantiated: caller falls back to the 128x128 kernel
 }
 
-#if DVT_GEMM256_UNIT == 0
 template <typename E, int CFG>
 int launch_conv(const GemmParams& pin, hipStream_t st) {
   typedef Cfg<CFG> C;
@@ -741,10 +743,16 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
   return DVT_OK;
 }
 
-#endif
 }  // namespace
 
 #if DVT_GEMM256_UNIT == 1
+// configuration 6 (256x64x64 convolution tiles), kept out of the main module like configuration 5
+int dvt_conv_dma_launch_c6(const GemmParams& p, hipStream_t st) {
+  return p.elem == DVT_F16 ? launch_conv<f16, 6>(p, st) : launch_conv<bf16, 6>(p, st);
+}
+int dvt_conv_wgrad_dma_launch_c6(const GemmParams& p, int split, hipStream_t st) {
+  return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 6>(p, split, st) : launch_conv_wgrad<bf16, 6>(p, split, st);
+}
 // configuration 5 (antiphase main loop), compiled as a module of its own
 int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, hipStream_t st) {
   if (p.elem == DVT_F16) return launch_cfg<f16, 5>(p, a_kmajor, b_kmajor, split, st);
@@ -753,6 +761,7 @@ int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, in
 #else
 // Weight gradient with the column matrix gathered on the fly: slab[z][M = kh*kw*C][N = Cout] partial sums.
 int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st) {
+  if (cfg == 6) return dvt_conv_wgrad_dma_launch_c6(p, split, st);
   if (p.elem == DVT_F16)
     return cfg == 0 ? launch_conv_wgrad<f16, 0>(p, split, st) : cfg == 4 ? launch_conv_wgrad<f16, 4>(p, split, st) : launch_conv_wgrad<f16, 1>(p, split, st);
   return cfg == 0 ? launch_conv_wgrad<bf16, 0>(p, split, st) : cfg == 4 ? launch_conv_wgrad<bf16, 4>(p, split, st) : launch_conv_wgrad<bf16, 1>(p, split, st);
@@ -761,6 +770,7 @@ int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream
 // Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
 // fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32, cfg 4 = 256x64x32 (Cout <= 64).
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
+  if (cfg == 6) return dvt_conv_dma_launch_c6(p, st);
   if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : cfg == 4 ? launch_conv<f16, 4>(p, st) : launch_conv<f16, 1>(p, st);
   return cfg == 0 ? launch_conv<bf16, 0>(p, st) : cfg == 4 ? launch_conv<bf16, 4>(p, st) : launch_conv<bf16, 1>(p, st);
 }
