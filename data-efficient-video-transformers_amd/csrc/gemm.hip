@@ -803,8 +803,13 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 // 256x128x32 up to 128, 256x256x64 beyond.
 // Up to 64 output channels: 64-deep k-tiles (cfg 6) when a k-tile can stay inside one filter tap (C % 64 == 0: a pixel's
 // channels of the tap are then one whole 128-byte line per gather), else 32-deep (cfg 4: the stem's C = 8 form, C = 32).
-static int conv_cfg(int cout, int c) { return cout <= 64 ? (c % 64 == 0 ? 6 : 4) : cout <= 128 ? 1 : 0; }
-static int conv_tk(int cfg) { return cfg == 0 || cfg == 6 ? 64 : 32; }
+// 65..128 output channels: 256x128x32 with two workgroups per CU for forward / data gradient; the weight gradient (deep K,
+// no epilogue to overlap) is faster on the 64-deep form of that tile (cfg 7: layer 2 of ResNet-18 104 -> 93 us, forward
+// 92 -> 97 us).
+static int conv_cfg(int cout, int c, bool wgrad = false) {
+  return cout <= 64 ? (c % 64 == 0 ? 6 : 4) : cout <= 128 ? (wgrad && c % 64 == 0 ? 7 : 1) : 0;
+}
+static int conv_tk(int cfg) { return cfg == 0 || cfg >= 6 ? 64 : 32; }
 
 // Forward / data-gradient launches with few output rows (layer 4 of a ResNet-18 on 224^2 frames: 49 pixels per frame)
 // leave most CUs without a 256x256 tile: the 256x128 configuration doubles the tile count (and runs two per CU).
@@ -859,12 +864,13 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   return dvt_conv_dma_launch(p, conv_fwd_cfg(p.M, d->Cout, d->C), (hipStream_t)stream);
 }
 
-// one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4
+// one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4, 6, 7
 int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   if (!d || d->sh <= 0 || d->sw <= 0) return 0;
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
-  return dvt_cdiv(d->N * Ho * Wo, 256) * (d->Cout <= 64 ? 4 : 2);
+  const int cfg = conv_fwd_cfg(d->N * Ho * Wo, d->Cout, d->C);
+  return dvt_cdiv(d->N * Ho * Wo, 256) * (cfg == 4 || cfg == 6 || cfg == 7 ? 4 : 2);   // wave rows per 256-row tile
 }
 
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* d) {
@@ -883,15 +889,17 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
   if (Ho <= 0 || Wo <= 0) return false;
   const int64_t rows = d->N * Ho * Wo;
-  pl->cfg = conv_cfg(d->Cout, d->C);
+  pl->cfg = conv_cfg(d->Cout, d->C, true);
   if (pl->cfg == 6 && rows % 64) pl->cfg = 4;
+  if (pl->cfg == 7 && rows % 64) pl->cfg = 1;
   pl->tk = conv_tk(pl->cfg);
   if (rows % pl->tk || rows >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
   pl->K = d->kh * d->kw * d->C;
   pl->rows = rows; pl->Ho = (int)Ho; pl->Wo = (int)Wo;
   const int tn = pl->cfg == 4 || pl->cfg == 6 ? 64 : pl->cfg ? 128 : 256;
+  const bool two_per_cu = pl->cfg == 1 || pl->cfg == 4 || pl->cfg == 6;
   const int64_t tiles = dvt_cdiv(pl->K, 256) * dvt_cdiv(d->Cout, tn);
-  const int64_t target = (int64_t)dvt_num_cus() * (pl->cfg ? 2 : 1);       // cfg 1 runs two workgroups per CU
+  const int64_t target = (int64_t)dvt_num_cus() * (two_per_cu ? 2 : 1);
   int64_t split = target / tiles;
   if (split < 1) split = 1;
   const int64_t ktiles = rows / pl->tk;
