@@ -815,7 +815,7 @@ static int conv_tk(int cfg) { return cfg == 0 || cfg >= 6 ? 64 : 32; }
 // leave most CUs without a 256x256 tile: the 256x128 configuration doubles the tile count (and runs two per CU).
 static int conv_fwd_cfg(int64_t rows, int cout, int c) {
   const int cfg = conv_cfg(cout, c);
-  if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < (int64_t)dvt_num_cus() * 3) return 1;
+  if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < (int64_t)dvt_num_cus() * 3) return c % 64 == 0 ? 7 : 1;
   return cfg;
 }
 
