@@ -713,6 +713,46 @@ __global__ void nchw_to_nhwc_pad8_kernel(const S* __restrict__ x, D* __restrict_
   }
 }
 
+// Cpad = 4: two horizontally adjacent pixels per 16-byte chunk (x0 c0 c1 c2 0 | x1 c0 c1 c2 0) -- the [N, H, W/2, 8] view
+// in which a stride-2 stem is a stride-(2,1) convolution over pixel PAIRS (dvt_conv_weight_pairs).  W even.
+template <typename S, typename D>
+__global__ void nchw_to_nhwc_pair4_kernel(const S* __restrict__ x, D* __restrict__ y, int64_t N, int C, int64_t H, int64_t W) {
+  const int64_t W2 = W >> 1, HW = H * W, total = N * H * W2;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = it / (H * W2), r = it - n * (H * W2);
+    const int64_t h = r / W2, w2 = r - h * W2;
+    const int64_t px = h * W + 2 * w2;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) {
+      v[c] = to_f32<S>(x[(n * C + c) * HW + px]);
+      v[4 + c] = to_f32<S>(x[(n * C + c) * HW + px + 1]);
+    }
+    store8<D>(y + it * 8, v);
+  }
+}
+
+// Stem weights in the pixel-pair form: wp[co, px*4 + c, ki, p] = w[co, c, ki, 2p - off + px] (zero outside 0 <= kj < kw,
+// c < Cin); off = pw & 1 makes the first pixel of every pair an even input column.  bwd: the adjoint gather.
+__global__ void conv_weight_pairs_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int kh,
+                                         int kw, int kwp, int off) {
+  const int total = Cout * 8 * kh * kwp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int p = i % kwp, ki = (i / kwp) % kh, e = (i / (kwp * kh)) % 8, co = i / (kwp * kh * 8);
+    const int px = e >> 2, c = e & 3, kj = 2 * p - off + px;
+    wp[i] = (c < Cin && kj >= 0 && kj < kw) ? w[((co * Cin + c) * kh + ki) * kw + kj] : 0.f;
+  }
+}
+__global__ void conv_weight_pairs_bwd_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin, int kh,
+                                             int kw, int kwp, int off, int accumulate) {
+  const int total = Cout * Cin * kh * kw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int kj = i % kw, ki = (i / kw) % kh, c = (i / (kw * kh)) % Cin, co = i / (kw * kh * Cin);
+    const int p = (kj + off) >> 1, px = (kj + off) & 1;
+    const float g = dwp[((co * 8 + px * 4 + c) * kh + ki) * kwp + p];
+    dw[i] = accumulate ? dw[i] + g : g;
+  }
+}
+
 // ------------------------------------------------------------------ batched 2-D transpose [B, R, Cc] -> [B, Cc, R]
 template <typename T>
 __global__ void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
@@ -1089,11 +1129,29 @@ int dvt_maxpool_bwd(const void* dy, const void* idx, void* dx, int64_t N, int C,
 int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64_t N, int C, int H, int W, int Cpad,
                          dvt_stream_t stream) {
   DVT_REQUIRE(x && y && N >= 0 && C > 0 && H > 0 && W > 0, "dvt_nchw_to_nhwc_pad: bad arguments");
-  DVT_REQUIRE(Cpad == 8 && C <= 8, "dvt_nchw_to_nhwc_pad: Cpad must be 8 and C <= 8");
+  DVT_REQUIRE((Cpad == 8 && C <= 8) || (Cpad == 4 && C <= 4 && W % 2 == 0),
+              "dvt_nchw_to_nhwc_pad: Cpad must be 8 (C <= 8) or 4 (C <= 4, W even)");
   DVT_REQUIRE(dvt_aligned16(y) && dvt_is_16bit(y_dtype), "dvt_nchw_to_nhwc_pad: output must be 16-bit and 16-byte aligned");
   if (N == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   const int64_t HW = (int64_t)H * W;
+  if (Cpad == 4) {
+#define DVT_PAIR4(SD, S, DD, D)                                                                                      \
+  if (x_dtype == SD && y_dtype == DD) {                                                                             \
+    hipLaunchKernelGGL((nchw_to_nhwc_pair4_kernel<S, D>), dim3(cgrid(N * HW / 2)), dim3(kB), 0, st, (const S*)x, (D*)y, N, C, \
+                       (int64_t)H, (int64_t)W);                                                                     \
+    DVT_LAUNCH_CHECK("dvt_nchw_to_nhwc_pad");                                                                       \
+    return DVT_OK;                                                                                                  \
+  }
+    DVT_PAIR4(DVT_F32, float, DVT_BF16, bf16)
+    DVT_PAIR4(DVT_F32, float, DVT_F16, f16)
+    DVT_PAIR4(DVT_BF16, bf16, DVT_BF16, bf16)
+    DVT_PAIR4(DVT_F16, f16, DVT_F16, f16)
+    DVT_PAIR4(DVT_BF16, bf16, DVT_F16, f16)
+    DVT_PAIR4(DVT_F16, f16, DVT_BF16, bf16)
+#undef DVT_PAIR4
+    DVT_UNSUPPORTED("dvt_nchw_to_nhwc_pad: dtype pair (%d, %d) unsupported", x_dtype, y_dtype);
+  }
 #define DVT_PAD8(SD, S, DD, D)                                                                                      \
   if (x_dtype == SD && y_dtype == DD) {                                                                             \
     hipLaunchKernelGGL((nchw_to_nhwc_pad8_kernel<S, D>), dim3(cgrid(N * HW)), dim3(kB), 0, st, (const S*)x, (D*)y, N, C, HW); \
@@ -1108,6 +1166,27 @@ int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64
   DVT_PAD8(DVT_F16, f16, DVT_BF16, bf16)
 #undef DVT_PAD8
   DVT_UNSUPPORTED("dvt_nchw_to_nhwc_pad: dtype pair (%d, %d) unsupported", x_dtype, y_dtype);
+}
+
+int dvt_conv_weight_pairs(const float* w, float* wp, int Cout, int Cin, int kh, int kw, int pw, int kwp, dvt_stream_t stream) {
+  DVT_REQUIRE(w && wp && Cout > 0 && Cin > 0 && Cin <= 4 && kh > 0 && kw > 0 && pw >= 0 && kwp > 0,
+              "dvt_conv_weight_pairs: bad arguments");
+  DVT_REQUIRE(2 * kwp - (pw & 1) >= kw, "dvt_conv_weight_pairs: kwp pairs do not cover the kernel width");
+  hipLaunchKernelGGL(conv_weight_pairs_kernel, dim3(cgrid((int64_t)Cout * 8 * kh * kwp)), dim3(kB), 0, (hipStream_t)stream, w, wp,
+                     Cout, Cin, kh, kw, kwp, pw & 1);
+  DVT_LAUNCH_CHECK("dvt_conv_weight_pairs");
+  return DVT_OK;
+}
+
+int dvt_conv_weight_pairs_bwd(const float* dwp, float* dw, int Cout, int Cin, int kh, int kw, int pw, int kwp, int accumulate,
+                              dvt_stream_t stream) {
+  DVT_REQUIRE(dwp && dw && Cout > 0 && Cin > 0 && Cin <= 4 && kh > 0 && kw > 0 && pw >= 0 && kwp > 0,
+              "dvt_conv_weight_pairs_bwd: bad arguments");
+  DVT_REQUIRE(2 * kwp - (pw & 1) >= kw, "dvt_conv_weight_pairs_bwd: kwp pairs do not cover the kernel width");
+  hipLaunchKernelGGL(conv_weight_pairs_bwd_kernel, dim3(cgrid((int64_t)Cout * Cin * kh * kw)), dim3(kB), 0, (hipStream_t)stream,
+                     dwp, dw, Cout, Cin, kh, kw, kwp, pw & 1, accumulate);
+  DVT_LAUNCH_CHECK("dvt_conv_weight_pairs_bwd");
+  return DVT_OK;
 }
 
 int dvt_transpose_last2(const void* src, void* dst, int64_t B, int R, int Cc, int dtype, dvt_stream_t stream) {

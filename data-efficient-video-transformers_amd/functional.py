@@ -928,6 +928,7 @@ class _ConvBnAct(torch.autograd.Function):
         (kh, kw), (sh, sw) = ops._pair(k), ops._pair(stride)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         xc = x.contiguous()
+        ctx.pair = pair = None
         stem8 = (IMPLICIT_CONV and nchw and Cin <= 8 and not x.requires_grad and dtype in (torch.bfloat16, torch.float16)
                  and Cout % 8 == 0 and (N * Ho * Wo) % 32 == 0)
         if stem8:
@@ -936,7 +937,20 @@ class _ConvBnAct(torch.autograd.Function):
             # matching zero planes, and from here on it is an ordinary NHWC convolution with Cin = 8 -- no column matrix
             # (0.94 GB at 256 frames of 224^2) in forward or in the weight gradient.  Not taken when the frames need a
             # gradient (the pixel-space CLS clip of FrameTransformer): that path keeps the explicit gather.
-            xc = ops.nchw_to_nhwc_pad8(xc.view(N, Cin, H, W), dtype)
+            (ph, pw) = ops._pair(pad)
+            off = pw & 1
+            kwp = W // 2 + (pw + off) + 1 - Wo if (sw == 2 and W % 2 == 0) else 0
+            if Cin <= 4 and Cin == Cin_l and kwp > 0 and 2 * kwp - off >= kw:
+                # Stride 2 and <= 4 channels: two horizontally adjacent pixels share a 16-byte chunk (Cpad = 4), and in that
+                # [N, H, W/2, 8] view the stem is a (kh, kwp) convolution of stride (sh, 1) over pixel pairs whose weights
+                # are the stem's, re-laid by dvt_conv_weight_pairs (zero taps where a pair sticks out of the kernel): 35
+                # gathered chunks per output pixel instead of 49, K = 280 instead of 392.  From here on it IS that convolution.
+                ctx.pair = pair = (kh, kw, pw, kwp)
+                xc = ops.nchw_to_nhwc_pad(xc.view(N, Cin, H, W), dtype, 4)
+                W, k, stride, pad = W // 2, (kh, kwp), (sh, 1), (ph, (pw + off) // 2)
+                (kh, kw), (sh, sw) = k, stride
+            else:
+                xc = ops.nchw_to_nhwc_pad(xc.view(N, Cin, H, W), dtype, 8)
             Cin, nchw = 8, False
             geom = (N, Cin, H, W, k, stride, pad, nchw)
         padded = Cout != Cout_l or Cin != Cin_l
@@ -945,9 +959,16 @@ class _ConvBnAct(torch.autograd.Function):
         K = kh * kw * Cin
         direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
         ld = K if direct else (ops.conv2d_implicit_k(Cin, Cout, k) if stem8 else _kpad(K, dtype))
-        w4 = w.reshape(Cout_l, Cin_l, kh, kw)
-        if padded:
-            w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
+        if pair is not None:
+            kh_o, kw_o, pw_o, _ = pair
+            w4 = w.reshape(Cout_l, Cin_l, kh_o * kw_o)
+            if Cout != Cout_l:
+                w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh_o * kw_o, Cout, Cin_l)
+            w4 = ops.conv_weight_pairs(w4, Cout, Cin_l, kh_o, kw_o, pw_o, kwp)          # [Cout, 8, kh, kwp]
+        else:
+            w4 = w.reshape(Cout_l, Cin_l, kh, kw)
+            if padded:
+                w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
         wp = ops.conv_weight_pack(w4, ld, dtype)
         implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8) and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
@@ -1033,7 +1054,22 @@ class _ConvBnAct(torch.autograd.Function):
             if col is None:
                 col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
             unpack, dwp = ops.conv_weight_unpack_grad, ops.linear_wgrad(dz, col)             # [Cout, ld] fp32
-        if padded:                                                       # full-width gradient, then the reference slice
+        if ctx.pair is not None:                                         # pixel-pair stem: adjoint of dvt_conv_weight_pairs
+            kh_o, kw_o, pw_o, kwp = ctx.pair
+            dw_pairs = unpack(dwp, w4)                                   # [Cout, 8, kh, kwp]
+            if sw is not None and Cout == Cout_l:
+                ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp, out=sw.buf, accumulate=not sw.fresh)
+                sw.mark_written()
+                dw = None
+            else:
+                dwo = ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp)
+                if sw is not None:
+                    ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l, out=sw.buf, accumulate=not sw.fresh)
+                    sw.mark_written()
+                    dw = None
+                else:
+                    dw = ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l).view(wshape)
+        elif padded:                                                     # full-width gradient, then the reference slice
             dw_full = unpack(dwp, w4)
             if sw is not None:
                 ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin, out=sw.buf, accumulate=not sw.fresh)

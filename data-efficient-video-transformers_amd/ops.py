@@ -818,15 +818,41 @@ def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, strid
     return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad))))
 
 
-def nchw_to_nhwc_pad8(x: Tensor, dtype: torch.dtype) -> Tensor:
-    """Raw frames [N, C <= 8, H, W] -> NHWC matrix [N*H*W, 8] in ``dtype`` (channels C.. zero): the stem's input form."""
+def nchw_to_nhwc_pad(x: Tensor, dtype: torch.dtype, cpad: int = 8) -> Tensor:
+    """Raw frames [N, C, H, W] -> the stem's input form in ``dtype``: cpad 8 = NHWC matrix [N*H*W, 8] (channels C.. zero);
+    cpad 4 (C <= 4, W even) = [N*H*(W/2), 8], one row per pair of horizontally adjacent pixels (4 channels each)."""
     _need_cuda(x)
     x = x.contiguous()
     N, Cc, H, W = x.shape
-    y = torch.empty((N * H * W, 8), dtype=dtype, device=x.device)
-    L.check(L.load().dvt_nchw_to_nhwc_pad(x.data_ptr(), dt(x), y.data_ptr(), _DT[dtype], N, Cc, H, W, 8, _stream()),
+    y = torch.empty((N * H * W * cpad // 8, 8), dtype=dtype, device=x.device)
+    L.check(L.load().dvt_nchw_to_nhwc_pad(x.data_ptr(), dt(x), y.data_ptr(), _DT[dtype], N, Cc, H, W, cpad, _stream()),
             "dvt_nchw_to_nhwc_pad")
     return y
+
+
+def conv_weight_pairs(w: Tensor, Cout: int, Cin: int, kh: int, kw: int, pw: int, kwp: int) -> Tensor:
+    """Stem weights f32 [Cout, Cin <= 4, kh, kw] -> pixel-pair form f32 [Cout, 8, kh, kwp] (dvt_conv_weight_pairs)."""
+    _need_cuda(w)
+    w = w.detach().contiguous()
+    assert w.dtype == torch.float32 and w.numel() == Cout * Cin * kh * kw
+    out = torch.empty((Cout, 8, kh, kwp), dtype=torch.float32, device=w.device)
+    L.check(L.load().dvt_conv_weight_pairs(w.data_ptr(), out.data_ptr(), Cout, Cin, kh, kw, pw, kwp, _stream()),
+            "dvt_conv_weight_pairs")
+    return out
+
+
+def conv_weight_pairs_bwd(dwp: Tensor, Cout: int, Cin: int, kh: int, kw: int, pw: int, kwp: int, *,
+                          out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """Adjoint: f32 [Cout, 8, kh, kwp] -> f32 [Cout, Cin, kh, kw] (+= into ``out`` when accumulate)."""
+    _need_cuda(dwp)
+    assert dwp.dtype == torch.float32 and dwp.is_contiguous() and dwp.numel() == Cout * 8 * kh * kwp
+    if out is None:
+        assert not accumulate
+        out = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dwp.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == Cout * Cin * kh * kw
+    L.check(L.load().dvt_conv_weight_pairs_bwd(dwp.data_ptr(), out.data_ptr(), Cout, Cin, kh, kw, pw, kwp, int(accumulate),
+                                               _stream()), "dvt_conv_weight_pairs_bwd")
+    return out
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,

@@ -321,10 +321,19 @@ int dvt_average_precision(const float* probs, const unsigned char* labels, int64
 int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype, int64_t N, int C, int H,
                int W, int kh, int kw, int sh, int sw, int ph, int pw, int64_t ld, dvt_stream_t stream);
 /* Raw NCHW frames x[N, C, H, W] (custom_resnet.py:138: the stem reads the clip frames) -> NHWC matrix y[N*H*W, Cpad] with
- * the channels C .. Cpad-1 zero (Cpad = 8: one 16-byte chunk per pixel, the input form of the implicit stem
- * convolution; C <= Cpad, Cpad % 8 == 0). */
+ * the channels C .. Cpad-1 zero.  Cpad = 8: one 16-byte chunk per pixel (C <= 8).  Cpad = 4 (C <= 4, W even): one chunk per
+ * pair of horizontally adjacent pixels, i.e. the [N, H, W/2, 8] view in which a stride-2 stem (custom_resnet.py:100,
+ * frame_transformer.py:67) is a stride-(sh, 1) convolution over pixel pairs with the weights of dvt_conv_weight_pairs --
+ * 35 instead of 49 gathered chunks per output pixel and half the zero padding of the C = 8 form. */
 int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64_t N, int C, int H, int W, int Cpad,
                          dvt_stream_t stream);
+/* Stem weights for the pixel-pair view: w[Cout, Cin <= 4, kh, kw] f32 -> wp[Cout, 8, kh, kwp] f32 with
+ * wp[co, px*4 + c, ki, p] = w[co, c, ki, 2p - (pw & 1) + px], zero outside the kernel / beyond Cin (pw = the horizontal
+ * padding of the stride-2 convolution; the pair convolution has kernel (kh, kwp), stride (sh, 1), padding
+ * (ph, (pw + (pw & 1)) / 2)).  _bwd: the adjoint gather of the weight gradient (+= when accumulate). */
+int dvt_conv_weight_pairs(const float* w, float* wp, int Cout, int Cin, int kh, int kw, int pw, int kwp, dvt_stream_t stream);
+int dvt_conv_weight_pairs_bwd(const float* dwp, float* dw, int Cout, int Cin, int kh, int kw, int pw, int kwp, int accumulate,
+                              dvt_stream_t stream);
 /* Adjoint gather (data gradient of the convolution), NHWC, C % 8 == 0. */
 int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
                int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream);
