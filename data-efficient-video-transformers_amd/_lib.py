@@ -103,6 +103,8 @@ SIGNATURES = {
     "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_bn_bwd": (c_int, [c_p] * 12 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
+    "dvt_bn_relu_maxpool_fwd": (c_int, [c_p] * 7 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_bn_bwd_pooled": (c_int, [c_p] * 11 + [c_i64] + [c_int] * 7 + [c_p]),
     "dvt_maxpool_bwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_transpose_last2": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_bce_logits_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),

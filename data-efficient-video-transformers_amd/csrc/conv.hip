@@ -221,14 +221,20 @@ __global__ void weight_pack_dgrad_kernel(const float* __restrict__ w, D* __restr
 // ------------------------------------------------------------------ BatchNorm (columns of [rows, C])
 // partial[b][0][c] = sum x, partial[b][1][c] = sum x^2 over the block's rows  (MODE 0)
 // partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat                 (MODE 1), dz = dy * (y > 0 if relu)
-template <typename T, int MODE>
+// POOL: dy is the gradient of a 3x3 / 2 / 1 max-pool of this map (rows = N*H*W pixels); the map's own gradient is
+// gathered from it on the fly (pooled_dy8_k3s2p1) instead of being read from a materialised tensor.
+struct PoolGeom { const unsigned char* idx; int H, W, Ho, Wo; };
+template <typename T> __device__ __forceinline__ void pooled_dy8_k3s2p1(const T*, const unsigned char*, int64_t, int, int, int, int, int, int, float*);
+
+template <typename T, int MODE, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int64_t rows, int C,
                                                           int rows_per_block, int relu, int vc_log2,
                                                           float* __restrict__ partial,
                                                           const float* __restrict__ gamma = nullptr,
-                                                          const float* __restrict__ beta = nullptr) {
+                                                          const float* __restrict__ beta = nullptr,
+                                                          PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0}) {
   // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
   // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.
   __shared__ float red[2][256][8];
@@ -251,7 +257,12 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
         for (int k = 0; k < 8; ++k) { a[k] += xv[k]; b[k] = fmaf(xv[k], xv[k], b[k]); }
       } else {
         float dv[8], yv[8];
-        load8<T>(dy + r * C + c, dv);
+        if (POOL) {
+          const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
+          pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
+        } else {
+          load8<T>(dy + r * C + c, dv);
+        }
         if (relu && !remask) load8<T>(y + r * C + c, yv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -401,20 +412,27 @@ __global__ void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __rest
 
 // dz = dy * (y > 0 if relu);  dres = dz (if wanted);
 // train: dx = gamma*invstd*(dz - sum_dz/rows - xhat*sum_dzxhat/rows);  eval: dx = gamma*invstd*dz
-template <typename T>
+template <typename T, bool POOL = false>
 __global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
                                     int64_t rows, int C, int relu, int training, float inv_rows,
-                                    const float* __restrict__ beta = nullptr) {
+                                    const float* __restrict__ beta = nullptr, PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0}) {
   const int cv = C >> 3;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
     const int c = (int)(it % cv) << 3;
     const int64_t off = (it / cv) * C + c;
     float dv[8], xv[8], yv[8], mu[8], is[8], g[8], dg[8], db[8], o[8], be[8];
-    load8<T>(dy + off, dv); load8<T>(x + off, xv);
+    if (POOL) {
+      const int64_t r = it / cv;
+      const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
+      pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
+    } else {
+      load8<T>(dy + off, dv);
+    }
+    load8<T>(x + off, xv);
     const bool remask = relu && y == nullptr;
     if (relu && !remask) load8<T>(y + off, yv);
     if (remask) load8<float>(beta + c, be);
@@ -658,6 +676,42 @@ __global__ void maxpool_bwd_vec_kernel(const T* __restrict__ dy, const unsigned 
 // windows can have chosen it.  All four (dy, argmax) pairs are requested up front with clamped coordinates and the
 // invalid ones masked afterwards -- the generic kernel's tap loops with their divisions and early exits issue one
 // dependent load pair at a time (393 us for the 256-frame stem map against 113 us of traffic).
+// gradient of input pixel (n, h, w), channels c .. c+7, of a 3x3 / stride 2 / pad 1 max-pool from the pooled gradient dy
+// and the stored argmax taps
+template <typename T>
+__device__ __forceinline__ void pooled_dy8_k3s2p1(const T* __restrict__ dy, const unsigned char* __restrict__ idx, int64_t n,
+                                                  int h, int w, int c, int C, int Ho, int Wo, float* acc) {
+  // axis candidates: (window, tap); odd coordinate: ((x+1)/2, tap 0) and ((x-1)/2, tap 2); even: (x/2, tap 1)
+  const int hoA = (h + 1) >> 1, hoB = (h - 1) >> 1, woA = (w + 1) >> 1, woB = (w - 1) >> 1;
+  const bool hodd = h & 1, wodd = w & 1;
+  const int ho[2] = {hodd ? hoA : (h >> 1), hoB}, kih[2] = {hodd ? 0 : 1, 2};
+  const int wo[2] = {wodd ? woA : (w >> 1), woB}, kjw[2] = {wodd ? 0 : 1, 2};
+  const bool hv[2] = {ho[0] < Ho, hodd && hoB >= 0}, wv[2] = {wo[0] < Wo, wodd && woB >= 0};
+  unsigned long long pk[4];
+  float v[4][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int hc = min(max(ho[a], 0), Ho - 1), wc = min(max(wo[b], 0), Wo - 1);
+      const int64_t o = ((n * Ho + hc) * Wo + wc) * C + c;
+      pk[a * 2 + b] = *reinterpret_cast<const unsigned long long*>(idx + o);
+      load8<T>(dy + o, v[a * 2 + b]);
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (!(hv[a] && wv[b])) continue;
+      const unsigned tap = (unsigned)(kih[a] * 3 + kjw[b]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (((pk[a * 2 + b] >> (8 * e)) & 0xffu) == tap) acc[e] += v[a * 2 + b][e];
+    }
+}
+
 template <typename T>
 __global__ void maxpool_bwd_k3s2p1_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
                                           T* __restrict__ dx, int N, int C, int H, int W, int Ho, int Wo) {
@@ -668,35 +722,58 @@ __global__ void maxpool_bwd_k3s2p1_kernel(const T* __restrict__ dy, const unsign
     const int64_t px = it / cv;
     const int w = (int)(px % W), h = (int)((px / W) % H);
     const int64_t n = px / ((int64_t)W * H);
-    // axis candidates: (window, tap); odd coordinate: ((x+1)/2, tap 0) and ((x-1)/2, tap 2); even: (x/2, tap 1)
-    const int hoA = (h + 1) >> 1, hoB = (h - 1) >> 1, woA = (w + 1) >> 1, woB = (w - 1) >> 1;
-    const bool hodd = h & 1, wodd = w & 1;
-    const int ho[2] = {hodd ? hoA : (h >> 1), hoB}, kih[2] = {hodd ? 0 : 1, 2};
-    const int wo[2] = {wodd ? woA : (w >> 1), woB}, kjw[2] = {wodd ? 0 : 1, 2};
-    const bool hv[2] = {ho[0] < Ho, hodd && hoB >= 0}, wv[2] = {wo[0] < Wo, wodd && woB >= 0};
-    unsigned long long pk[4];
-    float v[4][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int hc = min(max(ho[a], 0), Ho - 1), wc = min(max(wo[b], 0), Wo - 1);
-        const int64_t o = ((n * Ho + hc) * Wo + wc) * C + c;
-        pk[a * 2 + b] = *reinterpret_cast<const unsigned long long*>(idx + o);
-        load8<T>(dy + o, v[a * 2 + b]);
-      }
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (!(hv[a] && wv[b])) continue;
-        const unsigned tap = (unsigned)(kih[a] * 3 + kjw[b]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (((pk[a * 2 + b] >> (8 * e)) & 0xffu) == tap) acc[e] += v[a * 2 + b][e];
-      }
+    float acc[8];
+    pooled_dy8_k3s2p1<T>(dy, idx, n, h, w, c, C, Ho, Wo, acc);
     store8<T>(dx + px * C + c, acc);
+  }
+}
+
+// BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over z (the ResNet stem, custom_resnet.py:100-105,138-142):
+// the normalised map (411 MB at 256 frames of 224^2) is neither written nor read back.  Values are rounded to T before the
+// comparison, ties go to the first tap: the same output and argmax as bn_apply_fwd followed by maxpool_fwd.
+template <typename T>
+__global__ void bn_relu_maxpool_k3s2p1_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, T* __restrict__ y,
+                                              unsigned char* __restrict__ idx, int N, int C, int H, int W, int Ho, int Wo,
+                                              int relu) {
+  const int cv = C >> 3;
+  const int64_t items = (int64_t)N * Ho * Wo * cv;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t r = it / cv;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+    const int64_t n = r / ((int64_t)Wo * Ho);
+    float mu[8], is[8], g[8], b[8];
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g); load8<float>(beta + c, b);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki) {
+      const int h = ho * 2 - 1 + ki;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj) {
+        const int w = wo * 2 - 1 + kj;
+        if (w < 0 || w >= W) continue;
+        float v[8];
+        load8<T>(z + ((n * H + h) * W + w) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = fmaf((v[e] - mu[e]) * is[e], g[e], b[e]);
+          if (relu) t = fmaxf(t, 0.f);
+          t = to_f32<T>(from_f32<T>(t));
+          if (bi[e] < 0 || t > best[e]) { best[e] = t; bi[e] = ki * 3 + kj; }
+        }
+      }
+    }
+    store8<T>(y + r * C + c, best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(unsigned char)(bi[e] < 0 ? 0 : bi[e]) << (8 * e);
+    *reinterpret_cast<unsigned long long*>(idx + r * C + c) = packed;
   }
 }
 
@@ -1080,6 +1157,56 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(apply)");
   // publish dgamma / dbeta (overwrite or accumulate) from the local copy
+  int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
+  if (rc) return rc;
+  return dvt_axpby_f32(loc + C, DVT_F32, 1.f, dbeta, accumulate ? 1.f : 0.f, C, stream);
+}
+
+int dvt_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            void* y, void* idx, int64_t N, int C, int H, int W, int relu, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(z && mean && invstd && gamma && beta && y && idx && N >= 0 && C > 0 && H > 0 && W > 0,
+              "dvt_bn_relu_maxpool_fwd: bad arguments");
+  DVT_REQUIRE(C % 8 == 0 && dvt_aligned16(z) && dvt_aligned16(y) && ((uintptr_t)idx & 7) == 0 && dvt_aligned16(mean) &&
+              dvt_aligned16(invstd) && dvt_aligned16(gamma) && dvt_aligned16(beta),
+              "dvt_bn_relu_maxpool_fwd: needs C %% 8 == 0 and 16-byte aligned buffers");
+  if (N == 0) return DVT_OK;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_relu_maxpool_k3s2p1_kernel<T>), dim3(cgrid(N * Ho * Wo * (C >> 3))), dim3(kB), 0,
+                                                  (hipStream_t)stream, (const T*)z, mean, invstd, gamma, beta, (T*)y,
+                                                  (unsigned char*)idx, (int)N, C, H, W, Ho, Wo, relu));
+  DVT_LAUNCH_CHECK("dvt_bn_relu_maxpool_fwd");
+  return DVT_OK;
+}
+
+int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t N,
+                      int C, int H, int W, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dy_pool && idx && x && mean && invstd && gamma && beta && dx && dgamma && dbeta && workspace && N > 0 && C > 0 &&
+              H > 0 && W > 0, "dvt_bn_bwd_pooled: bad arguments");
+  DVT_REQUIRE(C % 8 == 0 && dvt_aligned16(dy_pool) && dvt_aligned16(x) && dvt_aligned16(dx) && ((uintptr_t)idx & 7) == 0 &&
+              dvt_aligned16(mean) && dvt_aligned16(invstd) && dvt_aligned16(gamma) && dvt_aligned16(beta) &&
+              dvt_aligned16(workspace), "dvt_bn_bwd_pooled: needs C %% 8 == 0 and 16-byte aligned buffers");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = N * H * W;
+  PoolGeom pg{(const unsigned char*)idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
+  int rpb;
+  const int parts = bn_parts(rows, C, &rpb);
+  const int vcl = bn_vc_log2(C);
+  const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
+  float* part = (float*)workspace;
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, true>), grid, dim3(256), 0, st, (const T*)x,
+                                                  (const T*)dy_pool, (const T*)nullptr, mean, invstd, rows, C, rpb, relu, vcl,
+                                                  part, gamma, beta, pg));
+  DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(stats)");
+  float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
+                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
+  DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(finalize)");
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, true>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                  (const T*)dy_pool, (const T*)x, (const T*)nullptr, mean, invstd, gamma, loc,
+                                                  loc + C, (T*)dx, (T*)nullptr, rows, C, relu, training, 1.0f / (float)rows,
+                                                  beta, pg));
+  DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(apply)");
   int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
   if (rc) return rc;
   return dvt_axpby_f32(loc + C, DVT_F32, 1.f, dbeta, accumulate ? 1.f : 0.f, C, stream);

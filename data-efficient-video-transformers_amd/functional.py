@@ -918,7 +918,10 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
-                cpad=0, dx_frames=None):
+                cpad=0, dx_frames=None, pool=False):
+        # pool: the layer is followed by MaxPool2d(3, 2, 1) (the ResNet stem, custom_resnet.py:100-105): BatchNorm, ReLU and
+        # the pooling run as one pass over the convolution output and the pooled map is returned; backward gathers the
+        # layer's gradient from the pooled gradient inside the BatchNorm backward (neither full-resolution map exists).
         # dx_frames (NCHW stem only): [(first_frame, count), ...] -- the only input frames whose gradient is consumed (the
         # learnable pixel-space CLS chunk of each sample, frame_transformer.py:105,195); other frames get zeros unseen.
         ctx.dx_frames = dx_frames
@@ -1003,7 +1006,14 @@ class _ConvBnAct(torch.autograd.Function):
         res = None if residual is None else residual.contiguous()
         if res is not None and res.shape[1] != Cout:
             raise ValueError("residual width must equal the (padded) output width")
-        y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
+        pooled = bool(pool) and res is None and Cout % 8 == 0
+        if pool and not pooled:
+            raise ValueError("pool=True needs a layer without a residual branch and a multiple of 8 output channels")
+        pidx = None
+        if pooled:
+            y, pidx = ops.bn_relu_maxpool_fwd(z, mean, invstd, g32, b32, N, Cout, Ho, Wo, relu)
+        else:
+            y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
         # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
         wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
                        ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad))
@@ -1011,7 +1021,7 @@ class _ConvBnAct(torch.autograd.Function):
         # a ReLU layer without a residual branch recomputes its mask from z in backward (saves two passes over y)
         keep_y = relu and residual is not None
         ctx.save_for_backward(None if keep_col else xc, wp, z, y if keep_y else None, mean, invstd, g32,
-                              col if keep_col else None, b32 if (relu and not keep_y) else None)
+                              col if keep_col else None, b32 if ((relu and not keep_y) or pooled) else None, pidx)
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -1023,19 +1033,26 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wp, z, y, mean, invstd, g32, col, b32 = ctx.saved_tensors
+        xc, wp, z, y, mean, invstd, g32, col, b32, pidx = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l, padded = ctx.logical
         sw, sg, sb = ctx.sinks
         dy = _as(dy.contiguous(), z.dtype)
+        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+
+        def bn_backward(**kw):
+            if pidx is not None:       # dy is the pooled gradient
+                dz_, dg_, db_ = ops.bn_bwd_pooled(dy, pidx, z, mean, invstd, g32, b32, N, Ho, Wo, relu, training, **kw)
+                return dz_, None, dg_, db_
+            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, **kw)
+
         if sg is not None and sb is not None and Cout == Cout_l:
-            dz, dres, _, _ = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res,
-                                        dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh, beta=b32)
+            dz, dres, _, _ = bn_backward(dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
             sg.mark_written(); sb.mark_written()
             dgam = dbet = None
         else:
-            dz, dres, dgam, dbet = ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32)
+            dz, dres, dgam, dbet = bn_backward()
             if Cout != Cout_l:                                           # drop the padded channels
                 if sg is not None and sb is not None:
                     ops.unpad3_f32(dgam, Cout_l, 1, 1, 1, out=sg.buf.view(-1), accumulate=not sg.fresh)
@@ -1107,20 +1124,21 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
-                dtype=torch.bfloat16):
-    """geom = (N, Cin, H, W, nchw).  Kernel size / stride / padding come from ``conv``."""
+                dtype=torch.bfloat16, pool: bool = False):
+    """geom = (N, Cin, H, W, nchw).  Kernel size / stride / padding come from ``conv``.  pool: the layer is followed by
+    MaxPool2d(3, 2, 1); the pooled map is returned (see _ConvBnAct)."""
     N, Cin, H, W, nchw = geom
     assert conv.bias is None and conv.groups == 1
     return conv_bn_act_raw(x, conv.weight, bn, geom, tuple(conv.kernel_size), tuple(conv.stride),
-                           tuple(conv.padding), relu=relu, residual=residual, dtype=dtype)
+                           tuple(conv.padding), relu=relu, residual=residual, dtype=dtype, pool=pool)
 
 
 def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16,
-                    cpad: int = 0, dx_frames=None):
+                    cpad: int = 0, dx_frames=None, pool: bool = False):
     """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
     Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
     (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
@@ -1128,7 +1146,7 @@ def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames)
+                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool)
 
 
 class _Subsample(torch.autograd.Function):

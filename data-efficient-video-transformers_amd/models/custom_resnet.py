@@ -136,10 +136,12 @@ class ResNet(nn.Module):
             raise ValueError("ResNet expects frames [N, 3, H, W]")
         dt = self.compute_dtype
         N, _, H, W = x.shape
-        y = F.conv_bn_act(x, self.conv1, self.bn1, (N, 3, H, W, True), relu=True, dtype=dt)   # stem reads NCHW
-        H1, W1 = _out_hw(self.conv1, H, W)
         mp = self.maxpool
-        y = F.maxpool_nhwc(y, N, 64, H1, W1, mp.kernel_size, mp.stride, mp.padding)
+        fused_pool = (mp.kernel_size, mp.stride, mp.padding) == (3, 2, 1)     # bn1 -> relu -> maxpool in one pass
+        y = F.conv_bn_act(x, self.conv1, self.bn1, (N, 3, H, W, True), relu=True, dtype=dt, pool=fused_pool)   # stem reads NCHW
+        H1, W1 = _out_hw(self.conv1, H, W)
+        if not fused_pool:
+            y = F.maxpool_nhwc(y, N, 64, H1, W1, mp.kernel_size, mp.stride, mp.padding)
         H2 = (H1 + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
         W2 = (W1 + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
         fm: FMap = (y, N, H2, W2)

@@ -1025,6 +1025,38 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
     return dz, dres, dgamma, dbeta
 
 
+def bn_relu_maxpool_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, N: int, Cc: int, H: int, W: int,
+                        relu: bool):
+    """BatchNorm (+ ReLU) + max-pool(3, 2, 1) of the NHWC map z in one pass -> (pooled [N*Ho*Wo, C], argmax taps)."""
+    Ho, Wo = conv_out_hw(H, W, 3, 2, 1)
+    y = torch.empty((N * Ho * Wo, Cc), dtype=z.dtype, device=z.device)
+    idx = torch.empty((N * Ho * Wo * Cc,), dtype=torch.uint8, device=z.device)
+    L.check(L.load().dvt_bn_relu_maxpool_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             y.data_ptr(), idx.data_ptr(), N, Cc, H, W, int(relu), dt(z), _stream()),
+            "dvt_bn_relu_maxpool_fwd")
+    return y, idx
+
+
+def bn_bwd_pooled(dy_pool: Tensor, idx: Tensor, z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, N: int,
+                  H: int, W: int, relu: bool, training: bool, *, dgamma: Optional[Tensor] = None,
+                  dbeta: Optional[Tensor] = None, accumulate: bool = False):
+    """bn_bwd with the incoming gradient gathered from the gradient of the max-pool(3, 2, 1) that follows the layer."""
+    rows, Cc = z.shape
+    assert rows == N * H * W
+    dz = torch.empty_like(z)
+    if dgamma is None:
+        assert not accumulate
+        dgamma = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+    lib = L.load()
+    ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
+    L.check(lib.dvt_bn_bwd_pooled(dy_pool.data_ptr(), idx.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                  gamma.data_ptr(), beta.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  ws.data_ptr(), N, Cc, H, W, int(relu), int(training), int(accumulate), dt(z), _stream()),
+            "dvt_bn_bwd_pooled")
+    return dz, dgamma, dbeta
+
+
 def maxpool_fwd(x: Tensor, N: int, Cc: int, H: int, W: int, k: int, stride: int, pad: int):
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     y = torch.empty((N * Ho * Wo, Cc), dtype=x.dtype, device=x.device)

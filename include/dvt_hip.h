@@ -415,6 +415,16 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
                int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
+/* The ResNet stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) without the normalised map in HBM:
+ * _fwd reads the convolution output z once and writes the pooled map y[N*Ho*Wo, C] and the argmax taps idx (same values
+ * and taps as dvt_bn_apply_fwd followed by dvt_maxpool_fwd); dvt_bn_bwd_pooled is dvt_bn_bwd whose incoming gradient
+ * is gathered from the pooled gradient dy_pool and idx on the fly (the ReLU mask is recomputed from z), so neither the
+ * max-pool's input gradient nor the BatchNorm output exist as tensors.  C % 8 == 0. */
+int dvt_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            void* y, void* idx, int64_t N, int C, int H, int W, int relu, int dtype, dvt_stream_t stream);
+int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t N,
+                      int C, int H, int W, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC; idx: uint8 [N*Ho*Wo*C] window position of the (first) maximum. */
 int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, int W, int k, int stride, int pad,
                     int dtype, dvt_stream_t stream);

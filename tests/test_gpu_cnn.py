@@ -125,6 +125,33 @@ def test_maxpool_fwd_bwd_matches_torch(dvt, device, H, W, k, stride, pad):
     assert torch.allclose(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, C), atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(9, 11), (12, 16)])
+def test_bn_relu_maxpool_in_one_pass_matches_the_three_ops(dvt, device, dtype, H, W):
+    """The stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) as one forward pass and a BatchNorm
+    backward that gathers its incoming gradient from the pooled gradient: same pooled values and argmax taps as the three
+    separate kernels, same dz / dgamma / dbeta (the fused backward skips one 16-bit rounding of the un-pooled gradient)."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(35)
+    N, C = 3, 16
+    z = torch.randn(N * H * W, C, generator=g).to(dtype).cuda()
+    mean = (0.2 * torch.randn(C, generator=g)).cuda()
+    invstd = (0.5 + torch.rand(C, generator=g)).cuda()
+    gamma = torch.randn(C, generator=g).cuda()                    # both signs: the affine map is not monotonic in z
+    beta = (0.3 * torch.randn(C, generator=g)).cuda()
+    y_ref = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, None, True)
+    p_ref, i_ref = ops.maxpool_fwd(y_ref, N, C, H, W, 3, 2, 1)
+    p, i = ops.bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta, N, C, H, W, True)
+    assert torch.equal(p, p_ref) and torch.equal(i, i_ref)
+    dyp = torch.randn(p.shape, generator=g).to(dtype).cuda()
+    dx_ref = ops.maxpool_bwd(dyp, i_ref, N, C, H, W, 3, 2, 1)
+    dz_ref, _, dg_ref, db_ref = ops.bn_bwd(dx_ref, z, None, mean, invstd, gamma, True, True, False, beta=beta)
+    dz, dg, db = ops.bn_bwd_pooled(dyp, i, z, mean, invstd, gamma, beta, N, H, W, True, True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_l2(dz.float(), dz_ref.float()) < tol
+    assert rel_l2(dg, dg_ref) < tol and rel_l2(db, db_ref) < tol
+
+
 def test_maxpool_first_max_and_eval_bn(dvt, device):
     g = torch.Generator().manual_seed(32)
     N, C, H, W = 2, 8, 9, 11
