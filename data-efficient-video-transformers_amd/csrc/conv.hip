@@ -451,6 +451,72 @@ __global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
   }
 }
 
+// bn_apply_bwd<POOL> for even H and W, one thread per 2 x 2 input pixels (and 8 channels): the four pooling windows that
+// can have selected any of them -- (qh, qw) .. (qh+1, qw+1) -- are loaded once for the quad instead of four (clamped)
+// windows per pixel; an even row can only be tap row 1 of window qh, an odd row tap row 2 of qh or tap row 0 of qh+1.
+template <typename T>
+__global__ void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T* __restrict__ x,
+                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                              T* __restrict__ dx, int64_t N, int C, int relu, int training, float inv_rows,
+                                              PoolGeom pg) {
+  const int cv = C >> 3, H2 = pg.H >> 1, W2 = pg.W >> 1;
+  const int64_t items = N * H2 * W2 * cv;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(it % cv) << 3;
+    const int64_t q = it / cv;
+    const int qw = (int)(q % W2), qh = (int)((q / W2) % H2);
+    const int64_t n = q / ((int64_t)W2 * H2);
+    unsigned long long pk[2][2];
+    float v[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int hc = min(qh + a, pg.Ho - 1), wc = min(qw + b, pg.Wo - 1);
+        const int64_t o = ((n * pg.Ho + hc) * pg.Wo + wc) * C + c;
+        pk[a][b] = *reinterpret_cast<const unsigned long long*>(pg.idx + o);
+        load8<T>(dyp + o, v[a][b]);
+      }
+    float xv[2][2][8];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+        load8<T>(x + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, xv[ph][pw]);
+    float mu[8], is[8], g[8], be[8], dg[8], db[8];
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g); load8<float>(beta + c, be);
+    load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
+    const bool va[2] = {true, qh + 1 < pg.Ho}, vb[2] = {true, qw + 1 < pg.Wo};
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw) {
+        float dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a <= ph; ++a)            // even row: window qh only (tap row 1); odd: qh (tap row 2), qh+1 (tap row 0)
+#pragma unroll
+          for (int b = 0; b <= pw; ++b) {
+            if (!(va[a] && vb[b])) continue;
+            const unsigned ki = ph == 0 ? 1u : (a == 0 ? 2u : 0u), kj = pw == 0 ? 1u : (b == 0 ? 2u : 0u);
+            const unsigned tap = ki * 3 + kj;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (((pk[a][b] >> (8 * e)) & 0xffu) == tap) dv[e] += v[a][b][e];
+          }
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = (xv[ph][pw][k] - mu[k]) * is[k];
+          const float dz = (relu && !(fmaf(xh, g[k], be[k]) > 0.f)) ? 0.f : dv[k];
+          o[k] = training ? g[k] * is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : g[k] * is[k] * dz;
+        }
+        store8<T>(dx + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, o);
+      }
+  }
+}
+
 // ------------------------------------------------------------------ scalar fallbacks (C % 8 != 0)
 // R(2+1)D mid-plane counts (45, 230, 460, 921) are not multiples of 8.  One thread per column.
 template <typename T, int MODE>
@@ -1202,10 +1268,16 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
   hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(finalize)");
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, true>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                  (const T*)dy_pool, (const T*)x, (const T*)nullptr, mean, invstd, gamma, loc,
-                                                  loc + C, (T*)dx, (T*)nullptr, rows, C, relu, training, 1.0f / (float)rows,
-                                                  beta, pg));
+  if (H % 2 == 0 && W % 2 == 0) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_pool_quad_kernel<T>), dim3(cgrid(rows / 4 * (C >> 3))), dim3(kB), 0,
+                                                    st, (const T*)dy_pool, (const T*)x, mean, invstd, gamma, beta, loc, loc + C,
+                                                    (T*)dx, N, C, relu, training, 1.0f / (float)rows, pg));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, true>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                    (const T*)dy_pool, (const T*)x, (const T*)nullptr, mean, invstd, gamma, loc,
+                                                    loc + C, (T*)dx, (T*)nullptr, rows, C, relu, training, 1.0f / (float)rows,
+                                                    beta, pg));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(apply)");
   int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
   if (rc) return rc;
