@@ -174,6 +174,33 @@ def newest_pmc_traffic():
         return {}, None
 
 
+def full_k_reference(ops):
+    """The dominant kernel on a product without the metric shapes' structure (4096^3 bf16, 64 k-tiles per tile, one round of
+    256 tiles, negligible epilogue), measured live on this device on random data: what the same main loop sustains when the
+    K = 512 effects DESIGN 4.1 lists (epilogue 33 %, prologue 7 %, partial rounds) are absent.  On random bf16 data the chip
+    holds 1.9-2.0 GHz in such a loop (MI355X_MICROARCH.md, DVFS give-back (1)), so 2.5 PFLOP/s is not reachable by any kernel."""
+    try:
+        n = 4096
+        a = torch.randn(n, n, device="cuda").to(torch.bfloat16)
+        b = torch.randn(n, n, device="cuda").to(torch.bfloat16)
+        c = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
+        run = lambda: ops.gemm(a, b, n, n, n, a_kmajor=True, b_kmajor=True, lda=n, ldb=n, out=c)
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        tf = 2.0 * n ** 3 / (us * 1e-6) / 1e12
+        return {"shape": "4096^3 bf16, A and B k-major", "us_per_launch": round(us, 1), "achieved": round(tf, 1),
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
+    except Exception as e:      # informational: never takes the line down
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def build_workload(args, workload, rank, comm):
     """Model, flat parameter store, synthetic batch and the step closure of one workload."""
     from dvt_amd import functional as F
@@ -447,6 +474,7 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
                                                         "algorithmic_MB_per_launch": round(v[3] / v[2] / 1e6, 1)}
                                  for k, v in fam.items()},
                     "hbm_kernels": hbm,
+                    "same_kernel_full_k": full_k_reference(ops),
                     "event_bracket_overhead_us": round(bracket_us, 1),
                     "timing_note": "HIP-event pair per launch on the launch stream, behind a device-side delay so that the host "
                                    "runs ahead; the measured cost of an empty bracket is subtracted from every record"}
