@@ -819,6 +819,12 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c) {
   return cfg;
 }
 
+// output size of the convolution a descriptor names (trim_w: columns dropped at the right edge)
+static inline void conv_out_hw(const dvt_conv_desc* d, int64_t* Ho, int64_t* Wo) {
+  *Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1;
+  *Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1 - (d->trim_w > 0 ? d->trim_w : 0);
+}
+
 static bool conv_implicit_ok(const dvt_conv_desc* d) {
   if (!d || !d->x || !d->w || !d->y) return false;
   if (!dvt_is_16bit(d->dtype)) return false;
@@ -828,7 +834,8 @@ static bool conv_implicit_ok(const dvt_conv_desc* d) {
   // C % k-tile == 0 (a k-tile inside one filter tap), or C == 8: the stem, its 3 channels zero-extended to one 16-byte
   // chunk per (pixel, tap) by dvt_nchw_to_nhwc_pad
   if ((d->C % tk && d->C != 8) || d->Cout % 8) return false;
-  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  int64_t Ho, Wo;
+  conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0) return false;
   if (d->N * Ho * Wo >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
   if ((int64_t)d->kh * d->kw * d->C >= ((int64_t)1 << 31)) return false;
@@ -850,7 +857,9 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   if (!conv_implicit_ok(d))
     DVT_UNSUPPORTED("dvt_conv2d_implicit: needs a 16-bit dtype, C %% 64 == 0 (C %% 32 for Cout <= 128), Cout %% 8 == 0 and "
                     "16-byte aligned buffers");
-  const int Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  int64_t Ho64, Wo64;
+  conv_out_hw(d, &Ho64, &Wo64);
+  const int Ho = (int)Ho64, Wo = (int)Wo64;
   GemmParams p{};
   p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
   p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = (int)dvt_conv2d_implicit_k(d);
@@ -867,7 +876,8 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
 // one partial row per wave row of a 256-row tile: 2 (128 output rows each) in configurations 0 and 1, 4 (64 rows) in 4, 6, 7
 int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   if (!d || d->sh <= 0 || d->sw <= 0) return 0;
-  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  int64_t Ho, Wo;
+  conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
   const int cfg = conv_fwd_cfg(d->N * Ho * Wo, d->Cout, d->C);
   return dvt_cdiv(d->N * Ho * Wo, 256) * (cfg == 4 || cfg == 6 || cfg == 7 ? 4 : 2);   // wave rows per 256-row tile
@@ -886,7 +896,8 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->kh <= 0 || d->kw <= 0 || d->sh <= 0 || d->sw <= 0 || d->ph < 0 || d->pw < 0)
     return false;
   if (d->C % 8 || d->Cout % 8) return false;
-  const int64_t Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1, Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+  int64_t Ho, Wo;
+  conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0) return false;
   const int64_t rows = d->N * Ho * Wo;
   pl->cfg = conv_cfg(d->Cout, d->C, true);

@@ -932,6 +932,7 @@ class _ConvBnAct(torch.autograd.Function):
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         xc = x.contiguous()
         ctx.pair = pair = None
+        ctx.trim = 0
         stem8 = (IMPLICIT_CONV and nchw and Cin <= 8 and not x.requires_grad and dtype in (torch.bfloat16, torch.float16)
                  and Cout % 8 == 0 and (N * Ho * Wo) % 32 == 0)
         if stem8:
@@ -942,13 +943,17 @@ class _ConvBnAct(torch.autograd.Function):
             # gradient (the pixel-space CLS clip of FrameTransformer): that path keeps the explicit gather.
             (ph, pw) = ops._pair(pad)
             off = pw & 1
-            kwp = W // 2 + (pw + off) + 1 - Wo if (sw == 2 and W % 2 == 0) else 0
-            if Cin <= 4 and Cin == Cin_l and kwp > 0 and 2 * kwp - off >= kw:
+            kwp = (kw + off + 1) // 2                      # pairs that cover the taps: (-1,0) (1,2) (3,4) (5,6) for 7 / pad 3
+            trim = (W // 2 + (pw + off) - kwp + 1) - Wo if (sw == 2 and W % 2 == 0) else -1
+            if Cin <= 4 and Cin == Cin_l and trim >= 0:
                 # Stride 2 and <= 4 channels: two horizontally adjacent pixels share a 16-byte chunk (Cpad = 4), and in that
                 # [N, H, W/2, 8] view the stem is a (kh, kwp) convolution of stride (sh, 1) over pixel pairs whose weights
-                # are the stem's, re-laid by dvt_conv_weight_pairs (zero taps where a pair sticks out of the kernel): 35
-                # gathered chunks per output pixel instead of 49, K = 280 instead of 392.  From here on it IS that convolution.
+                # are the stem's, re-laid by dvt_conv_weight_pairs (zero taps where a pair sticks out of the kernel): 28
+                # gathered chunks per output pixel instead of 49, K = 224 instead of 392 (one tile column of the weight
+                # gradient instead of two).  Its symmetric padding of (pw + off) / 2 pair columns yields `trim` output
+                # columns too many on the right (dvt_conv_desc.trim_w).  From here on it IS that convolution.
                 ctx.pair = pair = (kh, kw, pw, kwp)
+                ctx.trim = trim
                 xc = ops.nchw_to_nhwc_pad(xc.view(N, Cin, H, W), dtype, 4)
                 W, k, stride, pad = W // 2, (kh, kwp), (sh, 1), (ph, (pw + off) // 2)
                 (kh, kw), (sh, sw) = k, stride
@@ -974,14 +979,17 @@ class _ConvBnAct(torch.autograd.Function):
                 w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
         wp = ops.conv_weight_pack(w4, ld, dtype)
         implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8) and xc.dtype == dtype and
-                    ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad))
+                    ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad, ctx.trim))
+        if ctx.trim and not implicit:
+            raise RuntimeError("the pixel-pair stem needs the implicit convolution kernels")
         stats_partial = None
         if implicit:
             col = None
             if training and FUSE_BN_STATS:       # column sums for the BatchNorm come out of the GEMM epilogue
-                z, stats_partial, stats_parts = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True)
+                z, stats_partial, stats_parts = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True,
+                                                                    trim_w=ctx.trim)
             else:
-                z = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad)
+                z = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad, trim_w=ctx.trim)
         else:
             col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
             z = ops.linear_fwd(col, wp)                                 # [N*Ho*Wo, Cout]
@@ -1016,7 +1024,9 @@ class _ConvBnAct(torch.autograd.Function):
             y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
         # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
         wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
-                       ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad))
+                       ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad, ctx.trim))
+        if ctx.trim and not wg_implicit:
+            raise RuntimeError("the pixel-pair stem needs the implicit weight-gradient kernel")
         keep_col = SAVE_CONV_COLUMNS and not direct and col is not None and not wg_implicit
         # a ReLU layer without a residual branch recomputes its mask from z in backward (saves two passes over y)
         keep_y = relu and residual is not None
@@ -1040,6 +1050,7 @@ class _ConvBnAct(torch.autograd.Function):
         sw, sg, sb = ctx.sinks
         dy = _as(dy.contiguous(), z.dtype)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        Wo -= ctx.trim
 
         def bn_backward(**kw):
             if pidx is not None:       # dy is the pooled gradient
@@ -1065,7 +1076,7 @@ class _ConvBnAct(torch.autograd.Function):
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
         if ctx.wg_implicit:
-            dwt = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad)      # [kh*kw*Cin, Cout] fp32
+            dwt = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim)   # [kh*kw*Cin, Cout] fp32
             unpack, dwp = ops.conv_weight_unpack_grad_t, dwt
         else:
             if col is None:

@@ -792,13 +792,14 @@ def col2im_nchw(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad, d
     return dx
 
 
-def _conv_desc(x: Tensor, wp: Tensor, y, N, Cc, H, W, Cout, k, stride, pad):
+def _conv_desc(x: Tensor, wp: Tensor, y, N, Cc, H, W, Cout, k, stride, pad, trim_w: int = 0):
     (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     d = L.ConvDesc()
     d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), (y.data_ptr() if y is not None else 1 << 4)
     d.N, d.H, d.W, d.C, d.Cout = N, H, W, Cc, Cout
     d.kh, d.kw, d.sh, d.sw, d.ph, d.pw = kh, kw, sh, sw, ph, pw
     d.dtype = dt(x)
+    d.trim_w = trim_w
     return d
 
 
@@ -810,12 +811,12 @@ def conv2d_implicit_k(Cc: int, Cout: int, k) -> int:
     return int(L.load().dvt_conv2d_implicit_k(C.byref(d)))
 
 
-def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:
+def conv2d_implicit_supported(x: Tensor, wp: Tensor, N, Cc, H, W, Cout, k, stride, pad, trim_w: int = 0) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
         return False
     if not (x.is_contiguous() and wp.is_contiguous() and wp.shape == (Cout, conv2d_implicit_k(Cc, Cout, k))):
         return False
-    return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad))))
+    return bool(L.load().dvt_conv2d_implicit_supported(C.byref(_conv_desc(x, wp, None, N, Cc, H, W, Cout, k, stride, pad, trim_w))))
 
 
 def nchw_to_nhwc_pad(x: Tensor, dtype: torch.dtype, cpad: int = 8) -> Tensor:
@@ -856,14 +857,15 @@ def conv_weight_pairs_bwd(dwp: Tensor, Cout: int, Cin: int, kh: int, kw: int, pw
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                    want_stats: bool = False):
+                    want_stats: bool = False, trim_w: int = 0):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
     want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
     epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
     _need_cuda(x, wp)
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    Wo -= trim_w                                  # columns dropped at the right edge (dvt_conv_desc.trim_w)
     y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
-    d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad)
+    d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad, trim_w)
     lib = L.load()
     partial, parts = None, 0
     if want_stats:
@@ -888,20 +890,21 @@ def bn_stats_from_partials(partial: Tensor, parts: int, rows: int, Cc: int, runn
     return mean, invstd
 
 
-def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k, stride, pad) -> bool:
+def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k, stride, pad, trim_w: int = 0) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
         return False
     if not (x.is_contiguous() and dz.is_contiguous()):
         return False
-    return bool(L.load().dvt_conv2d_implicit_wgrad_supported(C.byref(_conv_desc(x, dz, None, N, Cc, H, W, Cout, k, stride, pad))))
+    return bool(L.load().dvt_conv2d_implicit_wgrad_supported(C.byref(_conv_desc(x, dz, None, N, Cc, H, W, Cout, k, stride, pad, trim_w))))
 
 
-def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad) -> Tensor:
+def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
+                          trim_w: int = 0) -> Tensor:
     """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised."""
     _need_cuda(x, dz)
     (kh, kw) = _pair(k)
     out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
-    d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad)
+    d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad, trim_w)
     lib = L.load()
     ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device)
     d.workspace = _p(ws)

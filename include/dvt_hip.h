@@ -371,6 +371,9 @@ typedef struct dvt_conv_desc {
    * parts = dvt_conv2d_implicit_stats_parts(desc); dvt_bn_stats_from_partials turns them into mean / invstd.  Saves the
    * separate statistics pass over y. */
   float* stats_partial;
+  /* output columns dropped at the right edge: Wo = (W + 2*pw - kw)/sw + 1 - trim_w (0: the usual convolution).  The
+   * pixel-pair stem (dvt_conv_weight_pairs) pads two pair columns on the left and needs only one on the right. */
+  int32_t trim_w;
 } dvt_conv_desc;
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
