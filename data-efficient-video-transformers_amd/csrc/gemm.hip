@@ -807,7 +807,8 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 // no epilogue to overlap) is faster on the 64-deep form of that tile (cfg 7: layer 2 of ResNet-18 104 -> 93 us, forward
 // 92 -> 97 us).
 static int conv_cfg(int cout, int c, bool wgrad = false) {
-  return cout <= 64 ? (c % 64 == 0 ? 6 : 4) : cout <= 128 ? (wgrad && c % 64 == 0 ? 7 : 1) : 0;
+  // (the weight gradient's k-tile runs over output pixels, not channels: its 64-deep forms take any C % 8 == 0)
+  return cout <= 64 ? (c % 64 == 0 || wgrad ? 6 : 4) : cout <= 128 ? (wgrad ? 7 : 1) : 0;
 }
 static int conv_tk(int cfg) { return cfg == 0 || cfg >= 6 ? 64 : 32; }
 
