@@ -905,6 +905,7 @@ IMPLICIT_CONV = True
 # BatchNorm batch statistics from the implicit convolution's GEMM epilogue (fp32 accumulators) instead of a separate pass
 # over the stored output
 FUSE_BN_STATS = True
+HALO_CONV = True          # 64 -> 64 channel 3x3 / 1 / 1 convolutions from an LDS-resident halo patch (dvt_conv3x3_c64)
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -983,7 +984,15 @@ class _ConvBnAct(torch.autograd.Function):
         if ctx.trim and not implicit:
             raise RuntimeError("the pixel-pair stem needs the implicit convolution kernels")
         stats_partial = None
-        if implicit:
+        halo = (HALO_CONV and implicit and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and (sh, sw) == (1, 1)
+                and ops._pair(pad) == (1, 1) and ops.conv3x3_c64_supported(xc, wp, N, H, W))
+        if halo:                                  # layer 1 of ResNet-18: LDS-resident halo patch instead of nine gathers
+            col = None
+            if training and FUSE_BN_STATS:
+                z, stats_partial, stats_parts = ops.conv3x3_c64(xc, wp, N, H, W, want_stats=True)
+            else:
+                z = ops.conv3x3_c64(xc, wp, N, H, W)
+        elif implicit:
             col = None
             if training and FUSE_BN_STATS:       # column sums for the BatchNorm come out of the GEMM epilogue
                 z, stats_partial, stats_parts = ops.conv2d_implicit(xc, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True,
@@ -1118,7 +1127,10 @@ class _ConvBnAct(torch.autograd.Function):
                 and (Ho, Wo) == (H + 2 * ph_ - kh + 1, W + 2 * pw_ - kw + 1)):
             wd = ops.conv_weight_pack_dgrad(ctx.w4, dtype)               # [Cin, kh*kw*Cout]
             pd = (kh - 1 - ph_, kw - 1 - pw_)
-            if ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
+            if (HALO_CONV and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and pd == (1, 1)
+                    and ops.conv3x3_c64_supported(dz, wd, N, Ho, Wo)):
+                dx = ops.conv3x3_c64(dz, wd, N, Ho, Wo)
+            elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd)     # [N*H*W, Cin], no dcol / col2im
         if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
             dx = torch.zeros(ctx.x_shape, dtype=ctx.x_dtype, device=dz.device).view(N, Cin, H, W)

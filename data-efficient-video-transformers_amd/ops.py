@@ -856,6 +856,30 @@ def conv_weight_pairs_bwd(dwp: Tensor, Cout: int, Cin: int, kh: int, kw: int, pw
     return out
 
 
+def conv3x3_c64_supported(x: Tensor, wp: Tensor, N: int, H: int, W: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
+        return False
+    if not (x.is_contiguous() and wp.is_contiguous() and tuple(wp.shape) == (64, 576) and x.shape == (N * H * W, 64)):
+        return False
+    return bool(L.load().dvt_conv3x3_c64_supported(N, H, W, dt(x)))
+
+
+def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool = False):
+    """3x3 / 1 / 1 convolution, 64 -> 64 channels, from an LDS-resident halo patch (dvt_conv3x3_c64); same contract as
+    conv2d_implicit."""
+    _need_cuda(x, wp)
+    y = torch.empty((N * H * W, 64), dtype=x.dtype, device=x.device)
+    lib = L.load()
+    partial, parts = None, 0
+    if want_stats:
+        parts = int(lib.dvt_conv3x3_c64_stats_parts(N, H, W))
+        partial = workspace((parts + 64) * 2 * 64 * 4, x.device, slot="bn_partial")
+    with _timed(("gemm", 1, 1, N * H * W, 64, 576, 0, (2 * x.numel() + wp.numel()) * x.element_size()), 2.0 * N * H * W * 64 * 576):
+        L.check(lib.dvt_conv3x3_c64(x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(partial), N, H, W, dt(x), _stream()),
+                "dvt_conv3x3_c64")
+    return (y, partial, parts) if want_stats else y
+
+
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
                     want_stats: bool = False, trim_w: int = 0):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.

@@ -375,6 +375,17 @@ typedef struct dvt_conv_desc {
    * pixel-pair stem (dvt_conv_weight_pairs) pads two pair columns on the left and needs only one on the right. */
   int32_t trim_w;
 } dvt_conv_desc;
+/* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
+ * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a
+ * workgroup stages the (R + 2) x (W + 2) input patch of R whole output rows once and the nine taps read it from LDS, the
+ * 64 x 576 weights stay resident (the implicit GEMM gathers every input element nine times from L2).  x, y NHWC
+ * [N*H*W, 64], w [64][576] (dvt_conv_weight_pack, ld = 576).  stats_partial (optional): [dvt_conv3x3_c64_stats_parts + 64]
+ * [2][64] f32 partial column sums for dvt_bn_stats_from_partials.  _supported: 16-bit dtype and W <= 56-ish (two patches
+ * must fit beside the weights in 160 KiB); callers fall back to dvt_conv2d_implicit otherwise. */
+int dvt_conv3x3_c64_supported(int64_t N, int H, int W, int dtype);
+int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
+int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, int64_t N, int H, int W, int dtype,
+                    dvt_stream_t stream);
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */

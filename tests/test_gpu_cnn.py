@@ -152,6 +152,30 @@ def test_bn_relu_maxpool_in_one_pass_matches_the_three_ops(dvt, device, dtype, H
     assert rel_l2(dg, dg_ref) < tol and rel_l2(db, db_ref) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (2, 13, 20), (1, 5, 56), (300, 8, 8)])
+def test_conv3x3_c64_from_an_lds_halo_patch(dvt, device, dtype, N, H, W):
+    """dvt_conv3x3_c64 (layer 1 of ResNet-18, custom_resnet.py:19-22,109: 64 -> 64 channels, 3 x 3 / 1 / 1) against
+    F.conv2d on the same 16-bit operands, and its BatchNorm partial sums against the statistics of its own output; tile
+    heights that do and do not divide H, more tiles than CUs (persistent loop, both patch buffers)."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, 64, H, W, generator=g).to(dtype)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05)
+    ref = TF.conv2d(x.float(), w.to(dtype).float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 64)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous().cuda()
+    wp = ops.conv_weight_pack(w.cuda(), 576, dtype)
+    assert ops.conv3x3_c64_supported(xd, wp, N, H, W)
+    z, partial, parts = ops.conv3x3_c64(xd, wp, N, H, W, want_stats=True)
+    assert rel_l2(z.float().cpu(), ref) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, z.shape[0], 64, None, None, 1e-5, 0.1)
+    zf = ref.double()
+    assert torch.allclose(mean.cpu().double(), zf.mean(0), atol=2e-3)
+    assert rel_l2(invstd.cpu().double(), 1.0 / torch.sqrt(zf.var(0, unbiased=False) + 1e-5)) < 2e-3
+    z2 = ops.conv3x3_c64(xd, wp, N, H, W)                            # no statistics: same values
+    assert torch.equal(z, z2)
+
+
 def test_maxpool_first_max_and_eval_bn(dvt, device):
     g = torch.Generator().manual_seed(32)
     N, C, H, W = 2, 8, 9, 11
