@@ -19,10 +19,6 @@
 //     column sums / sums of squares of the fp32 accumulators for the BatchNorm that follows (one partial row per wave).
 #include "common.h"
 
-#ifndef DVT_C3_ABL
-#define DVT_C3_ABL 0   // dev ablations: 1 no fragment reads / MFMAs, 2 no output stores, 3 no patch DMA after the first
-#endif
-
 namespace {
 
 constexpr int kC = 64;                       // input channels = output channels
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
 
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
     const char* cur = pb[it & 1];
-    if (DVT_C3_ABL != 3 && tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x, pb[(it + 1) & 1]);
+    if (tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x, pb[(it + 1) & 1]);
 
     f32x4 acc[4][2];
 #pragma unroll
@@ -135,9 +131,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) xv[t] = *reinterpret_cast<const V8*>(cur + ki * prow + xo[t][kj][kk]);
     };
-    if (DVT_C3_ABL != 1) { rd(0, xf[0], wf[0]); rd(1, xf[1], wf[1]); }
+    rd(0, xf[0], wf[0]);
+    rd(1, xf[1], wf[1]);
 #pragma unroll
-    for (int s = 0; s < (DVT_C3_ABL == 1 ? 0 : 18); ++s) {
+    for (int s = 0; s < 18; ++s) {
       // two steps ahead: a step's 8 MFMAs (128 cycles) are shorter than an LDS round trip under load
       if (s + 2 < 18) rd(s + 2, xf[(s + 2) % 3], wf[(s + 2) % 3]);
       __builtin_amdgcn_sched_barrier(0);          // keep the pipeline as written (the scheduler otherwise hoists every read)
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
       for (int ps = 0; ps < 2; ++ps) {
         const int r = ps * 8 + (lane >> 3), c = lane & 7;
         const V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-        if (DVT_C3_ABL != 2 && m0 + r < valid) *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * kC + c * 8) = v;
+        if (m0 + r < valid) *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * kC + c * 8) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();

@@ -1,5 +1,5 @@
 """Dev probe: dvt_conv3x3_c64 on the layer-1 shape (256 frames of 56^2) against the implicit GEMM; DVT_PROBE_LIB selects
-an ablation build (tools/dev/conv3_abl.sh)."""
+another build of the library."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 import dvt_amd
