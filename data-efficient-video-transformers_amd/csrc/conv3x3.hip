@@ -16,7 +16,7 @@
 //     halves of the 64 banks, and the XOR spreads the 16 lanes of a ds_read_b128 group over all slots;
 //   * fragments of step s + 2 (a step = one tap x 32 channels: 2 + 4 reads, 8 MFMAs) are requested before the MFMAs of s;
 //   * epilogue: per-wave 2 KiB staging inside the consumed patch buffer, whole 128-byte rows stored; optional per-wave
-//     column sums / sums of squares of the fp32 accumulators for the BatchNorm that follows (one partial row per wave).
+//     column sums / sums of squares of the stored values for the BatchNorm that follows (one partial row per wave).
 #include "common.h"
 
 namespace {
@@ -154,24 +154,17 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
     const int valid = rows_ok * p.W;             // pixels of this tile that exist
     E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * kC;
     char* stg = const_cast<char*>(cur) + wid * 2048;
-    float bs[4][4], bq[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { bs[u][r] = 0.f; bq[u][r] = 0.f; }
+    // BatchNorm partial sums: taken from the staged rows (lane = 8 channels of one pixel, the values as stored), so the
+    // cross-lane part is a tree over the 8 row lanes only (48 shuffles; per-accumulator sums needed 256 and cost 47 us)
+    float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;
-      const bool live = m0 + li < valid;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         V4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[u][t][r];
-          o[r] = (E)v;
-          if (live) { bs[u][r] += v; bq[u][r] = fmaf(v, v, bq[u][r]); }
-        }
+        for (int r = 0; r < 4; ++r) o[r] = (E)acc[u][t][r];
         // staged row li = pixel, 16-byte chunk (2 u + (g >> 1)) ^ ((li >> 1) & 7), 8-byte half g & 1
         *reinterpret_cast<V4*>(stg + li * 128 + (((u * 2 + (g >> 1)) ^ ((li >> 1) & 7)) << 4) + (g & 1) * 8) = o;
       }
@@ -181,30 +174,35 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
       for (int ps = 0; ps < 2; ++ps) {
         const int r = ps * 8 + (lane >> 3), c = lane & 7;
         const V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-        if (m0 + r < valid) *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * kC + c * 8) = v;
+        if (m0 + r < valid) {
+          *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * kC + c * 8) = v;
+          if (p.bn_partial) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float f = (float)v[k];
+              bs[k] += f;
+              bq[k] = fmaf(f, f, bq[k]);
+            }
+          }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
     if (p.bn_partial) {
-      // sum over the 16 pixel lanes (li); lanes li == 0 then hold the wave's sums of channels 16 u + 4 g + r
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            bs[u][r] += __shfl_xor(bs[u][r], o, 64);
-            bq[u][r] += __shfl_xor(bq[u][r], o, 64);
-          }
+        for (int k = 0; k < 8; ++k) {
+          bs[k] += __shfl_xor(bs[k], o, 64);
+          bq[k] += __shfl_xor(bq[k], o, 64);
         }
-      if (li == 0) {
-        float* pr = p.bn_partial + ((int64_t)tile * 8 + wid) * 2 * kC;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          *reinterpret_cast<f32x4*>(pr + 16 * u + 4 * g) = f32x4{bs[u][0], bs[u][1], bs[u][2], bs[u][3]};
-          *reinterpret_cast<f32x4*>(pr + kC + 16 * u + 4 * g) = f32x4{bq[u][0], bq[u][1], bq[u][2], bq[u][3]};
-        }
+      if ((lane >> 3) == 0) {                      // lane c holds channels 8 c .. 8 c + 7
+        float* pr = p.bn_partial + ((int64_t)tile * 8 + wid) * 2 * kC + (lane & 7) * 8;
+        *reinterpret_cast<f32x4*>(pr) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+        *reinterpret_cast<f32x4*>(pr + 4) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+        *reinterpret_cast<f32x4*>(pr + kC) = f32x4{bq[0], bq[1], bq[2], bq[3]};
+        *reinterpret_cast<f32x4*>(pr + kC + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
       }
     }
     // every wave is done with the staging area before the next iteration's DMA overwrites it

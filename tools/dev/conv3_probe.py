@@ -21,3 +21,6 @@ def t(f, n=20):
 a = t(lambda: ops.conv3x3_c64(x, wp, N, H, W))
 b = t(lambda: ops.conv2d_implicit(x, wp, N, 64, H, W, 64, 3, 1, 1))
 print(f"{os.environ.get('DVT_PROBE_LIB', 'product')}: halo {a:.1f} us, implicit GEMM {b:.1f} us")
+c = t(lambda: ops.conv3x3_c64(x, wp, N, H, W, want_stats=True))
+d = t(lambda: ops.conv2d_implicit(x, wp, N, 64, H, W, 64, 3, 1, 1, want_stats=True))
+print(f"with BatchNorm partial sums: halo {c:.1f} us, implicit GEMM {d:.1f} us")
