@@ -30,7 +30,7 @@ struct Conv3Params {
   const void* x;        // [N, H, W, 64]
   const void* w;        // [64][576] k-major, k = tap * 64 + c
   void* y;              // [N, H, W, 64]
-  float* bn_partial;    // [ntiles * 8][2][64] or nullptr
+  float* bn_partial;    // [grid * 8][2][64] or nullptr
   int N, H, W, R, tiles_per_img, ntiles, patch_bytes;
 };
 
@@ -114,6 +114,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) wb[kk][u] = wsm + (16 * u + li) * (kK * 2) + (((kk * 4 + g) ^ (li & 7)) << 4);
 
+  // BatchNorm partial sums: taken from the staged rows (lane = 8 channels of one pixel, the values as stored), carried over
+  // the workgroup's whole tile sequence and reduced over the 8 row lanes once, after the loop (one partial row per wave and
+  // workgroup; per-tile trees over the accumulators' 16 pixel lanes cost 47 us of a 128 us launch).
+  float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
     const char* cur = pb[it & 1];
     if (tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x, pb[(it + 1) & 1]);
@@ -154,9 +158,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
     const int valid = rows_ok * p.W;             // pixels of this tile that exist
     E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * kC;
     char* stg = const_cast<char*>(cur) + wid * 2048;
-    // BatchNorm partial sums: taken from the staged rows (lane = 8 channels of one pixel, the values as stored), so the
-    // cross-lane part is a tree over the 8 row lanes only (48 shuffles; per-accumulator sums needed 256 and cost 47 us)
-    float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;
@@ -189,24 +190,24 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
-    if (p.bn_partial) {
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          bs[k] += __shfl_xor(bs[k], o, 64);
-          bq[k] += __shfl_xor(bq[k], o, 64);
-        }
-      if ((lane >> 3) == 0) {                      // lane c holds channels 8 c .. 8 c + 7
-        float* pr = p.bn_partial + ((int64_t)tile * 8 + wid) * 2 * kC + (lane & 7) * 8;
-        *reinterpret_cast<f32x4*>(pr) = f32x4{bs[0], bs[1], bs[2], bs[3]};
-        *reinterpret_cast<f32x4*>(pr + 4) = f32x4{bs[4], bs[5], bs[6], bs[7]};
-        *reinterpret_cast<f32x4*>(pr + kC) = f32x4{bq[0], bq[1], bq[2], bq[3]};
-        *reinterpret_cast<f32x4*>(pr + kC + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
-      }
-    }
     // every wave is done with the staging area before the next iteration's DMA overwrites it
     __builtin_amdgcn_s_barrier();
+  }
+  if (p.bn_partial) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bs[k] += __shfl_xor(bs[k], o, 64);
+        bq[k] += __shfl_xor(bq[k], o, 64);
+      }
+    if ((lane >> 3) == 0) {                      // lane c holds channels 8 c .. 8 c + 7
+      float* pr = p.bn_partial + ((int64_t)blockIdx.x * 8 + wid) * 2 * kC + (lane & 7) * 8;
+      *reinterpret_cast<f32x4*>(pr) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+      *reinterpret_cast<f32x4*>(pr + 4) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+      *reinterpret_cast<f32x4*>(pr + kC) = f32x4{bq[0], bq[1], bq[2], bq[3]};
+      *reinterpret_cast<f32x4*>(pr + kC + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
+    }
   }
 }
 
@@ -236,7 +237,8 @@ int dvt_conv3x3_c64_supported(int64_t N, int H, int W, int dtype) {
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W) {
   int R, pb;
   if (!plan(H, W, &R, &pb)) return 0;
-  return N * dvt_cdiv(H, R) * 8;
+  const int64_t ntiles = N * dvt_cdiv(H, R);
+  return (ntiles < dvt_num_cus() ? ntiles : dvt_num_cus()) * 8;      // one partial row per wave of the persistent grid
 }
 
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, int64_t N, int H, int W, int dtype,
