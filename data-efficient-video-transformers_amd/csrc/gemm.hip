@@ -602,6 +602,14 @@ GemmPlan plan_gemm(const dvt_gemm_desc* d) {
       // (interleaved medians, tools/gemm_bench.hip; 4096^3: 1,316 -> 1,358 TF/s).
       const bool heavy_epi = d->epilogue == DVT_EPI_GELU || d->epilogue == DVT_EPI_DGELU;
       pl.cfg = heavy_epi && s == 1 ? 3 : 5;
+      // 224-row tiles (cfg 8: 7/8 of the MFMAs, 15/16 of the operand bytes of a 256-row tile) when they need no more rounds of
+      // workgroups than 256-row tiles do and the last 256-row round is far from full: N = 512 at 50,432 rows is 394 tiles =
+      // 2 rounds for 1.54 rounds of work, 452 tiles of 224 rows are 2 shorter rounds (3..7 % per launch).
+      if (pl.cfg == 5 && s == 1 && d->a_kmajor && (d->epilogue == DVT_EPI_NONE || d->epilogue == DVT_EPI_RESIDUAL) &&
+          d->out_dtype != DVT_F32) {
+        const int64_t r256 = dvt_cdiv(t256, cus), r224 = dvt_cdiv(dvt_cdiv(d->M, 224) * dvt_cdiv(d->N, 256), cus);
+        if (r224 <= r256 && r256 * cus - t256 > cus / 4) pl.cfg = 8;
+      }
       return pl;
     }
   }

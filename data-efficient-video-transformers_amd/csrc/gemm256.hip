@@ -47,6 +47,8 @@ namespace {
 //          memory-operation concurrency in the epilogue, a slower main loop.
 //   CFG 6  CFG 4's tile with BK=64 and 2 stages (80 KiB): a pixel's 64 channels of one filter tap are one 128-byte line per
 //          gather instead of two half lines (convolutions with <= 64 output channels and C % 64 == 0).
+//   CFG 8  CFG 5 with 224-row tiles (7 m sub-tiles per wave row): N = 512 launches at M = 50,432 are 394 tiles of 256 rows =
+//          two rounds on 256 CUs for 1.54 rounds of work; 452 tiles of 224 rows are two rounds of 7/8 the work each.
 //   CFG 5  CFG 0's tile with the two wave rows in antiphase (one reads a 32-deep slice's fragments while its SIMD partner
 //          runs the previous slice's MFMAs out of registers; four phase barriers per k-tile): +3..6 % on most shapes.
 //   CFG 4  256x64 tile, BK=32, 3 LDS stages (60 KiB), 4 waves (4x1) of 64x64: convolutions with <= 64 output channels
@@ -58,6 +60,7 @@ template <> struct Cfg<3> { enum { TM = 256, TN = 256, TK = 64, NW = 16, WN = 4,
 template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, NSTG = 3, PP = 0 }; };    // 4 waves of 64 x 64, 60 KiB: 2 workgroups / CU
 template <> struct Cfg<6> { enum { TM = 256, TN = 64, TK = 64, NW = 4, WN = 1, NSTG = 2, PP = 0 }; };    // CFG 4 with 64-deep k-tiles, 2 x 40 KiB: 2 workgroups / CU
 template <> struct Cfg<7> { enum { TM = 256, TN = 128, TK = 64, NW = 8, WN = 2, NSTG = 2, PP = 0 }; };   // CFG 1's tile with 64-deep k-tiles: 8 waves of 64 x 64, 96 KiB
+template <> struct Cfg<8> { enum { TM = 224, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 5 with 7 sub-tiles per wave row
 template <> struct Cfg<5> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 0 with the two wave rows in antiphase
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
@@ -76,10 +79,11 @@ template <bool KMAJOR, int ROWS, int TK, int NW>
 __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim,
                                          int k0, char* tile, int wid, int lane) {
   constexpr int PIECES = ROWS * TK * 2 / 1024;
-  constexpr int PPW = PIECES / NW;
+  constexpr int PPW = (PIECES + NW - 1) / NW;        // (224-row tiles: 28 pieces, 4 each for waves 0 .. 6)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int piece = wid * PPW + i;
+    if (PIECES % NW != 0 && piece >= PIECES) continue;   // wave-uniform
     const bf16* src;
     if (KMAJOR) {
       constexpr int CPR = TK / 8;               // 16-byte chunks per row
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     // k-tile kt+1 is requested at the start of the wave's R(kt,0) (row 1 requests k-tile 1 in its idle phase 0; k-tile 0 is the
     // prologue) into the stage that held kt-1 (last read in phase 4kt-1), and must have landed by the barrier that ends
     // phase 4kt+3.
-    static_assert(NSTG == 2 && TK == 64 && NW == 8 && MT == 8, "antiphase loop: 256x256x64, 8 waves");
+    static_assert(NSTG == 2 && TK == 64 && NW == 8 && (MT == 8 || MT == 7), "antiphase loop: 256x256x64 or 224x256x64, 8 waves");
     auto issue = [&](int kt) {
       char* st = smem + (kt & 1) * kStage;
       if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + kt * TK, st, wid);
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bias[k]));
   // all sixteen residual / aux rows of the wave's four passes are requested up front (the fragment registers are dead
   // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
-  constexpr int NPS = WROWS / 32;                      // passes of 32 rows
+  constexpr int NPS = (WROWS + 31) / 32;               // passes of 32 rows (the last one half empty when WROWS = 112)
   V8 rs[kNeedLd ? NPS : 1][4];
   if (kNeedLd) {
 #pragma unroll
@@ -571,8 +575,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        *reinterpret_cast<f32x4*>(es + (tt * 16 + li) * kEpiStride + u * 16 + 4 * g) =
-            acc[u][ps * 2 + tt] * p.alpha;
+        if (ps * 2 + tt < MT)
+          *reinterpret_cast<f32x4*>(es + (tt * 16 + li) * kEpiStride + u * 16 + 4 * g) = acc[u][ps * 2 + tt] * p.alpha;
     wave_lds_fence();
     float v[4][8];
     V8 cur[4];
@@ -588,7 +592,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
-      if (m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
+      const bool mine = WROWS % 32 == 0 || ps * 32 + (lane >> 3) + 8 * j < WROWS;   // rows past the wave's 112 are the next wave row's
+      if (mine && m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
         if (OUT == OUT_SLAB) {
           store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);   // re-read from cache by the reduce: streaming stores cost 10 %
         } else if (OUT == OUT_F32) {
@@ -756,6 +761,24 @@ int dvt_conv_wgrad_dma_launch_c6(const GemmParams& p, int split, int cfg, hipStr
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 7>(p, split, st) : launch_conv_wgrad<bf16, 7>(p, split, st);
   return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 6>(p, split, st) : launch_conv_wgrad<bf16, 6>(p, split, st);
 }
+// configuration 8 (224-row tiles of the antiphase loop): A k-major only, the epilogues N = 512 launches use
+template <typename E>
+int launch_224(const GemmParams& pin, bool bk, hipStream_t st) {
+  typedef Cfg<8> C;
+  constexpr int kSmem = smem_bytes<8>();
+  GemmParams p = pin;
+  p.stream_out = (int64_t)p.M * p.N * 2 >= (int64_t)180 * 1000000;
+  p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
+  const dim3 grid((unsigned)(dvt_cdiv(p.M, C::TM) * p.tiles_n), 1, 1), block(C::NW * 64);
+  if (p.slab || p.out_f32) return 1;
+  if (bk && p.epilogue == DVT_EPI_NONE) return launch_one<E, true, true, 8, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+  if (bk && p.epilogue == DVT_EPI_RESIDUAL) return launch_one<E, true, true, 8, DVT_EPI_RESIDUAL, OUT_BF16>(p, grid, block, kSmem, st);
+  if (!bk && p.epilogue == DVT_EPI_NONE) return launch_one<E, true, false, 8, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
+  return 1;
+}
+int dvt_gemm_dma_launch_224(const GemmParams& p, bool b_kmajor, hipStream_t st) {
+  return p.elem == DVT_F16 ? launch_224<f16>(p, b_kmajor, st) : launch_224<bf16>(p, b_kmajor, st);
+}
 // configuration 5 (antiphase main loop), compiled as a module of its own
 int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, hipStream_t st) {
   if (p.elem == DVT_F16) return launch_cfg<f16, 5>(p, a_kmajor, b_kmajor, split, st);
@@ -782,6 +805,10 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
 // combination has no LDS-DMA instantiation.
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st) {
   if (cfg == 5) return dvt_gemm_dma_launch_pp(p, a_kmajor, b_kmajor, split, st);
+  if (cfg == 8) {
+    const int rc = a_kmajor && split == 1 ? dvt_gemm_dma_launch_224(p, b_kmajor, st) : 1;
+    return rc == 1 ? dvt_gemm_dma_launch_pp(p, a_kmajor, b_kmajor, split, st) : rc;   // no 224-row instantiation: 256 rows
+  }
   if (p.elem == DVT_F16)
     return cfg == 3 ? launch_cfg<f16, 3>(p, a_kmajor, b_kmajor, split, st) : launch_cfg<f16, 0>(p, a_kmajor, b_kmajor, split, st);
   if (cfg == 3) return launch_cfg<bf16, 3>(p, a_kmajor, b_kmajor, split, st);

@@ -56,12 +56,12 @@ int main(int argc, char** argv) {
     if (split > 1) { p.bias = nullptr; }
     // configurations interleaved over several rounds, median per configuration: the clock the chip holds drifts by a few
     // per cent within seconds, which is the size of the differences being measured
-    const int cfgs[3] = {0, 3, 5};
-    std::vector<double> t[3];
-    for (int c = 0; c < 3; ++c) { for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfgs[c], 0); }
+    const int cfgs[4] = {0, 3, 5, 8};
+    std::vector<double> t[4];
+    for (int c = 0; c < 4; ++c) { for (int it = 0; it < 3; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfgs[c], 0); }
     hipDeviceSynchronize();
     for (int round = 0; round < 7; ++round)
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < 4; ++c) {
         const int reps = 10;
         hipEventRecord(e0, 0);
         for (int it = 0; it < reps; ++it) dvt_gemm_dma_launch(p, s.ak, s.bk, split, cfgs[c], 0);
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
         t[c].push_back(ms * 1e3 / reps);
       }
     printf("ABL=%d %-40s", DVT_ABL, s.name);
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
       std::sort(t[c].begin(), t[c].end());
       const double us = t[c][t[c].size() / 2];
       printf("  cfg%d %7.1f us %7.1f TF/s", cfgs[c], us, 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12);
