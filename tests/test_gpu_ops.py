@@ -268,7 +268,8 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
 
 
 @pytest.mark.parametrize("M,N,K", [(50432, 512, 512), (50432, 2048, 512), (12345 * 8, 1536, 256), (23000, 1000, 192),
-                                   (50432, 512, 2048), (3000 * 8, 256, 64)])
+                                   (50432, 512, 2048), (3000 * 8, 256, 64),
+                                   (50395, 512, 512)])     # 224-row tiles (configuration 8) with a ragged last tile
 def test_gemm_large_m_every_row_written_exactly_once(dvt, device, M, N, K):
     """The metric workload's token counts (M = 50,432 and ragged variants) through the LDS-DMA kernel's XCD-aware tile
     remap: every output row must be written exactly once -- ragged M (not a multiple of the tile), ragged N, 1 / 2 / 4 / 6
