@@ -85,6 +85,7 @@ SIGNATURES = {
     "dvt_layernorm_bwd_workspace_bytes": (C.c_size_t, [c_i64]),
     "dvt_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "dvt_layernorm_bwd_first": (c_int, [c_p] * 10 + [c_i64] * 7 + [c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dvt_gemm": (c_int, [C.POINTER(GemmDesc), c_p]),
     "dvt_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kLnBlock) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* dx_add,
     T* dx, float* __restrict__ partial /* [gridDim.x][2][d] */, int64_t rows, int64_t n1, int d,
-    int64_t xs0, int64_t xs1, int64_t ys0, int64_t ys1) {
+    int64_t xs0, int64_t xs1, int64_t ys0, int64_t ys1,
+    const T* __restrict__ dy_first, int64_t dyf_s, const T* __restrict__ dx_first, int64_t dxf_s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][d]
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -117,6 +118,12 @@ __global__ __launch_bounds__(kLnBlock) void ln_bwd_kernel(
         float xv[8], dv[8];
         load8<T>(xr + c, xv);
         load8<T>(dyr + c, dv);
+        if (dy_first && i1 == 0) {          // a second gradient path into the first row of each group
+          float fv[8];
+          load8<T>(dy_first + i0 * dyf_s + c, fv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dv[k] += fv[k];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           xh[i][k] = (xv[k] - mu) * rs;
@@ -140,6 +147,12 @@ __global__ __launch_bounds__(kLnBlock) void ln_bwd_kernel(
         if (dx_add) {
           float a[8];
           load8<T>(dx_add + (dxr - dx) + c, a);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] += a[k];
+        }
+        if (dx_first && i1 == 0) {
+          float a[8];
+          load8<T>(dx_first + i0 * dxf_s + c, a);
 #pragma unroll
           for (int k = 0; k < 8; ++k) o[k] += a[k];
         }
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
                                                             int nparts, int d,
                                                             float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta,
-                                                            int accumulate) {
+                                                            int accumulate /* bit 0: dgamma, bit 1: dbeta */) {
   __shared__ float red[8][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -199,7 +212,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[i][cl];
     float* o = c < d ? dgamma + c : dbeta + (c - d);
-    *o = accumulate ? *o + t : t;
+    const bool acc = c < d ? (accumulate & 1) : (accumulate & 2);
+    *o = acc ? *o + t : t;
   }
 }
 
@@ -253,17 +267,22 @@ size_t dvt_layernorm_bwd_workspace_bytes(int64_t d) {
   return (size_t)kLnBwdMaxBlocks * 2 * (size_t)(d > 0 ? d : 0) * sizeof(float);
 }
 
-int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                      const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
-                      void* workspace,
-                      int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
-                      int64_t ys1, int dtype, int accumulate, dvt_stream_t stream) {
+int dvt_layernorm_bwd_first(const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                            void* workspace,
+                            int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
+                            int64_t ys1, const void* dy_first, int64_t dy_first_stride,
+                            const void* dx_first, int64_t dx_first_stride, int dtype,
+                            int accumulate_gamma, int accumulate_beta, dvt_stream_t stream) {
   int rc = ln_check("dvt_layernorm_bwd", x, dy, n0, n1, d, xs0, xs1, ys0, ys1);
   if (rc) return rc;
   DVT_REQUIRE(gamma && mean && rstd && dx && dgamma && dbeta && workspace,
               "dvt_layernorm_bwd: null pointer");
-  DVT_REQUIRE(dvt_aligned16(dx) && dvt_aligned16(gamma) && dvt_aligned16(workspace) && dvt_aligned16(dx_add),
+  DVT_REQUIRE(dvt_aligned16(dx) && dvt_aligned16(gamma) && dvt_aligned16(workspace) && dvt_aligned16(dx_add) &&
+                  dvt_aligned16(dy_first) && dvt_aligned16(dx_first),
               "dvt_layernorm_bwd: buffers must be 16-byte aligned");
+  DVT_REQUIRE(dy_first_stride % 8 == 0 && dx_first_stride % 8 == 0,
+              "dvt_layernorm_bwd: first-row strides must be multiples of 8 elements");
   const int64_t rows = n0 * n1;
   DVT_REQUIRE(rows > 0, "dvt_layernorm_bwd: no rows");
   hipStream_t st = (hipStream_t)stream;
@@ -274,12 +293,23 @@ int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
   float* partial = (float*)workspace;
   DVT_DISPATCH_DTYPE(dtype, T, DVT_LN_VPL_SWITCH(vpl, hipLaunchKernelGGL(
       (ln_bwd_kernel<T, VPL>), dim3((unsigned)blocks), dim3(kLnBlock), lds, st, (const T*)dy,
-      (const T*)x, gamma, mean, rstd, (const T*)dx_add, (T*)dx, partial, rows, n1, (int)d, xs0, xs1, ys0, ys1)));
+      (const T*)x, gamma, mean, rstd, (const T*)dx_add, (T*)dx, partial, rows, n1, (int)d, xs0, xs1, ys0, ys1,
+      (const T*)dy_first, dy_first_stride, (const T*)dx_first, dx_first_stride)));
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd");
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)dvt_cdiv(2 * d, 32)), dim3(256), 0, st,
-                     (const float*)partial, (int)blocks, (int)d, dgamma, dbeta, accumulate);
+                     (const float*)partial, (int)blocks, (int)d, dgamma, dbeta,
+                     (accumulate_gamma ? 1 : 0) | (accumulate_beta ? 2 : 0));
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd(reduce)");
   return DVT_OK;
+}
+
+int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                      void* workspace,
+                      int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
+                      int64_t ys1, int dtype, int accumulate, dvt_stream_t stream) {
+  return dvt_layernorm_bwd_first(dy, x, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, workspace, n0, n1, d, xs0,
+                                 xs1, ys0, ys1, nullptr, 0, nullptr, 0, dtype, accumulate, accumulate, stream);
 }
 
 }  // extern "C"

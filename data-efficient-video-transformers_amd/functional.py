@@ -87,11 +87,19 @@ def _ln_bwd(dy, x, g, mean, rstd, sg, sb, **kw):
     """LayerNorm backward with optional sinks for dgamma / dbeta."""
     if sg is None or sb is None:
         return ops.layernorm_bwd(dy, x, g, mean, rstd, **kw)
+    # one flag per sink: gamma and beta may sit in different gradient buckets (dp.GradSink late-write redirect)
     dx, _, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dg=sg.buf.view(-1), db=sb.buf.view(-1),
-                                 accumulate=not sg.fresh, **kw)
+                                 accumulate=not sg.fresh, accumulate_beta=not sb.fresh, **kw)
     sg.mark_written()
     sb.mark_written()
     return dx, None, None
+
+
+def _emit_into(sink, t: Tensor):
+    """Add (or store, when the sink is fresh) an fp32 temporary into a sink: the slow form for kernels that take one
+    accumulate flag for two destinations whose sinks disagree (one of them redirected to its late buffer)."""
+    ops.axpby_f32_(sink.buf.view(-1), t.reshape(-1).contiguous(), 1.0, 0.0 if sink.fresh else 1.0)
+    sink.mark_written()
 
 
 def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -274,6 +282,11 @@ class _Tokens(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         sc, sp = ctx.sinks
+        if sc is not None and sp is not None and sc.fresh != sp.fresh:
+            demb, dcls, dpos = ops.tokens_assemble_bwd(dout, ctx.T, ctx.pos_rows)
+            _emit_into(sc, dcls)
+            _emit_into(sp, dpos)
+            return demb, None, None, None, None, None
         if sc is not None and sp is not None:
             demb, _, _ = ops.tokens_assemble_bwd(dout, ctx.T, ctx.pos_rows, dcls=sc.buf.view(-1),
                                                  dpos=sp.buf.view(ctx.T, ctx.pos_rows, -1),
@@ -513,6 +526,88 @@ def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, resid
     """attn_dropout > 0: dropout on the attention probabilities (training mode of nn.MultiheadAttention)."""
     return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first,
                             float(attn_dropout))
+
+
+class _AttnBlockCls(torch.autograd.Function):
+    """Row 0 of ``x + to_out(attention(to_qkv(LN(x))))`` for every sequence: x [S, N, d] -> [S, d].
+
+    The reference keeps only ``x[:, 0]`` of the space transformer's output (vit.py:119-120) and only
+    ``x[:, 0]`` of the temporal one under ``pool == 'cls'`` (:126), so in the LAST layer of a stack
+    everything behind the keys and values is needed for the first row alone: LayerNorm and the K / V
+    projection run on all rows, the Q projection, the attention (one query per head), the output
+    projection and the residual on S rows.  Values and gradients equal the dense block followed by the
+    slice: the rows that are dropped contribute exact zeros to every gradient.  Backward: dK / dV come
+    from the one query; the gradient into LN(x) is ``dkv W_kv`` on all rows plus ``dq W_q`` on row 0,
+    summed inside the LayerNorm backward kernel together with the residual path of row 0.
+    """
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps):
+        S, N, d = x.shape
+        T = x.dtype
+        x2 = x.reshape(S * N, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        g, bb = _f32(ln_w), _f32(ln_b)
+        xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+        wqkv = _wc(w_qkv, T)
+        inner = wqkv.shape[0] // 3
+        dh = inner // heads
+        w_q, w_kv = wqkv[:inner], wqkv[inner:]                          # row slices of the packed weight, no copies
+        kv = ops.linear_fwd(xn, w_kv)                                    # [S*N, 2*inner]
+        xn0 = xn.view(S, N, d)[:, 0]                                     # [S, d], row stride N*d
+        q = ops.linear_fwd(xn0, w_q)                                     # [S, inner]
+        kv5 = kv.view(S, N, 2, heads, dh)
+        k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
+        o = torch.empty((S, inner), dtype=T, device=x.device)
+        lse = ops.attention_fwd(q.view(S, 1, heads, dh).permute(0, 2, 1, 3), k4, v4,
+                                o.view(S, 1, heads, dh).permute(0, 2, 1, 3), dh ** -0.5)
+        wo = _wc(w_out, T)
+        y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2.view(S, N, d)[:, 0])
+        ctx.save_for_backward(x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse)
+        ctx.cfg = (S, N, d, heads, dh, inner, b_out is not None)
+        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse = ctx.saved_tensors
+        S, N, d, heads, dh, inner, has_bias = ctx.cfg
+        T = x2.dtype
+        s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
+        dy2 = _as(dy.reshape(S, d).contiguous(), T)
+        do = ops.linear_dgrad(dy2, wo)                                   # [S, inner]
+        dwo, dbo = _emit_wgrad_bias(s_o, s_bo, dy2, o, has_bias)
+        kv5 = kv.view(S, N, 2, heads, dh)
+        k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dkv5 = dkv.view(S, N, 2, heads, dh)
+        one = lambda t: t.view(S, 1, heads, dh).permute(0, 2, 1, 3)
+        ops.attention_bwd(one(q), k4, v4, one(o), lse, one(do), one(dq),
+                          dkv5[:, :, 0].permute(0, 2, 1, 3), dkv5[:, :, 1].permute(0, 2, 1, 3), dh ** -0.5)
+        xn0 = xn.view(S, N, d)[:, 0]
+        w_q, w_kv = wqkv[:inner], wqkv[inner:]
+        if s_qkv is not None:                                            # the two row ranges of one packed gradient
+            buf, acc = s_qkv.buf.view(3 * inner, d), not s_qkv.fresh
+            ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)
+            ops.linear_wgrad(dkv, xn, out=buf[inner:], accumulate=acc)
+            s_qkv.mark_written()
+            dwqkv = None
+        else:
+            dwqkv = torch.empty((3 * inner, d), dtype=torch.float32, device=x2.device)
+            ops.linear_wgrad(dq, xn0, out=dwqkv[:inner])
+            ops.linear_wgrad(dkv, xn, out=dwqkv[inner:])
+        dxn = ops.linear_dgrad(dkv, w_kv)                                # [S*N, d]: the K / V path, all rows
+        dxn0 = ops.linear_dgrad(dq, w_q)                                 # [S, d]: the Q path, row 0
+        dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d),
+                             dy_first=dxn0, dx_first=dy2)
+        return dx.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None
+
+
+def attn_block_cls(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, eps=1e-5):
+    """``attn_block(x, ...)[:, 0]`` for x [S, N, d] without the rows that are never read."""
+    return _AttnBlockCls.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps)
 
 
 class _CrossAttnBlock(torch.autograd.Function):
@@ -1067,7 +1162,11 @@ class _ConvBnAct(torch.autograd.Function):
                 return dz_, None, dg_, db_
             return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, **kw)
 
-        if sg is not None and sb is not None and Cout == Cout_l:
+        if sg is not None and sb is not None and Cout == Cout_l and sg.fresh != sb.fresh:
+            dz, dres, dgam, dbet = bn_backward()
+            _emit_into(sg, dgam); _emit_into(sb, dbet)
+            dgam = dbet = None
+        elif sg is not None and sb is not None and Cout == Cout_l:
             dz, dres, _, _ = bn_backward(dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
             sg.mark_written(); sb.mark_written()
             dgam = dbet = None

@@ -108,8 +108,10 @@ class PyramidViViT(nn.Module):
         n, T = self.num_patches, self.compute_dtype
         emb = self.pyramid_tokens(x.reshape(b * t, *x.shape[2:]))
         tok = F.tokens_assemble(emb, self.space_token, self.pos_embedding, b * t, t, n)
-        s = self.space_transformer.forward_layers(tok)
-        sn = self.space_transformer.norm
+        st = self.space_transformer
+        sn = st.norm
+        # only row 0 of the space transformer's output is read (vit.py:119-120): last layer on the CLS rows
+        s = st.forward_layers_cls(tok).view(b * t, 1, -1) if st.cls_prunable() else st.forward_layers(tok)
         seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)       # [b, t+1, d]
         if self.audio_tokens:
             if audio.shape[:2] != (b, self.audio_tokens):

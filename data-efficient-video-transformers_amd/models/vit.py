@@ -146,6 +146,40 @@ class Transformer(nn.Module):
                 x = ff.fn(x, _norm=ff.norm, _residual=True)
         return x
 
+    def cls_prunable(self) -> bool:
+        """True when the last layer may be evaluated for row 0 only (``forward_layers_cls``)."""
+        if len(self.layers) == 0:
+            return False
+        attn = self.layers[-1][0].fn
+        dropping = self.training and (attn.dropout_p > 0.0 or self.layers[-1][1].fn.dropout_p > 0.0)
+        return attn.project_out and not dropping
+
+    def forward_layers_cls(self, x):
+        """``forward_layers(x)[:, 0]`` for x [S, N, d] -> [S, d]: what the reference reads of the space
+        transformer (vit.py:119-120) and, under pool == 'cls', of the temporal one (:126).  In the last
+        layer only the keys and values are computed for all rows; query, attention, output projection and
+        the whole feed-forward run on row 0 of every sequence (F.attn_block_cls)."""
+        *head, (attn, ff) = self.layers
+        for a, f in head:
+            if self.checkpoint and self.training and torch.is_grad_enabled():
+                def block(t, a=a, f=f):
+                    t = a.fn(t, _norm=a.norm, _residual=True)
+                    return f.fn(t, _norm=f.norm, _residual=True)
+                x = F.checkpoint(block, x, tuple(a.parameters()) + tuple(f.parameters()))
+            else:
+                x = a.fn(x, _norm=a.norm, _residual=True)
+                x = f.fn(x, _norm=f.norm, _residual=True)
+
+        def last(t):
+            an, af = attn.norm, attn.fn
+            c = F.attn_block_cls(t, an.weight, an.bias, af.to_qkv.weight, af.to_out[0].weight, af.to_out[0].bias,
+                                 af.heads, eps=an.eps)
+            return ff.fn(c, _norm=ff.norm, _residual=True)
+
+        if self.checkpoint and self.training and torch.is_grad_enabled():
+            return F.checkpoint(last, x, tuple(attn.parameters()) + tuple(ff.parameters()))
+        return last(x)
+
     def forward(self, x):
         x = self.forward_layers(x)
         return F.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -198,11 +232,18 @@ class ViViT(nn.Module):
         emb = F.patch_embed(x, pe.weight, pe.bias, self.patch_size, T)              # vit.py:110
         tok = F.tokens_assemble(emb, self.space_token, self.pos_embedding, b * t, t, n)   # :113-115
         tok = F.dropout(tok, self.emb_dropout_p, self.training)                            # :116
-        s = self.space_transformer.forward_layers(tok)                              # :118-119
-        sn = self.space_transformer.norm
+        st, tt = self.space_transformer, self.temporal_transformer
+        sn = st.norm
+        if st.cls_prunable():                                                       # only x[:, 0] is read (:120)
+            s = st.forward_layers_cls(tok).view(b * t, 1, -1)
+        else:
+            s = st.forward_layers(tok)                                              # :118-119
         seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)  # :119-123
-        z = self.temporal_transformer(seq)                                          # :125
-        pooled = F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)  # :126
+        if self.pool == 'cls' and tt.cls_prunable():                                # only x[:, 0] is read (:126)
+            pooled = F.layernorm(tt.forward_layers_cls(seq), tt.norm.weight, tt.norm.bias, tt.norm.eps)
+        else:
+            z = tt(seq)                                                             # :125
+            pooled = F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)  # :126
         hn, hl = self.mlp_head[0], self.mlp_head[1]
         h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)
         return F.linear(h, hl.weight, hl.bias, out_f32=True)                        # :128

@@ -326,8 +326,11 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, *, 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *,
                   dx_add: Optional[Tensor] = None, rows=None, dy_rows=None,
                   dx: Optional[Tensor] = None, dg: Optional[Tensor] = None, db: Optional[Tensor] = None,
-                  accumulate: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
-    _need_cuda(dy, x, gamma, mean, rstd, dx_add)
+                  accumulate: bool = False, accumulate_beta: Optional[bool] = None,
+                  dy_first: Optional[Tensor] = None, dx_first: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """``accumulate`` applies to dgamma (and to dbeta unless ``accumulate_beta`` is given).
+    ``dy_first`` / ``dx_first`` [n0, d] (row stride free): added to dy / dx of row (i0, 0) only."""
+    _need_cuda(dy, x, gamma, mean, rstd, dx_add, dy_first, dx_first)
     d = x.shape[-1]
     if rows is None:
         assert x.is_contiguous() and dy.is_contiguous()
@@ -336,18 +339,24 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     else:
         n0, n1, xs0, xs1 = rows
         ys0, ys1 = dy_rows if dy_rows is not None else (d * n1, d)
+    for f in (dy_first, dx_first):
+        assert f is None or (f.dim() == 2 and f.shape == (n0, d) and f.stride(1) == 1 and f.dtype == x.dtype)
     if dx is None:
         dx = torch.empty_like(x)
     if dg is None or db is None:
-        assert not accumulate and dg is None and db is None
+        assert not accumulate and not accumulate_beta and dg is None and db is None
         dg = torch.empty((d,), dtype=torch.float32, device=x.device)
         db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    acc_b = accumulate if accumulate_beta is None else accumulate_beta
     lib = L.load()
     ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
     with _timed(("hbm", "layernorm_bwd", n0 * n1), n0 * n1 * ((3 + (dx_add is not None)) * d * x.element_size() + 8)):
-        L.check(lib.dvt_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      _p(dx_add), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d,
-                                      xs0, xs1, ys0, ys1, dt(x), int(accumulate), _stream()), "dvt_layernorm_bwd")
+        L.check(lib.dvt_layernorm_bwd_first(
+            dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
+            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1,
+            _p(dy_first), dy_first.stride(0) if dy_first is not None else 0,
+            _p(dx_first), dx_first.stride(0) if dx_first is not None else 0,
+            dt(x), int(accumulate), int(acc_b), _stream()), "dvt_layernorm_bwd")
     return dx, dg, db
 
 

@@ -168,6 +168,18 @@ int dvt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       float* dbeta, void* workspace,
                       int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
                       int64_t ys1, int dtype, int accumulate, dvt_stream_t stream);
+/* The same with (a) two more operands that enter only the FIRST row of each group (i1 == 0), indexed by i0:
+ * dy_first is added to dy before the backward (a second gradient path into LN(x)[:, 0]: the query projection
+ * of a block whose output is read at the CLS row only, src/models/vit.py:119-120 `x[:, 0]`), dx_first is added
+ * to dx (the residual path of that row); either may be NULL; and (b) separate accumulate flags for dgamma and
+ * dbeta (the two may sit in different gradient buckets). */
+int dvt_layernorm_bwd_first(const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta,
+                            void* workspace,
+                            int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1, int64_t ys0,
+                            int64_t ys1, const void* dy_first, int64_t dy_first_stride,
+                            const void* dx_first, int64_t dx_first_stride, int dtype,
+                            int accumulate_gamma, int accumulate_beta, dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- GEMM family
  * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).  One kernel family serves

@@ -522,6 +522,66 @@ def test_attn_and_mlp_blocks(dvt, device, dtype, dim, heads, dh, N):
             assert rel_l2(D[k].grad, R[k].grad) < 3 * tol, k
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dim,heads,dh,N,S", [(128, 2, 64, 17, 5), (512, 8, 64, 197, 6), (64, 2, 32, 10, 3),
+                                              (128, 2, 64, 33, 8)])
+def test_attn_block_cls_equals_dense_block_row0(dvt, device, dtype, dim, heads, dh, N, S):
+    """F.attn_block_cls(x) == (attention block of vit.py:71-73)(x)[:, 0] (vit.py:119-120 reads only that row), values
+    and every gradient: the oracle runs the dense block and slices."""
+    g = torch.Generator().manual_seed(21)
+    inner = heads * dh
+    x_d, x = _rnd((S, N, dim), dtype, g)
+    P = {
+        "ln_w": 1 + 0.1 * torch.randn(dim, generator=g), "ln_b": 0.1 * torch.randn(dim, generator=g),
+        "wqkv": torch.randn(3 * inner, dim, generator=g) / math.sqrt(dim),
+        "wout": torch.randn(dim, inner, generator=g) / math.sqrt(inner), "bout": 0.1 * torch.randn(dim, generator=g),
+    }
+    rd = lambda t: t.to(dtype).float()
+    R = {k: (rd(v) if v.dim() == 2 else v).clone().requires_grad_(True) for k, v in P.items()}
+    D = {k: v.cuda().requires_grad_(True) for k, v in P.items()}
+    xr, xd = x.clone().requires_grad_(True), x_d.clone().requires_grad_(True)
+    ref = (O.self_attention(O.layernorm(xr, R["ln_w"], R["ln_b"]), R["wqkv"], R["wout"], R["bout"], heads) + xr)[:, 0]
+    out = dvt.functional.attn_block_cls(xd, D["ln_w"], D["ln_b"], D["wqkv"], D["wout"], D["bout"], heads)
+    tol = _tol(dtype)
+    assert out.shape == (S, dim) and rel_l2(out, ref) < tol
+    gy_d, gy = _rnd(out.shape, dtype, g)
+    ref.backward(gy)
+    out.backward(gy_d)
+    assert rel_l2(xd.grad, xr.grad) < 3 * tol
+    for k in P:
+        assert rel_l2(D[k].grad, R[k].grad) < 3 * tol, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_bwd_first_row_operands(dvt, device, dtype):
+    """dvt_layernorm_bwd_first: dy_first enters dy of row (i0, 0), dx_first enters dx of that row; dgamma / dbeta
+    accumulate independently."""
+    g = torch.Generator().manual_seed(22)
+    S, N, d = 5, 7, 128
+    x_d, x = _rnd((S, N, d), dtype, g)
+    dy_d, dy = _rnd((S, N, d), dtype, g)
+    f_d, f = _rnd((S, d), dtype, g)
+    r_d, r = _rnd((S, d), dtype, g)
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.1 * torch.randn(d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    dy_tot = dy.clone()
+    dy_tot[:, 0] += f
+    O.layernorm(xr, wr, br).backward(dy_tot)
+    dx_ref = xr.grad.clone()
+    dx_ref[:, 0] += r
+    _, mean, rstd = dvt.ops.layernorm_fwd(x_d.view(-1, d), w.cuda(), b.cuda())
+    dg0 = torch.full((d,), 2.0, device="cuda")
+    db0 = torch.full((d,), 3.0, device="cuda")
+    dx, dg, db = dvt.ops.layernorm_bwd(dy_d.view(-1, d), x_d.view(-1, d), w.cuda(), mean, rstd, rows=(S, N, N * d, d),
+                                       dy_first=f_d, dx_first=r_d, dg=dg0, db=db0, accumulate=True,
+                                       accumulate_beta=False)
+    tol = _tol(dtype)
+    assert rel_l2(dx.view(S, N, d), dx_ref) < 2 * tol
+    assert rel_l2(dg - 2.0, wr.grad) < 2 * tol and rel_l2(db, br.grad) < 2 * tol
+
+
 # ------------------------------------------------------------------ losses / optimizer
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_losses(dvt, device, dtype):
