@@ -48,6 +48,27 @@ def algorithmic_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch
     return fwd, 3 * fwd
 
 
+def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, pool_cls=True):
+    """FLOPs the build actually launches: the reference reads only row 0 of the space transformer's output
+    (vit.py:119-120) and, under pool == 'cls', of the temporal one (:126), so in the last layer of each stack the query /
+    attention / output projection / feed-forward run on one row per sequence (keys and values on all rows)."""
+    inner = heads * dh
+
+    def layer(tokens_per_seq, seqs, rows_out):
+        m, q = tokens_per_seq * seqs, rows_out * seqs
+        kv = 2 * m * d * 2 * inner
+        qp = 2 * q * d * inner
+        qk = 2 * heads * q * tokens_per_seq * dh
+        proj = 2 * q * inner * d
+        ff = 4 * q * d * 4 * d
+        return kv + qp + 2 * qk + proj + ff
+
+    fwd = 2 * T * n_patch * patch_dim * d
+    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1)
+    fwd += (depth - 1) * layer(T + 1, 1, T + 1) + layer(T + 1, 1, 1 if pool_cls else T + 1)
+    return fwd, 3 * fwd
+
+
 class EventProfiler:
     """HIP-event pairs around tagged launches on the current (launch) stream."""
 
@@ -304,6 +325,21 @@ def collective_capture_ok(comm):
         return False, f"{type(e).__name__}: {e}"[:200]
 
 
+def rebuild_communicator(comm):
+    """A capture that failed inside a collective leaves the communicator and its side stream in an undefined state."""
+    from dvt_amd.dp import Communicator
+    try:
+        comm.destroy()
+    except Exception:
+        pass
+    torch.cuda.synchronize()
+    _LIVE["comm"] = Communicator.from_torch_distributed()
+    return _LIVE["comm"]
+
+
+_LIVE = {"comm": None}      # the communicator main() destroys at exit (a rebuild replaces it)
+
+
 def timed_steps(run, steps, barrier):
     torch.cuda.synchronize()
     barrier()
@@ -346,6 +382,16 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             launch = "hipGraph replay"
         else:
             ok, why = (True, "") if comm is None else collective_capture_ok(comm)
+            if comm is not None:
+                # every rank must take the same launch form (they enqueue different collective sequences otherwise):
+                # MIN over the group; a rank whose capture failed part-way re-creates its communicator before reuse
+                flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag) == 0.0:             # creating a communicator is itself collective: every rank rebuilds
+                    comm = W["flat"].comm = rebuild_communicator(comm)
+                    if ok:
+                        why = "another rank could not capture the collective"
+                ok = float(flag) == 1.0
             if comm is not None and ok:
                 replay, static_loss = capture_step(step, warmup=2)
                 launch = "hipGraph replay (bucketed RCCL all-reduce captured inside the step graph)"
@@ -479,6 +525,11 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
                     "timing_note": "HIP-event pair per launch on the launch stream, behind a device-side delay so that the host "
                                    "runs ahead; the measured cost of an empty bracket is subtracted from every record"}
 
+    rank_devices = None
+    if use_dist:                       # which device every rank ran on ("RCCL saw N ranks" is checkable from the line)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, f"rank {rank}: cuda:{torch.cuda.current_device()} "
+                                             f"{torch.cuda.get_device_name()} pid {os.getpid()}")
     out = None
     if rank == 0:
         ms_step = elapsed / steps * 1e3
@@ -502,6 +553,12 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             if workload in ("vivit", "longclip") else None,
             "model_mfma_frac": round(tot * B / (elapsed / steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
             if workload in ("vivit", "longclip") else None,
+            # model_tflops prices the step at the REFERENCE's algorithmic FLOPs (dense last layers); executed_tflops at
+            # what is launched (last layer of each stack on the CLS rows only)
+            "executed_tflops": round(executed_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
+                                                             3 * cfg["patch"] ** 2, n_tok - 1)[1]
+                                     * B * world / (elapsed / steps) / 1e12, 1)
+            if workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
             "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3)},
             "optimizer_ms_per_step": round(optimizer_ms, 3),
@@ -510,7 +567,9 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
         if note:
             out["launch_note"] = note
         if use_dist:
-            out["gradient_exchange"] = {"dtype": args.grad_dtype if comm is not None else "fp32", "bucket_mb": args.bucket_mb,
+            out["gradient_exchange"] = {"world": comm.world if comm is not None else dist.get_world_size(),
+                                        "rank_devices": rank_devices,
+                                        "dtype": args.grad_dtype if comm is not None else "fp32", "bucket_mb": args.bucket_mb,
                                         "through": "dvt_comm_allreduce (RCCL behind the C ABI)" if comm is not None
                                         else f"torch.distributed ({args.backend})", **extra}
         if cdt == torch.float16:
@@ -526,6 +585,58 @@ def release_gpu_memory():
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+
+
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, exit non-zero when any rank fails.  This
+    parent never touches the GPU (no HIP call before or after the spawn; a process that has initialised the GPU must not
+    be re-exec'd), it only waits."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:                    # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DVT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    box = {"line": None}
+
+    def relay():                                   # rank 0 prints the ONE JSON line; anything else it prints is passed on
+        for ln in procs[0].stdout:
+            if ln.lstrip().startswith("{"):
+                box["line"] = ln.strip()
+            else:
+                sys.stderr.write(ln)
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True                          # a dead rank leaves the others in a collective: end exactly those PIDs
+            for q in procs:
+                if q.poll() is None:
+                    q.send_signal(signal.SIGTERM)
+            time.sleep(2.0)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    th.join(timeout=5.0)
+    line = box["line"]
+    if failed or any(rcs) or line is None:
+        raise SystemExit(f"[bench] rank exit codes {rcs}; JSON line {'missing' if line is None else 'present'}")
+    print(line, flush=True)
 
 
 def main():
@@ -560,13 +671,29 @@ def main():
                     "single-GPU box -- the gradient exchange then goes through torch.distributed as well)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and the RCCL communicator even "
                     "with one rank (rehearses the multi-GPU code path on a single GPU)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test (runs without a GPU): every rank joins "
+                    "the process group, sums its rank over the group and rank 0 prints a JSON line with n_gpus = world")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])            # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong rank count")
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank} pid {os.getpid()}")
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "rank_sum": float(t), "ranks": names}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     use_dist = world > 1 or args.force_dist
     comm = None
@@ -588,6 +715,7 @@ def main():
             if rank == 0:
                 print(f"[bench] dvt_comm_init failed ({type(e).__name__}: {e}); falling back to torch.distributed", file=sys.stderr)
             comm = None
+    _LIVE["comm"] = comm
 
     out = run_workload(args, args.workload, rank, world, use_dist, comm, steps=args.steps, warmup=args.warmup,
                        roofline=not args.no_roofline)
@@ -610,8 +738,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":
             out["cpu_baseline"] = cpu_baseline(dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64))
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        comm.destroy()
+    if _LIVE["comm"] is not None:
+        _LIVE["comm"].destroy()
     if use_dist:
         dist.destroy_process_group()
 
