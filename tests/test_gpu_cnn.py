@@ -390,6 +390,73 @@ def test_frame_transformer_with_reference_encoders(dvt, device):
     assert torch.equal(net.vid_cls.grad, g_restricted) and torch.equal(net.vid_model.backbone.stem[0].weight.grad, w_restricted)
 
 
+def test_default_frame_transformer_vid_step_matches_oracle(dvt, device):
+    """The reference-DEFAULT composition (frame_transformer.py:192-210 with the encoder of :64-74): CLS chunk + chunks
+    -> R(2+1)D-18 (TRAIN-mode BatchNorm3d) -> fc(512 -> 896) -> positional table -> 4 post-norm encoder layers -> CLS
+    -> 3-layer head -> BCE, fp32 kernels, forward AND backward, every parameter gradient, against
+    oracle.cnn_path.r2plus1d_features + oracle.clip_path.{transformer_base, mlp_head3} on the same weights.
+    Dropout is set to 0 (torch's mask stream cannot be reproduced); chunks are 8 x 64^2 so that the deepest BatchNorm
+    sees 128 samples per channel.  The R(2+1)D stage itself stays unpinned against torchvision."""
+    from oracle import cnn_path as C
+    from oracle import clip_path as O
+    from dvt_amd.models.frame_transformer import FrameTransformer
+    torch.manual_seed(3)
+    net = FrameTransformer(batch_size=2, seq_len=3, cls=1, model="vid", opt="adamW", learning_rate=5e-6, weight_decay=0.09,
+                           momentum=0.005, frame_len=8, clip_size=64, tokens=4, encoder_dropout=0.0,
+                           compute_dtype=torch.float32)
+    rng = np.random.default_rng(93)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            a = rng.standard_normal(tuple(p.shape)).astype(np.float32)
+            if name == "vid_cls":
+                a = np.float32(0.5) * a
+            elif p.dim() == 5:
+                a *= np.float32(np.sqrt(2.0 / (p.shape[1] * p.shape[2] * p.shape[3] * p.shape[4])))
+            elif p.dim() == 2:
+                a *= np.float32(1.0 / np.sqrt(p.shape[1]))
+            elif name.endswith("weight"):
+                a = 1 + np.float32(0.1) * a
+            else:
+                a = np.float32(0.1) * a
+            p.copy_(torch.from_numpy(a))
+    B = 2
+    vid = torch.from_numpy(rng.standard_normal((B, 3, 8, 3, 64, 64)).astype(np.float32))
+    target = torch.from_numpy((rng.random((B, 19)) < 0.3).astype(np.float32))
+    P = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    pnames = [k for k, _ in net.named_parameters()]
+    for k in pnames:
+        P[k].requires_grad_(True)
+    # oracle: vid_step (:192-210)
+    cls = P["vid_cls"]                                                            # [1, T, 3, H, W]
+    data = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)        # [B, 4, T, 3, H, W]   (:194-196)
+    data = data.reshape(-1, *data.shape[2:]).permute(0, 2, 1, 3, 4)               # [B*4, 3, T, H, W]    (:197-198)
+    bbP = {k[len("vid_model.backbone."):]: v for k, v in P.items() if k.startswith("vid_model.backbone.")}
+    feats = C.r2plus1d_features(data, bbP, training=True)                         # [B*4, 512]
+    emb = O.linear(feats, P["vid_model.backbone.fc.0.weight"], P["vid_model.backbone.fc.0.bias"])
+    seq = emb.reshape(B, 4, -1).permute(1, 0, 2) + P["position_encoder.pe"][:4]   # (:203-206)
+    ref_logits = O.mlp_head3(O.transformer_base(seq, P, "distil_transformer.", 4, 2)[0], P)
+    ref_loss = O.bce_with_logits(ref_logits, target)
+    ref_loss.backward()
+    net = net.cuda().train()                                                      # BatchNorm on batch statistics
+    loss = net.training_step((target.cuda(), None, vid.cuda()), 0)
+    loss.backward()
+    e_loss = abs(float(loss.detach()) - float(ref_loss.detach()))
+    Pn = dict(net.named_parameters())
+    errs = {k: rel_l2(Pn[k].grad, P[k].grad) for k in pnames if P[k].grad is not None and Pn[k].grad is not None}
+    missing = [k for k in pnames if (P[k].grad is None) != (Pn[k].grad is None) and k != "norm.weight" and k != "norm.bias"]
+    assert not missing, missing
+    wk = max(errs, key=errs.get)
+    print(f"[default FrameTransformer vid/fp32] loss abs {e_loss:.2e}; worst gradient {wk} {errs[wk]:.2e} over {len(errs)}; "
+          f"median {float(np.median(list(errs.values()))):.2e}")
+    assert e_loss < 1e-5
+    assert len(errs) > 100
+    for k, e in errs.items():
+        assert e < 2e-3, (k, e)
+    with torch.no_grad():
+        logits = net(None, vid.cuda())
+    assert rel_l2(logits, ref_logits) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("geom", [
     # N, Cin, H, W, Cout, k, stride, pad

@@ -4,15 +4,15 @@ against the CPU oracle.
 
 fp32 mode: logits / loss / every parameter gradient within 1e-3 rel (north_star)
 -- asserted at 2e-4.  bf16 / fp16 modes follow the protocol of SURVEY section 7 and
-BASELINE.md section 2: logits <= 1e-2 rel-L2 and <= 2x the reference's own
-low-precision deviation on the same inputs; the median gradient deviation <= 2x
-the reference's median; every single gradient <= 3x its yardstick (the rule and
-the reason for the wider single-parameter bound: tests/util.py).
-That deviation is not quoted from prose: tools/gen_golden.py runs the imported
-reference under torch.autocast(bf16 / fp16) on the CPU and stores the digests
-(tests/golden/vivit_*_lowprec.npz); at configs[0] it reproduces BASELINE.md's
-4.6e-3 / 1e-2, at the metric shape it is 6.8e-3 (logits) and 3.5e-3 .. 1.7e-2
-(gradients, per parameter).
+BASELINE.md section 2: logits <= 1e-2 rel-L2, and logits, every single gradient
+and the median gradient deviation <= 2x the reference's own low-precision
+deviation on the same inputs.  That deviation is not quoted from prose:
+tools/gen_golden.py runs the imported reference on the CPU both under
+torch.autocast(bf16 / fp16) and cast to the 16-bit type (residual stream in 16
+bits, as the HIP path stores it) and stores the digests
+(tests/golden/vivit_*_lowprec.npz); the yardstick per quantity is the larger of
+the two (tests/util.py::reference_lowprec_yardstick).  At configs[0] the autocast
+run reproduces BASELINE.md's 4.6e-3 / 1e-2.
 """
 import numpy as np
 import pytest
@@ -20,7 +20,7 @@ import torch
 
 from oracle import clip_path as O
 from tests.util import (golden, rel_l2, fill_state_from_numpy, digest_inputs, check_grad_digest, grad_digest_errors,
-                        reference_lowprec_errors, assert_within_reference_lowprec)
+                        reference_lowprec_yardstick, assert_within_reference_lowprec)
 
 pytestmark = pytest.mark.gpu
 
@@ -67,11 +67,11 @@ def test_vivit_matches_reference_golden(device, mode, case):
         for k, e in errs.items():
             assert e < 2e-4, (k, e)
         return
-    ref_out, ref_errs = reference_lowprec_errors(g, golden(f"vivit_{case}_lowprec.npz"), "amp_" + mode)
+    ref_out, ref_errs = reference_lowprec_yardstick(g, golden(f"vivit_{case}_lowprec.npz"), mode)
     w = assert_within_reference_lowprec(f"{case}/{mode}", e_out, grad_digest_errors(g, grads), ref_out, ref_errs,
                                         out_cap=1e-2)
     print(f"[{case}/{mode}] reference's own {mode}: logits {ref_out:.2e}; worst gradient ratio ours/reference {w[0][1]:.2f} "
-          f"({w[0][0]}); against the raw per-parameter deviation {w[1][1]:.2f} ({w[1][0]}); median ratio {w[2]:.2f}")
+          f"({w[0][0]}); median ratio {w[1]:.2f}")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
@@ -104,13 +104,12 @@ def test_vivit_large_configs_match_reference_digest(device, tag, mode):
         assert e_out < 1e-3
         return
     errs = grad_digest_errors(g, grads)
-    ref_out, ref_errs = reference_lowprec_errors(g, golden(f"vivit_{tag.split('_')[0]}_lowprec.npz"), "amp_" + mode)
+    ref_out, ref_errs = reference_lowprec_yardstick(g, golden(f"vivit_{tag.split('_')[0]}_lowprec.npz"), mode)
     wk = max(errs, key=errs.get)
     print(f"[{tag}/{mode}] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} worst grad digest "
           f"{wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
     w = assert_within_reference_lowprec(f"{tag}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=1e-2)
-    print(f"[{tag}/{mode}] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); against the raw per-parameter "
-          f"deviation {w[1][1]:.2f} ({w[1][0]}); median ratio {w[2]:.2f}")
+    print(f"[{tag}/{mode}] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); median ratio {w[1]:.2f}")
 
 
 def test_longclip_config_composed_matches_reference_digest(device):
@@ -141,14 +140,14 @@ def test_longclip_config_composed_matches_reference_digest(device):
     e_out = rel_l2(logits, torch.from_numpy(g["logits"]))
     e_loss = abs(float(loss) - float(g["loss"][0]))
     errs = grad_digest_errors(g, grads)
-    ref_out, ref_errs = reference_lowprec_errors(g, golden("vivit_longclip_lowprec.npz"), "amp_fp16")
+    ref_out, ref_errs = reference_lowprec_yardstick(g, golden("vivit_longclip_lowprec.npz"), "fp16")
     wk = max(errs, key=errs.get)
     print(f"[longclip/fp16+scaling+ckpt] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} "
           f"worst grad digest {wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
     assert e_loss < 1e-3
     w = assert_within_reference_lowprec("longclip/fp16", e_out, errs, ref_out, ref_errs, out_cap=4e-3)
-    print(f"[longclip/fp16+scaling+ckpt] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); against the raw "
-          f"per-parameter deviation {w[1][1]:.2f} ({w[1][0]}); median ratio {w[2]:.2f}")
+    print(f"[longclip/fp16+scaling+ckpt] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); median ratio "
+          f"{w[1]:.2f}")
     # the optimizer consumes the scaled gradients: one AdamW step must not overflow-skip and must move the weights
     before = flat.data.clone()
     flat.adamw_step(lr=1e-3, weight_decay=0.0)

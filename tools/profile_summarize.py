@@ -81,6 +81,23 @@ def main():
                 fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
                          f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
             fh.write(f"\nTotal kernel time {tot/1e6:.2f} ms over 9 steps = {tot/9e6:.2f} ms/step.\n")
+    # ---- the same trace split by (kernel, grid): rocprofv3's per-name averages mix the 50,432-row space launches with the
+    #      264-row temporal ones
+    tr = find(os.path.join(prof, "stats"), "*kernel_trace.csv")
+    if tr:
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(tr)):
+            k = (r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            agg[k][0] += 1
+            agg[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        tot = sum(v[1] for v in agg.values())
+        with open(os.path.join(outd, f"{tag}_bench_kernel_by_grid.md"), "w") as fh:
+            fh.write(f"# kernel trace split by (kernel, grid, block) ({tag})\n\n9 steps in the trace; calls and ms are per step.\n\n"
+                     "| kernel | grid | block | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|---|---|\n")
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
+                fh.write(f"| `{short(k[0])}` | {k[1]} | {k[2]} | {v[0]/9:.2f} | {v[1]/9e6:.4f} | {v[1]/v[0]/1e3:.1f} | "
+                         f"{100*v[1]/tot:.1f} |\n")
+            fh.write(f"\nTotal kernel time {tot/9e6:.3f} ms/step.\n")
     for wl in ("pyramid", "frametransformer", "longclip"):      # secondary workloads: eager, 1 warm-up + 3 timed steps
         st2 = find(os.path.join(prof, f"stats_{wl}"), "*kernel_stats.csv")
         if not st2:
