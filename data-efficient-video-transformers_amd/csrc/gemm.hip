@@ -24,6 +24,7 @@
 // generic path (gemm_generic_kernel): any dtype / shape / alignment, fp32 FMA,
 // 64x64x16 tiles -- the fp32 parity mode and odd shapes (19-class head).
 #include "common.h"
+#include <type_traits>
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -336,6 +337,9 @@ struct GenericParams {
   float alpha;
 };
 
+__device__ __forceinline__ float acc_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double acc_fma(float a, float b, double c) { return fma((double)a, (double)b, c); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p) {
   constexpr int TM = 64, TN = 64, TK = 16;
@@ -346,11 +350,15 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const T* A = (const T*)p.A;
   const T* B = (const T*)p.B;
-  float acc[4][4];
+  // fp32 operands (the parity mode) accumulate in double: the products are exact in double, so the result is the
+  // correctly rounded dot product -- the mode's deviation from the reference then comes from storage rounding alone
+  // (behind BatchNorm'd ReLU stacks the forward noise decides how many ReLU masks flip, tests/test_gpu_cnn.py)
+  using Acc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  Acc acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
 
   for (int k0 = 0; k0 < p.K; k0 += TK) {
 #pragma unroll
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_fma(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericParams p
       if (p.epilogue == DVT_EPI_RESIDUAL) res = to_f32<T>(((const T*)p.residual)[(int64_t)m * p.ldr + n]);
       if (p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU)
         aux = to_f32<T>(((const T*)p.aux)[(int64_t)m * p.ldaux + n]);
-      float v = epi_apply(p.epilogue, acc[i][j] * p.alpha, bias, res, aux, pre);
+      float v = epi_apply(p.epilogue, (float)(acc[i][j] * (Acc)p.alpha), bias, res, aux, pre);
       if (p.epilogue == DVT_EPI_GELU && p.aux) ((T*)p.aux)[(int64_t)m * p.ldaux + n] = from_f32<T>(pre);
       if (p.out_f32) {
         float* o = (float*)p.C + (int64_t)m * p.ldc + n;
@@ -422,15 +430,19 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(const GenericParams p) {
   const int64_t o = WAVE ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= total) return;
   const int m = (int)(o / p.N), n = (int)(o % p.N);
-  float acc = 0.f;
+  using Acc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  Acc acc_ = 0;
   if (WAVE) {
     for (int k = threadIdx.x & 63; k < p.K; k += 64)
-      acc = fmaf(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc);
-    acc = wave_sum(acc);
-    if (threadIdx.x & 63) return;
+      acc_ = acc_fma(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc_);
   } else {
     for (int k = 0; k < p.K; ++k)
-      acc = fmaf(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc);
+      acc_ = acc_fma(to_f32<T>(A[(int64_t)m * p.sam + (int64_t)k * p.sak]), to_f32<T>(B[(int64_t)k * p.sbk + (int64_t)n * p.sbn]), acc_);
+  }
+  float acc = (float)acc_;
+  if (WAVE) {
+    acc = wave_sum(acc);
+    if (threadIdx.x & 63) return;
   }
   const float bias = p.bias ? p.bias[n] : 0.f;
   float res = 0.f, aux = 0.f, pre = 0.f;

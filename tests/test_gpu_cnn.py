@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from tests.util import golden, rel_l2, fill_resnet_from_numpy
+from tests.util import assert_within_reference_lowprec, golden, rel_l2, fill_resnet_from_numpy
 
 pytestmark = pytest.mark.gpu
 T = lambda a: torch.from_numpy(np.asarray(a))
@@ -316,12 +316,17 @@ def test_tpn_end_to_end_tokens(dvt, device):
     assert tok.shape == (4, 896) and rel_l2(tok, ref) < 2e-4
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 8e-2)])
-def test_r2plus1d_18_matches_conv3d_restatement(dvt, device, dtype, tol):
-    """R(2+1)D-18 features (factorised (1,3,3)+(3,1,1) convolutions, BatchNorm3d, strided
-    1x1x1 downsample) vs a torch-CPU conv3d restatement.  UNPINNED against torchvision (not installed)."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])       # (torch's CPU conv3d in fp16 takes ~25 s per oracle run)
+def test_r2plus1d_18_matches_conv3d_restatement(dvt, device, mode):
+    """R(2+1)D-18 features (factorised (1,3,3)+(3,1,1) convolutions, BatchNorm3d -- batch statistics in
+    the fp32 case --, strided 1x1x1 downsample), forward and EVERY parameter gradient, vs a torch-CPU conv3d restatement.  UNPINNED against
+    torchvision (not installed).  Protocol (tests/util.py): fp32 kernels against the restatement in float64, within 2x
+    the deviation of its own fp32 run from that (ReLU-mask flips set an fp32 gradient noise floor of ~1e-2 behind 20
+    BatchNorm'd ReLU layers, whoever computes them); 16-bit kernels against its fp32 run, within 2x the larger of its
+    own autocast and cast-to-16-bit deviations on the same inputs."""
     from oracle import cnn_path as C
     from dvt_amd.models.video_resnet import r2plus1d_18
+    dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[mode]
     net = r2plus1d_18(False, compute_dtype=dtype)
     rng = np.random.default_rng(91)
     with torch.no_grad():
@@ -336,33 +341,52 @@ def test_r2plus1d_18_matches_conv3d_restatement(dvt, device, dtype, tol):
             else:
                 a = np.float32(0.1) * a
             p.copy_(torch.from_numpy(a))
-    x = torch.from_numpy(rng.standard_normal((2, 3, 4, 32, 32)).astype(np.float32))
-    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    for k in P:
-        if P[k].dtype.is_floating_point and "running" not in k:
+    x = torch.from_numpy(rng.standard_normal((4, 3, 8, 48, 48)).astype(np.float32))     # deepest BatchNorm: 36 samples
+    gy = torch.from_numpy(rng.standard_normal((4, 512)).astype(np.float32))
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    pnames = [k for k, _ in net.named_parameters() if not k.startswith("fc.")]
+
+    training = mode == "fp32"      # 16-bit: BatchNorm on running statistics -- on batch statistics the restatement's own bf16 gradients
+    # deviate from its fp32 ones by ~100 % at any size that runs on the CPU in seconds (36 samples per channel in layer 4)
+
+    def oracle(kind, dt):
+        cast = (lambda t: t.to(dt)) if kind == "cast" else (lambda t: t)
+        P = {k: (cast(v) if v.dtype.is_floating_point else v).clone() for k, v in state.items()}
+        for k in pnames:
             P[k].requires_grad_(True)
-    # fp32: train mode (batch statistics).  bf16: eval mode -- at this toy size the deepest BatchNorms see
-    # 8-32 samples, whose batch statistics are too ill-conditioned for a bf16 comparison.
-    training = dtype == torch.float32
-    ref = C.r2plus1d_features(x, P, training=training)
-    gy = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
-    (ref * gy).sum().backward()
+        scale = 256.0 if dt == torch.float16 else 1.0
+        if kind == "amp":
+            with torch.autocast("cpu", dtype=dt):
+                out = C.r2plus1d_features(x, P, training=training)
+        else:
+            out = C.r2plus1d_features(cast(x), P, training=training)
+        (out.double() * gy.double()).sum().mul(scale).backward()
+        return out.detach().double(), {k: P[k].grad.double() / scale for k in pnames}
+
+    if mode == "fp32":
+        truth, tg = oracle("cast", torch.float64)
+        o, og = oracle("cast", torch.float32)
+        yard_out, yard = rel_l2(o, truth), {k: rel_l2(og[k], tg[k]) for k in tg}
+    else:
+        truth, tg = oracle("cast", torch.float32)
+        yard_out, yard = 0.0, {k: 0.0 for k in tg}
+        for kind in ("amp", "cast"):
+            o, og = oracle(kind, dtype)
+            yard_out = max(yard_out, rel_l2(o, truth))
+            yard = {k: max(yard[k], rel_l2(og[k], tg[k])) for k in tg}
     net = net.cuda().train(training)
     out = net.features(x.cuda())
-    assert out.shape == (2, 512)
-    e = rel_l2(out, ref)
-    print(f"[r2plus1d/{dtype}] feature rel {e:.2e}")
-    assert e < tol
-    out.backward(gy.to(out.dtype).cuda())
+    assert out.shape == (4, 512)
+    scale = 256.0 if mode == "fp16" else 1.0
+    out.backward((gy * scale).to(out.dtype).cuda())
     Pn = dict(net.named_parameters())
-    for k in ("layer4.1.conv2.0.3.weight", "layer3.0.downsample.0.weight", "layer2.0.conv1.0.0.weight", "stem.3.weight",
-              "layer4.1.conv2.1.weight"):
-        ge = rel_l2(Pn[k].grad, P[k].grad)
-        print(f"[r2plus1d/{dtype}] grad {k} rel {ge:.2e}")
-        # fp32 bound: the deepest maps here are 8 x 1152; ONE ReLU-mask flip of an activation that is 0 +- 1 ulp
-        # (seen: 3.8e-7 vs 0.0) moves every upstream gradient by ~1/sqrt(9216) = 1e-2.  Without a flip the
-        # error is ~3e-6 (measured on isolated blocks).
-        assert ge < (3e-2 if dtype == torch.float32 else 0.25), (k, ge)
+    errs = {k: rel_l2(Pn[k].grad.double() / scale, tg[k]) for k in tg}
+    e_out = rel_l2(out, truth)
+    w = assert_within_reference_lowprec(f"r2plus1d/{mode}", e_out, errs, yard_out, yard,
+                                        floor=1e-4 if mode == "fp32" else 2e-4)
+    print(f"[r2plus1d/{mode}] features rel {e_out:.2e} (restatement's own {yard_out:.2e}); {len(errs)} gradients: median "
+          f"{float(np.median(list(errs.values()))):.2e} (own {float(np.median(list(yard.values()))):.2e}); worst ratio "
+          f"{w[0][1]:.2f} ({w[0][0]})")
 
 
 def test_frame_transformer_with_reference_encoders(dvt, device):
@@ -422,39 +446,51 @@ def test_default_frame_transformer_vid_step_matches_oracle(dvt, device):
     B = 2
     vid = torch.from_numpy(rng.standard_normal((B, 3, 8, 3, 64, 64)).astype(np.float32))
     target = torch.from_numpy((rng.random((B, 19)) < 0.3).astype(np.float32))
-    P = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    state = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
     pnames = [k for k, _ in net.named_parameters()]
-    for k in pnames:
-        P[k].requires_grad_(True)
-    # oracle: vid_step (:192-210)
-    cls = P["vid_cls"]                                                            # [1, T, 3, H, W]
-    data = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid), dim=1)        # [B, 4, T, 3, H, W]   (:194-196)
-    data = data.reshape(-1, *data.shape[2:]).permute(0, 2, 1, 3, 4)               # [B*4, 3, T, H, W]    (:197-198)
-    bbP = {k[len("vid_model.backbone."):]: v for k, v in P.items() if k.startswith("vid_model.backbone.")}
-    feats = C.r2plus1d_features(data, bbP, training=True)                         # [B*4, 512]
-    emb = O.linear(feats, P["vid_model.backbone.fc.0.weight"], P["vid_model.backbone.fc.0.bias"])
-    seq = emb.reshape(B, 4, -1).permute(1, 0, 2) + P["position_encoder.pe"][:4]   # (:203-206)
-    ref_logits = O.mlp_head3(O.transformer_base(seq, P, "distil_transformer.", 4, 2)[0], P)
-    ref_loss = O.bce_with_logits(ref_logits, target)
-    ref_loss.backward()
+
+    def oracle(dt):
+        """vid_step (:192-210) + head + BCE on explicit formulas, in ``dt``: (logits, loss, {name: gradient})."""
+        P = {k: v.to(dt).clone() for k, v in state.items()}
+        for k in pnames:
+            P[k].requires_grad_(True)
+        cls = P["vid_cls"]                                                            # [1, T, 3, H, W]
+        data = torch.cat((cls.unsqueeze(0).expand(B, *cls.shape), vid.to(dt)), dim=1)  # [B, 4, T, 3, H, W]   (:194-196)
+        data = data.reshape(-1, *data.shape[2:]).permute(0, 2, 1, 3, 4)               # [B*4, 3, T, H, W]    (:197-198)
+        bbP = {k[len("vid_model.backbone."):]: v for k, v in P.items() if k.startswith("vid_model.backbone.")}
+        feats = C.r2plus1d_features(data, bbP, training=True)                         # [B*4, 512]
+        emb = O.linear(feats, P["vid_model.backbone.fc.0.weight"], P["vid_model.backbone.fc.0.bias"])
+        seq = emb.reshape(B, 4, -1).permute(1, 0, 2) + P["position_encoder.pe"][:4]   # (:203-206)
+        logits = O.mlp_head3(O.transformer_base(seq, P, "distil_transformer.", 4, 2)[0], P)
+        loss = O.bce_with_logits(logits, target.to(dt))
+        loss.backward()
+        return logits.detach(), loss.detach(), {k: P[k].grad for k in pnames if P[k].grad is not None}
+
+    # Truth = the oracle in float64; yardstick = the oracle's own fp32 run against it.  Behind 20 BatchNorm'd ReLU layers
+    # the fp32 noise floor of a gradient is set by ReLU-mask flips of activations that are 0 +- round-off: torch's own
+    # fp32 gradients deviate from its float64 ones by ~8e-3 (median) here, whoever computes them.
+    l64, loss64, g64 = oracle(torch.float64)
+    l32, loss32, g32 = oracle(torch.float32)
+    own = {k: rel_l2(g32[k], g64[k]) for k in g64}
     net = net.cuda().train()                                                      # BatchNorm on batch statistics
     loss = net.training_step((target.cuda(), None, vid.cuda()), 0)
     loss.backward()
-    e_loss = abs(float(loss.detach()) - float(ref_loss.detach()))
+    e_loss = abs(float(loss.detach()) - float(loss64))
     Pn = dict(net.named_parameters())
-    errs = {k: rel_l2(Pn[k].grad, P[k].grad) for k in pnames if P[k].grad is not None and Pn[k].grad is not None}
-    missing = [k for k in pnames if (P[k].grad is None) != (Pn[k].grad is None) and k != "norm.weight" and k != "norm.bias"]
+    errs = {k: rel_l2(Pn[k].grad, g64[k]) for k in g64 if Pn[k].grad is not None}
+    missing = [k for k in pnames if (k in g64) != (Pn[k].grad is not None) and k not in ("norm.weight", "norm.bias")]
     assert not missing, missing
-    wk = max(errs, key=errs.get)
-    print(f"[default FrameTransformer vid/fp32] loss abs {e_loss:.2e}; worst gradient {wk} {errs[wk]:.2e} over {len(errs)}; "
-          f"median {float(np.median(list(errs.values()))):.2e}")
-    assert e_loss < 1e-5
-    assert len(errs) > 100
+    wk = max(errs, key=lambda k: errs[k] / (own[k] + 1e-4))
+    med, med_own = float(np.median(list(errs.values()))), float(np.median(list(own.values())))
+    print(f"[default FrameTransformer vid/fp32] loss abs {e_loss:.2e}; {len(errs)} gradients vs float64: median {med:.2e} "
+          f"(oracle's own fp32: {med_own:.2e}); worst ratio {wk} {errs[wk]:.2e} vs {own[wk]:.2e}")
+    assert e_loss < 1e-5 and len(errs) > 100
+    assert med <= 2 * med_own + 1e-4
     for k, e in errs.items():
-        assert e < 2e-3, (k, e)
+        assert e <= 2 * max(own[k], med_own) + 1e-4, (k, e, own[k])
     with torch.no_grad():
         logits = net(None, vid.cuda())
-    assert rel_l2(logits, ref_logits) < 1e-4
+    assert rel_l2(logits, l64) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

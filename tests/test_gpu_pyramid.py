@@ -54,6 +54,17 @@ def test_cross_attention_block(device, dtype, tol):
         assert rel_l2(p.grad, P[k].grad) < 3 * tol, k
 
 
+class _F64View:
+    """The ``f64:`` entries of a pyramid digest presented like a digest of their own (``files`` / ``[]``)."""
+
+    def __init__(self, npz):
+        self.d = {k[4:]: npz[k] for k in npz.files if k.startswith("f64:")}
+        self.files = list(self.d)
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+
 def _oracle_run(clip, audio, target, state, pnames, variant, depth, heads, mode, training_bn):
     """The oracle composition in fp32 (mode None), under torch.autocast (``amp_<prec>``) or with parameters and inputs
     cast to the 16-bit type (``pure_<prec>``): (student, teacher, loss, {name: gradient})."""
@@ -172,11 +183,26 @@ def test_pyramid_full_size_matches_digest(device, variant, mode):
     print(f"[full {variant}/{mode}] logits rel {e_out:.2e} loss abs {e_loss:.2e} worst grad digest {wk} {errs[wk]:.2e} "
           f"over {len(errs)} gradients")
     if mode == "fp32":
-        assert e_out < 1e-3 and e_loss < 1e-4
+        # fp32 kernels against the oracle's FLOAT64 run, held to 2x the deviation of the oracle's own fp32 run from it (+ 1e-4):
+        # behind 17 BatchNorm'd ReLU layers a gradient's fp32 noise floor is set by ReLU-mask flips of activations that are
+        # 0 +- round-off (the oracle's fp32 backbone gradients deviate from its float64 ones by 1.5-3.7e-3 here; logits,
+        # loss and every gradient outside the backbone by ~1e-6, and those are thereby held to 1e-4).
+        t64 = _F64View(g)
+        e64 = grad_digest_errors(t64, grads)
+        own = grad_digest_errors(t64, {k[3:]: (g[k], g["gn:" + k[3:]]) for k in g.files if k.startswith("gs:")})
+        wk = max(e64, key=lambda k: e64[k] / (own[k] + 1e-4))
+        print(f"[full {variant}/fp32] vs float64: worst {wk} {e64[wk]:.2e} (oracle's own fp32 {own[wk]:.2e}); backbone median "
+              f"{float(np.median([e for k, e in e64.items() if k.startswith('backbone')])):.2e} (oracle's own "
+              f"{float(np.median([e for k, e in own.items() if k.startswith('backbone')])):.2e})")
+        assert e_out < 1e-4 and e_loss < 1e-5
         if cm:
-            assert rel_l2(out[1], torch.from_numpy(g["teacher"])) < 1e-3
-        for k, e in errs.items():
-            assert e < 1e-3, (k, e)
+            assert rel_l2(out[1], torch.from_numpy(g["teacher"])) < 1e-4
+        bb_med = float(np.median([e for k, e in own.items() if k.startswith("backbone")]))
+        for k, e in e64.items():
+            # a gradient's flip noise is a Poisson draw: a backbone parameter for which the oracle's fp32 run happened to
+            # draw (almost) none is held to the backbone's typical (median) floor
+            bound = 2 * max(own[k], bb_med) + 1e-4 if k.startswith("backbone") else 1e-4
+            assert e <= bound, (k, e, own[k], bb_med)
         return
     ref_out, ref_errs = reference_lowprec_yardstick(g, g, mode)
     w = assert_within_reference_lowprec(f"full {variant}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=3e-2)

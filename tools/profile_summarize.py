@@ -87,7 +87,9 @@ def main():
     if tr:
         agg = defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(tr)):
-            k = (r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            gs = int(r.get("Grid_Size") or int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
+            ws = int(r.get("Workgroup_Size") or int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+            k = (r["Kernel_Name"], gs, ws)
             agg[k][0] += 1
             agg[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         tot = sum(v[1] for v in agg.values())
