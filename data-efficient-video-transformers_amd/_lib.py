@@ -129,6 +129,7 @@ SIGNATURES = {
     "dvt_adamw_step_scaled": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_int, c_f,
                                       c_f, c_p, c_f, c_p, c_p]),
     "dvt_device_delay": (c_int, [C.c_uint64, c_p]),
+    "dvt_zero": (c_int, [c_p, C.c_size_t, c_p]),
     "dvt_dropout": (c_int, [c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_p]),
     "dvt_rng_advance": (c_int, [c_p, C.c_uint64, c_p]),
     "dvt_conv_weight_pack_dgrad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
@@ -158,6 +159,7 @@ SIGNATURES = {
     "dvt_comm_broadcast": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p]),
     "dvt_comm_destroy": (c_int, [c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
+    "dvt_adamw_step_fused": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_int, c_p]),
 }
 
 _lib: Optional[C.CDLL] = None

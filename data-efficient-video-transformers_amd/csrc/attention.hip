@@ -232,6 +232,159 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic_kernel(const AttnPar
   }
 }
 
+// ======================================================================= one query per (b, h), dh = 64
+// The last layer of a stack is read at row 0 only (src/models/vit.py:119-120, :126), so its attention has ONE query per
+// (sequence, head): a matrix-vector problem, bound by streaming K and V once (HBM), no MFMA.  One wave per (b, h): a
+// wave-instruction covers 8 keys x 8 lanes, a lane holds 8 of the 64 head channels (16-byte loads: eight whole 128-byte
+// key rows per instruction); the 64-channel dot products close over the 8 lanes of a key with three xor-shuffles.  The
+// scores pass through LDS (Lk floats per wave) between the score pass and the weighted V sum; U key groups are requested
+// before the first is consumed.
+constexpr int kQ1Unroll = 4;
+
+template <typename E>
+__global__ __launch_bounds__(256) void attn_fwd_q1_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t bh = (int64_t)blockIdx.x * 4 + wid;
+  if (bh >= (int64_t)p.B * p.H) return;
+  float* sc = lds_f + (size_t)wid * p.Lkp;
+  const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  const int g = lane >> 3, c = (lane & 7) * 8;
+  const E* q = (const E*)p.q + b * p.q_sb + h * p.q_sh + c;
+  const E* k = (const E*)p.k + b * p.k_sb + h * p.k_sh + c;
+  const E* v = (const E*)p.v + b * p.v_sb + h * p.v_sh + c;
+  float qv[8];
+  load8<E>(q, qv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qv[e] *= p.scale;
+  const int groups = (p.Lk + 7) >> 3;
+  float m = -INFINITY;
+  for (int i0 = 0; i0 < groups; i0 += kQ1Unroll) {
+    float kv[kQ1Unroll][8];
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      const int j = min((i0 + u) * 8 + g, p.Lk - 1);            // clamped: the surplus keys are dropped below
+      load8<E>(k + (int64_t)j * p.k_sl, kv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[u][e], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      const int j = (i0 + u) * 8 + g;
+      if (j < p.Lk) {
+        m = fmaxf(m, s);
+        if ((lane & 7) == 0) sc[j] = s;
+      }
+    }
+  }
+  m = wave_max(m);
+  wave_lds_sync();
+  float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i0 = 0; i0 < groups; i0 += kQ1Unroll) {
+    float vv[kQ1Unroll][8];
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      const int j = min((i0 + u) * 8 + g, p.Lk - 1);
+      load8<E>(v + (int64_t)j * p.v_sl, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      const int j = (i0 + u) * 8 + g;
+      const float pr = j < p.Lk ? __expf(sc[min(j, p.Lk - 1)] - m) : 0.f;
+      l += pr;                                                   // (the same value on the 8 lanes of a key)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pr, vv[u][e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (g == 0) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    store8<E>((E*)p.out + b * p.o_sb + h * p.o_sh + c, acc);
+    if (lane == 0) p.lse[bh] = m + __logf(l);
+  }
+}
+
+// backward of the same: dV_j = p_j dO, dS_j = p_j (dO . v_j - delta), dK_j = scale dS_j q, dq = scale sum_j dS_j k_j --
+// one pass over K and V, every dK / dV row written once (whole 128-byte rows), no atomics.
+template <typename E>
+__global__ __launch_bounds__(256) void attn_bwd_q1_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t bh = (int64_t)blockIdx.x * 4 + wid;
+  if (bh >= (int64_t)p.B * p.H) return;
+  const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  const int g = lane >> 3, c = (lane & 7) * 8;
+  const int64_t qoff = b * p.q_sb + h * p.q_sh + c, ooff = b * p.o_sb + h * p.o_sh + c;
+  const int64_t koff = b * p.k_sb + h * p.k_sh + c, voff = b * p.v_sb + h * p.v_sh + c;
+  float qv[8], gv[8], ov[8];
+  load8<E>((const E*)p.q + qoff, qv);
+  load8<E>((const E*)p.d_o + ooff, gv);
+  load8<E>((const E*)p.o + ooff, ov);
+  float delta = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) delta = fmaf(gv[e], ov[e], delta);
+  delta += __shfl_xor(delta, 1, 64);
+  delta += __shfl_xor(delta, 2, 64);
+  delta += __shfl_xor(delta, 4, 64);
+  const float lse = p.lse[bh];
+  const E* k = (const E*)p.k + koff;
+  const E* v = (const E*)p.v + voff;
+  E* dk = (E*)p.dk + koff;
+  E* dv = (E*)p.dv + voff;
+  float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int groups = (p.Lk + 7) >> 3;
+  for (int i0 = 0; i0 < groups; i0 += kQ1Unroll) {
+    float kv[kQ1Unroll][8], vv[kQ1Unroll][8];
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      const int j = min((i0 + u) * 8 + g, p.Lk - 1);
+      load8<E>(k + (int64_t)j * p.k_sl, kv[u]);
+      load8<E>(v + (int64_t)j * p.v_sl, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kQ1Unroll; ++u) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s = fmaf(qv[e], kv[u][e], s);
+        dp = fmaf(gv[e], vv[u][e], dp);
+      }
+      s += __shfl_xor(s, 1, 64);   dp += __shfl_xor(dp, 1, 64);
+      s += __shfl_xor(s, 2, 64);   dp += __shfl_xor(dp, 2, 64);
+      s += __shfl_xor(s, 4, 64);   dp += __shfl_xor(dp, 4, 64);
+      const int j = (i0 + u) * 8 + g;
+      if (j < p.Lk) {
+        const float pr = __expf(fmaf(s, p.scale, -lse));
+        const float ds = pr * (dp - delta) * p.scale;
+        float ok[8], ovv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ok[e] = ds * qv[e];
+          ovv[e] = pr * gv[e];
+          dq[e] = fmaf(ds, kv[u][e], dq[e]);
+        }
+        store8<E>(dk + (int64_t)j * p.k_sl, ok);
+        store8<E>(dv + (int64_t)j * p.v_sl, ovv);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] += __shfl_xor(dq[e], o, 64);
+  if (g == 0) store8<E>((E*)p.dq + qoff, dq);
+}
+
 // ======================================================================= MFMA bf16, dh = 64
 constexpr int DH = 64;
 constexpr int kRowBytes = DH * 2;  // 128
@@ -874,6 +1027,13 @@ bool mfma_fwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
          2 * p.Lkp * kRowBytes <= kMaxLds;
 }
 
+// one query per (b, h): the streaming matrix-vector kernels (LDS: Lk floats per wave)
+bool q1_ok(const dvt_attn_desc* d, const AttnParams& p) {
+  return p.Lq == 1 && d->dropout_p == 0.f && dvt_is_16bit(d->dtype) && d->dh == DH && strides_vec_ok(d) &&
+         dvt_aligned16(d->q) && dvt_aligned16(d->k) && dvt_aligned16(d->v) && dvt_aligned16(d->o) &&
+         (size_t)4 * p.Lkp * sizeof(float) <= (size_t)kMaxLds;
+}
+
 bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
   return mfma_fwd_ok(d, p) && dvt_aligned16(d->d_o) && dvt_aligned16(d->dq) && dvt_aligned16(d->dk) &&
          dvt_aligned16(d->dv) && 2 * p.Lqp * kRowBytes + 2 * p.Lqp * 4 <= kMaxLds;
@@ -924,6 +1084,16 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   if (rc) return rc;
   if (p.B == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (q1_ok(d, p)) {                             // one query per (b, h): the CLS-row form of a stack's last layer
+    const dim3 grid((unsigned)dvt_cdiv((int64_t)p.B * p.H, 4)), block(256);
+    const size_t lds = (size_t)4 * p.Lkp * sizeof(float);
+    DVT_DISPATCH_16BIT(d->dtype, E, {
+      set_lds(attn_fwd_q1_kernel<E>, lds);
+      hipLaunchKernelGGL((attn_fwd_q1_kernel<E>), grid, block, lds, st, p);
+    });
+    DVT_LAUNCH_CHECK("dvt_attention_fwd(q1)");
+    return DVT_OK;
+  }
   if (mfma_fwd_ok(d, p)) {
     const size_t lds_img = (size_t)2 * p.Lkp * kRowBytes;
     const int nkp = p.Lkp >> 5;
@@ -975,6 +1145,12 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   if (rc) return rc;
   if (p.B == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (q1_ok(d, p) && dvt_aligned16(d->d_o) && dvt_aligned16(d->dq) && dvt_aligned16(d->dk) && dvt_aligned16(d->dv)) {
+    const dim3 grid((unsigned)dvt_cdiv((int64_t)p.B * p.H, 4)), block(256);
+    DVT_DISPATCH_16BIT(d->dtype, E, hipLaunchKernelGGL((attn_bwd_q1_kernel<E>), grid, block, 0, st, p));
+    DVT_LAUNCH_CHECK("dvt_attention_bwd(q1)");
+    return DVT_OK;
+  }
   if (mfma_bwd_ok(d, p)) {
     DVT_REQUIRE(d->workspace, "dvt_attention_bwd: workspace (dvt_attention_bwd_workspace_bytes) required");
     p.delta = (float*)d->workspace;             // dq kernel -> dk/dv kernel

@@ -3,6 +3,7 @@
 // CLS row gather, losses, AdamW.  All are streaming kernels: 16-byte accesses
 // per lane, grid-stride over at most 256 CUs x 8 blocks.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -644,6 +645,71 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
 
 __global__ void inc_step_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
+// The flat-buffer step of the training loop in ONE launch: AdamW on four elements per thread (16-byte accesses), the
+// 16-bit mirror of the updated weights that the next step's GEMMs read (M = bf16 / f16; float: no mirror), and the step
+// counter: every block reads step_dev[0] before it takes a ticket in step_dev[1], the last ticket stores the increment.
+template <typename M>
+__global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                          float b1, float b2, float eps, float wd, int64_t* step_dev,
+                                                          const uint8_t* __restrict__ skip, M* __restrict__ mirror) {
+  const int64_t steps = step_dev[0];
+  const float t = (float)(steps + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1, decay = 1.0f - lr * wd;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t e = i << 2;
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + e);
+    if (!(skip && skip[e >> 6])) {                     // parameter without a gradient this step: untouched (torch: grad None)
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
+      f32x4 mv = *reinterpret_cast<const f32x4*>(m + e), vv = *reinterpret_cast<const f32x4*>(v + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pi = pv[k] * decay;
+        mv[k] = fmaf(b1, mv[k], (1.0f - b1) * gv[k]);
+        vv[k] = fmaf(b2, vv[k], (1.0f - b2) * gv[k] * gv[k]);
+        pi -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
+        pv[k] = pi;
+      }
+      *reinterpret_cast<f32x4*>(p + e) = pv;
+      *reinterpret_cast<f32x4*>(m + e) = mv;
+      *reinterpret_cast<f32x4*>(v + e) = vv;
+    }
+    if (!std::is_same<M, float>::value) {
+      typedef M m4 __attribute__((ext_vector_type(4)));
+      m4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (M)pv[k];
+      *reinterpret_cast<m4*>(mirror + e) = o;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // tail of a buffer whose length is not a multiple of 4
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    float pi = p[i];
+    if (!(skip && skip[i >> 6])) {
+      const float gi = g[i];
+      pi *= decay;
+      const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+      const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+      pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+      p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+    if (!std::is_same<M, float>::value) mirror[i] = (M)pi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // every thread of this block has read step_dev[0]; relaxed device-scope ticket: the last block publishes the increment
+    const unsigned long long ticket = __hip_atomic_fetch_add((unsigned long long*)(step_dev + 1), 1ull, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (unsigned long long)gridDim.x - 1) {
+      step_dev[0] = steps + 1;
+      step_dev[1] = 0;
+    }
+  }
+}
+
 // ---- dropout (nn.Dropout in training mode: frame_transformer.py:22,41-44; TPN.py:92,95; vit.py:23,25,43,104)
 // Counter-based Philox4x32-10: element i draws word (i & 3) of block (offset + i / 4) under the key (seed).  No mask
 // is stored: backward re-draws the same words.  state[0] = seed, state[1] = per-step base offset live on the device
@@ -1044,6 +1110,30 @@ int dvt_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
   hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, param, grad, state_sum,
                      n, clr, eps, weight_decay, skip64);
   DVT_LAUNCH_CHECK("dvt_adagrad_step");
+  return DVT_OK;
+}
+
+int dvt_adamw_step_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
+                         const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream) {
+  if (n == 0) return DVT_OK;
+  DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev2 && n >= 0, "dvt_adamw_step_fused: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(param) && dvt_aligned16(grad) && dvt_aligned16(exp_avg) && dvt_aligned16(exp_avg_sq),
+              "dvt_adamw_step_fused: buffers must be 16-byte aligned");
+  DVT_REQUIRE(!mirror || (dvt_is_16bit(mirror_dtype) && ((uintptr_t)mirror & 7u) == 0),
+              "dvt_adamw_step_fused: mirror must be bf16 / f16 and 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(grid_for((n >> 2) + 1)), block(256);
+  if (!mirror)
+    hipLaunchKernelGGL((adamw_fused_kernel<float>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, step_dev2, skip64, (float*)nullptr);
+  else if (mirror_dtype == DVT_BF16)
+    hipLaunchKernelGGL((adamw_fused_kernel<bf16>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, step_dev2, skip64, (bf16*)mirror);
+  else
+    hipLaunchKernelGGL((adamw_fused_kernel<f16>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, step_dev2, skip64, (f16*)mirror);
+  DVT_LAUNCH_CHECK("dvt_adamw_step_fused");
   return DVT_OK;
 }
 

@@ -60,6 +60,14 @@ int dvt_device_delay(uint64_t microseconds, dvt_stream_t stream) {
   return DVT_OK;
 }
 
+int dvt_zero(void* dst, size_t nbytes, dvt_stream_t stream) {
+  DVT_REQUIRE(dst || nbytes == 0, "dvt_zero: null pointer");
+  if (nbytes == 0) return DVT_OK;
+  const hipError_t e = hipMemsetAsync(dst, 0, nbytes, (hipStream_t)stream);
+  if (e != hipSuccess) return dvt_fail_hip(e, "dvt_zero");
+  return DVT_OK;
+}
+
 int dvt_version(void) { return DVT_ABI_VERSION; }
 
 const char* dvt_last_error(void) { return g_err; }

@@ -21,8 +21,8 @@ Design (MI355X-first, not a DDP clone):
     115 MB of fp32 gradients of the d=512 model) to amortise latency.
   * averaging is folded into the loss gradient (1/world), so the collective is a
     plain sum and no extra pass over the gradients exists.
-  * the optimizer step is one fused AdamW launch over the flat buffers, followed
-    by one cast launch that refreshes the bf16 compute copy of all weights.
+  * the optimizer step is one fused launch over the flat buffers: AdamW, the
+    16-bit compute copy of the updated weights, and the device step counter.
 """
 from __future__ import annotations
 
@@ -390,10 +390,13 @@ class FlatParameters:
             self.sync_compute_copy()
             self._after_step()
             return
-        # step counter lives on the device so the launch can be captured in a hipGraph
-        ops.adamw_step_dev_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
-                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, skip=self.skip_mask)
-        self.sync_compute_copy()
+        # one launch: the update, the 16-bit mirror of the new weights, the step counter (on the device, so that the launch
+        # can be captured in a hipGraph)
+        ops.adamw_step_fused_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, lr=lr,
+                              beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, skip=self.skip_mask,
+                              mirror=self.compute)
+        if self.compute is not None:
+            self.compute_valid = True
         self._after_step()
 
     def sgd_step(self, lr: float, momentum: float = 0.0, weight_decay: float = 0.0) -> None:
@@ -419,7 +422,7 @@ class FlatParameters:
     def init_optimizer_state(self) -> None:
         self.exp_avg = torch.zeros_like(self.data)
         self.exp_avg_sq = torch.zeros_like(self.data)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.data.device)
+        self.step_dev = torch.zeros(2, dtype=torch.int64, device=self.data.device)    # {steps taken, ticket of the fused step}
 
     # ------------------------------------------------------------------ checkpoint / resume of the optimizer side
     _STATE_TENSORS = ("exp_avg", "exp_avg_sq", "step_dev", "momentum_buf", "state_sum", "scale_dev", "good_steps")
@@ -444,10 +447,13 @@ class FlatParameters:
         for k in self._STATE_TENSORS:
             if k in sd:
                 cur = getattr(self, k, None)
+                src = sd[k].to(dev)
+                if k == "step_dev":                      # {steps, ticket}; older checkpoints hold the count alone
+                    src = torch.stack((src.reshape(-1)[0], torch.zeros((), dtype=torch.int64, device=dev)))
                 if cur is None:
-                    setattr(self, k, sd[k].to(dev).clone())
+                    setattr(self, k, src.clone())
                 else:
-                    cur.copy_(sd[k].to(dev))
+                    cur.copy_(src)
         if getattr(self, "scaler", None) is not None:
             self.loss_grad.copy_(self.scale_dev.reshape(()) * self.loss_scale)
         self.invalidate_compute_copy()

@@ -193,6 +193,30 @@ def add(a: Tensor, b: Tensor) -> Tensor:
     return _Add.apply(a, b)
 
 
+class _Fork(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (a residual block's input feeds the convolution path and the
+    shortcut, custom_resnet.py:38-54): the two incoming gradients are summed by ``dvt_add`` instead of autograd's own
+    accumulate kernel, so that no ATen kernel runs inside the step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view(x.shape), x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None or db is None:
+            return da if db is None else db
+        if da.dtype != db.dtype:
+            db = _as(db.contiguous(), da.dtype)
+        return ops.add(da.contiguous(), db.contiguous())
+
+
+def fork(x: Tensor):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return _Fork.apply(x)
+
+
 class _Cast(torch.autograd.Function):
     """Differentiable dtype change of an activation (grad cast back)."""
 
@@ -342,7 +366,7 @@ class _ClsNormConcat(torch.autograd.Function):
             dtok = None
         else:
             dtok = ops.rows_gather_bwd(dseq, drows, d, ctx.tok_shape is not None, B, T, d)
-        dx = torch.zeros_like(xc)   # rows other than CLS receive no gradient
+        dx = ops.zeros(xc.shape, xc.dtype, xc.device)   # rows other than CLS receive no gradient
         _, dg, db = _ln_bwd(drows, xc, g, mean, rstd, sg, sb, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
         if dtok is not None:
             dtok = dtok.view(ctx.tok_shape)
@@ -367,7 +391,7 @@ class _RowsSelect(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, Ln, d = ctx.shape
-        dx = torch.zeros((B, Ln, d), dtype=dy.dtype, device=dy.device)
+        dx = ops.zeros((B, Ln, d), dy.dtype, dy.device)
         ops.rows_gather_bwd(dy.contiguous().view(B, 1, d), dx, Ln * d, False, B, 1, d)
         return dx
 
@@ -934,7 +958,7 @@ class _SelectRow(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dx = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        dx = ops.zeros(ctx.shape, dy.dtype, dy.device)
         ops.copy_(dx[ctx.i], dy.contiguous())
         return dx, None
 
@@ -1232,7 +1256,7 @@ class _ConvBnAct(torch.autograd.Function):
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd)     # [N*H*W, Cin], no dcol / col2im
         if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
-            dx = torch.zeros(ctx.x_shape, dtype=ctx.x_dtype, device=dz.device).view(N, Cin, H, W)
+            dx = ops.zeros(ctx.x_shape, ctx.x_dtype, dz.device).view(N, Cin, H, W)
             hw = Ho * Wo
             for f0, cnt in ctx.dx_frames:                                # only the frames whose gradient is read
                 dcol = ops.linear_dgrad(dz[f0 * hw:(f0 + cnt) * hw], wp)

@@ -66,9 +66,10 @@ class _ResidualBlock(nn.Module):
         self.stride = stride
 
     def forward_nhwc(self, fm: FMap, dtype) -> FMap:
-        shortcut = fm[0]
+        x_main, shortcut = F.fork(fm[0])                       # two consumers: their gradients are summed by dvt_add
+        fm = (x_main,) + tuple(fm[1:])
         if self.downsample is not None:
-            shortcut = _cba(fm, self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
+            shortcut = _cba((shortcut,) + tuple(fm[1:]), self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
         out = fm
         for i in range(1, self.depth):
             out = _cba(out, getattr(self, f"conv{i}"), getattr(self, f"bn{i}"), True, dtype=dtype)
@@ -150,7 +151,12 @@ class ResNet(nn.Module):
             for blk in getattr(self, f"layer{i}"):
                 fm = blk.forward_nhwc(fm, dt)
             if i >= 2:
-                pyramid.append(fm)
+                if i < 4:                                       # x2 / x3 also feed the next stage
+                    keep, cont = F.fork(fm[0])
+                    pyramid.append((keep,) + tuple(fm[1:]))
+                    fm = (cont,) + tuple(fm[1:])
+                else:
+                    pyramid.append(fm)
         return pyramid
 
     def forward(self, x):

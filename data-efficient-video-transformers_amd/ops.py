@@ -96,6 +96,15 @@ def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def zeros(shape, dtype: torch.dtype, device) -> Tensor:
+    """A zero-filled tensor without an ATen fill kernel (hipMemsetAsync on the launch stream)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if not t.is_cuda:
+        raise RuntimeError("dvt_amd ops have no CPU path")
+    L.check(L.load().dvt_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "dvt_zero")
+    return t
+
+
 def add(a: Tensor, b: Tensor) -> Tensor:
     _need_cuda(a, b)
     assert a.shape == b.shape and a.dtype == b.dtype
@@ -755,6 +764,22 @@ def adamw_step_dev_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Te
                                         exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps,
                                         weight_decay, step_dev.data_ptr(), _skip(skip, param), _stream()),
             "dvt_adamw_step_dev")
+
+
+def adamw_step_fused_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step_dev2: Tensor, *,
+                      lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+                      skip: Optional[Tensor] = None, mirror: Optional[Tensor] = None) -> None:
+    """AdamW + the 16-bit weight mirror + the device step counter (int64[2]: steps, ticket) in one launch."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev2, mirror)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert step_dev2.dtype == torch.int64 and step_dev2.numel() == 2
+    if mirror is not None:
+        assert mirror.numel() == param.numel() and mirror.is_contiguous() and mirror.dtype in (torch.bfloat16, torch.float16)
+    L.check(L.load().dvt_adamw_step_fused(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                          param.numel(), lr, beta1, beta2, eps, weight_decay, step_dev2.data_ptr(),
+                                          _skip(skip, param), _p(mirror), _DT[mirror.dtype] if mirror is not None else 0,
+                                          _stream()), "dvt_adamw_step_fused")
 
 
 # ------------------------------------------------------------------ per-frame CNN encoder (csrc/conv.hip)

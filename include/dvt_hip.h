@@ -89,6 +89,9 @@ int dvt_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int
  * enqueue a whole step behind it and HIP-event brackets around individual launches then measure device time only
  * (bench.py's roofline pass). */
 int dvt_device_delay(uint64_t microseconds, dvt_stream_t stream);
+/* Asynchronous zero fill (a memset node inside a captured graph): the rows a gather's adjoint does not write --
+ * `x[:, 0]` at src/models/vit.py:120,126 has a zero gradient on every other row. */
+int dvt_zero(void* dst, size_t nbytes, dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- dropout
  * nn.Dropout(p) in training mode (frame_transformer.py:22,41-44 p = 0.5; TPN.py:92,95; vit.py:23,25,43,104):
@@ -490,6 +493,13 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_dev, const uint8_t* skip64, dvt_stream_t stream);
+/* The whole flat-buffer optimizer step of the training loop in one launch: the dvt_adamw_step_dev update, the 16-bit
+ * mirror of the updated weights that the next step's GEMMs read (mirror nullable; mirror_dtype DVT_BF16 / DVT_F16) and
+ * the step counter.  step_dev2: int64[2] = {steps already taken, 0}: element 1 is a ticket the launch uses to let its
+ * last workgroup store the increment (it is 0 again when the launch has finished). */
+int dvt_adamw_step_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
+                         const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream);
 /* AdamW under dynamic loss scaling (BASELINE configs[4]: fp16 + loss scaling; torch.cuda.amp.GradScaler rule).
  * grad holds the gradient of (scale * loss).  On the device, in stream order: found_inf |= any non-finite grad;
  * unless found_inf: the dvt_adamw_step_dev update with grad / scale and step_dev += 1; then

@@ -174,7 +174,7 @@ def test_flat_parameters_checkpoint_roundtrip():
     a = _model()
     fa = FlatParameters(a, compute_dtype=None)
     fa.init_optimizer_state()
-    fa.exp_avg.uniform_(-1, 1); fa.exp_avg_sq.uniform_(0, 1); fa.step_dev.fill_(7); fa.step_count = 7
+    fa.exp_avg.uniform_(-1, 1); fa.exp_avg_sq.uniform_(0, 1); fa.step_dev[0] = 7; fa.step_count = 7
     with torch.no_grad():
         fa.data.add_(0.25)
     b = _model()
@@ -184,7 +184,7 @@ def test_flat_parameters_checkpoint_roundtrip():
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):      # (alignment gaps of the flat buffer are not state)
         assert torch.equal(p, q), k
     assert torch.equal(fb.exp_avg, fa.exp_avg) and torch.equal(fb.exp_avg_sq, fa.exp_avg_sq)
-    assert int(fb.step_dev) == 7 and fb.step_count == 7
+    assert int(fb.step_dev[0]) == 7 and int(fb.step_dev[1]) == 0 and fb.step_count == 7
     bad = fa.state_dict(); bad["total"] = 1
     with pytest.raises(ValueError, match="layout"):
         fb.load_state_dict(bad)

@@ -629,6 +629,31 @@ def test_adamw_matches_torch(dvt, device):
         gr = torch.randn(1000, generator=g2)
         dvt.ops.adamw_step_dev_(p2, gr.cuda(), m2, v2, sd, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.09)
     assert int(sd) == 3 and rel_l2(p2, pr) < 1e-6
+    # the fused step of the training loop: update + 16-bit mirror + counter in one launch (also a length that is not a
+    # multiple of 4, a skip mask, and enough elements for many workgroups to take the ticket)
+    for n, dt in ((1000, torch.bfloat16), (1003, torch.float16), (300001, None)):
+        g3 = torch.Generator().manual_seed(14)
+        p0 = torch.randn(n, generator=g3)
+        pr3 = p0.clone().requires_grad_(True)
+        opt3 = torch.optim.AdamW([pr3], lr=5e-3, weight_decay=0.09)
+        p3, m3, v3 = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        sd2 = torch.zeros(2, dtype=torch.int64, device="cuda")
+        mirror = torch.empty(n, dtype=dt, device="cuda") if dt is not None else None
+        skip = torch.zeros((n + 63) // 64, dtype=torch.uint8)
+        skip[1] = 1                                      # elements 64..127: no gradient this run -> untouched
+        for step in range(3):
+            gr = torch.randn(n, generator=g3)
+            pr3.grad = gr.clone()
+            keep = pr3.detach()[64:128].clone()
+            opt3.step()
+            with torch.no_grad():
+                pr3[64:128] = keep
+            dvt.ops.adamw_step_fused_(p3, gr.cuda(), m3, v3, sd2, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                                      weight_decay=0.09, skip=skip.cuda(), mirror=mirror)
+        assert sd2.tolist() == [3, 0] and rel_l2(p3, pr3) < 1e-6
+        assert torch.equal(p3[64:128].cpu(), p0[64:128]) and float(m3[64:128].abs().max()) == 0.0
+        if mirror is not None:
+            assert torch.equal(mirror, p3.to(dt))
 
 
 @pytest.mark.parametrize("kind", ["sgd", "sgd_nomom", "adagrad", "adamW"])
@@ -692,7 +717,7 @@ def test_fp16_loss_scaling_skips_overflow_and_recovers(dvt, device):
     grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
     before = flat.data.clone()
     step(grads, overflow=True)
-    assert torch.equal(flat.data, before) and float(flat.scale_dev) == 512.0 and int(flat.step_dev) == 0
+    assert torch.equal(flat.data, before) and float(flat.scale_dev) == 512.0 and int(flat.step_dev[0]) == 0
     assert float(flat.loss_grad) == 512.0 and int(flat.found_inf) == 0
     for _ in range(2):
         grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
@@ -700,7 +725,7 @@ def test_fp16_loss_scaling_skips_overflow_and_recovers(dvt, device):
             p.grad = gr.clone()
         opt.step()
         step(grads)
-    assert int(flat.step_dev) == 2 and float(flat.scale_dev) == 1024.0          # grew after 2 clean steps
+    assert int(flat.step_dev[0]) == 2 and float(flat.scale_dev) == 1024.0          # grew after 2 clean steps
     for p, q in zip(lin.parameters(), ref.parameters()):
         assert rel_l2(p, q) < 1e-6
     w16 = lin.weight._dvt_compute
