@@ -184,7 +184,8 @@ def newest_pmc_traffic():
     WRITE_SIZE passes cannot run inside this process; tools/run_profiles.sh collects them with this same command)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")),
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+                    if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f))),
                    key=lambda f: int(re.search(r"r(\d+)_pmc_traffic", f).group(1)))
     if not files:
         return {}, None
@@ -325,6 +326,84 @@ def collective_capture_ok(comm):
         return False, f"{type(e).__name__}: {e}"[:200]
 
 
+def profile_pass(ops, step, ms_per_step, steps):
+    """A separate short pass with a HIP-event pair around every tagged launch (so that the records do not perturb the
+    headline timing).  The host needs longer to issue a step than the GPU to run it when every launch is bracketed; a
+    device-side delay in front of each profiled step lets the host run ahead, so the brackets see device time only.
+    -> ({key: (ms, units, launches)}, profiled steps, bracket overhead in us)."""
+    prof = EventProfiler()
+    ops.set_profiler(prof)
+    nprof = max(1, min(3, steps))
+    host_ms = max(20.0, 4.0 * ms_per_step)
+    ops.device_delay(20000)
+    bracket_us = prof.calibrate(lambda: ops.device_delay(0)) * 1e3
+    for _ in range(nprof):
+        for _ in range(int(host_ms // 200) + 1):
+            ops.device_delay(int(min(host_ms, 200.0) * 1000))
+        step()
+    torch.cuda.synchronize()
+    ops.set_profiler(None)
+    return prof.summary(), nprof, bracket_us
+
+
+def cnn_roofline(summ, nprof, workload):
+    """Roofline of the per-frame CNN encoder's kernels inside a secondary workload (custom_resnet.py:19-22,100-109): the
+    convolution families against the dense bf16 MFMA peak (algorithmic FLOPs 2 * pixels * Cout * kh * kw * Cin), the
+    BatchNorm passes against the HBM peak (algorithmic bytes: every operand / result once per pass), and -- from the
+    committed PMC profile of the same workload -- HBM bytes per launch against the algorithmic bytes."""
+    fams = {}
+    for key, (ms, fl, cnt) in summ.items():
+        if key[0] != "conv":
+            continue
+        _, kind, M, N, K, nbytes = key
+        if kind == "wgrad":                # key = (.., K_out = kh*kw*Cin, Cout, rows): class by output channels
+            name = f"implicit weight gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'} (split-K incl. reduce)"
+        elif kind == "halo3x3_c64":
+            name = "conv3x3_c64 (LDS halo patch; forward and data gradient of layer 1)"
+        else:
+            name = f"implicit forward / data gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'}"
+        f = fams.setdefault(name, [0.0, 0.0, 0, 0.0, kind])
+        f[0] += ms; f[1] += fl; f[2] += cnt; f[3] += float(nbytes) * cnt
+    pmc = {}
+    pfile = None
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_traffic.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if files:
+        try:
+            with open(files[-1]) as fh:
+                pmc, pfile = json.load(fh)["families"], os.path.relpath(files[-1], ROOT)
+        except Exception:
+            pmc = {}
+    pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64"}
+    out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
+           "traffic_source": pfile}
+    for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
+        tf = fl / (ms * 1e-3) / 1e12
+        traffic = (pmc.get(pmc_key[kind], {}) or {}).get("hbm_bytes_corrected")
+        alg_kind = sum(v[3] for v in fams.values() if v[4] == kind) / max(1, sum(v[2] for v in fams.values() if v[4] == kind))
+        out["conv_families"][name] = {"ms_per_step": round(ms / nprof, 3), "launches_per_step": cnt // nprof,
+                                      "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                                      "algorithmic_MB_per_launch": round(nb / cnt / 1e6, 1),
+                                      "traffic_ratio": round(traffic / alg_kind, 3) if traffic else None}
+    agg = {}
+    for key, (ms, units, cnt) in summ.items():
+        if key[0] == "hbm" and key[1].startswith("bn_"):
+            a = agg.setdefault(key[1], [0.0, 0.0, 0])
+            a[0] += ms; a[1] += units; a[2] += cnt
+    for name, (ms, units, cnt) in agg.items():
+        out["hbm_kernels"][name] = {"ms_per_step": round(ms / nprof, 3), "launches_per_step": cnt // nprof,
+                                    "algorithmic_GBps": round(units / (ms * 1e-3) / 1e9, 1),
+                                    "frac_of_hbm_peak": round(units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+    if fams:
+        dom = max(fams.values(), key=lambda v: v[0])
+        out["achieved"] = round(dom[1] / (dom[0] * 1e-3) / 1e12, 1)
+        out["frac"] = round(out["achieved"] / MFMA_PEAK_TFLOPS, 4)
+        out["kernel"] = [k for k, v in fams.items() if v is dom][0]
+    return out
+
+
 def rebuild_communicator(comm):
     """A capture that failed inside a collective leaves the communicator and its side stream in an undefined state."""
     from dvt_amd.dp import Communicator
@@ -455,22 +534,11 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
     roof = None
-    if roofline:
-        prof = EventProfiler()
-        ops.set_profiler(prof)
-        nprof = max(1, min(3, steps))
-        # The host needs longer to issue a step than the GPU to run it when every launch is bracketed by events; a
-        # device-side delay in front of each profiled step lets the host run ahead, so the brackets see device time only.
-        host_ms = max(20.0, 4.0 * elapsed / steps * 1e3)
-        ops.device_delay(20000)
-        bracket_us = prof.calibrate(lambda: ops.device_delay(0)) * 1e3
-        for _ in range(nprof):
-            for _ in range(int(host_ms // 200) + 1):
-                ops.device_delay(int(min(host_ms, 200.0) * 1000))
-            step()
-        torch.cuda.synchronize()
-        ops.set_profiler(None)
-        summ = prof.summary()
+    if roofline and workload in ("pyramid", "crossmodal"):      # the per-frame CNN encoder's kernels
+        summ, nprof, _ = profile_pass(ops, step, elapsed / steps * 1e3, steps)
+        roof = cnn_roofline(summ, nprof, "pyramid")
+    elif roofline:
+        summ, nprof, bracket_us = profile_pass(ops, step, elapsed / steps * 1e3, steps)
         fam, hbm, big = {}, {}, {}
         for key in summ:                       # per kernel: its largest launch shape (the space-transformer one)
             if key[0] == "hbm" and (key[1] not in big or key[2] > big[key[1]][2]):
@@ -726,9 +794,10 @@ def main():
         for wl in ("pyramid", "crossmodal", "longclip"):
             release_gpu_memory()
             try:
-                r = run_workload(args, wl, rank, world, False, None, steps=3, warmup=1, roofline=False, secondary=True)
+                r = run_workload(args, wl, rank, world, False, None, steps=3, warmup=1,
+                                 roofline=wl == "pyramid" and not args.no_roofline, secondary=True)
                 sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "launch", "peak_hbm_GiB",
-                                             "final_loss")}
+                                             "final_loss", "roofline") if k in r}
                 sec[wl]["workload"] = r["config"]["workload"]
             except Exception as e:   # a secondary line must never take the headline down with it
                 sec[wl] = {"error": f"{type(e).__name__}: {e}"[:300]}

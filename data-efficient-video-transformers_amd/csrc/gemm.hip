@@ -672,15 +672,28 @@ extern "C" {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// The ONE routing decision, shared by dvt_gemm_workspace_bytes and dvt_gemm, so that the size reported is the size used:
+// SMALL = panel-streaming kernel (no workspace), MFMA = LDS-DMA / register-staged kernels under `pl`, GENERIC = fp32 FMA.
+enum GemmRouteKind { ROUTE_SMALL, ROUTE_MFMA, ROUTE_GENERIC };
+struct GemmRoute { GemmRouteKind kind; GemmPlan pl; };
+static GemmRoute route_gemm(const dvt_gemm_desc* d) {
+  GemmRoute r{ROUTE_GENERIC, GemmPlan{}};
+  if (!(mfma_eligible(d) && d->K > 0)) return r;
+  if (small_regime(d)) { r.kind = ROUTE_SMALL; return r; }
+  r.kind = ROUTE_MFMA;
+  r.pl = plan_gemm(d);
+  return r;
+}
+
 // workspace = [split-K slabs][bias-gradient slabs or stand-alone colsum scratch]
 // The fused bias gradient writes one row of M floats per K slice (gemm256.hip: colsum_slab[slice * M + m]); the planner
 // allows up to 256 slices, so the scratch is sized from the plan, never from a fixed slice bound.
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
   if (!d) return 0;
-  const bool mfma = mfma_eligible(d) && d->K > 0;
-  if (mfma && small_regime(d)) return 0;          // no slabs, the bias gradient comes out of the same launch
-  GemmPlan pl{};
-  if (mfma) pl = plan_gemm(d);
+  const GemmRoute route = route_gemm(d);
+  if (route.kind == ROUTE_SMALL) return 0;        // no slabs, the bias gradient comes out of the same launch
+  const bool mfma = route.kind == ROUTE_MFMA;
+  const GemmPlan pl = route.pl;
   size_t cs = 0;
   if (d->colsum_out) {
     const size_t fused = mfma ? (size_t)(pl.split > 1 ? pl.split : 1) * (size_t)d->M * sizeof(float) : 0;
@@ -699,7 +712,8 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DVT_REQUIRE(!d->colsum_out || !d->a_kmajor, "dvt_gemm: colsum_out needs an mn-major A");
 
-  if (mfma_eligible(d) && d->K > 0 && small_regime(d)) {
+  const GemmRoute route = route_gemm(d);
+  if (route.kind == ROUTE_SMALL) {
     GemmParams p{};
     p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
     p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
@@ -709,11 +723,13 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     p.alpha = d->alpha; p.elem = d->in_dtype; p.k_per_split = (int)d->K; p.slab = nullptr;
     p.colsum_slab = d->colsum_out; p.accumulate_colsum = d->colsum_accumulate;
     rc = dvt_gemm_small_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, st);
-    if (rc <= 0) return rc;                       // launched (or failed); 1 = no instantiation: fall through
+    if (rc == 1)        // cannot happen: small_regime() asks the same dvt_gemm_small_tile() the launcher dispatches on
+      return dvt_fail(DVT_ERR_UNSUPPORTED, "dvt_gemm: the panel-streaming kernel has no instantiation for a shape its planner accepted");
+    return rc;
   }
   DVT_REQUIRE(!d->colsum_out || d->workspace, "dvt_gemm: colsum_out needs a workspace (dvt_gemm_workspace_bytes)");
-  if (mfma_eligible(d) && d->K > 0) {
-    GemmPlan pl = plan_gemm(d);
+  if (route.kind == ROUTE_MFMA) {
+    GemmPlan pl = route.pl;
     if (pl.split > 1 && !d->workspace) {   // no scratch: fall back to an unsplit 128x128 launch
       pl.use256 = false;
       pl.split = 1;
@@ -855,6 +871,8 @@ static bool conv_implicit_ok(const dvt_conv_desc* d) {
   // C % k-tile == 0 (a k-tile inside one filter tap), or C == 8: the stem, its 3 channels zero-extended to one 16-byte
   // chunk per (pixel, tap) by dvt_nchw_to_nhwc_pad
   if ((d->C % tk && d->C != 8) || d->Cout % 8) return false;
+  // the C == 8 gather derives a lane's tap by a 16-bit multiply-shift division (ConvRows::dma): exact for these bounds only
+  if (d->C == 8 && !((int64_t)d->kh * d->kw < 1024 && d->kw < 64)) return false;
   int64_t Ho, Wo;
   conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0) return false;

@@ -24,9 +24,6 @@
 #include "gemm_common.h"
 #include <cstdlib>
 
-#ifndef DVT_ABL
-#define DVT_ABL 0   // dev ablations (tools/gemm_bench.hip); 0 = product kernel
-#endif
 // Translation units of this file: 0 (gemm256.hip itself) = configurations 0, 1, 3, 4 and every entry point; 1
 // (gemm256_pp.hip includes this file) = the antiphase configuration 5 alone.  Instantiated beside the others it changed
 // THEIR register allocation (spills in the 16-wave and implicit weight-gradient kernels), so it gets its own module.
@@ -238,8 +235,6 @@ __device__ __forceinline__ typename Elem16<E>::v8 frag(const char* tile, int bas
   }
 }
 
-__device__ __forceinline__ bool v_dummy(const GemmParams& p) { return p.M < 0; }  // ablation 3: never true
-
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave complete in order; only the compiler must not reorder
   // across this point.  (A wavefront-scope fence would also emit s_waitcnt vmcnt(0)
@@ -256,14 +251,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-
-#ifdef DVT_GEMM_TIMING
-// dev instrumentation (tools/gemm_timing.sh): per-workgroup s_memtime stamps {start, prologue issued, main loop done, end}
-__device__ long long* g_gemm_tb = nullptr;
-#define DVT_GSTAMP(i) if (threadIdx.x == 0 && g_gemm_tb) g_gemm_tb[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (i)] = __builtin_amdgcn_s_memtime()
-#else
-#define DVT_GSTAMP(i)
-#endif
 
 #ifndef DVT_GEMM_NT
 #define DVT_GEMM_NT 1
@@ -316,9 +303,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   const int n0 = (tile % p.tiles_n) * TN;
   const int kbeg = zsl * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (DVT_ABL == 5 || DVT_ABL == 6) ? 0 : (kend - kbeg) / TK;   // ablations 5/6: epilogue only
+  const int nk = (kend - kbeg) / TK;
 
-  DVT_GSTAMP(0);
   f32x4 acc[4][MT];  // [u: n sub-tile][t: m sub-tile]
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -360,7 +346,6 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + kt * TK, st + kATile, wid, lane);
     };
     if (nk > 0) issue(0);
-    DVT_GSTAMP(1);
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     V8 fa[MT], fb[4];
@@ -429,15 +414,11 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
       dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
     }
-  DVT_GSTAMP(1);
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
-  constexpr int NB = DVT_ABL == 1 ? 0 : NTH * (TK / 32);
+  constexpr int NB = NTH * (TK / 32);
   constexpr bool kPipe = NW <= 8;                // 16 waves (4 per SIMD, 128 VGPRs) hide the read latency by occupancy instead
   V8 bfr[kPipe ? 2 : 1][4], af[kPipe ? 2 : 1][4];
   for (int kt = 0; kt < nko; ++kt) {
-#ifdef DVT_GEMM_TIMING
-    const long long tw0 = __builtin_amdgcn_s_memtime();
-#endif
     // (1) this wave's pieces of k-tile kt have landed (younger k-tiles may stay in flight)
     {
       const int issued = min(nko - 1, kt + NSTG - 2);                 // youngest k-tile in flight
@@ -447,19 +428,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     }
     // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
     //     stage that the DMA below overwrites (it was consumed in iteration kt-1)
-#ifdef DVT_GEMM_TIMING
-    const long long tw1 = __builtin_amdgcn_s_memtime();
-#endif
     __builtin_amdgcn_s_barrier();
-#ifdef DVT_GEMM_TIMING
-    if (threadIdx.x == 0 && g_gemm_tb) {
-      const long long tw2 = __builtin_amdgcn_s_memtime();
-      long long* w = g_gemm_tb + (1 << 19) + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 2;
-      if (kt == 0) { w[0] = 0; w[1] = 0; }
-      w[0] += tw1 - tw0;
-      w[1] += tw2 - tw1;
-    }
-#endif
     const char* sa = smem + st_cur * kStage;
     const char* sb = sa + kATile;
     // Software-pipelined over the 2 * TK/32 blocks of 16 MFMAs (block = one 32-deep k-slice x one 64-row half of the
@@ -473,7 +442,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     }
     // the next k-tile's DMA is issued behind the first fragment reads: its address arithmetic runs under their latency
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + NSTG - 1 < nko && DVT_ABL != 2) {
+    if (kt + NSTG - 1 < nko) {
       const int k0 = kbeg + (kt + NSTG - 1) * TK;
       if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
       else if (A_CONV) cvm.dma(p, smem + st_nxt * kStage, wid);
@@ -522,7 +491,6 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     st_nxt = st_nxt + 1 == NSTG ? 0 : st_nxt + 1;
   }
   if (!C::PP) __builtin_amdgcn_s_barrier();    // all LDS reads done before the staging overlay
-  DVT_GSTAMP(2);
   if (kCanColsum && do_cs && g == 0) {         // every row of the ones-product is the column sum: take row 0
 #pragma unroll
     for (int tt = 0; tt < CS; ++tt) {
@@ -593,7 +561,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     for (int j = 0; j < 4; ++j) {
       const int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
       const bool mine = WROWS % 32 == 0 || ps * 32 + (lane >> 3) + 8 * j < WROWS;   // rows past the wave's 112 are the next wave row's
-      if (mine && m < p.M && n_ok && (DVT_ABL != 3 || v_dummy(p))) {
+      if (mine && m < p.M && n_ok) {
         if (OUT == OUT_SLAB) {
           store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);   // re-read from cache by the reduce: streaming stores cost 10 %
         } else if (OUT == OUT_F32) {
@@ -622,12 +590,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             }
           }
           if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
-          if (DVT_ABL == 6) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(v[j][k]));
-          } else {
-            DVT_C_STORE((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
-          }
+          DVT_C_STORE((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
         }
       }
     }
@@ -648,14 +611,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       store8<float>(p.bn_partial + ((int64_t)part * 2 + 1) * p.N + n, bsq);
     }
   }
-  DVT_GSTAMP(3);
 }
 
-#ifdef DVT_GEMM_TIMING
-extern "C" int dvt_debug_gemm_timing_buffer(void* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tb), &buf, sizeof(buf));
-}
-#endif
 
 // ---------------------------------------------------------------- host side
 // dynamic LDS of a configuration: the stage ring, or the epilogue staging that overlays it

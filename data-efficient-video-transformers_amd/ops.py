@@ -908,7 +908,7 @@ def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool 
     if want_stats:
         parts = int(lib.dvt_conv3x3_c64_stats_parts(N, H, W))
         partial = workspace((parts + 64) * 2 * 64 * 4, x.device, slot="bn_partial")
-    with _timed(("gemm", 1, 1, N * H * W, 64, 576, 0, (2 * x.numel() + wp.numel()) * x.element_size()), 2.0 * N * H * W * 64 * 576):
+    with _timed(("conv", "halo3x3_c64", N * H * W, 64, 576, (2 * x.numel() + wp.numel()) * x.element_size()), 2.0 * N * H * W * 64 * 576):
         L.check(lib.dvt_conv3x3_c64(x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(partial), N, H, W, dt(x), _stream()),
                 "dvt_conv3x3_c64")
     return (y, partial, parts) if want_stats else y
@@ -932,7 +932,7 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
     nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
-    with _timed(("gemm", 1, 1, N * Ho * Wo, Cout, kh * kw * Cc, 0, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
+    with _timed(("conv", "implicit", N * Ho * Wo, Cout, kh * kw * Cc, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
     return (y, partial, parts) if want_stats else y
 
@@ -968,7 +968,7 @@ def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int
     d.workspace = _p(ws)
     rows = dz.shape[0]
     nb = (x.numel() + dz.numel()) * x.element_size() + out.numel() * out.element_size()
-    with _timed(("gemm", 0, 0, kh * kw * Cc, Cout, rows, 0, nb), 2.0 * rows * Cout * kh * kw * Cc):
+    with _timed(("conv", "wgrad", kh * kw * Cc, Cout, rows, nb), 2.0 * rows * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit_wgrad(C.byref(d), _stream()), "dvt_conv2d_implicit_wgrad")
     return out
 
@@ -1045,8 +1045,9 @@ def bn_stats(z: Tensor, running_mean: Optional[Tensor], running_var: Optional[Te
     invstd = torch.empty((Cc,), dtype=torch.float32, device=z.device)
     lib = L.load()
     ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
-    L.check(lib.dvt_bn_stats(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
-                             ws.data_ptr(), rows, Cc, eps, momentum, dt(z), _stream()), "dvt_bn_stats")
+    with _timed(("hbm", "bn_stats", rows * Cc), z.numel() * z.element_size()):
+        L.check(lib.dvt_bn_stats(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
+                                 ws.data_ptr(), rows, Cc, eps, momentum, dt(z), _stream()), "dvt_bn_stats")
     return mean, invstd
 
 
@@ -1061,9 +1062,10 @@ def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: T
                  relu: bool) -> Tensor:
     rows, Cc = z.shape
     y = torch.empty_like(z)
-    L.check(L.load().dvt_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                      beta.data_ptr(), _p(residual), y.data_ptr(), rows, Cc, int(relu), dt(z),
-                                      _stream()), "dvt_bn_apply_fwd")
+    with _timed(("hbm", "bn_apply_fwd", rows * Cc), z.numel() * z.element_size() * (2 + (residual is not None))):
+        L.check(L.load().dvt_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), _p(residual), y.data_ptr(), rows, Cc, int(relu), dt(z),
+                                          _stream()), "dvt_bn_apply_fwd")
     return y
 
 
@@ -1080,9 +1082,13 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
         dbeta = torch.empty((Cc,), dtype=torch.float32, device=z.device)
     lib = L.load()
     ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
-    L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                           _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
-                           int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
+    # train-mode BatchNorm backward is two passes by construction (the sums over the batch, then the input gradient):
+    # each reads dy and z (and y for a ReLU mask that cannot be recomputed), the second writes dz (and the shortcut's gradient)
+    nb = z.numel() * z.element_size() * (2 * (2 + (y is not None)) + 1 + int(want_dres))
+    with _timed(("hbm", "bn_bwd", rows * Cc), nb):
+        L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                               _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
+                               int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
     return dz, dres, dgamma, dbeta
 
 

@@ -339,7 +339,7 @@ int dvt_im2col(const void* x, int x_dtype, int x_nchw, void* out, int out_dtype,
  * the channels C .. Cpad-1 zero.  Cpad = 8: one 16-byte chunk per pixel (C <= 8).  Cpad = 4 (C <= 4, W even): one chunk per
  * pair of horizontally adjacent pixels, i.e. the [N, H, W/2, 8] view in which a stride-2 stem (custom_resnet.py:100,
  * frame_transformer.py:67) is a stride-(sh, 1) convolution over pixel pairs with the weights of dvt_conv_weight_pairs --
- * 35 instead of 49 gathered chunks per output pixel and half the zero padding of the C = 8 form. */
+ * 28 instead of 49 gathered chunks per output pixel (7 rows x 4 pixel pairs) and half the zero padding of the C = 8 form. */
 int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64_t N, int C, int H, int W, int Cpad,
                          dvt_stream_t stream);
 /* Stem weights for the pixel-pair view: w[Cout, Cin <= 4, kh, kw] f32 -> wp[Cout, 8, kh, kwp] f32 with
@@ -489,7 +489,11 @@ int dvt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * buffer; blocks whose byte is non-zero are left untouched -- parameter, moments and all.  torch's optimizers skip
  * parameters whose .grad is None (frame_transformer.py:123-134 hands every parameter to the optimizer, and the frozen
  * image encoder :59 / unused members never get a gradient): without the mask a flat-buffer step would still weight-
- * decay them. */
+ * decay them.
+ * The bias correction uses the ONE step counter of the flat buffer, where torch keeps a counter per parameter: the two
+ * agree when the set of masked (gradient-less) parameters is the same in every step of a run -- a frozen encoder, an
+ * unused member --, which is what the path's models do; a parameter that receives a gradient only in some steps would
+ * see a larger step number here than under torch.optim.AdamW (same for dvt_adagrad_step's decayed learning rate). */
 int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t* step_dev, const uint8_t* skip64, dvt_stream_t stream);

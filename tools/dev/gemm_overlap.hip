@@ -1,6 +1,6 @@
 // Dev probe: does a split-K weight-gradient launch on a second stream fill the partial last round of a
 // data-gradient launch?  Times A alone, B alone, and A||B on two streams.
-//   hipcc --offload-arch=gfx950 -O3 -DDVT_ABL=0 tools/dev/gemm_overlap.hip <csrc>/runtime.hip -o tools/_bin/gemm_overlap
+//   hipcc --offload-arch=gfx950 -O3 tools/dev/gemm_overlap.hip <csrc>/runtime.hip -o tools/_bin/gemm_overlap
 #include "../../data-efficient-video-transformers_amd/csrc/gemm256.hip"
 #include <vector>
 #include <string.h>

@@ -1,6 +1,6 @@
 // Dev probe: N = 512 launches (394 tiles of 256x256 = 1.54 rounds on 256 CUs).  A: one launch.  B: the first 128 row tiles
 // (one full round) as 256x256 tiles, the remaining 17,664 rows as 256x128 tiles (276 workgroups, two may share a CU).
-//   hipcc --offload-arch=gfx950 -O3 -DDVT_ABL=0 tools/dev/gemm_tailsplit.hip <csrc>/runtime.hip -o tools/_bin/gemm_tailsplit
+//   hipcc --offload-arch=gfx950 -O3 tools/dev/gemm_tailsplit.hip <csrc>/runtime.hip -o tools/_bin/gemm_tailsplit
 #include "../../data-efficient-video-transformers_amd/csrc/gemm256.hip"
 #include <vector>
 

@@ -1,6 +1,6 @@
 // Dev tool (not shipped): times gemm256_kernel variants on the metric shapes.
-//   hipcc --offload-arch=gfx950 -O3 -DDVT_ABL=<n> -I include tools/gemm_bench.hip <csrc>/gemm256_pp.hip <csrc>/runtime.hip -o gemm_bench
-// DVT_ABL: 0 full, 1 no MFMA/ds_read, 2 no DMA inside the loop, 3 no epilogue stores
+//   hipcc --offload-arch=gfx950 -O3 -I include tools/gemm_bench.hip <csrc>/gemm256_pp.hip <csrc>/runtime.hip -o gemm_bench
+// (the compile-time ablations 1..6 and the s_memtime stamps of rounds 1-2 were removed from the product source in round 3; they live in commit feba3d0)
 #include "../data-efficient-video-transformers_amd/csrc/gemm256.hip"
 #include <vector>
 #include <algorithm>
@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         t[c].push_back(ms * 1e3 / reps);
       }
-    printf("ABL=%d %-40s", DVT_ABL, s.name);
+    printf("%-40s", s.name);
     for (int c = 0; c < 4; ++c) {
       std::sort(t[c].begin(), t[c].end());
       const double us = t[c][t[c].size() / 2];

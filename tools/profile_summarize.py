@@ -47,6 +47,54 @@ def gemm_family(name):
     return "fwd" if (ak and bk) else "dgrad" if ak else "wgrad"
 
 
+def conv_family(name):
+    """Kernels of the per-frame CNN encoder: the implicit-GEMM convolution (gemm_dma_kernel with A_CONV = true: forward /
+    data gradient when A is k-major, weight gradient when both operands are mn-major) and the LDS-halo 3x3 kernel."""
+    if "conv3x3_c64_kernel" in name:
+        return "conv3x3_c64"
+    if "gemm_dma_kernel" not in name:
+        return None
+    m = re.search(r"gemm_dma_kernelIDF16[b_]Lb(\d)ELb(\d)ELi\d+ELi\d+ELi\d+ELb(\d)E", name)
+    if m:
+        ak, conv = m.group(1) == "1", m.group(3) == "1"
+    else:
+        m = re.search(r"E, (true|false), \d+, \d+, \d+, (true|false)>", name)
+        if not m:
+            return None
+        ak, conv = True, m.group(2) == "true"
+    if not conv:
+        return None
+    return "conv_implicit" if ak else "conv_wgrad"
+
+
+def traffic_tables(prof, sub_f, sub_w, outd, stem, title, family_of):
+    """FETCH_SIZE / WRITE_SIZE passes -> <stem>.md (per kernel and grid) and <stem>.json (per family)."""
+    fe, wr = load_counters(os.path.join(prof, sub_f)), load_counters(os.path.join(prof, sub_w))
+    if not (fe or wr):
+        return
+    keys = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe[k].get("FETCH_SIZE", 0) + wr[k].get("WRITE_SIZE", 0)))
+    fam = {}
+    with open(os.path.join(outd, stem + ".md"), "w") as fh:
+        fh.write(title + "| kernel | grid | launches | FETCH raw | WRITE | corrected 2F+W |\n|---|---|---|---|---|---|\n")
+        for k in keys[:48]:
+            n = max(fe[k].get("n", 0), wr[k].get("n", 0), 1)
+            f_mb = fe[k].get("FETCH_SIZE", 0) * KIB / n / 1e6      # rocprofv3 reports both counters in KiB
+            w_mb = wr[k].get("WRITE_SIZE", 0) * KIB / n / 1e6
+            fh.write(f"| `{short(k[0])}` | {k[1]} | {int(n)} | {f_mb:.1f} | {w_mb:.1f} | {2*f_mb+w_mb:.1f} |\n")
+        for k in keys:
+            n = max(fe[k].get("n", 0), wr[k].get("n", 0), 1)
+            f_mb = fe[k].get("FETCH_SIZE", 0) * KIB / n / 1e6
+            w_mb = wr[k].get("WRITE_SIZE", 0) * KIB / n / 1e6
+            famname = family_of(k[0])
+            if famname:
+                a = fam.setdefault(famname, [0.0, 0])
+                a[0] += (2 * f_mb + w_mb) * 1e6 * n
+                a[1] += n
+    json.dump({"families": {k: {"hbm_bytes_corrected": int(v[0] / max(v[1], 1)), "launches": int(v[1])} for k, v in fam.items()},
+               "note": "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE, averaged over the family's launches"},
+              open(os.path.join(outd, stem + ".json"), "w"), indent=1)
+
+
 def load_counters(d):
     """-> {(kernel, grid): {"n": launches, counter: sum}}"""
     f = find(d, "*counter_collection.csv")
@@ -114,29 +162,14 @@ def main():
                          f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
             fh.write(f"\nTotal kernel time {tot/4e6:.2f} ms/step.\n")
     # ---- traffic
-    fe, wr = load_counters(os.path.join(prof, "fetch")), load_counters(os.path.join(prof, "write"))
-    if fe or wr:
-        keys = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe[k].get("FETCH_SIZE", 0) + wr[k].get("WRITE_SIZE", 0)))
-        fam = {}
-        with open(os.path.join(outd, f"{tag}_pmc_traffic.md"), "w") as fh:
-            fh.write(f"# HBM traffic per launch from PMC counters ({tag})\n\nrocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-                     "(separate passes, --kernel-trace only), bench.py --steps 2 --warmup 1 --no-graph.  gfx950: FETCH_SIZE counts 64 B "
-                     "per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact.  FETCH_SIZE is counted at the L2 "
-                     "fabric side and includes Infinity-Cache hits (upper bound of HBM reads).  Values: MB per launch.\n\n"
-                     "| kernel | grid | launches | FETCH raw | WRITE | corrected 2F+W |\n|---|---|---|---|---|---|\n")
-            for k in keys[:40]:
-                n = max(fe[k].get("n", 0), wr[k].get("n", 0), 1)
-                f_mb = fe[k].get("FETCH_SIZE", 0) * KIB / n / 1e6      # rocprofv3 reports both counters in KiB
-                w_mb = wr[k].get("WRITE_SIZE", 0) * KIB / n / 1e6
-                fh.write(f"| `{short(k[0])}` | {k[1]} | {int(n)} | {f_mb:.1f} | {w_mb:.1f} | {2*f_mb+w_mb:.1f} |\n")
-                famname = gemm_family(k[0])
-                if famname:
-                    a = fam.setdefault(famname, [0.0, 0])
-                    a[0] += (2 * f_mb + w_mb) * 1e6 * n
-                    a[1] += n
-        json.dump({"families": {k: {"hbm_bytes_corrected": int(v[0] / max(v[1], 1)), "launches": int(v[1])} for k, v in fam.items()},
-                   "note": "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE, averaged over the family's launches"},
-                  open(os.path.join(outd, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {cmd}.  gfx950: FETCH_SIZE counts "
+            "64 B per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact.  FETCH_SIZE is counted at the L2 fabric side "
+            "and includes Infinity-Cache hits (upper bound of HBM reads).  Values: MB per launch.\n\n")
+    traffic_tables(prof, "fetch", "write", outd, f"{tag}_pmc_traffic", f"# HBM traffic per launch from PMC counters ({tag})\n\n"
+                   + note.format(cmd="bench.py --steps 2 --warmup 1 --no-graph"), gemm_family)
+    traffic_tables(prof, "fetch_pyramid", "write_pyramid", outd, f"{tag}_pyramid_pmc_traffic",
+                   f"# HBM traffic per launch from PMC counters, bench.py --workload pyramid ({tag})\n\n"
+                   + note.format(cmd="bench.py --workload pyramid --steps 1 --warmup 1 --no-graph"), conv_family)
     # ---- MFMA busy
     mf = load_counters(os.path.join(prof, "mfma"))
     if mf:
