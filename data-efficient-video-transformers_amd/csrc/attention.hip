@@ -62,6 +62,17 @@ struct AttnParams {
   uint64_t rng_off;
 };
 
+#ifdef DVT_ATTN_TIMING
+// dev build only (tools/attn_timing.sh): per-workgroup s_memtime stamps of the forward kernel, 8 slots per workgroup
+__device__ long long* g_attn_tb = nullptr;
+#define DVT_ASTAMP(i) do { if (threadIdx.x == 0 && g_attn_tb) g_attn_tb[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DVT_ASTAMP_ID() do { if (threadIdx.x == 0 && g_attn_tb) { g_attn_tb[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+                                                                  g_attn_tb[(int64_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#else
+#define DVT_ASTAMP(i)
+#define DVT_ASTAMP_ID()
+#endif
+
 // dropout multiplier of probability (b, h, i, j): 0 or 1 / (1 - p); 1 when dropout is off
 __device__ __forceinline__ float attn_drop(const AttnParams& p, int b, int h, int i, int j) {
   if (p.drop_thr == 0u) return 1.0f;
@@ -656,9 +667,12 @@ __global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel
     for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const V8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
   };
   V8 qf[2];
+  DVT_ASTAMP(0);
+  DVT_ASTAMP_ID();
   load_q(wid, qf);                                   // in flight while K / V are staged
   stage_images<E>(ks, kb, p.k_sl, vs, vb, p.v_sl, p.Lk, NKP * 32);
   __syncthreads();
+  DVT_ASTAMP(1);
 
   const float c2 = p.scale * kLog2e;
   char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
@@ -730,10 +744,19 @@ __global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel
     const int qi = qt * 16 + li;
     consume(qf[0]);
     consume(qf[1]);
+    if (qt == wid) DVT_ASTAMP(2);
     store_tile<E>(patch, ob, p.o_sl, qt * 16, p.Lq, o, inv, lane);
     if (qi < p.Lq && g == 0) lse[qi] = (mn + __builtin_amdgcn_logf(l)) * kLn2;
+    if (qt == wid) DVT_ASTAMP(3);
   }
+  DVT_ASTAMP(4);
 }
+
+#ifdef DVT_ATTN_TIMING
+extern "C" int dvt_debug_attn_timing_buffer(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tb), &buf, sizeof(buf));
+}
+#endif
 
 // ---------------------------------------------------------------- backward: dq
 // Query on the lane.  dQ^T[d][q] = scale * sum_key K[key][d] * (P (dP - delta))^T[key][q].

@@ -17,6 +17,15 @@
 // LDS is lane-linear for the DMA, so both swizzles sit on the per-lane SOURCE address and again on the fragment read.
 #include "gemm_common.h"
 
+#ifdef DVT_SMALL_TIMING
+// dev build only (tools/dev/small_gemm_timing.sh): per-workgroup s_memtime stamps, 8 slots per workgroup
+__device__ long long* g_small_tb = nullptr;
+#define DVT_SSTAMP(i) do { if (threadIdx.x == 0 && g_small_tb) g_small_tb[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dvt_debug_small_timing_buffer(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_small_tb), &buf, sizeof(buf)); }
+#else
+#define DVT_SSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int SK = 256;                      // k chunk
@@ -96,7 +105,23 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WNC, wn = wid % WNC;
   const int g = lane >> 4, li = lane & 15;
-  const int m0 = (blockIdx.x / p.tiles_n) * TM, n0 = (blockIdx.x % p.tiles_n) * STN;
+  // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the L2), so all row
+  // tiles of one column tile -- the readers of one 64-column weight panel -- go to one XCD: the panel is fetched from
+  // HBM into ONE L2 instead of into up to eight (the weights are cold at every launch of a training step; the
+  // activation panels, 264 rows in all, are the ones every XCD re-reads).  Placement is a speed matter only.
+  int rt, ct;
+  {
+    const int bid = blockIdx.x, tiles_m = gridDim.x / p.tiles_n;
+    if ((p.tiles_n & 7) == 0) {
+      const int j = bid >> 3;
+      ct = (bid & 7) + 8 * (j / tiles_m);
+      rt = j % tiles_m;
+    } else {
+      rt = bid / p.tiles_n;
+      ct = bid % p.tiles_n;
+    }
+  }
+  const int m0 = rt * TM, n0 = ct * STN;
   // Weight-gradient form with K <= 512 (the temporal encoder: K = 264 rows): ONE chunk of K rounded up to 32 rows --
   // two 256-row chunks would spend half their DMA instructions and MFMA steps on zero rows.
   const int ck = (!A_KMAJOR && !B_KMAJOR && p.K <= 512) ? ((p.K + 31) & ~31) : SK;
@@ -114,8 +139,36 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     dma_chunk<A_KMAJOR, TM>(p.A, p.lda, m0, p.M, ch * ck, p.K, st, wid, lane, ck);
     dma_chunk<B_KMAJOR, STN>(p.B, p.ldb, n0, p.N, ch * ck, p.K, st + boff, wid, lane, ck);
   };
+  DVT_SSTAMP(0);
+  // Epilogue operands (bias, residual / activation-derivative operand, the old value under accumulate) are requested
+  // FIRST -- clamped addresses, no branches -- so that their round trip runs under the panel DMA instead of behind the
+  // main loop (the epilogue was 2.9 k of the kernel's 10.7 k ticks, nearly all of it these dependent loads); being the
+  // oldest vector-memory operations they do not disturb the counted waits of the DMA pipeline.
+  typedef typename Elem16<E>::v4 V4;
+  const bool want_ld = p.epilogue == DVT_EPI_RESIDUAL || p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU;
+  const bool want_old = p.out_f32 && p.accumulate;
+  f32x4 pre_bias[NU], pre_old[2][NU];
+  V4 pre_ld[2][NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int n = min(n0 + wn * WCOLS + u * 16 + 4 * g, p.N - 4);
+    pre_bias[u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int m = min(m0 + wm * 32 + t * 16 + li, p.M - 1);
+      pre_ld[t][u] = V4{0, 0, 0, 0};
+      pre_old[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (want_ld) {
+        const E* src = p.epilogue == DVT_EPI_RESIDUAL ? (const E*)p.residual + (int64_t)m * p.ldr + n
+                                                      : (const E*)p.aux + (int64_t)m * p.ldaux + n;
+        pre_ld[t][u] = *reinterpret_cast<const V4*>(src);
+      }
+      if (want_old) pre_old[t][u] = *reinterpret_cast<const f32x4*>((const float*)p.C + (int64_t)m * p.ldc + n);
+    }
+  }
   issue(0);
   if (nch > 1) issue(1);
+  DVT_SSTAMP(1);
 
   // fused bias gradient (weight-gradient form): colsum[m] = sum_k A(m, k) for the tiles of the first tile column
   const bool do_cs = !A_KMAJOR && p.colsum_slab != nullptr && n0 == 0;
@@ -124,10 +177,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) swait_vm<kPPC>(); else swait_vm<0>();   // chunk ch landed (ch + 1 may stay in flight; then ck == SK)
     __builtin_amdgcn_s_barrier();
+    if (ch == 0) DVT_SSTAMP(2);
     const char* sa = smem + (ch & 1) * kStage;
     const char* sb = sa + boff;
-#pragma unroll 4
-    for (int kk = 0; kk < ck / 32; ++kk) {
+    auto kstep = [&](int kk) {
       V8 af[2], bfr[NU];
 #pragma unroll
       for (int t = 0; t < 2; ++t) af[t] = sfrag<E, A_KMAJOR>(sa, wm * 32 + t * 16, kk, g, li);
@@ -137,6 +190,13 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[u][t] = Elem16<E>::mma(bfr[u], af[t], acc[u][t]);
+    };
+    if (ck == SK) {                                        // the common 256-deep chunk: straight-line code, the fragment
+#pragma unroll                                             // reads of later steps are issued under the MFMAs of earlier ones
+      for (int kk = 0; kk < SK / 32; ++kk) kstep(kk);
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < ck / 32; ++kk) kstep(kk);
     }
     if (do_cs && tid < TM) {                               // thread = one column m of the [k][64] image
 #pragma unroll 8
@@ -153,52 +213,66 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     *o = p.accumulate_colsum ? *o + cs : cs;
   }
 
-  // ---- epilogue on the accumulators: lane (g, li) holds C[row = .. + li][col = .. + 4g .. 4g+3]
+  DVT_SSTAMP(3);
+  // ---- epilogue on the accumulators: lane (g, li) holds C[row = .. + li][col = .. + 4g .. 4g+3].
+  // ONE switch over the epilogue kind with the element loops inside it: the per-element form (a runtime switch around
+  // every value) compiled to a scalar branch chain per element -- 2.4 k of the kernel's 10 k ticks at eight elements.
+  float v[2][NU][4], pre[2][NU][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[t][u][r] = acc[u][t][r] * p.alpha;
+        pre[t][u][r] = 0.f;
+      }
+#define DVT_SMALL_EPI(EXPR)                                  \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t)              \
+  _Pragma("unroll") for (int u = 0; u < NU; ++u)             \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {            \
+    const float bi = pre_bias[u][r], ld = (float)pre_ld[t][u][r]; \
+    float& x = v[t][u][r];                                   \
+    (void)bi; (void)ld;                                      \
+    EXPR;                                                    \
+  }
+  switch (p.epilogue) {
+    case DVT_EPI_GELU: DVT_SMALL_EPI(pre[t][u][r] = x + bi; x = gelu_erf_f(pre[t][u][r])) break;
+    case DVT_EPI_RELU: DVT_SMALL_EPI(x = fmaxf(x + bi, 0.f)) break;
+    case DVT_EPI_RESIDUAL: DVT_SMALL_EPI(x = x + bi + ld) break;
+    case DVT_EPI_DGELU: DVT_SMALL_EPI(x *= gelu_erf_grad_f(ld)) break;
+    case DVT_EPI_DRELU: DVT_SMALL_EPI(x = ld > 0.f ? x : 0.f) break;
+    default: DVT_SMALL_EPI(x += bi) break;
+  }
+#undef DVT_SMALL_EPI
+  const bool save_pre = p.epilogue == DVT_EPI_GELU && p.aux != nullptr;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int m = m0 + wm * 32 + t * 16 + li;
-    if (m >= p.M) continue;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int n = n0 + wn * WCOLS + u * 16 + 4 * g;
-      if (n >= p.N) continue;                              // N % 8 == 0: a group of four is inside or outside
-      float v[4];
-      float bias[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (m >= p.M || n >= p.N) continue;                  // N % 8 == 0: a group of four is inside or outside
+      if (save_pre) {
+        V4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = b[r];
-      }
-      float ld[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.epilogue == DVT_EPI_RESIDUAL || p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU) {
-        const E* src = p.epilogue == DVT_EPI_RESIDUAL ? (const E*)p.residual + (int64_t)m * p.ldr + n
-                                                      : (const E*)p.aux + (int64_t)m * p.ldaux + n;
-        const typename Elem16<E>::v4 x = *reinterpret_cast<const typename Elem16<E>::v4*>(src);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ld[r] = (float)x[r];
-      }
-      float pre[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = epi_apply(p.epilogue, acc[u][t][r] * p.alpha, bias[r], ld[r], ld[r], pre[r]);
-      if (p.epilogue == DVT_EPI_GELU && p.aux) {
-        typename Elem16<E>::v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (E)pre[r];
-        *reinterpret_cast<typename Elem16<E>::v4*>((E*)p.aux + (int64_t)m * p.ldaux + n) = o;
+        for (int r = 0; r < 4; ++r) o[r] = (E)pre[t][u][r];
+        *reinterpret_cast<V4*>((E*)p.aux + (int64_t)m * p.ldaux + n) = o;
       }
       if (p.out_f32) {
         float* o = (float*)p.C + (int64_t)m * p.ldc + n;
-        f32x4 w = {v[0], v[1], v[2], v[3]};
-        if (p.accumulate) w += *reinterpret_cast<const f32x4*>(o);
+        f32x4 w = {v[t][u][0], v[t][u][1], v[t][u][2], v[t][u][3]};
+        if (p.accumulate) w += pre_old[t][u];
         *reinterpret_cast<f32x4*>(o) = w;
       } else {
-        typename Elem16<E>::v4 o;
+        V4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (E)v[r];
-        *reinterpret_cast<typename Elem16<E>::v4*>((E*)p.C + (int64_t)m * p.ldc + n) = o;
+        for (int r = 0; r < 4; ++r) o[r] = (E)v[t][u][r];
+        *reinterpret_cast<V4*>((E*)p.C + (int64_t)m * p.ldc + n) = o;
       }
     }
   }
+  DVT_SSTAMP(4);
 }
 
 template <typename E, bool AK, bool BK, int TM>
