@@ -296,7 +296,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float inv_rows, float eps, float* __restrict__ o0,
                                                            float* __restrict__ o1, float* __restrict__ run_mean,
                                                            float* __restrict__ run_var, float momentum, float unbias,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ pub0 = nullptr,
+                                                           float* __restrict__ pub1 = nullptr) {
   // block = 32 columns x 32 part lanes; fixed summation order (lane-strided partial sums, then a lane tree)
   // The partial sums are added in double and the variance is formed in double: the one-pass form E[x^2] - mu^2 in fp32
   // loses the variance of channels whose |mean| is large against their spread to the rounding of sums over 10^5..10^7
@@ -342,8 +343,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
   } else {
     const float d0 = (float)s0, d1 = (float)s1;
-    o0[c] = accumulate ? o0[c] + d1 : d1;   // dgamma
-    o1[c] = accumulate ? o1[c] + d0 : d0;   // dbeta
+    if (pub0) {                             // this launch's own sums for the apply pass; the caller's (accumulated) result
+      o0[c] = d1;
+      o1[c] = d0;
+      pub0[c] = accumulate ? pub0[c] + d1 : d1;   // dgamma
+      pub1[c] = accumulate ? pub1[c] + d0 : d0;   // dbeta
+    } else {
+      o0[c] = accumulate ? o0[c] + d1 : d1;   // dgamma
+      o1[c] = accumulate ? o1[c] + d0 : d0;   // dbeta
+    }
   }
 }
 
@@ -1207,8 +1215,9 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   DVT_LAUNCH_CHECK("dvt_bn_bwd(stats)");
   // keep the local dgamma/dbeta 16-byte aligned behind the partials
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
+  // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
   hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
-                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
+                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
@@ -1222,10 +1231,7 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
                                                     1.0f / (float)rows, beta));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd(apply)");
-  // publish dgamma / dbeta (overwrite or accumulate) from the local copy
-  int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
-  if (rc) return rc;
-  return dvt_axpby_f32(loc + C, DVT_F32, 1.f, dbeta, accumulate ? 1.f : 0.f, C, stream);
+  return DVT_OK;
 }
 
 int dvt_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -1265,8 +1271,9 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
                                                   part, gamma, beta, pg));
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(stats)");
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
+  // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
   hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
-                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
+                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(finalize)");
   if (H % 2 == 0 && W % 2 == 0) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_pool_quad_kernel<T>), dim3(cgrid(rows / 4 * (C >> 3))), dim3(kB), 0,
@@ -1279,9 +1286,7 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
                                                     beta, pg));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(apply)");
-  int rc = dvt_axpby_f32(loc, DVT_F32, 1.f, dgamma, accumulate ? 1.f : 0.f, C, stream);
-  if (rc) return rc;
-  return dvt_axpby_f32(loc + C, DVT_F32, 1.f, dbeta, accumulate ? 1.f : 0.f, C, stream);
+  return DVT_OK;
 }
 
 int dvt_maxpool_fwd(const void* x, void* y, void* idx, int64_t N, int C, int H, int W, int k, int stride, int pad,
