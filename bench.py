@@ -565,12 +565,15 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             f = fam.setdefault((ak, bk), [0.0, 0.0, 0, 0.0])
             f[0] += ms; f[1] += fl; f[2] += cnt; f[3] += float(nbytes) * cnt
         names = {(1, 1): "gemm_dma_kernel<A k-major, B k-major> (forward Linear)",
-                 (1, 0): "gemm_dma_kernel<A k-major, B mn-major> (data gradient)",
-                 (0, 0): "gemm_dma_kernel<A mn-major, B mn-major> (weight gradient, split-K incl. reduce)"}
+                 (1, 0): "gemm_dma_kernel<A k-major, B mn-major> (data gradient; carries the weight gradients' split-K reduces in its grid tail)",
+                 (0, 0): "gemm_dma_kernel<A mn-major, B mn-major> (weight gradient, split-K; its reduce rides in the data-gradient launch behind it)"}
         pmc, pmc_file = newest_pmc_traffic()
         pmc_key = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}
         if fam:
-            dom = max(fam, key=lambda k: fam[k][0])
+            # dominant = the layout that carries the most algorithmic FLOPs (the three sit within a few percent of each
+            # other in time; the data-gradient launches also carry the weight gradients' split-K reduces in their grid
+            # tails -- time without FLOPs --, which would otherwise decide the choice from run to run)
+            dom = max(fam, key=lambda k: (fam[k][1], fam[k][0]))
             ms, fl, cnt, nb = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
             traffic = (pmc.get(pmc_key.get(dom, ""), {}) or {}).get("hbm_bytes_corrected")
@@ -583,6 +586,7 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
                     "algorithmic_bytes_per_launch": int(alg),
                     "traffic_ratio": round(traffic / alg, 3) if traffic else None,
                     "launches": cnt // nprof, "avg_launch_us": round(ms * 1e3 / cnt, 1),
+                    "dominant_by": "algorithmic FLOPs per step among the kernel's three operand layouts",
                     "families": {names.get(k, str(k)): {"ms_per_step": round(v[0] / nprof, 3),
                                                         "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
                                                         "algorithmic_MB_per_launch": round(v[3] / v[2] / 1e6, 1)}
@@ -766,6 +770,19 @@ def main():
     use_dist = world > 1 or args.force_dist
     comm = None
     if use_dist:
+        # A collective that some rank never joins hangs every rank silently: a watchdog turns that into a loud exit (the
+        # launcher / torchrun then ends the other ranks) instead of a run that never returns its line.
+        import threading
+        limit = float(os.environ.get("DVT_BENCH_TIMEOUT_S", "900"))
+
+        def _give_up():
+            sys.stderr.write(f"[bench] rank {rank}: no result after {limit:.0f} s (a collective is stuck?) -- aborting\n")
+            sys.stderr.flush()
+            os._exit(124)
+
+        wd = threading.Timer(limit, _give_up)
+        wd.daemon = True
+        wd.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world)

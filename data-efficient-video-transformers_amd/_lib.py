@@ -21,6 +21,15 @@ c_p = C.c_void_p
 c_int = C.c_int
 
 
+class SplitKPending(C.Structure):
+    _fields_ = [
+        ("slab", c_p), ("splits", C.c_int32), ("valid", C.c_int32),
+        ("M", c_i64), ("N", c_i64), ("C", c_p), ("ldc", c_i64),
+        ("accumulate", C.c_int32), ("cs_accumulate", C.c_int32),
+        ("cs_slab", c_p), ("cs_out", c_p),
+    ]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", c_p), ("B", c_p), ("C", c_p),
@@ -34,6 +43,7 @@ class GemmDesc(C.Structure):
         ("alpha", c_f), ("split_k", C.c_int32),
         ("workspace", c_p),
         ("colsum_out", c_p), ("colsum_accumulate", C.c_int32),
+        ("defer_reduce", C.c_int32), ("pending", C.POINTER(SplitKPending)), ("carry", C.POINTER(SplitKPending)),
     ]
 
 
@@ -88,6 +98,7 @@ SIGNATURES = {
     "dvt_layernorm_bwd_first": (c_int, [c_p] * 10 + [c_i64] * 7 + [c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dvt_gemm": (c_int, [C.POINTER(GemmDesc), c_p]),
+    "dvt_splitk_reduce_pending": (c_int, [C.POINTER(SplitKPending), c_p]),
     "dvt_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
     "dvt_colsum": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),

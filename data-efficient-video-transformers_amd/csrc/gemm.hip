@@ -685,9 +685,29 @@ static GemmRoute route_gemm(const dvt_gemm_desc* d) {
   return r;
 }
 
+static int launch_pending_reduce(const dvt_splitk_pending* q, hipStream_t st) {
+  if (!q || !q->valid) return DVT_OK;
+  const int64_t nvec = q->M * q->N / 8;
+  int64_t blocks = dvt_cdiv(nvec, 256);
+  const int64_t cap = (int64_t)dvt_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, q->slab, q->splits, (int)q->M,
+                     (int)q->N, q->C, q->ldc, q->accumulate, q->cs_slab, q->cs_out, q->cs_accumulate);
+  DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce)");
+  return DVT_OK;
+}
+
 // workspace = [split-K slabs][bias-gradient slabs or stand-alone colsum scratch]
 // The fused bias gradient writes one row of M floats per K slice (gemm256.hip: colsum_slab[slice * M + m]); the planner
 // allows up to 256 slices, so the scratch is sized from the plan, never from a fixed slice bound.
+int dvt_splitk_reduce_pending(const dvt_splitk_pending* pending, dvt_stream_t stream) {
+  DVT_REQUIRE(pending, "dvt_splitk_reduce_pending: null descriptor");
+  if (!pending->valid) return DVT_OK;
+  DVT_REQUIRE(pending->slab && pending->C && pending->splits > 0 && pending->M > 0 && pending->N > 0 && pending->N % 8 == 0,
+              "dvt_splitk_reduce_pending: bad descriptor");
+  return launch_pending_reduce(pending, (hipStream_t)stream);
+}
+
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
   if (!d) return 0;
   const GemmRoute route = route_gemm(d);
@@ -713,6 +733,19 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(!d->colsum_out || !d->a_kmajor, "dvt_gemm: colsum_out needs an mn-major A");
 
   const GemmRoute route = route_gemm(d);
+  if (d->defer_reduce) {
+    DVT_REQUIRE(d->pending, "dvt_gemm: defer_reduce needs a pending descriptor to fill");
+    d->pending->valid = 0;
+  }
+  // a reduce carried over from an earlier call rides in this launch's grid tail when this is a one-slice LDS-DMA launch;
+  // every other route performs it first, as a launch of its own
+  const dvt_splitk_pending* carry = d->carry && d->carry->valid ? d->carry : nullptr;
+  bool carried = false;
+  if (carry && !(route.kind == ROUTE_MFMA && route.pl.use256 && route.pl.split == 1)) {
+    rc = launch_pending_reduce(carry, st);
+    if (rc) return rc;
+    carry = nullptr;
+  }
   if (route.kind == ROUTE_SMALL) {
     GemmParams p{};
     p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
@@ -758,9 +791,22 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
       if (rc) return rc;
     }
     if (pl.use256) {
+      if (carry && split == 1) {
+        // ~1 MB of slabs per tail workgroup, at most 64 of them: about what the CUs idle in a 1.77-round data gradient take in
+        const int64_t slab_bytes_c = carry->M * carry->N * 4 * carry->splits;
+        int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 20);
+        p.pig_blocks = (int)(nb < 1 ? 1 : nb > 64 ? 64 : nb);
+        p.pig = *carry;
+      }
       rc = dvt_gemm_dma_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, split, pl.cfg, st);
       if (rc < 0) return rc;
       if (rc == 1) pl.use256 = false;   // no instantiation for this combination
+      else carried = p.pig_blocks > 0;
+      p.pig_blocks = 0;
+    }
+    if (carry && !carried) {              // the LDS-DMA kernel did not take the launch after all
+      rc = launch_pending_reduce(carry, st);
+      if (rc) return rc;
     }
     if (!pl.use256) {
     const int tiles_m = (int)dvt_cdiv(d->M, BM);
@@ -792,6 +838,13 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
       if (!plain)
         DVT_DISPATCH_16BIT(d->in_dtype, E, hipLaunchKernelGGL((splitk_reduce_epi_kernel<E>), dim3((unsigned)blocks),
                                                               dim3(256), 0, st, (const float*)p.slab, split, p));
+      else if (p.out_f32 && d->defer_reduce) {          // left to the call that receives *pending as its `carry`
+        dvt_splitk_pending* q = d->pending;
+        q->slab = p.slab; q->splits = split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->C; q->ldc = d->ldc;
+        q->accumulate = d->accumulate; q->cs_accumulate = d->colsum_accumulate;
+        q->cs_slab = p.colsum_slab; q->cs_out = d->colsum_out;
+        return DVT_OK;
+      }
       else if (p.out_f32)
         hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const float*)p.slab, split, p.M, p.N, (float*)d->C, d->ldc, d->accumulate,

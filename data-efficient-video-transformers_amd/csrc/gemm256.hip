@@ -290,7 +290,13 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   // consecutive n-tiles of an A row-panel hit the same L2.  Split-K weight gradients: an XCD
   // owns whole K-slices, so every byte of dY and x is fetched by exactly one XCD (PMC: the
   // per-plane remap re-read the x slice once per XCD, 2.3x the algorithmic bytes).
-  const int ntiles = gridDim.x;
+  // Workgroups past the tiles carry a split-K reduce of the previous launch (dvt_splitk_pending): they are dispatched
+  // last, i.e. into the CUs the partial last round of tiles leaves idle.  (Launches with such a tail have one K slice.)
+  const int ntiles = gridDim.x - p.pig_blocks;
+  if (p.pig_blocks > 0 && (int)blockIdx.x >= ntiles) {
+    splitk_reduce_f32_part(p.pig, (int64_t)(blockIdx.x - ntiles) * blockDim.x + threadIdx.x, (int64_t)p.pig_blocks * blockDim.x);
+    return;
+  }
   int tile, zsl;
   {
     const int total = ntiles * gridDim.z;
@@ -647,7 +653,8 @@ int launch_cfg(const GemmParams& pin, bool ak, bool bk, int split, hipStream_t s
   p.stream_out = (int64_t)p.M * p.N * 2 * (p.epilogue == DVT_EPI_GELU && p.aux ? 2 : 1) >= (int64_t)180 * 1000000;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
-  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
+  if (split != 1) p.pig_blocks = 0;        // (the caller only hands a carried reduce to one-slice launches)
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n + p.pig_blocks), 1, (unsigned)split), block(C::NW * 64);
   const int e = p.epilogue;
   if (p.slab) {
     if (!ak && !bk) return launch_one<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB>(p, grid, block, kSmem, st);
@@ -673,6 +680,7 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
   typedef Cfg<CFG> C;
   constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
+  p.pig_blocks = 0;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, 1), block(C::NW * 64);
@@ -692,6 +700,7 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
   typedef Cfg<CFG> C;
   constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
+  p.pig_blocks = 0;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
@@ -726,7 +735,7 @@ int launch_224(const GemmParams& pin, bool bk, hipStream_t st) {
   GemmParams p = pin;
   p.stream_out = (int64_t)p.M * p.N * 2 >= (int64_t)180 * 1000000;
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
-  const dim3 grid((unsigned)(dvt_cdiv(p.M, C::TM) * p.tiles_n), 1, 1), block(C::NW * 64);
+  const dim3 grid((unsigned)(dvt_cdiv(p.M, C::TM) * p.tiles_n + p.pig_blocks), 1, 1), block(C::NW * 64);
   if (p.slab || p.out_f32) return 1;
   if (bk && p.epilogue == DVT_EPI_NONE) return launch_one<E, true, true, 8, DVT_EPI_NONE, OUT_BF16>(p, grid, block, kSmem, st);
   if (bk && p.epilogue == DVT_EPI_RESIDUAL) return launch_one<E, true, true, 8, DVT_EPI_RESIDUAL, OUT_BF16>(p, grid, block, kSmem, st);

@@ -23,6 +23,9 @@ struct GemmParams {
   float* colsum_slab;
   int accumulate_colsum;   // gemm_small.hip only: colsum_slab is the final bias-gradient vector; += when set
   float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
+  // a split-K reduce of an EARLIER launch carried in `pig_blocks` extra workgroups at the end of this grid (gemm256.hip)
+  int pig_blocks;
+  dvt_splitk_pending pig;
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
   int cH, cW, cC, cHo, cWo, ckh, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };
@@ -51,6 +54,49 @@ __device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float
   }
 }
 
+
+// C (+)= sum_z slab[z] in slice order for the vectors [rb * nthreads + tid, ...) strided by nrb * nthreads: the body of
+// splitk_reduce_kernel<float>, callable from the tail workgroups of a GEMM launch (same order of additions => same bits).
+__device__ __forceinline__ void splitk_reduce_f32_part(const dvt_splitk_pending& q, int64_t first, int64_t stride) {
+  const int64_t nvec = q.M * q.N / 8, MN = q.M * q.N;
+  if (q.cs_slab) {
+    for (int64_t m = first; m < q.M; m += stride) {
+      float t = 0.f;
+      for (int z = 0; z < q.splits; ++z) t += q.cs_slab[(int64_t)z * q.M + m];
+      q.cs_out[m] = q.cs_accumulate ? q.cs_out[m] + t : t;
+    }
+  }
+  for (int64_t i = first; i < nvec; i += stride) {
+    const int64_t e = i * 8;
+    const int64_t m = e / q.N, n = e % q.N;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int ZB = 8;
+    int z = 0;
+    for (; z + ZB <= q.splits; z += ZB) {
+      float v[ZB][8];
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) load8<float>(q.slab + (int64_t)(z + u) * MN + e, v[u]);
+#pragma unroll
+      for (int u = 0; u < ZB; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[u][k];
+    }
+    for (; z < q.splits; ++z) {
+      float v[8];
+      load8<float>(q.slab + (int64_t)z * MN + e, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    float* o = q.C + m * q.ldc + n;
+    if (q.accumulate) {
+      float old[8];
+      load8<float>(o, old);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += old[k];
+    }
+    store8<float>(o, acc);
+  }
+}
 
 // 8 consecutive outputs at once, the switch hoisted out of the element loop.
 __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (&bias)[8],

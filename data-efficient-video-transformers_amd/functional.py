@@ -54,25 +54,35 @@ def _emit_wgrad(sink, dy2: Tensor, x2: Tensor):
     return None
 
 
-def _emit_wgrad_bias(sink_w, sink_b, dy2: Tensor, x2: Tensor, has_bias: bool):
-    """(dW, db) from ONE pass over dy: the bias gradient rides on the weight-gradient GEMM."""
-    if not has_bias:
-        return _emit_wgrad(sink_w, dy2, x2), None
+def _emit_wgrad_bias(sink_w, sink_b, dy2: Tensor, x2: Tensor, has_bias: bool, defer: bool = False):
+    """(dW, db) from ONE pass over dy: the bias gradient rides on the weight-gradient GEMM.
+    defer: -> (dW, db, pending, finish): the split-K reduce of the launch is left to the data-gradient GEMM that follows
+    (``ops.linear_dgrad(..., carry=pending)`` performs it in the idle tail of its own grid); call ``finish()`` behind that
+    call -- only then are dW / db complete and the sinks marked written (a bucket's all-reduce may start on that mark)."""
     N, K = dy2.shape[1], x2.shape[1]
     w_out = sink_w.buf.view(N, K) if sink_w is not None else None
-    if sink_b is not None:
-        b_out, b_acc = sink_b.buf.view(-1), not sink_b.fresh
-    else:
-        b_out, b_acc = torch.empty((N,), dtype=torch.float32, device=dy2.device), False
-    dw = ops.linear_wgrad(dy2, x2, out=w_out, accumulate=(not sink_w.fresh) if sink_w is not None else False,
-                          bias_out=b_out, bias_accumulate=b_acc)
-    if sink_w is not None:
-        sink_w.mark_written()
-        dw = None
-    if sink_b is not None:
-        sink_b.mark_written()
-        b_out = None
-    return dw, b_out
+    b_out, b_acc = None, False
+    if has_bias:
+        if sink_b is not None:
+            b_out, b_acc = sink_b.buf.view(-1), not sink_b.fresh
+        else:
+            b_out = torch.empty((N,), dtype=torch.float32, device=dy2.device)
+    r = ops.linear_wgrad(dy2, x2, out=w_out, accumulate=(not sink_w.fresh) if sink_w is not None else False,
+                         bias_out=b_out, bias_accumulate=b_acc, defer_reduce=defer)
+    dw, pending = r if defer else (r, None)
+
+    def finish():
+        if sink_w is not None:
+            sink_w.mark_written()
+        if has_bias and sink_b is not None:
+            sink_b.mark_written()
+
+    dw_ret = None if sink_w is not None else dw
+    db_ret = None if (not has_bias or sink_b is not None) else b_out
+    if defer:
+        return dw_ret, db_ret, pending, finish
+    finish()
+    return dw_ret, db_ret
 
 
 def _emit_colsum(sink, dy2: Tensor):
@@ -525,8 +535,9 @@ class _AttnBlock(torch.autograd.Function):
         dy2 = _as(dy.reshape(M, -1).contiguous(), T)
         dwo = dbo = None
         if has_out:
-            do2 = ops.linear_dgrad(dy2, wo)                            # [M, inner]
-            dwo, dbo = _emit_wgrad_bias(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), has_bias)
+            dwo, dbo, pend, fin = _emit_wgrad_bias(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), has_bias, defer=True)
+            do2 = ops.linear_dgrad(dy2, wo, carry=pend)                # [M, inner]; carries the reduce of dwo
+            fin()
         else:
             do2 = dy2
         q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)
@@ -534,8 +545,9 @@ class _AttnBlock(torch.autograd.Function):
         dq, dk, dv = _split_qkv(dqkv, S, N, heads, dh, seq_first)
         ops.attention_bwd(q, k, v, _heads_view(o_mem, seq_first), lse,
                           _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5, ctx.drop)
-        dwq, dbq = _emit_wgrad_bias(ctx.sinks[2], ctx.sinks[5], dqkv, xn, has_qkv_bias)
-        dxn = ops.linear_dgrad(dqkv, wq)                               # [M, d]
+        dwq, dbq, pend, fin = _emit_wgrad_bias(ctx.sinks[2], ctx.sinks[5], dqkv, xn, has_qkv_bias, defer=True)
+        dxn = ops.linear_dgrad(dqkv, wq, carry=pend)                   # [M, d]
+        fin()
         dg = db = None
         if prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, ctx.sinks[0], ctx.sinks[1],
@@ -614,15 +626,15 @@ class _AttnBlockCls(torch.autograd.Function):
         w_q, w_kv = wqkv[:inner], wqkv[inner:]
         if s_qkv is not None:                                            # the two row ranges of one packed gradient
             buf, acc = s_qkv.buf.view(3 * inner, d), not s_qkv.fresh
-            ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)
-            ops.linear_wgrad(dkv, xn, out=buf[inner:], accumulate=acc)
-            s_qkv.mark_written()
             dwqkv = None
         else:
-            dwqkv = torch.empty((3 * inner, d), dtype=torch.float32, device=x2.device)
-            ops.linear_wgrad(dq, xn0, out=dwqkv[:inner])
-            ops.linear_wgrad(dkv, xn, out=dwqkv[inner:])
-        dxn = ops.linear_dgrad(dkv, w_kv)                                # [S*N, d]: the K / V path, all rows
+            buf, acc = torch.empty((3 * inner, d), dtype=torch.float32, device=x2.device), False
+            dwqkv = buf
+        ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)
+        _, pend = ops.linear_wgrad(dkv, xn, out=buf[inner:], accumulate=acc, defer_reduce=True)
+        dxn = ops.linear_dgrad(dkv, w_kv, carry=pend)                    # [S*N, d]: the K / V path, all rows (+ that reduce)
+        if s_qkv is not None:
+            s_qkv.mark_written()
         dxn0 = ops.linear_dgrad(dq, w_q)                                 # [S, d]: the Q path, row 0
         dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d),
                              dy_first=dxn0, dx_first=dy2)
@@ -743,13 +755,16 @@ class _MlpBlock(torch.autograd.Function):
             xn = x2
         dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
         sk = ctx.sinks
-        dw2, db2 = _emit_wgrad_bias(sk[4], sk[5], dy2, h, has_b2)
+        # each weight gradient's split-K reduce rides in the tail of the data-gradient launch behind it
+        dw2, db2, pend, fin = _emit_wgrad_bias(sk[4], sk[5], dy2, h, has_b2, defer=True)
         if act == "gelu":
-            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u)
+            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u, carry=pend)
         else:
-            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h)
-        dw1, db1 = _emit_wgrad_bias(sk[2], sk[3], du, xn, has_b1)
-        dxn = ops.linear_dgrad(du, w1c)
+            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h, carry=pend)
+        fin()
+        dw1, db1, pend, fin = _emit_wgrad_bias(sk[2], sk[3], du, xn, has_b1, defer=True)
+        dxn = ops.linear_dgrad(du, w1c, carry=pend)
+        fin()
         dg = db = None
         if prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, sk[0], sk[1], dx_add=dy2 if residual else None)

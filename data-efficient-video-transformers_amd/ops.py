@@ -374,7 +374,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
          lda: int, ldb: int, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
          epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
          aux: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0,
-         split_k: int = 0, colsum_out: Optional[Tensor] = None, colsum_accumulate: bool = False) -> Tensor:
+         split_k: int = 0, colsum_out: Optional[Tensor] = None, colsum_accumulate: bool = False,
+         defer_reduce: bool = False, carry=None):
+    """defer_reduce: a split-K reduce this call would launch is left undone and returned as a pending descriptor --
+    (out, pending) -- for the ``carry=`` argument of the NEXT gemm call on this stream (the data gradient of the same
+    Linear), which performs it in the idle tail of its own launch; ``out`` is complete only after that call."""
     _need_cuda(A, B, bias, residual, aux)
     assert A.dtype == B.dtype
     if out_dtype is None:
@@ -403,9 +407,20 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
         assert colsum_out.dtype == torch.float32 and colsum_out.numel() == M and colsum_out.is_contiguous()
     d.colsum_out = _p(colsum_out)
     d.colsum_accumulate = int(colsum_accumulate)
+    pending = None
+    if defer_reduce:
+        pending = L.SplitKPending()
+        pending._keep = (out, colsum_out)          # the descriptor names their storage
+        d.defer_reduce = 1
+        d.pending = C.pointer(pending)
+    if carry is not None:
+        d.carry = C.pointer(carry)
     lib = L.load()
-    ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device)
+    # the slabs of a deferred reduce must survive the next call: they get a scratch slot of their own
+    ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device, slot="deferred" if defer_reduce else "main")
     d.workspace = _p(ws)
+    if defer_reduce:
+        pending._keep += (ws,)
     prof = _profiler
     if prof is not None:
         # algorithmic bytes of the launch: both operands once, every output once, every extra epilogue operand once
@@ -416,9 +431,16 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
         prof.begin(key, 2.0 * M * N * K)
         L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
         prof.end(key)
-        return out
+        return (out, pending) if defer_reduce else out
     L.check(lib.dvt_gemm(C.byref(d), _stream()), "dvt_gemm")
-    return out
+    return (out, pending) if defer_reduce else out
+
+
+def splitk_reduce_pending(pending) -> None:
+    """Perform a deferred split-K reduce as a launch of its own (no data-gradient launch followed to carry it)."""
+    if pending is not None and pending.valid:
+        L.check(L.load().dvt_splitk_reduce_pending(C.byref(pending), _stream()), "dvt_splitk_reduce_pending")
+        pending.valid = 0
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, epilogue: int = L.EPI_NONE,
@@ -431,25 +453,30 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, epilogue:
                 bias=bias, residual=residual, aux=aux)
 
 
-def linear_dgrad(dy: Tensor, w: Tensor, *, epilogue: int = L.EPI_NONE, aux: Optional[Tensor] = None) -> Tensor:
-    """dx[M,K] = epi(dy[M,N] @ w[N,K])   (epilogue DGELU / DRELU multiplies by act'(aux))."""
+def linear_dgrad(dy: Tensor, w: Tensor, *, epilogue: int = L.EPI_NONE, aux: Optional[Tensor] = None,
+                 carry=None) -> Tensor:
+    """dx[M,K] = epi(dy[M,N] @ w[N,K])   (epilogue DGELU / DRELU multiplies by act'(aux)).
+    carry: the pending split-K reduce of the weight gradient launched just before (linear_wgrad(defer_reduce=True))."""
     M, N = dy.shape
     K = w.shape[1]
     assert w.shape[0] == N and dy.stride(1) == 1 and w.is_contiguous()
-    return gemm(dy, w, M, K, N, a_kmajor=True, b_kmajor=False, lda=dy.stride(0), ldb=K, epilogue=epilogue,
-                aux=aux)
+    out = gemm(dy, w, M, K, N, a_kmajor=True, b_kmajor=False, lda=dy.stride(0), ldb=K, epilogue=epilogue,
+               aux=aux, carry=carry)
+    if carry is not None:
+        carry.valid = 0                              # performed by this call, one way or the other
+    return out
 
 
 def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False,
-                 bias_out: Optional[Tensor] = None, bias_accumulate: bool = False) -> Tensor:
+                 bias_out: Optional[Tensor] = None, bias_accumulate: bool = False, defer_reduce: bool = False):
     """dW[N,K] (f32) = dy[M,N]^T @ x[M,K]; optionally also the bias gradient
-    bias_out[N] (+)= sum_m dy[m, :] from the same pass over dy."""
+    bias_out[N] (+)= sum_m dy[m, :] from the same pass over dy.  defer_reduce: -> (dW, pending), see ``gemm``."""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
     return gemm(dy, x, N, K, M, a_kmajor=False, b_kmajor=False, lda=dy.stride(0), ldb=x.stride(0), out=out,
                 out_dtype=torch.float32, accumulate=accumulate, colsum_out=bias_out,
-                colsum_accumulate=bias_accumulate)
+                colsum_accumulate=bias_accumulate, defer_reduce=defer_reduce)
 
 
 def colsum(x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:

@@ -203,6 +203,25 @@ enum dvt_epilogue {
   DVT_EPI_DRELU = 5          /* C = acc * (aux > 0)    (aux = saved post-activation) */
 };
 
+/* A split-K reduction that a dvt_gemm call left undone (desc.defer_reduce): C (+)= sum_z slab[z] in slice order, and
+ * the fused bias gradient's partial rows.  It is handed to the NEXT dvt_gemm call of the same stream (desc.carry) --
+ * the data gradient of the same Linear, src/models/vit.py:20-25,39-43 backward --, whose launch performs it in extra
+ * workgroups at the END of its grid: a data-gradient launch is 1.5-6 rounds of tiles and leaves CUs idle in its last
+ * round, which is where a reduce that reads 64 MB of slabs then runs instead of as a launch of its own.  A call that
+ * cannot carry it (not the LDS-DMA kernel) launches it stand-alone first; dvt_splitk_reduce_pending does so explicitly.
+ * The slabs live in the deferring call's workspace: it must stay untouched until the carrying call has been enqueued. */
+typedef struct dvt_splitk_pending {
+  const float* slab;       /* [splits][M][N] f32 */
+  int32_t splits, valid;   /* valid == 0: nothing pending (the deferring call did not split K) */
+  int64_t M, N;
+  float* C;                /* f32 [M, ldc] */
+  int64_t ldc;
+  int32_t accumulate;
+  int32_t cs_accumulate;
+  const float* cs_slab;    /* [splits][M] f32 or NULL */
+  float* cs_out;           /* [M] f32 */
+} dvt_splitk_pending;
+
 typedef struct dvt_gemm_desc {
   const void* A;
   const void* B;
@@ -227,10 +246,18 @@ typedef struct dvt_gemm_desc {
    * all-ones fragment) instead of a separate reduction.  NULL = off. */
   float* colsum_out;
   int32_t colsum_accumulate;
+  /* Optional (both may be NULL / 0).  defer_reduce: when this call splits K with the plain f32 reduce behind it
+   * (weight gradients), leave the reduce undone and describe it in *pending (pending->valid = 0 when there is none).
+   * carry: a pending reduce of an earlier call to perform with this call (see dvt_splitk_pending). */
+  int32_t defer_reduce;
+  dvt_splitk_pending* pending;
+  const dvt_splitk_pending* carry;
 } dvt_gemm_desc;
 
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* desc);
 int dvt_gemm(const dvt_gemm_desc* desc, dvt_stream_t stream);
+/* Performs a pending split-K reduction as a launch of its own. */
+int dvt_splitk_reduce_pending(const dvt_splitk_pending* pending, dvt_stream_t stream);
 
 /* out[n] (+)= sum_m x[m*ldx + n]  -- bias gradients. workspace >=
  * dvt_colsum_workspace_bytes(M, N). */

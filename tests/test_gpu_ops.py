@@ -390,6 +390,47 @@ def test_wgrad_split_k_reproducible(dvt, device):
     assert rel_l2(acc, dy.t() @ x + 1) < BF16_TOL
 
 
+@pytest.mark.parametrize("shape", [(50432, 2048, 512), (50432, 512, 2048), (8192, 1536, 512), (20000, 512, 512)])
+def test_deferred_split_k_reduce_rides_in_the_data_gradient_launch(dvt, device, shape):
+    """A Linear's backward (vit.py:20-25,39-43): dW = dy^T x with its split-K reduce left undone (defer_reduce) and
+    handed to the data-gradient GEMM dx = dy W behind it (carry), which performs it in tail workgroups of its own
+    grid.  Results must be BIT-identical to the two-launch form (same slice order), for dW, the fused bias gradient
+    and dx; accumulate into a destination; a pending reduce can also be flushed stand-alone or carried by a launch that
+    is not the LDS-DMA kernel (then it runs first, as a launch of its own)."""
+    g = torch.Generator().manual_seed(33)
+    M, N, K = shape                              # dy [M, N], x [M, K], W [N, K]
+    dy_d, _ = _rnd((M, N), torch.bfloat16, g)
+    x_d, _ = _rnd((M, K), torch.bfloat16, g)
+    w_d, _ = _rnd((N, K), torch.bfloat16, g, K ** -0.5)
+    ops = dvt.ops
+    dw_ref = torch.zeros((N, K), device="cuda")
+    db_ref = torch.zeros((N,), device="cuda")
+    ops.linear_wgrad(dy_d, x_d, out=dw_ref, bias_out=db_ref)
+    dx_ref = ops.linear_dgrad(dy_d, w_d)
+    # deferred + carried
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    db = torch.full((N,), float("nan"), device="cuda")
+    _, pend = ops.linear_wgrad(dy_d, x_d, out=dw, bias_out=db, defer_reduce=True)
+    dx = ops.linear_dgrad(dy_d, w_d, carry=pend)
+    assert torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    # accumulate into existing gradients
+    dw2 = torch.ones((N, K), device="cuda")
+    db2 = torch.ones((N,), device="cuda")
+    _, pend = ops.linear_wgrad(dy_d, x_d, out=dw2, accumulate=True, bias_out=db2, bias_accumulate=True, defer_reduce=True)
+    ops.linear_dgrad(dy_d, w_d, carry=pend)
+    assert rel_l2(dw2, dw_ref + 1) < 1e-6 and rel_l2(db2, db_ref + 1) < 1e-6
+    # stand-alone flush
+    dw3 = torch.full((N, K), float("nan"), device="cuda")
+    _, pend = ops.linear_wgrad(dy_d, x_d, out=dw3, defer_reduce=True)
+    ops.splitk_reduce_pending(pend)
+    assert torch.equal(dw3, dw_ref)
+    # carried by a launch of the panel-streaming kernel (264 rows): performed first, as a launch of its own
+    dw4 = torch.full((N, K), float("nan"), device="cuda")
+    _, pend = ops.linear_wgrad(dy_d, x_d, out=dw4, defer_reduce=True)
+    small = ops.linear_dgrad(dy_d[:264].contiguous(), w_d, carry=pend)
+    assert torch.equal(dw4, dw_ref) and rel_l2(small, dx_ref[:264]) < 1e-2      # (another kernel: another summation order)
+
+
 def test_wgrad_deep_k_fused_bias_with_exact_workspace(dvt, device):
     """Reference-default ViViT (dim 192) at batch 32: the to_out weight gradient is M = N = 192 with K = 100,864 token
     rows -> one 256x256 tile, 197 K slices, bias gradient fused (one scratch row of M floats per slice).  A C-ABI caller
