@@ -792,10 +792,11 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     }
     if (pl.use256) {
       if (carry && split == 1) {
-        // ~1 MB of slabs per tail workgroup, at most 64 of them: about what the CUs idle in a 1.77-round data gradient take in
+        // ~512 KB of slabs per tail workgroup, at most 128 of them: the first ~60 start in the CUs a 1.77-round data gradient
+        // leaves idle in its last round, the rest as its last tiles finish
         const int64_t slab_bytes_c = carry->M * carry->N * 4 * carry->splits;
-        int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 20);
-        p.pig_blocks = (int)(nb < 1 ? 1 : nb > 64 ? 64 : nb);
+        int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);
+        p.pig_blocks = (int)(nb < 1 ? 1 : nb > 128 ? 128 : nb);
         p.pig = *carry;
       }
       rc = dvt_gemm_dma_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, split, pl.cfg, st);
