@@ -357,7 +357,7 @@ def cnn_roofline(summ, nprof, workload):
             continue
         _, kind, M, N, K, nbytes = key
         if kind == "wgrad":                # key = (.., K_out = kh*kw*Cin, Cout, rows): class by output channels
-            name = f"implicit weight gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'} (split-K incl. reduce)"
+            name = f"implicit weight gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'} (split-K; the reduce rides in the layer's data-gradient launch)"
         elif kind == "halo3x3_c64":
             name = "conv3x3_c64 (LDS halo patch; forward and data gradient of layer 1)"
         else:

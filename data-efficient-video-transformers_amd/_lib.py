@@ -50,7 +50,8 @@ class GemmDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int64)] + \
                [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")] + \
-               [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32)]
+               [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32),
+                ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):

@@ -963,6 +963,12 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   p.bn_partial = d->stats_partial;
+  if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
+    const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
+    int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);
+    p.pig_blocks = (int)(nb < 1 ? 1 : nb > 128 ? 128 : nb);
+    p.pig = *d->carry;
+  }
   return dvt_conv_dma_launch(p, conv_fwd_cfg(p.M, d->Cout, d->C), (hipStream_t)stream);
 }
 
@@ -1044,6 +1050,13 @@ int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
   int rc = dvt_conv_wgrad_dma_launch(p, pl.split, pl.cfg, st);
   if (rc) return rc;
+  if (d->defer_reduce) {                           // left to the data-gradient launch of the same layer (d->pending -> its carry)
+    DVT_REQUIRE(d->pending, "dvt_conv2d_implicit_wgrad: defer_reduce needs a pending descriptor to fill");
+    dvt_splitk_pending* q = d->pending;
+    q->slab = p.slab; q->splits = pl.split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->y; q->ldc = d->Cout;
+    q->accumulate = 0; q->cs_accumulate = 0; q->cs_slab = nullptr; q->cs_out = nullptr;
+    return DVT_OK;
+  }
   const int64_t nvec = (int64_t)p.M * p.N / 8;
   int64_t blocks = dvt_cdiv(nvec, 256);
   const int64_t cap = (int64_t)dvt_num_cus() * 8;

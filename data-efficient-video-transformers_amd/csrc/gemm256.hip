@@ -680,10 +680,9 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
   typedef Cfg<CFG> C;
   constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
-  p.pig_blocks = 0;
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
-  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, 1), block(C::NW * 64);
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n + p.pig_blocks), 1, 1), block(C::NW * 64);   // + a carried split-K reduce
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>,

@@ -1223,41 +1223,49 @@ class _ConvBnAct(torch.autograd.Function):
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
         if ctx.wg_implicit:
-            dwt = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim)   # [kh*kw*Cin, Cout] fp32
+            dwt, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim,
+                                                  defer_reduce=True)                        # [kh*kw*Cin, Cout] fp32
             unpack, dwp = ops.conv_weight_unpack_grad_t, dwt
         else:
             if col is None:
                 col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)   # recomputed gather
-            unpack, dwp = ops.conv_weight_unpack_grad, ops.linear_wgrad(dz, col)             # [Cout, ld] fp32
-        if ctx.pair is not None:                                         # pixel-pair stem: adjoint of dvt_conv_weight_pairs
-            kh_o, kw_o, pw_o, kwp = ctx.pair
-            dw_pairs = unpack(dwp, w4)                                   # [Cout, 8, kh, kwp]
-            if sw is not None and Cout == Cout_l:
-                ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp, out=sw.buf, accumulate=not sw.fresh)
-                sw.mark_written()
-                dw = None
-            else:
-                dwo = ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp)
-                if sw is not None:
-                    ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l, out=sw.buf, accumulate=not sw.fresh)
+            dwp, pend = ops.linear_wgrad(dz, col, defer_reduce=True)                         # [Cout, ld] fp32
+            unpack = ops.conv_weight_unpack_grad
+        dw_box = [None]
+
+        def emit_dw():
+            """Unpack / scatter the reduced weight gradient into the parameter layout (and the sink).  Runs BEHIND the data
+            gradient: the implicit weight gradient leaves its split-K reduce to that launch's grid tail (``pend``)."""
+            if ctx.pair is not None:                                         # pixel-pair stem: adjoint of dvt_conv_weight_pairs
+                kh_o, kw_o, pw_o, kwp = ctx.pair
+                dw_pairs = unpack(dwp, w4)                                   # [Cout, 8, kh, kwp]
+                if sw is not None and Cout == Cout_l:
+                    ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp, out=sw.buf, accumulate=not sw.fresh)
                     sw.mark_written()
-                    dw = None
+                    dw_box[0] = None
                 else:
-                    dw = ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l).view(wshape)
-        elif padded:                                                     # full-width gradient, then the reference slice
-            dw_full = unpack(dwp, w4)
-            if sw is not None:
-                ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin, out=sw.buf, accumulate=not sw.fresh)
+                    dwo = ops.conv_weight_pairs_bwd(dw_pairs, Cout, Cin_l, kh_o, kw_o, pw_o, kwp)
+                    if sw is not None:
+                        ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l, out=sw.buf, accumulate=not sw.fresh)
+                        sw.mark_written()
+                        dw_box[0] = None
+                    else:
+                        dw_box[0] = ops.unpad3_f32(dwo, Cout_l, Cin_l, kh_o * kw_o, Cin_l).view(wshape)
+            elif padded:                                                     # full-width gradient, then the reference slice
+                dw_full = unpack(dwp, w4)
+                if sw is not None:
+                    ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin, out=sw.buf, accumulate=not sw.fresh)
+                    sw.mark_written()
+                    dw_box[0] = None
+                else:
+                    dw_box[0] = ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin).view(wshape)
+            elif sw is not None:
+                unpack(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
                 sw.mark_written()
-                dw = None
+                dw_box[0] = None
             else:
-                dw = ops.unpad3_f32(dw_full, Cout_l, Cin_l, kh * kw, Cin).view(wshape)
-        elif sw is not None:
-            unpack(dwp, w4, out=sw.buf, accumulate=not sw.fresh)
-            sw.mark_written()
-            dw = None
-        else:
-            dw = unpack(dwp, w4).view(wshape)
+                dw_box[0] = unpack(dwp, w4).view(wshape)
+
         dx = None
         (sh_, sw_), (ph_, pw_) = ops._pair(stride), ops._pair(pad)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
@@ -1269,7 +1277,7 @@ class _ConvBnAct(torch.autograd.Function):
                     and ops.conv3x3_c64_supported(dz, wd, N, Ho, Wo)):
                 dx = ops.conv3x3_c64(dz, wd, N, Ho, Wo)
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
-                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd)     # [N*H*W, Cin], no dcol / col2im
+                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend)   # [N*H*W, Cin], no dcol / col2im
         if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
             dx = ops.zeros(ctx.x_shape, ctx.x_dtype, dz.device).view(N, Cin, H, W)
             hw = Ho * Wo
@@ -1278,13 +1286,16 @@ class _ConvBnAct(torch.autograd.Function):
                 ops.copy_(dx[f0:f0 + cnt], ops.col2im_nchw(dcol, cnt, Cin, H, W, k, stride, pad, ctx.x_dtype))
             dx = dx.view(ctx.x_shape)
         if ctx.x_needs and dx is None:
-            dcol = ops.linear_dgrad(dz, wp)                              # [rows, ld]
+            dcol = ops.linear_dgrad(dz, wp, carry=pend)                  # [rows, ld]
             if direct:
                 dx = dcol
             elif nchw:      # gradient w.r.t. the raw NCHW frames (pixel-space CLS clip, frame_transformer.py:105)
                 dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
+        ops.splitk_reduce_pending(pend)          # nobody carried it (no data gradient wanted, or the halo kernel computed it)
+        emit_dw()
+        dw = dw_box[0]
         return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None
 
 

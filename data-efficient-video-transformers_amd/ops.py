@@ -942,7 +942,7 @@ def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool 
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                    want_stats: bool = False, trim_w: int = 0):
+                    want_stats: bool = False, trim_w: int = 0, carry=None):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
     want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
     epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
@@ -959,8 +959,12 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
     nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
+    if carry is not None and carry.valid:             # the layer's weight-gradient reduce rides in this launch's grid tail
+        d.carry = C.addressof(carry)
     with _timed(("conv", "implicit", N * Ho * Wo, Cout, kh * kw * Cc, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
+    if carry is not None:
+        carry.valid = 0
     return (y, partial, parts) if want_stats else y
 
 
@@ -984,20 +988,29 @@ def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k,
 
 
 def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                          trim_w: int = 0) -> Tensor:
-    """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised."""
+                          trim_w: int = 0, defer_reduce: bool = False):
+    """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised.
+    defer_reduce: -> (dWt, pending): the split-K reduce is left to the data-gradient launch of the same layer
+    (``conv2d_implicit(..., carry=pending)`` / ``linear_dgrad(..., carry=pending)``) or ``splitk_reduce_pending``."""
     _need_cuda(x, dz)
     (kh, kw) = _pair(k)
     out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
     d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad, trim_w)
     lib = L.load()
-    ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device)
+    ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device,
+                   slot="deferred" if defer_reduce else "main")
     d.workspace = _p(ws)
+    pending = None
+    if defer_reduce:
+        pending = L.SplitKPending()
+        pending._keep = (out, ws)
+        d.defer_reduce = 1
+        d.pending = C.addressof(pending)
     rows = dz.shape[0]
     nb = (x.numel() + dz.numel()) * x.element_size() + out.numel() * out.element_size()
     with _timed(("conv", "wgrad", kh * kw * Cc, Cout, rows, nb), 2.0 * rows * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit_wgrad(C.byref(d), _stream()), "dvt_conv2d_implicit_wgrad")
-    return out
+    return (out, pending) if defer_reduce else out
 
 
 def conv_weight_unpack_grad_t(gt: Tensor, shape, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:

@@ -416,6 +416,13 @@ typedef struct dvt_conv_desc {
   /* output columns dropped at the right edge: Wo = (W + 2*pw - kw)/sw + 1 - trim_w (0: the usual convolution).  The
    * pixel-pair stem (dvt_conv_weight_pairs) pads two pair columns on the left and needs only one on the right. */
   int32_t trim_w;
+  /* Optional, like the same three fields of the GEMM descriptor: the weight gradient (dvt_conv2d_implicit_wgrad) leaves its split-K
+   * reduce undone when defer_reduce != 0 and describes it in *pending; the data gradient of the same layer
+   * (dvt_conv2d_implicit on dz with the rotated weights) performs a pending reduce handed to it as `carry` in extra
+   * workgroups at the end of its grid.  The weight-gradient scatter (dvt_conv_weight_unpack_grad_t) goes behind the carrier. */
+  int32_t defer_reduce;
+  dvt_splitk_pending* pending;
+  const dvt_splitk_pending* carry;
 } dvt_conv_desc;
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
  * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a
