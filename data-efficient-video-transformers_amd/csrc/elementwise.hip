@@ -272,10 +272,12 @@ __global__ void tokens_bwd_emb_kernel(const T* __restrict__ dout, T* __restrict_
 }
 
 // dpos[t, j, :] (+)= sum_b dout[b*T + t, j, :]   (rows j > n get 0 when overwriting)
+// demb != nullptr: the same pass also writes the patch-row gradients demb[(b*T + t)*n + j - 1, :] = dout[b*T + t, j, :]
+// (j >= 1): one read of dout serves both (tokens_bwd_emb_kernel alone re-read it).
 template <typename T>
 __global__ void tokens_bwd_pos_kernel(const T* __restrict__ dout, float* __restrict__ dpos,
                                       int64_t S, int64_t Tn, int64_t n, int64_t d, int64_t pos_rows,
-                                      int accumulate) {
+                                      int accumulate, T* __restrict__ demb = nullptr) {
   const int64_t dv = d >> 3;
   const int64_t items = Tn * pos_rows * dv;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -290,6 +292,7 @@ __global__ void tokens_bwd_pos_kernel(const T* __restrict__ dout, float* __restr
       for (int64_t b = 0; b < B; ++b) {
         float v[8];
         load8<T>(dout + ((b * Tn + t) * (n + 1) + j) * d + c, v);
+        if (demb && j >= 1) store8<T>(demb + ((b * Tn + t) * n + j - 1) * d + c, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += v[k];
       }
@@ -906,12 +909,13 @@ int dvt_tokens_assemble_bwd(const void* dout, void* demb, float* dcls, float* dp
   hipStream_t st = (hipStream_t)stream;
   const int64_t dv = d >> 3;
   DVT_DISPATCH_DTYPE(dtype, Tt, {
-    if (demb && n > 0)
+    const bool one_pass = demb && n > 0 && dpos;     // the positional-gradient pass reads all of dout: it writes demb as well
+    if (demb && n > 0 && !one_pass)
       hipLaunchKernelGGL((tokens_bwd_emb_kernel<Tt>), dim3(grid_for(S * n * dv)), dim3(kBlock), 0, st,
                          (const Tt*)dout, (Tt*)demb, S, n, d);
     if (dpos)
       hipLaunchKernelGGL((tokens_bwd_pos_kernel<Tt>), dim3(grid_for(T * pos_rows * dv)), dim3(kBlock),
-                         0, st, (const Tt*)dout, dpos, S, T, n, d, pos_rows, accumulate);
+                         0, st, (const Tt*)dout, dpos, S, T, n, d, pos_rows, accumulate, one_pass ? (Tt*)demb : (Tt*)nullptr);
     if (dcls)
       hipLaunchKernelGGL((strided_rows_sum_kernel<Tt>), dim3((unsigned)dv), dim3(kBlock), 0, st,
                          (const Tt*)dout, (n + 1) * d, S, dcls, accumulate);
