@@ -257,3 +257,56 @@ def test_two_gloo_ranks_graph_segments_equal_eager_bit_for_bit(device, tmp_path)
     mp.spawn(_graph_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     res = torch.load(out)
     assert torch.equal(res["eager"], res["segments"])
+
+
+def test_twice_used_layernorm_with_gamma_and_beta_in_different_buckets(device):
+    """a LayerNorm used twice in a step whose gamma and beta sit in DIFFERENT gradient buckets.  Registration
+    order [W_pre, A, ln_weight, ln_bias, X] with 128-element buckets gives {ln.bias, X} and {A, ln.weight}; forward
+    h = LN(linear(x, W_pre, X)); y = LN(linear(h, A)).  In backward the second use writes gamma / beta first, A's weight
+    gradient then completes (and launches) gamma's bucket, and the first use's LayerNorm backward finds gamma redirected
+    to its late buffer (accumulate = False) while beta still accumulates into the bucket (X is unwritten): the two sinks
+    need their own accumulate flags.  Two steps (a stale late buffer would show in the second) against torch autograd."""
+    from dvt_amd.dp import Communicator, FlatParameters
+    from dvt_amd import functional as F
+    from oracle import clip_path as O
+    d = 64
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.w_pre = torch.nn.Parameter(torch.randn(d, d, generator=g) / 8)
+            self.a = torch.nn.Parameter(torch.randn(d, d, generator=g) / 8)
+            self.ln_weight = torch.nn.Parameter(1 + 0.1 * torch.randn(d, generator=g))     # (direct parameters: registration
+            self.ln_bias = torch.nn.Parameter(0.1 * torch.randn(d, generator=g))          #  order = this order)
+            self.x_bias = torch.nn.Parameter(0.1 * torch.randn(d, generator=g))
+
+        def forward(self, x):
+            h = F.layernorm(F.linear(x, self.w_pre, self.x_bias), self.ln_weight, self.ln_bias, 1e-5)
+            return F.layernorm(F.linear(h, self.a), self.ln_weight, self.ln_bias, 1e-5)
+
+    comm = Communicator(1, 0, Communicator.unique_id())
+    try:
+        net = Net().cuda()
+        flat = FlatParameters(net, bucket_mb=128 * 4 / (1 << 20), compute_dtype=None, comm=comm)
+        names = [n for n, _ in net.named_parameters()]
+        bucket = {n: flat.sinks[i].bucket for i, n in enumerate(names)}
+        assert (bucket["ln_weight"] != bucket["ln_bias"] and bucket["ln_bias"] == bucket["x_bias"]
+                and bucket["ln_weight"] == bucket["a"]), bucket
+        gen = torch.Generator().manual_seed(4)
+        for step in range(2):
+            x = torch.randn(16, d, generator=gen)
+            t = torch.randn(16, d, generator=gen)
+            P = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in net.named_parameters()}
+            h = O.layernorm(O.linear(x, P["w_pre"], P["x_bias"]), P["ln_weight"], P["ln_bias"])
+            ref = O.layernorm(O.linear(h, P["a"]), P["ln_weight"], P["ln_bias"])
+            ref.backward(t)
+            flat.zero_grad()
+            net(x.cuda()).backward(t.cuda())
+            flat.finish_backward()
+            torch.cuda.synchronize()
+            for n, p in net.named_parameters():
+                e = float((p.grad.cpu() - P[n].grad).norm() / P[n].grad.norm())
+                assert e < 1e-4, (step, n, e)
+    finally:
+        comm.destroy()
