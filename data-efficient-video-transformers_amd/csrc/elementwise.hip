@@ -143,6 +143,12 @@ __global__ void act_kernel(const T* __restrict__ dy, const T* __restrict__ x, T*
 
 // ------------------------------------------------------------------ patchify
 // out[(f*nh + ph)*nw + pw, (p1*P + p2)*C + c] = x[f, c, ph*P + p1, pw*P + p2]
+// LDS operations of one wave complete in order; this only keeps the compiler from moving them across the point
+__device__ __forceinline__ void wave_lds_fence_ew() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Work item = one patch row (frame, ph, p1, pw): C runs of P contiguous pixels in,
 // one run of P*C contiguous patch-vector elements out.  pw is the fastest index so
 // a wave reads 64 adjacent pixel runs (a contiguous span of the image row per channel).
@@ -204,6 +210,60 @@ __global__ void patchify_vec_kernel(const S* __restrict__ x, D* __restrict__ out
           store8<S>(dx + xoff + (int64_t)c * H * W + q * 8, t);
         }
     }
+  }
+}
+
+// Forward, 16 x 16 patches of 3 channels, 16-bit patch vectors (the metric shape): lane = (patch & 3) * 16 + p1, so a wave
+// owns FOUR consecutive patch vectors = 6 KiB of contiguous output.  The lane's 96 output bytes (one patch row: 16 pixels
+// x 3 channels) go through a wave-private LDS patch and leave as six fully contiguous 1-KiB store instructions; the
+// per-lane form above stores 16-byte pieces at a 1,536-byte stride (one 64-byte segment per piece: 3.3 TB/s).
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void patchify16_fwd_kernel(const S* __restrict__ x, D* __restrict__ out, int64_t npatches,
+                                                             int H, int W, int nh, int nw) {
+  constexpr int P = 16, C = 3, ROWB = P * C * 2;              // 96 bytes per patch row
+  __shared__ __attribute__((aligned(16))) char lds[4][64 * ROWB];
+  typedef D v8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t ngroups = (npatches + 3) >> 2, nwaves = (int64_t)gridDim.x * 4;
+  char* mine = lds[wid];
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < ngroups; g += nwaves) {
+    const int64_t patch = min(g * 4 + (lane >> 4), npatches - 1);
+    const int p1 = lane & 15;
+    const int pw = (int)(patch % nw);
+    const int64_t r = patch / nw;
+    const int ph = (int)(r % nh);
+    const int64_t f = r / nh;
+    const int64_t xoff = ((f * C) * H + (int64_t)ph * P + p1) * W + (int64_t)pw * P;
+    float pix[C][P];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int q = 0; q < P / 8; ++q) {
+        float t[8];
+        load8<S>(x + xoff + (int64_t)c * H * W + q * 8, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pix[c][q * 8 + k] = t[k];
+      }
+#pragma unroll
+    for (int q = 0; q < P * C / 8; ++q) {
+      v8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = q * 8 + k;                                // e = p2 * C + c
+        o[k] = (D)pix[e % C][e / C];
+      }
+      *reinterpret_cast<v8*>(mine + lane * ROWB + q * 16) = o;
+    }
+    wave_lds_fence_ew();
+    char* dst = reinterpret_cast<char*>(out) + g * 4 * (int64_t)(P * ROWB);
+    const int64_t lim = (npatches - g * 4) * (int64_t)(P * ROWB);  // bytes of this group that exist
+#pragma unroll
+    for (int q = 0; q < P * C / 8; ++q) {
+      const int off = (q * 64 + lane) * 16;
+      const v8 o = *reinterpret_cast<const v8*>(mine + off);
+      if (off < lim) *reinterpret_cast<v8*>(dst + off) = o;
+    }
+    wave_lds_fence_ew();
   }
 }
 
@@ -823,6 +883,18 @@ int patchify_dispatch(const void* x, void* out, void* dx, const void* dout, int6
   const void* vecp = FWD ? (const void*)out : dout;
   const bool vec_ok = (W % 8 == 0) && (P % 8 == 0) && ((P * C) % 8 == 0) && dvt_aligned16(pix) &&
                       dvt_aligned16(vecp) && ((int64_t)H * W % 8 == 0);
+  if constexpr (FWD && sizeof(D) == 2) {
+    if (vec_ok && P == 16 && C == 3) {
+      const int64_t npatches = frames * nh * nw;
+      int64_t blocks = dvt_cdiv(dvt_cdiv(npatches, 4), 4);
+      const int64_t cap = (int64_t)dvt_num_cus() * 16;
+      if (blocks > cap) blocks = cap;
+      hipLaunchKernelGGL((patchify16_fwd_kernel<S, D>), dim3((unsigned)blocks), dim3(256), 0, st, (const S*)x, (D*)out,
+                         npatches, H, W, nh, nw);
+      DVT_LAUNCH_CHECK(name);
+      return DVT_OK;
+    }
+  }
   if (vec_ok && P == 16 && C == 3) {
     hipLaunchKernelGGL((patchify_vec_kernel<16, 3, S, D, FWD>), dim3(grid_for(items)), dim3(kBlock),
                        0, st, (const S*)x, (D*)out, (S*)dx, (const D*)dout, frames, H, W);
