@@ -17,15 +17,6 @@
 // LDS is lane-linear for the DMA, so both swizzles sit on the per-lane SOURCE address and again on the fragment read.
 #include "gemm_common.h"
 
-#ifdef DVT_SMALL_TIMING
-// dev build only (tools/dev/small_gemm_timing.sh): per-workgroup s_memtime stamps, 8 slots per workgroup
-__device__ long long* g_small_tb = nullptr;
-#define DVT_SSTAMP(i) do { if (threadIdx.x == 0 && g_small_tb) g_small_tb[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int dvt_debug_small_timing_buffer(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_small_tb), &buf, sizeof(buf)); }
-#else
-#define DVT_SSTAMP(i)
-#endif
-
 namespace {
 
 constexpr int SK = 256;                      // k chunk
@@ -139,7 +130,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     dma_chunk<A_KMAJOR, TM>(p.A, p.lda, m0, p.M, ch * ck, p.K, st, wid, lane, ck);
     dma_chunk<B_KMAJOR, STN>(p.B, p.ldb, n0, p.N, ch * ck, p.K, st + boff, wid, lane, ck);
   };
-  DVT_SSTAMP(0);
   // Epilogue operands (bias, residual / activation-derivative operand, the old value under accumulate) are requested
   // FIRST -- clamped addresses, no branches -- so that their round trip runs under the panel DMA instead of behind the
   // main loop (the epilogue was 2.9 k of the kernel's 10.7 k ticks, nearly all of it these dependent loads); being the
@@ -168,7 +158,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   }
   issue(0);
   if (nch > 1) issue(1);
-  DVT_SSTAMP(1);
 
   // fused bias gradient (weight-gradient form): colsum[m] = sum_k A(m, k) for the tiles of the first tile column
   const bool do_cs = !A_KMAJOR && p.colsum_slab != nullptr && n0 == 0;
@@ -177,7 +166,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) swait_vm<kPPC>(); else swait_vm<0>();   // chunk ch landed (ch + 1 may stay in flight; then ck == SK)
     __builtin_amdgcn_s_barrier();
-    if (ch == 0) DVT_SSTAMP(2);
     const char* sa = smem + (ch & 1) * kStage;
     const char* sb = sa + boff;
     auto kstep = [&](int kk) {
@@ -213,7 +201,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
     *o = p.accumulate_colsum ? *o + cs : cs;
   }
 
-  DVT_SSTAMP(3);
   // ---- epilogue on the accumulators: lane (g, li) holds C[row = .. + li][col = .. + 4g .. 4g+3].
   // ONE switch over the epilogue kind with the element loops inside it: the per-element form (a runtime switch around
   // every value) compiled to a scalar branch chain per element -- 2.4 k of the kernel's 10 k ticks at eight elements.
@@ -272,7 +259,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
       }
     }
   }
-  DVT_SSTAMP(4);
 }
 
 template <typename E, bool AK, bool BK, int TM>

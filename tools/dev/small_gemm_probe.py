@@ -1,5 +1,6 @@
 """Dev probe: the launch-bound GEMMs of the temporal encoder (264 rows) in isolation: per-launch time from a chain of
-dependent launches, and (with tools/_bin/libdvt_hip_stiming.so) per-workgroup phase stamps."""
+launches in one graph, with warm and with cold weights.  (The per-workgroup phase stamps quoted in DESIGN 4.1 came from a
+-DDVT_SMALL_TIMING build of gemm_small.hip that lived in the round-3 commits before this one; they are not in the product source.)"""
 import os, sys, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
