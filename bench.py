@@ -743,6 +743,8 @@ def main():
                     "single-GPU box -- the gradient exchange then goes through torch.distributed as well)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and the RCCL communicator even "
                     "with one rank (rehearses the multi-GPU code path on a single GPU)")
+    ap.add_argument("--no-cls-fold", action="store_true", help="A/B switch: run the last space layer's single-query attention "
+                    "without folding the K / V projections into the query (functional.CLS_FOLD_MIN_ROWS)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test (runs without a GPU): every rank joins "
                     "the process group, sums its rank over the group and rank 0 prints a JSON line with n_gpus = world")
     args = ap.parse_args()
@@ -792,6 +794,8 @@ def main():
         args.batch //= world
 
     import dvt_amd  # noqa: F401
+    if args.no_cls_fold:
+        dvt_amd.functional.CLS_FOLD_MIN_ROWS = 1 << 62
     if use_dist and args.backend == "nccl":
         from dvt_amd.dp import Communicator
         try:

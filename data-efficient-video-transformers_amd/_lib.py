@@ -69,6 +69,16 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnClsDesc(C.Structure):
+    _fields_ = [
+        ("x", c_p), ("xs0", c_i64), ("xs1", c_i64), ("gamma", c_p), ("beta", c_p), ("eps", c_f),
+        ("S", c_i64), ("N", c_i64), ("d", c_i64), ("H", c_i64), ("dtype", C.c_int32),
+        ("R", c_p), ("A", c_p), ("lse", c_p), ("mean", c_p), ("rstd", c_p),
+        ("dM", c_p), ("dx", c_p), ("G", c_p), ("dgamma", c_p), ("dbeta", c_p),
+        ("accumulate_gamma", C.c_int32), ("accumulate_beta", C.c_int32), ("workspace", c_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/dvt_hip.h
 SIGNATURES = {
     "dvt_version": (c_int, []),
@@ -105,6 +115,13 @@ SIGNATURES = {
     "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "dvt_attention_fwd": (c_int, [C.POINTER(AttnDesc), c_p]),
     "dvt_attention_bwd": (c_int, [C.POINTER(AttnDesc), c_p]),
+    "dvt_attn_cls_supported": (c_int, [C.POINTER(AttnClsDesc)]),
+    "dvt_attn_cls_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnClsDesc)]),
+    "dvt_attn_cls_fwd": (c_int, [C.POINTER(AttnClsDesc), c_p]),
+    "dvt_attn_cls_bwd": (c_int, [C.POINTER(AttnClsDesc), c_p]),
+    "dvt_heads_expand": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    "dvt_heads_contract": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
+    "dvt_heads_outer": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_int, c_p]),
     "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
     "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 9 + [c_i64, c_int, c_p]),
     "dvt_col2im_nchw": (c_int, [c_p, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),

@@ -5,6 +5,7 @@
 // variance of the centred values), fp32 math.  Algorithmic traffic per row:
 // fwd reads d and writes d elements (+8 B of statistics); bwd reads 2d, writes d.
 #include "common.h"
+#include "ln_reduce.h"
 
 namespace {
 
@@ -183,41 +184,6 @@ __global__ __launch_bounds__(kLnBwdBlock) void ln_bwd_kernel(
   for (int c = threadIdx.x; c < 2 * d; c += kLnBwdBlock) out[c] = lds[c];
 }
 
-// out[c] (+)= sum_p partial[p][c]   for c in [0, 2d): dgamma then dbeta.
-// Block = 32 columns x 8 part-lanes; each thread sums nparts/8 partials (4 loads in
-// flight), then an LDS tree over the 8 part-lanes.
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial,
-                                                            int nparts, int d,
-                                                            float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta,
-                                                            int accumulate /* bit 0: dgamma, bit 1: dbeta */) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const int64_t ld = 2 * (int64_t)d;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (c < 2 * d) {
-    int p = pl;
-    for (; p + 24 < nparts; p += 32) {
-      a0 += partial[(int64_t)p * ld + c];
-      a1 += partial[(int64_t)(p + 8) * ld + c];
-      a2 += partial[(int64_t)(p + 16) * ld + c];
-      a3 += partial[(int64_t)(p + 24) * ld + c];
-    }
-    for (; p < nparts; p += 8) a0 += partial[(int64_t)p * ld + c];
-  }
-  red[pl][cl] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (pl == 0 && c < 2 * d) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][cl];
-    float* o = c < d ? dgamma + c : dbeta + (c - d);
-    const bool acc = c < d ? (accumulate & 1) : (accumulate & 2);
-    *o = acc ? *o + t : t;
-  }
-}
-
 int ln_check(const char* name, const void* a, const void* b, int64_t n0, int64_t n1, int64_t d,
              int64_t xs0, int64_t xs1, int64_t ys0, int64_t ys1) {
   DVT_REQUIRE(a && b, "%s: null pointer", name);
@@ -297,9 +263,7 @@ int dvt_layernorm_bwd_first(const void* dy, const void* x, const float* gamma, c
       (const T*)x, gamma, mean, rstd, (const T*)dx_add, (T*)dx, partial, rows, n1, (int)d, xs0, xs1, ys0, ys1,
       (const T*)dy_first, dy_first_stride, (const T*)dx_first, dx_first_stride)));
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)dvt_cdiv(2 * d, 32)), dim3(256), 0, st,
-                     (const float*)partial, (int)blocks, (int)d, dgamma, dbeta,
-                     (accumulate_gamma ? 1 : 0) | (accumulate_beta ? 2 : 0));
+  dvt_ln_partials_reduce(partial, (int)blocks, (int)d, dgamma, dbeta, accumulate_gamma, accumulate_beta, st);
   DVT_LAUNCH_CHECK("dvt_layernorm_bwd(reduce)");
   return DVT_OK;
 }

@@ -585,10 +585,25 @@ class _AttnBlockCls(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         g, bb = _f32(ln_w), _f32(ln_b)
-        xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
         wqkv = _wc(w_qkv, T)
         inner = wqkv.shape[0] // 3
         dh = inner // heads
+        wo = _wc(w_out, T)
+        ctx.cfg = (S, N, d, heads, dh, inner, b_out is not None, eps)
+        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
+        x3 = x2.view(S, N, d)
+        ctx.folded = S * N >= CLS_FOLD_MIN_ROWS and ops.attn_cls_supported(x3, heads)
+        if ctx.folded:
+            # K / V projections folded into the query (csrc/attention_cls.hip): LN(x), K and V of the rows 1 .. N-1 never exist
+            xn0, mean0, rstd0 = ops.layernorm_fwd(x2, g, bb, eps, rows=(S, 1, N * d, 0))          # [S, d]: row 0 only
+            q = ops.linear_fwd(xn0, wqkv[:inner])                                                  # [S, inner]
+            R = ops.heads_expand(q, wqkv[inner:2 * inner], heads, dh ** -0.5)                      # r_h = scale Wk_h^T q_h
+            A, lse, mean, rstd = ops.attn_cls_fwd(x3, g, bb, eps, R)                               # one pass over x
+            o = ops.heads_contract(A, wqkv[2 * inner:], 1.0, g, bb)                                # o_h = Wv_h (gamma A_h + beta)
+            y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0])
+            ctx.save_for_backward(x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, mean, rstd)
+            return y
+        xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
         w_q, w_kv = wqkv[:inner], wqkv[inner:]                          # row slices of the packed weight, no copies
         kv = ops.linear_fwd(xn, w_kv)                                    # [S*N, 2*inner]
         xn0 = xn.view(S, N, d)[:, 0]                                     # [S, d], row stride N*d
@@ -598,17 +613,57 @@ class _AttnBlockCls(torch.autograd.Function):
         o = torch.empty((S, inner), dtype=T, device=x.device)
         lse = ops.attention_fwd(q.view(S, 1, heads, dh).permute(0, 2, 1, 3), k4, v4,
                                 o.view(S, 1, heads, dh).permute(0, 2, 1, 3), dh ** -0.5)
-        wo = _wc(w_out, T)
-        y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2.view(S, N, d)[:, 0])
+        y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0])
         ctx.save_for_backward(x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse)
-        ctx.cfg = (S, N, d, heads, dh, inner, b_out is not None)
-        ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
         return y
 
     @staticmethod
+    def _backward_folded(ctx, dy):
+        x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, mean, rstd = ctx.saved_tensors
+        S, N, d, heads, dh, inner, has_bias, eps = ctx.cfg
+        T = x2.dtype
+        s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
+        scale = dh ** -0.5
+        dy2 = _as(dy.reshape(S, d).contiguous(), T)
+        do = ops.linear_dgrad(dy2, wo)                                   # [S, inner]
+        dwo, dbo = _emit_wgrad_bias(s_o, s_bo, dy2, o, has_bias)
+        if s_qkv is not None:                                            # three row ranges of one packed gradient
+            buf, acc = s_qkv.buf.view(3 * inner, d), not s_qkv.fresh
+            dwqkv = None
+        else:
+            buf, acc = torch.empty((3 * inner, d), dtype=torch.float32, device=x2.device), False
+            dwqkv = buf
+        w_q, w_k, w_v = wqkv[:inner], wqkv[inner:2 * inner], wqkv[2 * inner:]
+        dM = ops.heads_expand(do, w_v, heads, 1.0)                       # dm_h = Wv_h^T do_h
+        ops.heads_outer(do, A, buf[2 * inner:], 1.0, g, bb, accumulate=acc)          # dWv_h = do_h (x) m_h
+        if s_g is not None and s_b is not None:
+            dx2, G, _, _ = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, mean, rstd, dM, dg=s_g.buf.view(-1),
+                                            db=s_b.buf.view(-1), accumulate=not s_g.fresh, accumulate_beta=not s_b.fresh)
+            dg, db = s_g.buf.view(-1), s_b.buf.view(-1)
+        else:
+            dx2, G, dg, db = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, mean, rstd, dM)
+        dq = ops.heads_contract(G, w_k, scale, g)                        # dq_h = scale Wk_h (gamma G_h)
+        ops.heads_outer(q, G, buf[inner:2 * inner], scale, g, accumulate=acc)        # dWk_h = scale q_h (x) dr_h
+        ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)
+        if s_qkv is not None:
+            s_qkv.mark_written()
+        dxn0 = ops.linear_dgrad(dq, w_q)                                 # [S, d]: the query path into LN(x)[:, 0]
+        # row 0 of every sequence: the LayerNorm backward of the query path, plus the residual path, on top of its K / V part
+        dxf = dx2.view(S * N, d)
+        ops.layernorm_bwd(dxn0, x2, g, mean0, rstd0, rows=(S, 1, N * d, 0), dx=dxf, dx_add=dxf, dx_first=dy2,
+                          dg=dg, db=db, accumulate=True)
+        if s_g is not None and s_b is not None:
+            s_g.mark_written()
+            s_b.mark_written()
+            dg = db = None
+        return dx2.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.folded:
+            return _AttnBlockCls._backward_folded(ctx, dy)
         x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse = ctx.saved_tensors
-        S, N, d, heads, dh, inner, has_bias = ctx.cfg
+        S, N, d, heads, dh, inner, has_bias, _ = ctx.cfg
         T = x2.dtype
         s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
         dy2 = _as(dy.reshape(S, d).contiguous(), T)
@@ -639,6 +694,11 @@ class _AttnBlockCls(torch.autograd.Function):
         dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d),
                              dy_first=dxn0, dx_first=dy2)
         return dx.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None
+
+
+# Sequences x rows from which the last layer's single-query attention runs with the K / V projections folded into the query
+# (csrc/attention_cls.hip); below it (the 33-token temporal stack) the unfolded form has fewer launches.
+CLS_FOLD_MIN_ROWS = 4096
 
 
 def attn_block_cls(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, eps=1e-5):

@@ -548,6 +548,114 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: T
         L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
 
 
+# ------------------------------------------------------------------ single-query attention, K / V projections folded
+def _attn_cls_desc(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, H: int) -> L.AttnClsDesc:
+    """x [S, N, d] (16-bit), last dim contiguous."""
+    assert x.dim() == 3 and x.stride(2) == 1
+    q = L.AttnClsDesc()
+    q.x, q.xs0, q.xs1 = x.data_ptr(), x.stride(0), x.stride(1)
+    q.gamma, q.beta, q.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    q.S, q.N, q.d = x.shape
+    q.H, q.dtype = H, dt(x)
+    return q
+
+
+def attn_cls_supported(x: Tensor, H: int) -> bool:
+    """Shape / dtype test of the folded single-query kernels (no launch)."""
+    if not x.is_cuda or x.dim() != 3 or x.stride(2) != 1:
+        return False
+    q = L.AttnClsDesc()
+    q.xs0, q.xs1 = x.stride(0), x.stride(1)
+    q.S, q.N, q.d = x.shape
+    q.H, q.dtype = H, dt(x)
+    return bool(L.load().dvt_attn_cls_supported(C.byref(q)))
+
+
+def attn_cls_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor):
+    """x [S,N,d], R [S,H,d] f32 -> (A [S,H,d] f32, lse [S,H], mean [S*N], rstd [S*N])."""
+    _need_cuda(x, gamma, beta, R)
+    S, N, d = x.shape
+    H = R.shape[1]
+    assert R.shape == (S, H, d) and R.dtype == torch.float32 and R.is_contiguous()
+    q = _attn_cls_desc(x, gamma, beta, eps, H)
+    f32 = dict(dtype=torch.float32, device=x.device)
+    A, lse = torch.empty((S, H, d), **f32), torch.empty((S, H), **f32)
+    mean, rstd = torch.empty((S * N,), **f32), torch.empty((S * N,), **f32)
+    q.R, q.A, q.lse, q.mean, q.rstd = R.data_ptr(), A.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    with _timed(("hbm", "attn_cls_fwd", S * N), S * N * d * x.element_size() + 2 * S * H * d * 4):
+        L.check(L.load().dvt_attn_cls_fwd(C.byref(q), _stream()), "dvt_attn_cls_fwd")
+    return A, lse, mean, rstd
+
+
+def attn_cls_bwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor, A: Tensor, lse: Tensor, mean: Tensor,
+                 rstd: Tensor, dM: Tensor, *, dx: Optional[Tensor] = None, dg: Optional[Tensor] = None,
+                 db: Optional[Tensor] = None, accumulate: bool = False, accumulate_beta: Optional[bool] = None):
+    """-> (dx like x, G [S,H,d] f32, dgamma, dbeta)."""
+    _need_cuda(x, gamma, beta, R, A, lse, mean, rstd, dM)
+    S, N, d = x.shape
+    H = R.shape[1]
+    assert dM.shape == (S, H, d) and dM.dtype == torch.float32 and dM.is_contiguous()
+    q = _attn_cls_desc(x, gamma, beta, eps, H)
+    if dx is None:
+        dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+    assert dx.stride() == x.stride()
+    if dg is None or db is None:
+        assert not accumulate and not accumulate_beta and dg is None and db is None
+        dg = torch.empty((d,), dtype=torch.float32, device=x.device)
+        db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    G = torch.empty((S, H, d), dtype=torch.float32, device=x.device)
+    q.R, q.A, q.lse, q.mean, q.rstd = R.data_ptr(), A.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    q.dM, q.dx, q.G, q.dgamma, q.dbeta = dM.data_ptr(), dx.data_ptr(), G.data_ptr(), dg.data_ptr(), db.data_ptr()
+    q.accumulate_gamma = int(accumulate)
+    q.accumulate_beta = int(accumulate if accumulate_beta is None else accumulate_beta)
+    lib = L.load()
+    ws = workspace(lib.dvt_attn_cls_bwd_workspace_bytes(C.byref(q)), x.device)
+    q.workspace = _p(ws)
+    with _timed(("hbm", "attn_cls_bwd", S * N), 2 * S * N * d * x.element_size() + 4 * S * H * d * 4):
+        L.check(lib.dvt_attn_cls_bwd(C.byref(q), _stream()), "dvt_attn_cls_bwd")
+    return dx, G, dg, db
+
+
+def heads_expand(a: Tensor, W: Tensor, H: int, alpha: float = 1.0) -> Tensor:
+    """a [S, H*dh] (16-bit, row stride free), W [H*dh, d] rows of a 16-bit weight -> out[s,h,:] = alpha a[s,h,:] W_h (f32)."""
+    _need_cuda(a, W)
+    S, inner = a.shape
+    d = W.shape[1]
+    assert W.shape[0] == inner and a.stride(1) == 1 and W.stride(1) == 1 and a.dtype == W.dtype and inner % H == 0
+    out = torch.empty((S, H, d), dtype=torch.float32, device=a.device)
+    L.check(L.load().dvt_heads_expand(a.data_ptr(), a.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), S, H,
+                                      inner // H, d, alpha, dt(a), _stream()), "dvt_heads_expand")
+    return out
+
+
+def heads_contract(v: Tensor, W: Tensor, alpha: float = 1.0, gamma: Optional[Tensor] = None,
+                   beta: Optional[Tensor] = None) -> Tensor:
+    """v [S,H,d] f32 (entering as gamma*v+beta), W [H*dh, d] 16-bit -> out [S, H*dh] = alpha W_h v_h in W's dtype."""
+    _need_cuda(v, W, gamma, beta)
+    S, H, d = v.shape
+    inner = W.shape[0]
+    assert W.shape[1] == d and W.stride(1) == 1 and v.is_contiguous() and v.dtype == torch.float32 and inner % H == 0
+    out = torch.empty((S, inner), dtype=W.dtype, device=v.device)
+    L.check(L.load().dvt_heads_contract(v.data_ptr(), _p(gamma), _p(beta), W.data_ptr(), W.stride(0), out.data_ptr(),
+                                        inner, S, H, inner // H, d, alpha, dt(W), _stream()), "dvt_heads_contract")
+    return out
+
+
+def heads_outer(a: Tensor, v: Tensor, out: Tensor, alpha: float = 1.0, gamma: Optional[Tensor] = None,
+                beta: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[h*dh+e, c] (+)= alpha sum_s a[s, h*dh+e] (gamma*v+beta)[s,h,c]; a [S, H*dh] 16-bit, v [S,H,d] f32,
+    out [H*dh, d] f32 (row stride free): the weight gradient of a row range of the packed to_qkv."""
+    _need_cuda(a, v, out, gamma, beta)
+    S, H, d = v.shape
+    inner = a.shape[1]
+    assert out.shape == (inner, d) and out.stride(1) == 1 and out.dtype == torch.float32 and a.stride(1) == 1
+    assert v.is_contiguous() and v.dtype == torch.float32 and inner % H == 0
+    L.check(L.load().dvt_heads_outer(a.data_ptr(), a.stride(0), v.data_ptr(), _p(gamma), _p(beta), out.data_ptr(),
+                                     out.stride(0), S, H, inner // H, d, alpha, int(accumulate), dt(a), _stream()),
+            "dvt_heads_outer")
+    return out
+
+
 # ------------------------------------------------------------------ losses / optimizer
 def bce_logits_fwd(z: Tensor, target: Tensor) -> Tensor:
     _need_cuda(z, target)

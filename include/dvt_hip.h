@@ -305,6 +305,64 @@ size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);
 int dvt_attention_fwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
 
+/* ---------------------------------------------------------------- single-query attention with folded K / V projections
+ * The reference reads only row 0 of the space transformer's output (src/models/vit.py:119-120; :126 for the temporal
+ * one under pool == 'cls'), so the attention of a stack's LAST layer (vit.py:46-58) has ONE query per (sequence, head),
+ * and with one query the key / value projections of to_qkv (vit.py:39,48) commute with the attention sums:
+ *     s_jh = scale q_h . (Wk_h LN(x_j)) = r_h . LN(x_j),   r_h = scale Wk_h^T q_h   (dvt_heads_expand)
+ *     o_h  = sum_j p_jh Wv_h LN(x_j)    = Wv_h m_h,         m_h = sum_j p_jh LN(x_j) (dvt_heads_contract)
+ * -- neither K, V nor LN(x) of the rows that are never read again is materialised: dvt_attn_cls_fwd is one pass over
+ * the raw rows x[S][N][d] (LayerNorm statistics, H scores and H weighted sums per row), dvt_attn_cls_bwd one more, which
+ * also is the LayerNorm backward of those rows (the gradient of row 0's own query / residual paths is added by a
+ * dvt_layernorm_bwd call on the S first rows).  Row (s, j) of x sits at x + s*xs0 + j*xs1 (elements); dx uses the same
+ * strides.  All [S, H, d] arrays are f32.  With n_j = (x_j - mean_j) rstd_j, LN(x_j) = gamma n_j + beta:
+ *   fwd:  R -> A[s,h,:] = sum_j p_jh n_j (so m_h = gamma A_h + beta), lse[S,H], mean / rstd [S*N]
+ *   bwd:  dM (gradient of m) -> dx, G[s,h,:] = sum_j ds_jh n_j (so dr_h = gamma G_h), dgamma / dbeta (+= when the
+ *         accumulate flags are set; workspace >= dvt_attn_cls_bwd_workspace_bytes holds one partial row per sequence).
+ * 16-bit dtypes, d % 8 == 0, d <= 512, H <= 8, N <= 200; dvt_attn_cls_supported tells (callers keep the unfolded
+ * dvt_layernorm_fwd -> dvt_gemm -> dvt_attention_fwd sequence otherwise). */
+typedef struct dvt_attn_cls_desc {
+  const void* x;
+  int64_t xs0, xs1;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int64_t S, N, d, H;
+  int32_t dtype;
+  const float* R;
+  float* A;
+  float* lse;
+  float* mean;
+  float* rstd;
+  /* backward only */
+  const float* dM;
+  void* dx;
+  float* G;
+  float* dgamma;
+  float* dbeta;
+  int32_t accumulate_gamma, accumulate_beta;
+  void* workspace;
+} dvt_attn_cls_desc;
+
+int dvt_attn_cls_supported(const dvt_attn_cls_desc* desc);
+size_t dvt_attn_cls_bwd_workspace_bytes(const dvt_attn_cls_desc* desc);
+int dvt_attn_cls_fwd(const dvt_attn_cls_desc* desc, dvt_stream_t stream);
+int dvt_attn_cls_bwd(const dvt_attn_cls_desc* desc, dvt_stream_t stream);
+/* The head-wise products on either side of it, over S rows only; W is a row range of the packed to_qkv weight
+ * (vit.py:39; [H*dh, ldw] in the 16-bit compute dtype), the [S, H, d] operands are f32 and, when gamma / beta are
+ * given, enter as gamma * v + beta (either may be NULL):
+ *   expand:   out[s, h, c]     = alpha sum_e in[s, h*dh + e] W[h*dh + e, c]                (q -> r, do -> dm)
+ *   contract: out[s, h*dh + e] = alpha sum_c v[s, h, c] W[h*dh + e, c]                      (m -> o, dr -> dq)
+ *   outer:    dW[h*dh + e, c] (+)= alpha sum_s a[s, h*dh + e] v[s, h, c]                    (weight gradients of Wv, Wk) */
+int dvt_heads_expand(const void* in, int64_t ld_in, const void* W, int64_t ldw, float* out, int64_t S, int64_t H,
+                     int64_t dh, int64_t d, float alpha, int dtype, dvt_stream_t stream);
+int dvt_heads_contract(const float* in, const float* gamma, const float* beta, const void* W, int64_t ldw, void* out,
+                       int64_t ld_out, int64_t S, int64_t H, int64_t dh, int64_t d, float alpha, int dtype,
+                       dvt_stream_t stream);
+int dvt_heads_outer(const void* a, int64_t lda, const float* b, const float* gamma, const float* beta, float* dW,
+                    int64_t ldw, int64_t S, int64_t H, int64_t dh, int64_t d, float alpha, int accumulate, int dtype,
+                    dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- on-device input stage
  * transforms.Compose([Resize(resize), CenterCrop(crop), ToTensor(), Normalize(mean, std)]) of the reference's loader
  * (src/dataloaders/mmx/MMX_Light_dl.py:203-217; val_transform :195-201) applied to decoded uint8 RGB frames

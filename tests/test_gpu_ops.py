@@ -593,6 +593,111 @@ def test_attn_block_cls_equals_dense_block_row0(dvt, device, dtype, dim, heads, 
         assert rel_l2(D[k].grad, R[k].grad) < 3 * tol, k
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dim,heads,dh,N,S", [(128, 2, 64, 17, 5), (512, 8, 64, 197, 6), (64, 2, 32, 10, 3),
+                                              (384, 6, 64, 197, 3), (512, 8, 64, 200, 2), (512, 3, 64, 1, 9)])
+def test_attn_block_cls_folded_equals_dense_block_row0(dvt, device, dtype, dim, heads, dh, N, S, monkeypatch):
+    """The same contract with the K / V projections folded into the one query (csrc/attention_cls.hip: no LN(x), K, V
+    of the rows that are never read again): values and every gradient against the dense block + slice of the oracle."""
+    monkeypatch.setattr(dvt.functional, "CLS_FOLD_MIN_ROWS", 0)
+    g = torch.Generator().manual_seed(23)
+    inner = heads * dh
+    x_d, x = _rnd((S, N, dim), dtype, g)
+    assert dvt.ops.attn_cls_supported(x_d, heads)
+    P = {
+        "ln_w": 1 + 0.1 * torch.randn(dim, generator=g), "ln_b": 0.1 * torch.randn(dim, generator=g),
+        "wqkv": torch.randn(3 * inner, dim, generator=g) / math.sqrt(dim),
+        "wout": torch.randn(dim, inner, generator=g) / math.sqrt(inner), "bout": 0.1 * torch.randn(dim, generator=g),
+    }
+    rd = lambda t: t.to(dtype).float()
+    R = {k: (rd(v) if v.dim() == 2 else v).clone().requires_grad_(True) for k, v in P.items()}
+    D = {k: v.cuda().requires_grad_(True) for k, v in P.items()}
+    xr, xd = x.clone().requires_grad_(True), x_d.clone().requires_grad_(True)
+    ref = (O.self_attention(O.layernorm(xr, R["ln_w"], R["ln_b"]), R["wqkv"], R["wout"], R["bout"], heads) + xr)[:, 0]
+    out = dvt.functional.attn_block_cls(xd, D["ln_w"], D["ln_b"], D["wqkv"], D["wout"], D["bout"], heads)
+    assert out.shape == (S, dim) and rel_l2(out, ref) < BF16_TOL
+    gy_d, gy = _rnd(out.shape, dtype, g)
+    ref.backward(gy)
+    out.backward(gy_d)
+    assert rel_l2(xd.grad, xr.grad) < 3 * BF16_TOL
+    for k in P:
+        assert rel_l2(D[k].grad, R[k].grad) < 3 * BF16_TOL, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,N,d,H", [(4, 197, 512, 8), (3, 50, 384, 6), (2, 9, 64, 2), (5, 200, 512, 1)])
+def test_attn_cls_folded_kernels_against_float64(dvt, device, dtype, S, N, d, H):
+    """dvt_attn_cls_fwd / _bwd on 16-bit rows: everything between the rows and the fp32 results is fp32, so the fp32
+    outputs are held to 2e-5 against a float64 evaluation of the same formulas on the same inputs; dx (16-bit) to the
+    rounding of its element type.  Also: dgamma / dbeta accumulate flags, strided rows."""
+    g = torch.Generator().manual_seed(24)
+    xs = torch.randn(S, N + 2, d, generator=g).to(dtype)               # rows sit in a larger buffer: sequence stride (N+2) d
+    x_d = xs.cuda()[:, 1:N + 1]
+    x = xs[:, 1:N + 1].double()
+    gam, bet = 1 + 0.2 * torch.randn(d, generator=g), 0.2 * torch.randn(d, generator=g)
+    R = torch.randn(S, H, d, generator=g) * (1.5 / math.sqrt(d))
+    dM = torch.randn(S, H, d, generator=g)
+    eps = 1e-5
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rs = (var + eps).rsqrt()
+    n = ((x - mu) * rs).requires_grad_(True)
+    gd, bd, Rd = (t.double().requires_grad_(True) for t in (gam, bet, R))
+    xh = n * gd + bd
+    s = torch.einsum("shd,snd->snh", Rd, xh)
+    p = torch.softmax(s, dim=1)
+    M = torch.einsum("snh,snd->shd", p, xh)
+    A_ref = torch.einsum("snh,snd->shd", p, n)
+    A, lse, mean, rstd = dvt.ops.attn_cls_fwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda())
+    assert rel_l2(A, A_ref.detach()) < 2e-5
+    assert rel_l2(lse, torch.logsumexp(s, dim=1).detach()) < 2e-6
+    assert rel_l2(mean.view(S, N), mu[..., 0]) < 2e-5 and rel_l2(rstd.view(S, N), rs[..., 0]) < 2e-5
+    M.backward(dM.double())
+    # the LayerNorm backward of d LN(x) = n.grad (already multiplied by gamma on the way down)
+    dn = n.grad
+    dx_ref = rs * (dn - dn.mean(-1, keepdim=True) - n.detach() * (dn * n.detach()).mean(-1, keepdim=True))
+    G_ref = Rd.grad / gd.detach()                                      # dr_h = gamma G_h
+    dg0 = torch.full((d,), 2.0, device="cuda")
+    db0 = torch.full((d,), 3.0, device="cuda")
+    dx, G, dg, db = dvt.ops.attn_cls_bwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda(), A, lse, mean, rstd, dM.cuda(),
+                                         dg=dg0, db=db0, accumulate=True, accumulate_beta=False)
+    assert dx.stride() == x_d.stride()
+    unit = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel_l2(dx, dx_ref) < unit
+    assert rel_l2(G, G_ref) < 5e-5
+    assert rel_l2(dg - 2.0, gd.grad) < 5e-5 and rel_l2(db, bd.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,H,dh,d", [(13, 8, 64, 512), (256, 8, 64, 512), (5, 2, 32, 64), (9, 6, 64, 384), (3, 1, 96, 128)])
+def test_heads_products(dvt, device, dtype, S, H, dh, d):
+    """dvt_heads_expand / _contract / _outer (per-head products of the folded single-query attention) against einsum in
+    float64; the weight is a row range of a larger packed matrix (row stride d, offset rows)."""
+    g = torch.Generator().manual_seed(25)
+    inner = H * dh
+    Wp_d, Wp = _rnd((3 * inner, d), dtype, g, 1 / math.sqrt(d))
+    W_d, W = Wp_d[inner:2 * inner], Wp[inner:2 * inner].double().view(H, dh, d)
+    a_d, a = _rnd((S, inner + 8), dtype, g)
+    a_d, a = a_d[:, :inner], a[:, :inner].double().view(S, H, dh)
+    v = torch.randn(S, H, d, generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(d, generator=g), 0.2 * torch.randn(d, generator=g)
+    unit = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    out = dvt.ops.heads_expand(a_d, W_d, H, 0.37)
+    assert rel_l2(out, 0.37 * torch.einsum("she,hed->shd", a, W)) < 2e-6
+    vv = v.double() * gam.double() + bet.double()
+    out = dvt.ops.heads_contract(v.cuda(), W_d, 1.7, gam.cuda(), bet.cuda())
+    assert out.dtype == dtype and rel_l2(out, 1.7 * torch.einsum("shd,hed->she", vv, W).reshape(S, inner)) < unit
+    out = dvt.ops.heads_contract(v.cuda(), W_d, 1.0)
+    assert rel_l2(out, torch.einsum("shd,hed->she", v.double(), W).reshape(S, inner)) < unit
+    buf = torch.full((3 * inner, d), 0.5, device="cuda")
+    dvt.ops.heads_outer(a_d, v.cuda(), buf[inner:2 * inner], 0.9, gam.cuda(), bet.cuda(), accumulate=True)
+    ref = 0.9 * torch.einsum("she,shd->hed", a, vv).reshape(inner, d)
+    assert rel_l2(buf[inner:2 * inner] - 0.5, ref) < 5e-6
+    assert (buf[:inner] == 0.5).all() and (buf[2 * inner:] == 0.5).all()
+    dvt.ops.heads_outer(a_d, v.cuda(), buf[inner:2 * inner], 1.0, gam.cuda())
+    assert rel_l2(buf[inner:2 * inner], torch.einsum("she,shd->hed", a, v.double() * gam.double()).reshape(inner, d)) < 5e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_bwd_first_row_operands(dvt, device, dtype):
     """dvt_layernorm_bwd_first: dy_first enters dy of row (i0, 0), dx_first enters dx of that row; dgamma / dbeta
