@@ -73,7 +73,7 @@ class AttnClsDesc(C.Structure):
     _fields_ = [
         ("x", c_p), ("xs0", c_i64), ("xs1", c_i64), ("gamma", c_p), ("beta", c_p), ("eps", c_f),
         ("S", c_i64), ("N", c_i64), ("d", c_i64), ("H", c_i64), ("dtype", C.c_int32),
-        ("R", c_p), ("A", c_p), ("lse", c_p), ("mean", c_p), ("rstd", c_p),
+        ("R", c_p), ("A", c_p), ("lse", c_p), ("P", c_p), ("mean", c_p), ("rstd", c_p),
         ("dM", c_p), ("dx", c_p), ("G", c_p), ("dgamma", c_p), ("dbeta", c_p),
         ("accumulate_gamma", C.c_int32), ("accumulate_beta", C.c_int32), ("workspace", c_p),
     ]

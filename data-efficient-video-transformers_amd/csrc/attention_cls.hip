@@ -36,6 +36,7 @@ struct ClsParams {
   const float* R;
   float* A;
   float* lse;
+  float* P;
   float* mean;
   float* rstd;
   const float* dM;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
     if (lane == 0) p.lse[(int64_t)f * H + w] = mx + __logf(sum);
   }
   __syncthreads();
+  for (int i = tid; i < N * 8; i += kThreads) p.P[(int64_t)f * N * 8 + i] = sc[i];      // kept for the backward
 
   // pass B: a_h = sum_j p_jh n_j over this wave's rows
   f32x2 a[kMaxH][4];
@@ -335,30 +337,11 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
     st[2 * j] = p.mean[(int64_t)f * N + j];
     st[2 * j + 1] = p.rstd[(int64_t)f * N + j];
   }
-  f32x2 rp[kMaxH][4];
-  const float cmine = load_rprime(Rf, p.gamma, p.beta, H, d, c, act, lane, rp);
+  for (int i = tid; i < N * 8; i += kThreads) pd[2 * i] = p.P[(int64_t)f * N * 8 + i];   // p_jh of the forward
   const int hmine = (lane >> 3) & 7;
-  const float lmine = hmine < H ? p.lse[(int64_t)f * H + hmine] : 0.f;
   __syncthreads();
 
-  // sweep 1: p_jh = exp(s_jh - lse_h)
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    if (j < N) {
-      const float mu = st[2 * j], rs = st[2 * j + 1];
-      f32x2 v[4];
-      centred(row[i], mu, act, v);
-      float dots[8];
-#pragma unroll
-      for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
-      const float t = wave_sum8(dots, lane);
-      if ((lane & 7) == 0)
-        pd[(j * 8 + hmine) * 2] =
-            hmine < H ? __builtin_amdgcn_exp2f((fmaf(rs, t, cmine) - lmine) * 1.44269504088896340736f) : 0.f;
-    }
-  }
-  keep_packed(row);
+  f32x2 rp[kMaxH][4];
   // sweep 2: dp_jh = dm_h . LN(x_j) up to a per-head constant (dm_h . beta), which the softmax backward cancels
 #pragma unroll
   for (int h = 0; h < kMaxH; ++h) {
@@ -511,7 +494,7 @@ size_t cls_bwd_lds(int H, int d) {
 
 int cls_check(const char* name, const dvt_attn_cls_desc* q, bool bwd) {
   DVT_REQUIRE(q, "%s: null descriptor", name);
-  DVT_REQUIRE(q->x && q->gamma && q->beta && q->R && q->A && q->lse && q->mean && q->rstd, "%s: null pointer", name);
+  DVT_REQUIRE(q->x && q->gamma && q->beta && q->R && q->A && q->lse && q->P && q->mean && q->rstd, "%s: null pointer", name);
   DVT_REQUIRE(q->S > 0 && q->N > 0 && q->d > 0 && q->H > 0, "%s: bad sizes", name);
   if (!dvt_attn_cls_supported(q))
     DVT_UNSUPPORTED("%s: needs a 16-bit dtype, d %% 8 == 0, d <= 512, H <= 8, N <= %d, strides %% 8 == 0 (got d = %lld, H = %lld, "
@@ -530,7 +513,7 @@ ClsParams cls_params(const dvt_attn_cls_desc* q) {
   ClsParams p;
   p.x = q->x; p.xs0 = q->xs0; p.xs1 = q->xs1; p.gamma = q->gamma; p.beta = q->beta; p.eps = q->eps;
   p.S = (int)q->S; p.N = (int)q->N; p.d = (int)q->d; p.H = (int)q->H;
-  p.R = q->R; p.A = q->A; p.lse = q->lse; p.mean = q->mean; p.rstd = q->rstd;
+  p.R = q->R; p.A = q->A; p.lse = q->lse; p.P = q->P; p.mean = q->mean; p.rstd = q->rstd;
   p.dM = q->dM; p.dx = q->dx; p.G = q->G; p.partial = (float*)q->workspace;
   return p;
 }

@@ -598,10 +598,10 @@ class _AttnBlockCls(torch.autograd.Function):
             xn0, mean0, rstd0 = ops.layernorm_fwd(x2, g, bb, eps, rows=(S, 1, N * d, 0))          # [S, d]: row 0 only
             q = ops.linear_fwd(xn0, wqkv[:inner])                                                  # [S, inner]
             R = ops.heads_expand(q, wqkv[inner:2 * inner], heads, dh ** -0.5)                      # r_h = scale Wk_h^T q_h
-            A, lse, mean, rstd = ops.attn_cls_fwd(x3, g, bb, eps, R)                               # one pass over x
+            A, lse, P, mean, rstd = ops.attn_cls_fwd(x3, g, bb, eps, R)                            # one pass over x
             o = ops.heads_contract(A, wqkv[2 * inner:], 1.0, g, bb)                                # o_h = Wv_h (gamma A_h + beta)
             y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0])
-            ctx.save_for_backward(x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, mean, rstd)
+            ctx.save_for_backward(x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, P, mean, rstd)
             return y
         xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
         w_q, w_kv = wqkv[:inner], wqkv[inner:]                          # row slices of the packed weight, no copies
@@ -619,7 +619,7 @@ class _AttnBlockCls(torch.autograd.Function):
 
     @staticmethod
     def _backward_folded(ctx, dy):
-        x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, mean, rstd = ctx.saved_tensors
+        x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, P, mean, rstd = ctx.saved_tensors
         S, N, d, heads, dh, inner, has_bias, eps = ctx.cfg
         T = x2.dtype
         s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
@@ -637,11 +637,11 @@ class _AttnBlockCls(torch.autograd.Function):
         dM = ops.heads_expand(do, w_v, heads, 1.0)                       # dm_h = Wv_h^T do_h
         ops.heads_outer(do, A, buf[2 * inner:], 1.0, g, bb, accumulate=acc)          # dWv_h = do_h (x) m_h
         if s_g is not None and s_b is not None:
-            dx2, G, _, _ = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, mean, rstd, dM, dg=s_g.buf.view(-1),
+            dx2, G, _, _ = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, P, mean, rstd, dM, dg=s_g.buf.view(-1),
                                             db=s_b.buf.view(-1), accumulate=not s_g.fresh, accumulate_beta=not s_b.fresh)
             dg, db = s_g.buf.view(-1), s_b.buf.view(-1)
         else:
-            dx2, G, dg, db = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, mean, rstd, dM)
+            dx2, G, dg, db = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, P, mean, rstd, dM)
         dq = ops.heads_contract(G, w_k, scale, g)                        # dq_h = scale Wk_h (gamma G_h)
         ops.heads_outer(q, G, buf[inner:2 * inner], scale, g, accumulate=acc)        # dWk_h = scale q_h (x) dr_h
         ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)

@@ -572,29 +572,30 @@ def attn_cls_supported(x: Tensor, H: int) -> bool:
 
 
 def attn_cls_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor):
-    """x [S,N,d], R [S,H,d] f32 -> (A [S,H,d] f32, lse [S,H], mean [S*N], rstd [S*N])."""
+    """x [S,N,d], R [S,H,d] f32 -> (A [S,H,d] f32, lse [S,H], P [S,N,8], mean [S*N], rstd [S*N])."""
     _need_cuda(x, gamma, beta, R)
     S, N, d = x.shape
     H = R.shape[1]
     assert R.shape == (S, H, d) and R.dtype == torch.float32 and R.is_contiguous()
     q = _attn_cls_desc(x, gamma, beta, eps, H)
     f32 = dict(dtype=torch.float32, device=x.device)
-    A, lse = torch.empty((S, H, d), **f32), torch.empty((S, H), **f32)
+    A, lse, P = torch.empty((S, H, d), **f32), torch.empty((S, H), **f32), torch.empty((S, N, 8), **f32)
     mean, rstd = torch.empty((S * N,), **f32), torch.empty((S * N,), **f32)
-    q.R, q.A, q.lse, q.mean, q.rstd = R.data_ptr(), A.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    q.R, q.A, q.lse, q.P = R.data_ptr(), A.data_ptr(), lse.data_ptr(), P.data_ptr()
+    q.mean, q.rstd = mean.data_ptr(), rstd.data_ptr()
     with _timed(("hbm", "attn_cls_fwd", S * N), S * N * d * x.element_size() + 2 * S * H * d * 4):
         L.check(L.load().dvt_attn_cls_fwd(C.byref(q), _stream()), "dvt_attn_cls_fwd")
-    return A, lse, mean, rstd
+    return A, lse, P, mean, rstd
 
 
-def attn_cls_bwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor, A: Tensor, lse: Tensor, mean: Tensor,
-                 rstd: Tensor, dM: Tensor, *, dx: Optional[Tensor] = None, dg: Optional[Tensor] = None,
+def attn_cls_bwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor, A: Tensor, lse: Tensor, P: Tensor,
+                 mean: Tensor, rstd: Tensor, dM: Tensor, *, dx: Optional[Tensor] = None, dg: Optional[Tensor] = None,
                  db: Optional[Tensor] = None, accumulate: bool = False, accumulate_beta: Optional[bool] = None):
     """-> (dx like x, G [S,H,d] f32, dgamma, dbeta)."""
-    _need_cuda(x, gamma, beta, R, A, lse, mean, rstd, dM)
+    _need_cuda(x, gamma, beta, R, A, lse, P, mean, rstd, dM)
     S, N, d = x.shape
     H = R.shape[1]
-    assert dM.shape == (S, H, d) and dM.dtype == torch.float32 and dM.is_contiguous()
+    assert dM.shape == (S, H, d) and dM.dtype == torch.float32 and dM.is_contiguous() and P.shape == (S, N, 8)
     q = _attn_cls_desc(x, gamma, beta, eps, H)
     if dx is None:
         dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
@@ -604,7 +605,8 @@ def attn_cls_bwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, R: Tensor, 
         dg = torch.empty((d,), dtype=torch.float32, device=x.device)
         db = torch.empty((d,), dtype=torch.float32, device=x.device)
     G = torch.empty((S, H, d), dtype=torch.float32, device=x.device)
-    q.R, q.A, q.lse, q.mean, q.rstd = R.data_ptr(), A.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    q.R, q.A, q.lse, q.P = R.data_ptr(), A.data_ptr(), lse.data_ptr(), P.data_ptr()
+    q.mean, q.rstd = mean.data_ptr(), rstd.data_ptr()
     q.dM, q.dx, q.G, q.dgamma, q.dbeta = dM.data_ptr(), dx.data_ptr(), G.data_ptr(), dg.data_ptr(), db.data_ptr()
     q.accumulate_gamma = int(accumulate)
     q.accumulate_beta = int(accumulate if accumulate_beta is None else accumulate_beta)

@@ -316,7 +316,8 @@ int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
  * also is the LayerNorm backward of those rows (the gradient of row 0's own query / residual paths is added by a
  * dvt_layernorm_bwd call on the S first rows).  Row (s, j) of x sits at x + s*xs0 + j*xs1 (elements); dx uses the same
  * strides.  All [S, H, d] arrays are f32.  With n_j = (x_j - mean_j) rstd_j, LN(x_j) = gamma n_j + beta:
- *   fwd:  R -> A[s,h,:] = sum_j p_jh n_j (so m_h = gamma A_h + beta), lse[S,H], mean / rstd [S*N]
+ *   fwd:  R -> A[s,h,:] = sum_j p_jh n_j (so m_h = gamma A_h + beta), lse[S,H], the probabilities P[S,N,8] (head h of row
+ *         j at P[(s*N + j)*8 + h]; kept for the backward), mean / rstd [S*N]
  *   bwd:  dM (gradient of m) -> dx, G[s,h,:] = sum_j ds_jh n_j (so dr_h = gamma G_h), dgamma / dbeta (+= when the
  *         accumulate flags are set; workspace >= dvt_attn_cls_bwd_workspace_bytes holds one partial row per sequence).
  * 16-bit dtypes, d % 8 == 0, d <= 512, H <= 8, N <= 200; dvt_attn_cls_supported tells (callers keep the unfolded
@@ -332,6 +333,7 @@ typedef struct dvt_attn_cls_desc {
   const float* R;
   float* A;
   float* lse;
+  float* P;
   float* mean;
   float* rstd;
   /* backward only */

@@ -648,7 +648,8 @@ def test_attn_cls_folded_kernels_against_float64(dvt, device, dtype, S, N, d, H)
     p = torch.softmax(s, dim=1)
     M = torch.einsum("snh,snd->shd", p, xh)
     A_ref = torch.einsum("snh,snd->shd", p, n)
-    A, lse, mean, rstd = dvt.ops.attn_cls_fwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda())
+    A, lse, P, mean, rstd = dvt.ops.attn_cls_fwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda())
+    assert rel_l2(P[:, :, :H], p.detach()) < 2e-5
     assert rel_l2(A, A_ref.detach()) < 2e-5
     assert rel_l2(lse, torch.logsumexp(s, dim=1).detach()) < 2e-6
     assert rel_l2(mean.view(S, N), mu[..., 0]) < 2e-5 and rel_l2(rstd.view(S, N), rs[..., 0]) < 2e-5
@@ -659,7 +660,7 @@ def test_attn_cls_folded_kernels_against_float64(dvt, device, dtype, S, N, d, H)
     G_ref = Rd.grad / gd.detach()                                      # dr_h = gamma G_h
     dg0 = torch.full((d,), 2.0, device="cuda")
     db0 = torch.full((d,), 3.0, device="cuda")
-    dx, G, dg, db = dvt.ops.attn_cls_bwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda(), A, lse, mean, rstd, dM.cuda(),
+    dx, G, dg, db = dvt.ops.attn_cls_bwd(x_d, gam.cuda(), bet.cuda(), eps, R.cuda(), A, lse, P, mean, rstd, dM.cuda(),
                                          dg=dg0, db=db0, accumulate=True, accumulate_beta=False)
     assert dx.stride() == x_d.stride()
     unit = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
