@@ -25,6 +25,7 @@ namespace {
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kMaxH = 8;
+constexpr int kGroup = 5;                                 // rows a wave processes without a branch in between
 
 struct ClsParams {
   const void* x;
@@ -45,30 +46,8 @@ struct ClsParams {
   float* partial;
 };
 
-// Cross-lane sums without LDS round trips (a ds_bpermute chain is ~100 cycles per step and there are only two waves per
-// SIMD to hide it): DPP inside a row of 16 lanes, v_permlane{16,32}_swap between the rows.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
-
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ float wave_sum_fast(float v) {
-  v += dpp_mov<kDppXor1>(v);
-  v += dpp_mov<kDppXor2>(v);
-  v += dpp_mov<kDppHalfMirror>(v);
-  v += dpp_mov<kDppMirror>(v);                       // every row of 16 lanes holds its own total
-  float a = v, b = v;
-  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  v = a + b;
-  a = v;
-  b = v;
-  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-
 // Totals of 8 per-lane values over the wave: every step halves the values a lane still carries (the swaps exchange the
 // upper values of one half of the wave with the lower values of the other), 6 swaps + 4 DPP steps instead of 8 full
 // reductions.  Returns the total of v[(lane >> 3) & 7] (the same in the 8 lanes of a group).
@@ -155,7 +134,7 @@ __device__ __forceinline__ float load_rprime(const float* __restrict__ Rf, const
 #pragma unroll
         for (int k = 0; k < 4; ++k) rp[h][k] = rr[k] * g[k];
       }
-      cb = wave_sum_fast(cb);
+      cb = wave_sum_dpp(cb);
     }
     if (((lane >> 3) & 7) == h) cmine = cb;
   }
@@ -168,11 +147,11 @@ template <typename E, int RPW>
 __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
   typedef typename Row8<E>::type v8;
   constexpr int NP = RPW * kWaves;
-  static_assert(NP <= 256, "the softmax pass holds four rows per lane");
+  static_assert(NP <= 256 && RPW % kGroup == 0 && RPW <= 64, "the softmax pass holds four rows per lane");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sc = lds;
-  float* st = sc + NP * 8;
-  float* red = st + NP * 2;
+  float* sc = lds;                                       // one spare row each: where the rows behind N are written
+  float* st = sc + (NP + 1) * 8;
+  float* red = st + (NP + 1) * 2 + 6;                     // 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int f = blockIdx.x, N = p.N, d = p.d, H = p.H;
   const int c = lane * 8;
@@ -191,33 +170,43 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
 
   f32x2 rp[kMaxH][4];
   const float cmine = load_rprime(p.R + (int64_t)f * H * d, p.gamma, p.beta, H, d, c, act, lane, rp);
+  for (int i = N * 8 + tid; i < (NP + 1) * 8; i += kThreads) sc[i] = 0.f;      // rows behind N: zero probabilities,
+  for (int i = N * 2 + tid; i < (NP + 1) * 2; i += kThreads) st[i] = 0.f;      // zero statistics
+  __syncthreads();
 
-  // pass A: statistics and the H scores of every row
+  // pass A: statistics and the H scores of every row.  Branch-free inside a group of rows (a row behind N is all zeros
+  // and lands in the spare LDS row): the compiler then overlaps the rows' reductions and LDS traffic
+  float mu_keep = 0.f, rs_keep = 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    if (j < N) {
-      f32x2 v[4];
-      unpack8(row[i], v);
-      const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
-      const float mu = wave_sum_fast(s2[0] + s2[1]) * inv_d;
-      const f32x2 m = splat2(act ? mu : 0.f);
+  for (int g0 = 0; g0 < RPW; g0 += kGroup)
+    if (w + kWaves * g0 < N) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] - m;
-      const float q = dot8(v, v);
-      float dots[8];
+      for (int u = 0; u < kGroup; ++u) {
+        const int i = g0 + u, j = w + kWaves * i;
+        const int jj = j < N ? j : NP;
+        f32x2 v[4];
+        unpack8(row[i], v);
+        const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+        const float mu = wave_sum_dpp(s2[0] + s2[1]) * inv_d;
+        const f32x2 m = splat2(act ? mu : 0.f);
 #pragma unroll
-      for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
-      const float rs = rsqrtf(wave_sum_fast(q) * inv_d + p.eps);
-      const float t = wave_sum8(dots, lane);
-      if ((lane & 7) == 0) sc[j * 8 + (lane >> 3)] = fmaf(rs, t, cmine);
-      if (lane == 0) {
-        st[2 * j] = mu;
-        st[2 * j + 1] = rs;
-        p.mean[(int64_t)f * N + j] = mu;
-        p.rstd[(int64_t)f * N + j] = rs;
+        for (int k = 0; k < 4; ++k) v[k] = v[k] - m;
+        const float q = dot8(v, v);
+        float dots[8];
+#pragma unroll
+        for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
+        const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + p.eps);
+        const float t = wave_sum8(dots, lane);
+        sc[jj * 8 + (lane >> 3)] = fmaf(rs, t, cmine);       // the 8 lanes of a group store the same value
+        st[2 * jj] = mu;
+        st[2 * jj + 1] = rs;
+        mu_keep = lane == i ? mu : mu_keep;
+        rs_keep = lane == i ? rs : rs_keep;
       }
     }
+  if (lane < RPW && w + kWaves * lane < N) {
+    p.mean[(int64_t)f * N + w + kWaves * lane] = mu_keep;
+    p.rstd[(int64_t)f * N + w + kWaves * lane] = rs_keep;
   }
   __syncthreads();
   keep_packed(row);
@@ -238,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
       e[t] = __builtin_amdgcn_exp2f((e[t] - mx) * 1.44269504088896340736f);   // exp2(-inf) = 0 for the rows beyond N
       sum += e[t];
     }
-    sum = wave_sum_fast(sum);
+    sum = wave_sum_dpp(sum);
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -257,23 +246,24 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[h][k] = splat2(0.f);
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    if (j < N) {
-      const float mu = st[2 * j], rs = st[2 * j + 1];
-      const f32x4 p0 = *reinterpret_cast<const f32x4*>(sc + j * 8), p1 = *reinterpret_cast<const f32x4*>(sc + j * 8 + 4);
-      const float ph[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-      f32x2 n[4];
-      centred(row[i], mu, act, n);
+  for (int g0 = 0; g0 < RPW; g0 += kGroup)
+    if (w + kWaves * g0 < N) {
 #pragma unroll
-      for (int h = 0; h < kMaxH; ++h)
-        if (h < H) {
+      for (int u = 0; u < kGroup; ++u) {
+        const int i = g0 + u, j = w + kWaves * i;            // j < NP: the rows behind N carry zero probabilities
+        const float mu = st[2 * j], rs = st[2 * j + 1];
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(sc + j * 8), p1 = *reinterpret_cast<const f32x4*>(sc + j * 8 + 4);
+        const float ph[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        f32x2 n[4];
+        centred(row[i], mu, act, n);
+#pragma unroll
+        for (int h = 0; h < kMaxH; ++h) {
           const f32x2 t = splat2(ph[h] * rs);
 #pragma unroll
           for (int k = 0; k < 4; ++k) a[h][k] = fma2(t, n[k], a[h][k]);
         }
+      }
     }
-  }
   // the waves' partial sums, added in wave order (fixed order: reproducible)
   const int HD = H * d;
   if (act) {
@@ -301,12 +291,12 @@ template <typename E, int RPW>
 __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   typedef typename Row8<E>::type v8;
   constexpr int NP = RPW * kWaves;
-  constexpr int GR = 5;                                  // rows per group in the d LN(x) pass
+  constexpr int GR = kGroup;                             // rows per group in the d LN(x) pass
   static_assert(NP <= 256 && RPW % GR == 0, "row grouping");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* pd = lds;
-  float* st = pd + NP * 16;
-  float* big = st + NP * 2;
+  float* pd = lds;                                       // one spare row each: where the rows behind N are written
+  float* st = pd + (NP + 1) * 16;
+  float* big = st + (NP + 1) * 2 + 2;                     // 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int f = blockIdx.x, N = p.N, d = p.d, H = p.H, HD = H * d;
   const int c = lane * 8;
@@ -333,11 +323,14 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
     rl[e] = e < HD ? Rf[e] * g : 0.f;
     dl[e] = e < HD ? dMf[e] * g : 0.f;
   }
-  for (int j = tid; j < N; j += kThreads) {
-    st[2 * j] = p.mean[(int64_t)f * N + j];
-    st[2 * j + 1] = p.rstd[(int64_t)f * N + j];
+  for (int j = tid; j <= NP; j += kThreads) {
+    st[2 * j] = j < N ? p.mean[(int64_t)f * N + j] : 0.f;
+    st[2 * j + 1] = j < N ? p.rstd[(int64_t)f * N + j] : 0.f;
   }
-  for (int i = tid; i < N * 8; i += kThreads) pd[2 * i] = p.P[(int64_t)f * N * 8 + i];   // p_jh of the forward
+  for (int i = tid; i < (NP + 1) * 8; i += kThreads) {                                   // p_jh of the forward; zero behind N
+    pd[2 * i] = i < N * 8 ? p.P[(int64_t)f * N * 8 + i] : 0.f;
+    pd[2 * i + 1] = 0.f;
+  }
   const int hmine = (lane >> 3) & 7;
   __syncthreads();
 
@@ -350,19 +343,23 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
     if (act) load8x2(dl + h * d + c, rp[h]);
   }
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    if (j < N) {
-      const float mu = st[2 * j], rs = st[2 * j + 1];
-      f32x2 v[4];
-      centred(row[i], mu, act, v);
-      float dots[8];
+  for (int g0 = 0; g0 < RPW; g0 += kGroup)
+    if (w + kWaves * g0 < N) {
 #pragma unroll
-      for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
-      const float t = wave_sum8(dots, lane);
-      if ((lane & 7) == 0) pd[(j * 8 + hmine) * 2 + 1] = rs * t;
+      for (int u = 0; u < kGroup; ++u) {
+        const int i = g0 + u, j = w + kWaves * i;
+        const int jj = j < N ? j : NP;
+        const float mu = st[2 * j], rs = st[2 * j + 1];
+        f32x2 v[4];
+        centred(row[i], mu, act, v);
+        float dots[8];
+#pragma unroll
+        for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
+        const float t = wave_sum8(dots, lane);
+        pd[(jj * 8 + hmine) * 2 + 1] = rs * t;               // the 8 lanes of a group store the same value
+        if (u & 1) __builtin_amdgcn_sched_barrier(0);         // two rows in flight: all five would not fit the registers
+      }
     }
-  }
   __syncthreads();
 
   keep_packed(row);
@@ -374,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
       const int j = lane + 64 * t;
       if (j < N) acc = fmaf(pd[(j * 8 + w) * 2], pd[(j * 8 + w) * 2 + 1], acc);
     }
-    const float D = wave_sum_fast(acc);
+    const float D = wave_sum_dpp(acc);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int j = lane + 64 * t;
@@ -384,35 +381,36 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   __syncthreads();
 
   // d LN(x_j) = sum_h p_jh (gamma dm_h) + ds_jh (gamma r_h), then the LayerNorm backward of the row
+  // where the rows behind N and the lanes behind d store: this sequence's own partial row (written for real at the very end)
+  E* const trash = reinterpret_cast<E*>(p.partial + (int64_t)f * 2 * d) + ((w * 16 + (lane & 15)) * 8) % (4 * d);
 #pragma unroll
-  for (int g0 = 0; g0 < RPW; g0 += GR) {
-    f32x2 dn[GR][4];
+  for (int g0 = 0; g0 < RPW; g0 += GR)
+    if (w + kWaves * g0 < N) {
+      f32x2 dn[GR][4];
 #pragma unroll
-    for (int u = 0; u < GR; ++u)
+      for (int u = 0; u < GR; ++u)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dn[u][k] = splat2(0.f);
+        for (int k = 0; k < 4; ++k) dn[u][k] = splat2(0.f);
 #pragma unroll
-    for (int h = 0; h < kMaxH; ++h)
-      if (h < H) {
-        f32x2 rr[4], dd[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rr[k] = dd[k] = splat2(0.f);
-        if (act) { load8x2(rl + h * d + c, rr); load8x2(dl + h * d + c, dd); }
+      for (int h = 0; h < kMaxH; ++h)
+        if (h < H) {                                           // a (uniform) branch per head on purpose: it keeps the eight heads'
+        f32x2 rr[4], dd[4];                                    // vectors (128 registers) from being requested all at once
+        int off = h * d + (act ? c : 0);
+        asm volatile("" : "+v"(off));                          // ... and from being kept across the groups
+        load8x2(rl + off, rr);
+        load8x2(dl + off, dd);
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
-          const int j = w + kWaves * (g0 + u);
-          if (j < N) {
-            const f32x2 cf = *reinterpret_cast<const f32x2*>(pd + (j * 8 + h) * 2);
-            const f32x2 cp = splat2(cf[0]), cs = splat2(cf[1]);
+          const int j = w + kWaves * (g0 + u);                 // zero coefficients behind N and behind H
+          const f32x2 cf = *reinterpret_cast<const f32x2*>(pd + (j * 8 + h) * 2);
+          const f32x2 cp = splat2(act ? cf[0] : 0.f), cs = splat2(act ? cf[1] : 0.f);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dn[u][k] = fma2(cp, dd[k], fma2(cs, rr[k], dn[u][k]));
-          }
+          for (int k = 0; k < 4; ++k) dn[u][k] = fma2(cp, dd[k], fma2(cs, rr[k], dn[u][k]));
         }
       }
 #pragma unroll
-    for (int u = 0; u < GR; ++u) {
-      const int j = w + kWaves * (g0 + u);
-      if (j < N) {
+      for (int u = 0; u < GR; ++u) {
+        const int j = w + kWaves * (g0 + u);
         const float mu = st[2 * j], rs = st[2 * j + 1];
         f32x2 n[4];
         centred(row[g0 + u], mu, act, n);
@@ -420,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) n[k] = n[k] * r2;
         const f32x2 t1 = (dn[u][0] + dn[u][1]) + (dn[u][2] + dn[u][3]);
-        const float c1 = wave_sum_fast(t1[0] + t1[1]) * inv_d, c2 = wave_sum_fast(dot8(dn[u], n)) * inv_d;
+        const float c1 = wave_sum_dpp(t1[0] + t1[1]) * inv_d, c2 = wave_sum_dpp(dot8(dn[u], n)) * inv_d;
         const f32x2 c1v = splat2(c1), c2v = splat2(-c2);
         float o[8];
 #pragma unroll
@@ -429,10 +427,10 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
           o[2 * k] = t[0];
           o[2 * k + 1] = t[1];
         }
-        if (act) store8<E>(dxf + (int64_t)j * p.xs1 + c, o);
+        store8<E>(act && j < N ? dxf + (int64_t)j * p.xs1 + c : trash, o);
+        if (u & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
-  }
 
   keep_packed(row);
   // G_h = sum_j ds_jh n_j
@@ -442,21 +440,23 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[h][k] = splat2(0.f);
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    if (j < N) {
-      const float mu = st[2 * j], rs = st[2 * j + 1];
-      f32x2 n[4];
-      centred(row[i], mu, act, n);
+  for (int g0 = 0; g0 < RPW; g0 += kGroup)
+    if (w + kWaves * g0 < N) {
 #pragma unroll
-      for (int h = 0; h < kMaxH; ++h)
-        if (h < H) {
+      for (int u = 0; u < kGroup; ++u) {
+        const int i = g0 + u, j = w + kWaves * i;
+        const float mu = st[2 * j], rs = st[2 * j + 1];
+        f32x2 n[4];
+        centred(row[i], mu, act, n);
+#pragma unroll
+        for (int h = 0; h < kMaxH; ++h) {
           const f32x2 t = splat2(pd[(j * 8 + h) * 2 + 1] * rs);
 #pragma unroll
           for (int k = 0; k < 4; ++k) a[h][k] = fma2(t, n[k], a[h][k]);
         }
+        if (u & 1) __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
   __syncthreads();                                       // rl / dl are dead: the region becomes the waves' partial sums
   float* red = big;
   if (act) {
@@ -486,10 +486,10 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
 
 constexpr int kRPW = 25;                                  // N <= 200 (197 tokens of a 224^2 frame at patch 16)
 
-size_t cls_fwd_lds(int H, int d) { return sizeof(float) * ((size_t)kRPW * kWaves * 10 + (size_t)kWaves * H * d); }
+size_t cls_fwd_lds(int H, int d) { return sizeof(float) * ((size_t)(kRPW * kWaves + 1) * 10 + 6 + (size_t)kWaves * H * d); }
 size_t cls_bwd_lds(int H, int d) {
   const size_t big = (size_t)kWaves * H * d > (size_t)2 * kMaxH * d ? (size_t)kWaves * H * d : (size_t)2 * kMaxH * d;
-  return sizeof(float) * ((size_t)kRPW * kWaves * 18 + big);
+  return sizeof(float) * ((size_t)(kRPW * kWaves + 1) * 18 + 2 + big);
 }
 
 int cls_check(const char* name, const dvt_attn_cls_desc* q, bool bwd) {

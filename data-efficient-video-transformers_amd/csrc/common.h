@@ -143,6 +143,31 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Wave64 sum for wave-uniform control flow (ALL 64 lanes active), without LDS round trips: DPP inside a row of 16 lanes,
+// v_permlane{16,32}_swap between the rows (a ds_bpermute chain costs ~100 cycles per step of the butterfly).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<kDppXor1>(v);
+  v += dpp_mov<kDppXor2>(v);
+  v += dpp_mov<kDppHalfMirror>(v);
+  v += dpp_mov<kDppMirror>(v);                       // every row of 16 lanes holds its own total
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  v = a + b;
+  a = v;
+  b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+#pragma clang diagnostic pop
+
 // ---------------------------------------------------------------- device: activations
 // Exact-erf GELU evaluated with the Abramowitz-Stegun 7.1.26 rational form
 // (|erf error| <= 1.5e-7 absolute), sharing one exponential between the cdf and

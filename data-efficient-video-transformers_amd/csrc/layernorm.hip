@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kLnBlock) void ln_fwd_kernel(
         for (int k = 0; k < 8; ++k) s += v[i][k];
       }
     }
-    const float mu = wave_sum(s) * inv_d;
+    const float mu = wave_sum_dpp(s) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kLnBlock) void ln_fwd_kernel(
         }
       }
     }
-    const float rs = rsqrtf(wave_sum(q) * inv_d + eps);
+    const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + eps);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = (lane + 64 * i) * 8;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(kLnBwdBlock) void ln_bwd_kernel(
         }
       }
     }
-    const float c1 = wave_sum(s1) * inv_d;
-    const float c2 = wave_sum(s2) * inv_d;
+    const float c1 = wave_sum_dpp(s1) * inv_d;
+    const float c2 = wave_sum_dpp(s2) * inv_d;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = (lane + 64 * i) * 8;
