@@ -48,15 +48,19 @@ def algorithmic_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch
     return fwd, 3 * fwd
 
 
-def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, pool_cls=True):
+def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, pool_cls=True, fold_kv=True):
     """FLOPs the build actually launches: the reference reads only row 0 of the space transformer's output
     (vit.py:119-120) and, under pool == 'cls', of the temporal one (:126), so in the last layer of each stack the query /
-    attention / output projection / feed-forward run on one row per sequence (keys and values on all rows)."""
+    attention / output projection / feed-forward run on one row per sequence (keys and values on all rows).  fold_kv:
+    the space stack's last layer runs with the K / V projections folded into its one query (csrc/attention_cls.hip:
+    heads dot products and heads weighted sums of d elements per row instead of the [rows, d] x [d, 2 inner] product)."""
     inner = heads * dh
 
-    def layer(tokens_per_seq, seqs, rows_out):
+    def layer(tokens_per_seq, seqs, rows_out, folded=False):
         m, q = tokens_per_seq * seqs, rows_out * seqs
         kv = 2 * m * d * 2 * inner
+        if folded:
+            kv = 2 * m * d * 2 * heads + 3 * 2 * q * d * inner      # per row: scores + weighted sums; per sequence: r, o
         qp = 2 * q * d * inner
         qk = 2 * heads * q * tokens_per_seq * dh
         proj = 2 * q * inner * d
@@ -64,7 +68,7 @@ def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, p
         return kv + qp + 2 * qk + proj + ff
 
     fwd = 2 * T * n_patch * patch_dim * d
-    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1)
+    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1, folded=fold_kv and n_tok <= 200 and d <= 512 and heads <= 8)
     fwd += (depth - 1) * layer(T + 1, 1, T + 1) + layer(T + 1, 1, 1 if pool_cls else T + 1)
     return fwd, 3 * fwd
 
@@ -628,7 +632,8 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             # model_tflops prices the step at the REFERENCE's algorithmic FLOPs (dense last layers); executed_tflops at
             # what is launched (last layer of each stack on the CLS rows only)
             "executed_tflops": round(executed_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
-                                                             3 * cfg["patch"] ** 2, n_tok - 1)[1]
+                                                             3 * cfg["patch"] ** 2, n_tok - 1,
+                                                             fold_kv=not getattr(args, "no_cls_fold", False))[1]
                                      * B * world / (elapsed / steps) / 1e12, 1)
             if workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
@@ -745,6 +750,8 @@ def main():
                     "with one rank (rehearses the multi-GPU code path on a single GPU)")
     ap.add_argument("--no-cls-fold", action="store_true", help="A/B switch: run the last space layer's single-query attention "
                     "without folding the K / V projections into the query (functional.CLS_FOLD_MIN_ROWS)")
+    ap.add_argument("--no-pair-launch", action="store_true", help="A/B switch: weight and data gradient of the launch-bound "
+                    "Linears as two launches (ops.PAIR_LAUNCH)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test (runs without a GPU): every rank joins "
                     "the process group, sums its rank over the group and rank 0 prints a JSON line with n_gpus = world")
     args = ap.parse_args()
@@ -796,6 +803,8 @@ def main():
     import dvt_amd  # noqa: F401
     if args.no_cls_fold:
         dvt_amd.functional.CLS_FOLD_MIN_ROWS = 1 << 62
+    if args.no_pair_launch:
+        dvt_amd.ops.PAIR_LAUNCH = False
     if use_dist and args.backend == "nccl":
         from dvt_amd.dp import Communicator
         try:

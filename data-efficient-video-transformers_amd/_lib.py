@@ -110,6 +110,8 @@ SIGNATURES = {
     "dvt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dvt_gemm": (c_int, [C.POINTER(GemmDesc), c_p]),
     "dvt_splitk_reduce_pending": (c_int, [C.POINTER(SplitKPending), c_p]),
+    "dvt_gemm_pair_fused": (c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc)]),
+    "dvt_gemm_pair": (c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), c_p]),
     "dvt_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
     "dvt_colsum": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),

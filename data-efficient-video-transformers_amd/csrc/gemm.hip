@@ -708,6 +708,44 @@ int dvt_splitk_reduce_pending(const dvt_splitk_pending* pending, dvt_stream_t st
   return launch_pending_reduce(pending, (hipStream_t)stream);
 }
 
+static GemmParams small_params(const dvt_gemm_desc* d) {
+  GemmParams p{};
+  p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+  p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
+  p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
+  p.alpha = d->alpha; p.elem = d->in_dtype; p.k_per_split = (int)d->K; p.slab = nullptr;
+  p.colsum_slab = d->colsum_out; p.accumulate_colsum = d->colsum_accumulate;
+  return p;
+}
+
+// The pair is one launch when both products are launch-bound shapes of the panel-streaming kernel in the layouts of a
+// Linear's backward and neither takes part in a deferred split-K reduce.
+static bool pair_fusable(const dvt_gemm_desc* w, const dvt_gemm_desc* g) {
+  if (!w || !g || !w->A || !w->B || !w->C || !g->A || !g->B || !g->C) return false;
+  if (w->a_kmajor || w->b_kmajor || !g->a_kmajor || g->b_kmajor) return false;
+  if (w->in_dtype != g->in_dtype || !dvt_is_16bit(w->in_dtype)) return false;
+  if (w->defer_reduce || g->defer_reduce || (w->carry && w->carry->valid) || (g->carry && g->carry->valid)) return false;
+  if (w->M == 0 || w->N == 0 || g->M == 0 || g->N == 0) return false;
+  return route_gemm(w).kind == ROUTE_SMALL && route_gemm(g).kind == ROUTE_SMALL;
+}
+
+int dvt_gemm_pair_fused(const dvt_gemm_desc* wgrad, const dvt_gemm_desc* dgrad) { return pair_fusable(wgrad, dgrad) ? 1 : 0; }
+
+int dvt_gemm_pair(const dvt_gemm_desc* wgrad, const dvt_gemm_desc* dgrad, dvt_stream_t stream) {
+  int rc0 = check_desc(wgrad);
+  if (rc0) return rc0;
+  rc0 = check_desc(dgrad);
+  if (rc0) return rc0;
+  if (pair_fusable(wgrad, dgrad)) {
+    const int rc = dvt_gemm_small_launch_pair(small_params(wgrad), small_params(dgrad), (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  const int rc = dvt_gemm(wgrad, stream);
+  return rc ? rc : dvt_gemm(dgrad, stream);
+}
+
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* d) {
   if (!d) return 0;
   const GemmRoute route = route_gemm(d);
@@ -747,14 +785,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     carry = nullptr;
   }
   if (route.kind == ROUTE_SMALL) {
-    GemmParams p{};
-    p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
-    p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
-    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
-    p.epilogue = d->epilogue; p.out_f32 = d->out_dtype == DVT_F32; p.accumulate = d->accumulate;
-    p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
-    p.alpha = d->alpha; p.elem = d->in_dtype; p.k_per_split = (int)d->K; p.slab = nullptr;
-    p.colsum_slab = d->colsum_out; p.accumulate_colsum = d->colsum_accumulate;
+    const GemmParams p = small_params(d);
     rc = dvt_gemm_small_launch(p, d->a_kmajor != 0, d->b_kmajor != 0, st);
     if (rc == 1)        // cannot happen: small_regime() asks the same dvt_gemm_small_tile() the launcher dispatches on
       return dvt_fail(DVT_ERR_UNSUPPORTED, "dvt_gemm: the panel-streaming kernel has no instantiation for a shape its planner accepted");

@@ -140,3 +140,4 @@ int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, in
 // launch-bound shapes (gemm_small.hip): tile height (0 = shape / layout not taken), launch (1 = no instantiation)
 int dvt_gemm_small_tile(int64_t M, int64_t N, bool a_kmajor, bool b_kmajor);
 int dvt_gemm_small_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, hipStream_t st);
+int dvt_gemm_small_launch_pair(const GemmParams& pw, const GemmParams& pd, hipStream_t st);

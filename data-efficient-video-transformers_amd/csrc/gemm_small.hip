@@ -84,14 +84,14 @@ template <int N> __device__ __forceinline__ void swait_vm() {
 }
 
 // TM = 64: waves 2 x 2, each 32 x 32;  TM = 32: waves 1 x 4, each 32 x 16.
+// One TM x 64 output tile: workgroup `bid` of the `nblk` that serve this product.
 template <typename E, bool A_KMAJOR, bool B_KMAJOR, int TM>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_small_tile(const GemmParams& p, const int bid, const int nblk, char* smem) {
   static_assert(A_KMAJOR || TM == 64, "an mn-major A panel is 64 wide");
   typedef typename Elem16<E>::v8 V8;
   constexpr int WM = TM / 32, WNC = 4 / WM, WCOLS = STN / WNC, NU = WCOLS / 16;
   constexpr int kA = TM * SK * 2, kB = STN * SK * 2, kStage = kA + kB;
   constexpr int kPPC = (kA + kB) / 1024 / 4;           // DMA instructions per wave per chunk
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WNC, wn = wid % WNC;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   // activation panels, 264 rows in all, are the ones every XCD re-reads).  Placement is a speed matter only.
   int rt, ct;
   {
-    const int bid = blockIdx.x, tiles_m = gridDim.x / p.tiles_n;
+    const int tiles_m = nblk / p.tiles_n;
     if ((p.tiles_n & 7) == 0) {
       const int j = bid >> 3;
       ct = (bid & 7) + 8 * (j / tiles_m);
@@ -261,6 +261,39 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
   }
 }
 
+template <typename E, bool A_KMAJOR, bool B_KMAJOR, int TM>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_small_tile<E, A_KMAJOR, B_KMAJOR, TM>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// The two products of one Linear's backward -- weight gradient (both operands mn-major, 64-row tiles) and data gradient
+// (A k-major, B mn-major) -- in ONE launch: they are independent (both read dy), each is a fraction of a round of
+// workgroups, and between dependent launches of a few microseconds the launch itself is what costs.
+template <typename E, int TM2>
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(const GemmParams pw, const GemmParams pd, const int nblk_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < nblk_w) gemm_small_tile<E, false, false, 64>(pw, blockIdx.x, nblk_w, smem);
+  else gemm_small_tile<E, true, false, TM2>(pd, blockIdx.x - nblk_w, gridDim.x - nblk_w, smem);
+}
+
+template <typename E, int TM2>
+int launch_small_pair(const GemmParams& pw_in, const GemmParams& pd_in, hipStream_t st) {
+  constexpr int kSmem = 2 * (64 + STN) * SK * 2;
+  GemmParams pw = pw_in, pd = pd_in;
+  pw.tiles_n = (int)dvt_cdiv(pw.N, STN);
+  pd.tiles_n = (int)dvt_cdiv(pd.N, STN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_small_pair_kernel<E, TM2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_set = true;
+  }
+  const int nw = (int)(dvt_cdiv(pw.M, 64) * pw.tiles_n), nd = (int)(dvt_cdiv(pd.M, TM2) * pd.tiles_n);
+  hipLaunchKernelGGL((gemm_small_pair_kernel<E, TM2>), dim3((unsigned)(nw + nd)), dim3(256), kSmem, st, pw, pd, nw);
+  DVT_LAUNCH_CHECK("dvt_gemm_pair(small)");
+  return DVT_OK;
+}
+
 template <typename E, bool AK, bool BK, int TM>
 int launch_small(const GemmParams& pin, hipStream_t st) {
   constexpr int kSmem = 2 * (TM + STN) * SK * 2;
@@ -304,4 +337,14 @@ int dvt_gemm_small_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, hip
   if (tm == 0) return 1;
   if (p.elem == DVT_F16) return launch_small_any<f16>(p, a_kmajor, b_kmajor, tm, st);
   return launch_small_any<bf16>(p, a_kmajor, b_kmajor, tm, st);
+}
+
+// Weight gradient (A, B mn-major) + data gradient (A k-major, B mn-major) of one Linear in one launch; 1 when the pair
+// has no instantiation (the caller then launches them one after the other).
+int dvt_gemm_small_launch_pair(const GemmParams& pw, const GemmParams& pd, hipStream_t st) {
+  if (pw.elem != pd.elem) return 1;
+  const int tm2 = dvt_gemm_small_tile(pd.M, pd.N, true, false);
+  if (tm2 == 0 || dvt_gemm_small_tile(pw.M, pw.N, false, false) != 64) return 1;
+  if (pw.elem == DVT_F16) return tm2 == 32 ? launch_small_pair<f16, 32>(pw, pd, st) : launch_small_pair<f16, 64>(pw, pd, st);
+  return tm2 == 32 ? launch_small_pair<bf16, 32>(pw, pd, st) : launch_small_pair<bf16, 64>(pw, pd, st);
 }

@@ -85,6 +85,27 @@ def _emit_wgrad_bias(sink_w, sink_b, dy2: Tensor, x2: Tensor, has_bias: bool, de
     return dw_ret, db_ret
 
 
+def _linear_bwd(sink_w, sink_b, dy2: Tensor, x2: Tensor, w: Tensor, has_bias: bool, *, epilogue: int = L.EPI_NONE,
+                aux: Optional[Tensor] = None):
+    """Backward of y = x2 w^T (+ bias): -> (dW, db, dx) with dW / db None when they went into their sinks.  One launch for
+    launch-bound shapes, else weight gradient + data gradient with the split-K reduce carried (``ops.linear_backward``)."""
+    N, K = dy2.shape[1], x2.shape[1]
+    w_out = sink_w.buf.view(N, K) if sink_w is not None else None
+    b_out, b_acc = None, False
+    if has_bias:
+        if sink_b is not None:
+            b_out, b_acc = sink_b.buf.view(-1), not sink_b.fresh
+        else:
+            b_out = torch.empty((N,), dtype=torch.float32, device=dy2.device)
+    dw, dx = ops.linear_backward(dy2, x2, w, out=w_out, accumulate=(not sink_w.fresh) if sink_w is not None else False,
+                                 bias_out=b_out, bias_accumulate=b_acc, epilogue=epilogue, aux=aux)
+    if sink_w is not None:
+        sink_w.mark_written()
+    if has_bias and sink_b is not None:
+        sink_b.mark_written()
+    return (None if sink_w is not None else dw), (None if (not has_bias or sink_b is not None) else b_out), dx
+
+
 def _emit_colsum(sink, dy2: Tensor):
     if sink is None:
         return ops.colsum(dy2)
@@ -535,9 +556,7 @@ class _AttnBlock(torch.autograd.Function):
         dy2 = _as(dy.reshape(M, -1).contiguous(), T)
         dwo = dbo = None
         if has_out:
-            dwo, dbo, pend, fin = _emit_wgrad_bias(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), has_bias, defer=True)
-            do2 = ops.linear_dgrad(dy2, wo, carry=pend)                # [M, inner]; carries the reduce of dwo
-            fin()
+            dwo, dbo, do2 = _linear_bwd(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), wo, has_bias)   # do2 [M, inner]
         else:
             do2 = dy2
         q, k, v = _split_qkv(qkv, S, N, heads, dh, seq_first)
@@ -545,9 +564,7 @@ class _AttnBlock(torch.autograd.Function):
         dq, dk, dv = _split_qkv(dqkv, S, N, heads, dh, seq_first)
         ops.attention_bwd(q, k, v, _heads_view(o_mem, seq_first), lse,
                           _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5, ctx.drop)
-        dwq, dbq, pend, fin = _emit_wgrad_bias(ctx.sinks[2], ctx.sinks[5], dqkv, xn, has_qkv_bias, defer=True)
-        dxn = ops.linear_dgrad(dqkv, wq, carry=pend)                   # [M, d]
-        fin()
+        dwq, dbq, dxn = _linear_bwd(ctx.sinks[2], ctx.sinks[5], dqkv, xn, wq, has_qkv_bias)                    # dxn [M, d]
         dg = db = None
         if prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, ctx.sinks[0], ctx.sinks[1],
@@ -625,8 +642,7 @@ class _AttnBlockCls(torch.autograd.Function):
         s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
         scale = dh ** -0.5
         dy2 = _as(dy.reshape(S, d).contiguous(), T)
-        do = ops.linear_dgrad(dy2, wo)                                   # [S, inner]
-        dwo, dbo = _emit_wgrad_bias(s_o, s_bo, dy2, o, has_bias)
+        dwo, dbo, do = _linear_bwd(s_o, s_bo, dy2, o, wo, has_bias)      # do [S, inner]
         if s_qkv is not None:                                            # three row ranges of one packed gradient
             buf, acc = s_qkv.buf.view(3 * inner, d), not s_qkv.fresh
             dwqkv = None
@@ -644,10 +660,9 @@ class _AttnBlockCls(torch.autograd.Function):
             dx2, G, dg, db = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, P, mean, rstd, dM)
         dq = ops.heads_contract(G, w_k, scale, g)                        # dq_h = scale Wk_h (gamma G_h)
         ops.heads_outer(q, G, buf[inner:2 * inner], scale, g, accumulate=acc)        # dWk_h = scale q_h (x) dr_h
-        ops.linear_wgrad(dq, xn0, out=buf[:inner], accumulate=acc)
+        _, dxn0 = ops.linear_backward(dq, xn0, w_q, out=buf[:inner], accumulate=acc)   # dWq; dxn0 [S, d]: the query path into LN(x)[:, 0]
         if s_qkv is not None:
             s_qkv.mark_written()
-        dxn0 = ops.linear_dgrad(dq, w_q)                                 # [S, d]: the query path into LN(x)[:, 0]
         # row 0 of every sequence: the LayerNorm backward of the query path, plus the residual path, on top of its K / V part
         dxf = dx2.view(S * N, d)
         ops.layernorm_bwd(dxn0, x2, g, mean0, rstd0, rows=(S, 1, N * d, 0), dx=dxf, dx_add=dxf, dx_first=dy2,
@@ -667,8 +682,7 @@ class _AttnBlockCls(torch.autograd.Function):
         T = x2.dtype
         s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
         dy2 = _as(dy.reshape(S, d).contiguous(), T)
-        do = ops.linear_dgrad(dy2, wo)                                   # [S, inner]
-        dwo, dbo = _emit_wgrad_bias(s_o, s_bo, dy2, o, has_bias)
+        dwo, dbo, do = _linear_bwd(s_o, s_bo, dy2, o, wo, has_bias)      # do [S, inner]
         kv5 = kv.view(S, N, 2, heads, dh)
         k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
         dq = torch.empty_like(q)
@@ -815,16 +829,13 @@ class _MlpBlock(torch.autograd.Function):
             xn = x2
         dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
         sk = ctx.sinks
-        # each weight gradient's split-K reduce rides in the tail of the data-gradient launch behind it
-        dw2, db2, pend, fin = _emit_wgrad_bias(sk[4], sk[5], dy2, h, has_b2, defer=True)
+        # full-size shapes: each weight gradient's split-K reduce rides in the tail of the data-gradient launch behind it;
+        # launch-bound shapes: weight and data gradient of a Linear in one launch
         if act == "gelu":
-            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DGELU, aux=u, carry=pend)
+            dw2, db2, du = _linear_bwd(sk[4], sk[5], dy2, h, w2c, has_b2, epilogue=L.EPI_DGELU, aux=u)
         else:
-            du = ops.linear_dgrad(dy2, w2c, epilogue=L.EPI_DRELU, aux=h, carry=pend)
-        fin()
-        dw1, db1, pend, fin = _emit_wgrad_bias(sk[2], sk[3], du, xn, has_b1, defer=True)
-        dxn = ops.linear_dgrad(du, w1c, carry=pend)
-        fin()
+            dw2, db2, du = _linear_bwd(sk[4], sk[5], dy2, h, w2c, has_b2, epilogue=L.EPI_DRELU, aux=h)
+        dw1, db1, dxn = _linear_bwd(sk[2], sk[3], du, xn, w1c, has_b1)
         dg = db = None
         if prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, sk[0], sk[1], dx_add=dy2 if residual else None)

@@ -370,15 +370,12 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 
 # ------------------------------------------------------------------ GEMM family
-def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmajor: bool,
-         lda: int, ldb: int, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-         epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-         aux: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0,
-         split_k: int = 0, colsum_out: Optional[Tensor] = None, colsum_accumulate: bool = False,
-         defer_reduce: bool = False, carry=None):
-    """defer_reduce: a split-K reduce this call would launch is left undone and returned as a pending descriptor --
-    (out, pending) -- for the ``carry=`` argument of the NEXT gemm call on this stream (the data gradient of the same
-    Linear), which performs it in the idle tail of its own launch; ``out`` is complete only after that call."""
+def _gemm_desc(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmajor: bool, lda: int, ldb: int,
+               out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None, epilogue: int = L.EPI_NONE,
+               bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+               accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, colsum_out: Optional[Tensor] = None,
+               colsum_accumulate: bool = False):
+    """-> (dvt_gemm_desc, out): argument checks, output allocation and descriptor of one product."""
     _need_cuda(A, B, bias, residual, aux)
     assert A.dtype == B.dtype
     if out_dtype is None:
@@ -407,6 +404,22 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
         assert colsum_out.dtype == torch.float32 and colsum_out.numel() == M and colsum_out.is_contiguous()
     d.colsum_out = _p(colsum_out)
     d.colsum_accumulate = int(colsum_accumulate)
+    return d, out
+
+
+def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmajor: bool,
+         lda: int, ldb: int, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+         aux: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0,
+         split_k: int = 0, colsum_out: Optional[Tensor] = None, colsum_accumulate: bool = False,
+         defer_reduce: bool = False, carry=None):
+    """defer_reduce: a split-K reduce this call would launch is left undone and returned as a pending descriptor --
+    (out, pending) -- for the ``carry=`` argument of the NEXT gemm call on this stream (the data gradient of the same
+    Linear), which performs it in the idle tail of its own launch; ``out`` is complete only after that call."""
+    d, out = _gemm_desc(A, B, M, N, K, a_kmajor=a_kmajor, b_kmajor=b_kmajor, lda=lda, ldb=ldb, out=out, out_dtype=out_dtype,
+                        epilogue=epilogue, bias=bias, residual=residual, aux=aux, accumulate=accumulate, alpha=alpha,
+                        split_k=split_k, colsum_out=colsum_out, colsum_accumulate=colsum_accumulate)
+    out_dtype = out.dtype
     pending = None
     if defer_reduce:
         pending = L.SplitKPending()
@@ -477,6 +490,36 @@ def linear_wgrad(dy: Tensor, x: Tensor, *, out: Optional[Tensor] = None, accumul
     return gemm(dy, x, N, K, M, a_kmajor=False, b_kmajor=False, lda=dy.stride(0), ldb=x.stride(0), out=out,
                 out_dtype=torch.float32, accumulate=accumulate, colsum_out=bias_out,
                 colsum_accumulate=bias_accumulate, defer_reduce=defer_reduce)
+
+
+PAIR_LAUNCH = True        # A/B switch (bench.py --no-pair-launch): weight + data gradient of a launch-bound Linear in one launch
+
+
+def linear_backward(dy: Tensor, x: Tensor, w: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False,
+                    bias_out: Optional[Tensor] = None, bias_accumulate: bool = False, epilogue: int = L.EPI_NONE,
+                    aux: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Both gradients of y = x w^T (+ bias) from dy [M,N]: (dW [N,K] f32 (+ bias_out), dx [M,K] = epi(dy w)).
+    Launch-bound shapes (a few hundred rows: the temporal encoder, the CLS-row layers): ONE launch (dvt_gemm_pair) --
+    the two products are independent.  Otherwise the weight gradient with its split-K reduce deferred, then the data
+    gradient carrying that reduce in its grid tail."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1 and w.shape == (N, K) and w.is_contiguous()
+    wd, out = _gemm_desc(dy, x, N, K, M, a_kmajor=False, b_kmajor=False, lda=dy.stride(0), ldb=x.stride(0), out=out,
+                         out_dtype=torch.float32, accumulate=accumulate, colsum_out=bias_out,
+                         colsum_accumulate=bias_accumulate)
+    gd, _ = _gemm_desc(dy, w, M, K, N, a_kmajor=True, b_kmajor=False, lda=dy.stride(0), ldb=K, out=dy[:, :0].new_empty((0, K)),
+                       epilogue=epilogue, aux=aux)
+    gd.C, gd.ldc = dy.data_ptr(), K                     # a valid address for the shape test; the real one below
+    lib = L.load()
+    if PAIR_LAUNCH and lib.dvt_gemm_pair_fused(C.byref(wd), C.byref(gd)):
+        dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+        gd.C, gd.ldc = dx.data_ptr(), K
+        L.check(lib.dvt_gemm_pair(C.byref(wd), C.byref(gd), _stream()), "dvt_gemm_pair")
+        return out, dx
+    _, pend = linear_wgrad(dy, x, out=out, accumulate=accumulate, bias_out=bias_out, bias_accumulate=bias_accumulate,
+                           defer_reduce=True)
+    return out, linear_dgrad(dy, w, epilogue=epilogue, aux=aux, carry=pend)
 
 
 def colsum(x: Tensor, *, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:

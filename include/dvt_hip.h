@@ -256,6 +256,13 @@ typedef struct dvt_gemm_desc {
 
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* desc);
 int dvt_gemm(const dvt_gemm_desc* desc, dvt_stream_t stream);
+/* The two products of one Linear's backward (src/models/vit.py:20-25,39-43: dW = dy^T x with both operands mn-major,
+ * dx = dy W with A k-major / B mn-major) as ONE launch when both are launch-bound shapes (the 33-token temporal encoder,
+ * the CLS-row layers: a few hundred rows): they are independent, each fills a fraction of the chip, and between dependent
+ * launches of a few microseconds the launch itself is the cost.  Any other pair: the two dvt_gemm calls one after the
+ * other.  dvt_gemm_pair_fused tells which (1 = one launch). */
+int dvt_gemm_pair_fused(const dvt_gemm_desc* wgrad, const dvt_gemm_desc* dgrad);
+int dvt_gemm_pair(const dvt_gemm_desc* wgrad, const dvt_gemm_desc* dgrad, dvt_stream_t stream);
 /* Performs a pending split-K reduction as a launch of its own. */
 int dvt_splitk_reduce_pending(const dvt_splitk_pending* pending, dvt_stream_t stream);
 

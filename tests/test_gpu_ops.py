@@ -361,6 +361,40 @@ def test_gemm_launch_bound_shapes_panel_streaming_kernel(dvt, device, dtype, M, 
     assert torch.equal(dvt.ops.linear_wgrad(dy_d, x_d), dvt.ops.linear_wgrad(dy_d, x_d))      # no atomics: reproducible
 
 
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,epi", [(264, 1536, 512, "none"), (264, 512, 2048, "dgelu"), (256, 512, 512, "none"),
+                                       (8, 512, 512, "none"), (33, 192, 64, "drelu"), (50432 // 8, 512, 512, "none")])
+def test_linear_backward_pair_equals_the_two_launches(dvt, device, dt16, M, N, K, epi):
+    """ops.linear_backward: weight + data gradient of one Linear.  For launch-bound shapes both run in ONE launch
+    (dvt_gemm_pair, the same tile code): bit-identical to the two separate calls, incl. the fused bias gradient, the
+    accumulate flags and the activation-derivative epilogues; a full-size shape takes the deferred-reduce path."""
+    g = torch.Generator().manual_seed(31)
+    dy, _ = _rnd((M, N), dt16, g)
+    x, _ = _rnd((M, K), dt16, g)
+    w, _ = _rnd((N, K), dt16, g, 1 / math.sqrt(K))
+    aux, _ = _rnd((M, K), dt16, g)
+    L = dvt._lib
+    e = {"none": L.EPI_NONE, "dgelu": L.EPI_DGELU, "drelu": L.EPI_DRELU}[epi]
+    a = aux if epi != "none" else None
+    dw0 = torch.full((N, K), 0.25, device="cuda")
+    db0 = torch.full((N,), -1.0, device="cuda")
+    dw_ref = dvt.ops.linear_wgrad(dy, x, out=dw0.clone(), accumulate=True, bias_out=db0.clone(), bias_accumulate=True)
+    db_ref = db0 + dy.float().sum(0)
+    dx_ref = dvt.ops.linear_dgrad(dy, w, epilogue=e, aux=a)
+    dw, db = dw0.clone(), db0.clone()
+    dw_out, dx = dvt.ops.linear_backward(dy, x, w, out=dw, accumulate=True, bias_out=db, bias_accumulate=True, epilogue=e, aux=a)
+    assert dw_out.data_ptr() == dw.data_ptr()
+    small = M <= 512
+    if small:
+        assert torch.equal(dw, dw_ref) and torch.equal(dx, dx_ref)
+    else:
+        assert rel_l2(dw, dw_ref) < 1e-6 and torch.equal(dx, dx_ref)
+    assert rel_l2(db, db_ref) < 1e-5
+    # fresh outputs, no bias
+    dw2, dx2 = dvt.ops.linear_backward(dy, x, w, epilogue=e, aux=a)
+    assert rel_l2(dw2, dw_ref - 0.25) < 1e-4 and torch.equal(dx2, dx_ref)
+
+
 @pytest.mark.parametrize("rows", [28, 2, 13, 100])
 def test_wgrad_ragged_row_count_runs_on_mfma(dvt, device, rows):
     """Weight gradients of the 14-token encoders (K = B * 14 = 28 rows, frame_transformer.py:204) -- K is not a multiple of 8
