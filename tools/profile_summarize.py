@@ -18,7 +18,7 @@ from collections import defaultdict
 
 
 def find(d, pat):
-    f = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    f = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)   # the newest run's file
     return f[-1] if f else None
 
 
