@@ -68,7 +68,7 @@ def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, p
         return kv + qp + 2 * qk + proj + ff
 
     fwd = 2 * T * n_patch * patch_dim * d
-    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1, folded=fold_kv and n_tok <= 200 and d <= 512 and heads <= 8)
+    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1, folded=fold_kv and n_tok <= 400 and d <= 512 and heads <= 8)
     fwd += (depth - 1) * layer(T + 1, 1, T + 1) + layer(T + 1, 1, 1 if pool_cls else T + 1)
     return fwd, 3 * fwd
 

@@ -146,76 +146,86 @@ __device__ __forceinline__ float load_rprime(const float* __restrict__ Rf, const
 template <typename E, int RPW>
 __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
   typedef typename Row8<E>::type v8;
-  constexpr int NP = RPW * kWaves;
-  static_assert(NP <= 256 && RPW % kGroup == 0 && RPW <= 64, "the softmax pass holds four rows per lane");
+  constexpr int NP = RPW * kWaves;                        // rows a workgroup holds in registers at a time
+  static_assert(NP <= 256 && RPW % kGroup == 0 && RPW <= 64, "row grouping");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sc = lds;                                       // one spare row each: where the rows behind N are written
-  float* st = sc + (NP + 1) * 8;
-  float* red = st + (NP + 1) * 2 + 6;                     // 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int f = blockIdx.x, N = p.N, d = p.d, H = p.H;
+  // Sequences longer than NP rows (the 325-token frames of BASELINE configs[4]) are processed in NC chunks of NP rows:
+  // every pass walks the chunks and (NC > 1 only) requests its rows again -- they come from L2 / the Infinity Cache.
+  const int NC = (N + NP - 1) / NP, NT = NC * NP;
+  float* sc = lds;                                       // one spare row each: where the rows behind N are written
+  float* st = sc + (NT + 1) * 8;
+  float* red = st + (NT + 1) * 2 + 6;                     // 16-byte aligned
   const int c = lane * 8;
   const bool act = c < d;
   const float inv_d = 1.0f / (float)d;
   const E* xf = (const E*)p.x + (int64_t)f * p.xs0;
 
   v8 row[RPW];
+  auto request = [&](int base) {
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    v8 z = {};
-    row[i] = z;
-    if (act && j < N) row[i] = *reinterpret_cast<const v8*>(xf + (int64_t)j * p.xs1 + c);
-  }
+    for (int i = 0; i < RPW; ++i) {
+      const int j = base + w + kWaves * i;
+      v8 z = {};
+      row[i] = z;
+      if (act && j < N) row[i] = *reinterpret_cast<const v8*>(xf + (int64_t)j * p.xs1 + c);
+    }
+  };
+  request(0);
 
   f32x2 rp[kMaxH][4];
   const float cmine = load_rprime(p.R + (int64_t)f * H * d, p.gamma, p.beta, H, d, c, act, lane, rp);
-  for (int i = N * 8 + tid; i < (NP + 1) * 8; i += kThreads) sc[i] = 0.f;      // rows behind N: zero probabilities,
-  for (int i = N * 2 + tid; i < (NP + 1) * 2; i += kThreads) st[i] = 0.f;      // zero statistics
+  for (int i = N * 8 + tid; i < (NT + 1) * 8; i += kThreads) sc[i] = 0.f;      // rows behind N: zero probabilities,
+  for (int i = N * 2 + tid; i < (NT + 1) * 2; i += kThreads) st[i] = 0.f;      // zero statistics
   __syncthreads();
 
   // pass A: statistics and the H scores of every row.  Branch-free inside a group of rows (a row behind N is all zeros
   // and lands in the spare LDS row): the compiler then overlaps the rows' reductions and LDS traffic
-  float mu_keep = 0.f, rs_keep = 0.f;
+  for (int ch = 0; ch < NC; ++ch) {
+    const int base = ch * NP;
+    if (ch) { keep_packed(row); request(base); }
+    float mu_keep = 0.f, rs_keep = 0.f;
 #pragma unroll
-  for (int g0 = 0; g0 < RPW; g0 += kGroup)
-    if (w + kWaves * g0 < N) {
+    for (int g0 = 0; g0 < RPW; g0 += kGroup)
+      if (base + w + kWaves * g0 < N) {
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int i = g0 + u, j = w + kWaves * i;
-        const int jj = j < N ? j : NP;
-        f32x2 v[4];
-        unpack8(row[i], v);
-        const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
-        const float mu = wave_sum_dpp(s2[0] + s2[1]) * inv_d;
-        const f32x2 m = splat2(act ? mu : 0.f);
+        for (int u = 0; u < kGroup; ++u) {
+          const int i = g0 + u, j = base + w + kWaves * i;
+          const int jj = j < N ? j : NT;
+          f32x2 v[4];
+          unpack8(row[i], v);
+          const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float mu = wave_sum_dpp(s2[0] + s2[1]) * inv_d;
+          const f32x2 m = splat2(act ? mu : 0.f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] - m;
-        const float q = dot8(v, v);
-        float dots[8];
+          for (int k = 0; k < 4; ++k) v[k] = v[k] - m;
+          const float q = dot8(v, v);
+          float dots[8];
 #pragma unroll
-        for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
-        const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + p.eps);
-        const float t = wave_sum8(dots, lane);
-        sc[jj * 8 + (lane >> 3)] = fmaf(rs, t, cmine);       // the 8 lanes of a group store the same value
-        st[2 * jj] = mu;
-        st[2 * jj + 1] = rs;
-        mu_keep = lane == i ? mu : mu_keep;
-        rs_keep = lane == i ? rs : rs_keep;
+          for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
+          const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + p.eps);
+          const float t = wave_sum8(dots, lane);
+          sc[jj * 8 + (lane >> 3)] = fmaf(rs, t, cmine);       // the 8 lanes of a group store the same value
+          st[2 * jj] = mu;
+          st[2 * jj + 1] = rs;
+          mu_keep = lane == i ? mu : mu_keep;
+          rs_keep = lane == i ? rs : rs_keep;
+        }
       }
+    if (lane < RPW && base + w + kWaves * lane < N) {
+      p.mean[(int64_t)f * N + base + w + kWaves * lane] = mu_keep;
+      p.rstd[(int64_t)f * N + base + w + kWaves * lane] = rs_keep;
     }
-  if (lane < RPW && w + kWaves * lane < N) {
-    p.mean[(int64_t)f * N + w + kWaves * lane] = mu_keep;
-    p.rstd[(int64_t)f * N + w + kWaves * lane] = rs_keep;
   }
   __syncthreads();
   keep_packed(row);
 
   // softmax over the rows, one wave per head
   if (w < H) {
-    float e[4], mx = -INFINITY;
+    float e[8], mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       const int j = lane + 64 * t;
       e[t] = j < N ? sc[j * 8 + w] : -INFINITY;
       mx = fmaxf(mx, e[t]);
@@ -223,14 +233,14 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       e[t] = __builtin_amdgcn_exp2f((e[t] - mx) * 1.44269504088896340736f);   // exp2(-inf) = 0 for the rows beyond N
       sum += e[t];
     }
     sum = wave_sum_dpp(sum);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       const int j = lane + 64 * t;
       if (j < N) sc[j * 8 + w] = e[t] * inv;
     }
@@ -245,25 +255,29 @@ __global__ __launch_bounds__(kThreads) void attn_cls_fwd_kernel(ClsParams p) {
   for (int h = 0; h < kMaxH; ++h)
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[h][k] = splat2(0.f);
+  for (int ch = 0; ch < NC; ++ch) {
+    const int base = ch * NP;
+    if (NC > 1) { keep_packed(row); request(base); }
 #pragma unroll
-  for (int g0 = 0; g0 < RPW; g0 += kGroup)
-    if (w + kWaves * g0 < N) {
+    for (int g0 = 0; g0 < RPW; g0 += kGroup)
+      if (base + w + kWaves * g0 < N) {
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int i = g0 + u, j = w + kWaves * i;            // j < NP: the rows behind N carry zero probabilities
-        const float mu = st[2 * j], rs = st[2 * j + 1];
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(sc + j * 8), p1 = *reinterpret_cast<const f32x4*>(sc + j * 8 + 4);
-        const float ph[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-        f32x2 n[4];
-        centred(row[i], mu, act, n);
+        for (int u = 0; u < kGroup; ++u) {
+          const int i = g0 + u, j = base + w + kWaves * i;     // j < NT: the rows behind N carry zero probabilities
+          const float mu = st[2 * j], rs = st[2 * j + 1];
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(sc + j * 8), p1 = *reinterpret_cast<const f32x4*>(sc + j * 8 + 4);
+          const float ph[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+          f32x2 n[4];
+          centred(row[i], mu, act, n);
 #pragma unroll
-        for (int h = 0; h < kMaxH; ++h) {
-          const f32x2 t = splat2(ph[h] * rs);
+          for (int h = 0; h < kMaxH; ++h) {
+            const f32x2 t = splat2(ph[h] * rs);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) a[h][k] = fma2(t, n[k], a[h][k]);
+            for (int k = 0; k < 4; ++k) a[h][k] = fma2(t, n[k], a[h][k]);
+          }
         }
       }
-    }
+  }
   // the waves' partial sums, added in wave order (fixed order: reproducible)
   const int HD = H * d;
   if (act) {
@@ -294,11 +308,12 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   constexpr int GR = kGroup;                             // rows per group in the d LN(x) pass
   static_assert(NP <= 256 && RPW % GR == 0, "row grouping");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* pd = lds;                                       // one spare row each: where the rows behind N are written
-  float* st = pd + (NP + 1) * 16;
-  float* big = st + (NP + 1) * 2 + 2;                     // 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int f = blockIdx.x, N = p.N, d = p.d, H = p.H, HD = H * d;
+  const int NC = (N + NP - 1) / NP, NT = NC * NP;         // chunks of NP rows, as in the forward
+  float* pd = lds;                                       // one spare row each: where the rows behind N are written
+  float* st = pd + (NT + 1) * 16;
+  float* big = st + (NT + 1) * 2 + 2;                     // 16-byte aligned
   const int c = lane * 8;
   const bool act = c < d;
   const float inv_d = 1.0f / (float)d;
@@ -310,24 +325,27 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   float* dl = big + kMaxH * d;
 
   v8 row[RPW];
+  auto request = [&](int base) {
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int j = w + kWaves * i;
-    v8 z = {};
-    row[i] = z;
-    if (act && j < N) row[i] = *reinterpret_cast<const v8*>(xf + (int64_t)j * p.xs1 + c);
-  }
+    for (int i = 0; i < RPW; ++i) {
+      const int j = base + w + kWaves * i;
+      v8 z = {};
+      row[i] = z;
+      if (act && j < N) row[i] = *reinterpret_cast<const v8*>(xf + (int64_t)j * p.xs1 + c);
+    }
+  };
+  request(0);
   // gamma * r_h and gamma * dm_h for the d LN(x) pass (zero rows for h >= H), the rows' statistics
   for (int e = tid; e < kMaxH * d; e += kThreads) {
     const float g = p.gamma[e % d];
     rl[e] = e < HD ? Rf[e] * g : 0.f;
     dl[e] = e < HD ? dMf[e] * g : 0.f;
   }
-  for (int j = tid; j <= NP; j += kThreads) {
+  for (int j = tid; j <= NT; j += kThreads) {
     st[2 * j] = j < N ? p.mean[(int64_t)f * N + j] : 0.f;
     st[2 * j + 1] = j < N ? p.rstd[(int64_t)f * N + j] : 0.f;
   }
-  for (int i = tid; i < (NP + 1) * 8; i += kThreads) {                                   // p_jh of the forward; zero behind N
+  for (int i = tid; i < (NT + 1) * 8; i += kThreads) {                                   // p_jh of the forward; zero behind N
     pd[2 * i] = i < N * 8 ? p.P[(int64_t)f * N * 8 + i] : 0.f;
     pd[2 * i + 1] = 0.f;
   }
@@ -342,24 +360,28 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
     for (int k = 0; k < 4; ++k) rp[h][k] = splat2(0.f);
     if (act) load8x2(dl + h * d + c, rp[h]);
   }
+  for (int ch = 0; ch < NC; ++ch) {
+    const int base = ch * NP;
+    if (ch) { keep_packed(row); request(base); }
 #pragma unroll
-  for (int g0 = 0; g0 < RPW; g0 += kGroup)
-    if (w + kWaves * g0 < N) {
+    for (int g0 = 0; g0 < RPW; g0 += kGroup)
+      if (base + w + kWaves * g0 < N) {
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int i = g0 + u, j = w + kWaves * i;
-        const int jj = j < N ? j : NP;
-        const float mu = st[2 * j], rs = st[2 * j + 1];
-        f32x2 v[4];
-        centred(row[i], mu, act, v);
-        float dots[8];
+        for (int u = 0; u < kGroup; ++u) {
+          const int i = g0 + u, j = base + w + kWaves * i;
+          const int jj = j < N ? j : NT;
+          const float mu = st[2 * j], rs = st[2 * j + 1];
+          f32x2 v[4];
+          centred(row[i], mu, act, v);
+          float dots[8];
 #pragma unroll
-        for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
-        const float t = wave_sum8(dots, lane);
-        pd[(jj * 8 + hmine) * 2 + 1] = rs * t;               // the 8 lanes of a group store the same value
-        if (u & 1) __builtin_amdgcn_sched_barrier(0);         // two rows in flight: all five would not fit the registers
+          for (int h = 0; h < kMaxH; ++h) dots[h] = dot8(rp[h], v);
+          const float t = wave_sum8(dots, lane);
+          pd[(jj * 8 + hmine) * 2 + 1] = rs * t;               // the 8 lanes of a group store the same value
+          if (u & 1) __builtin_amdgcn_sched_barrier(0);         // two rows in flight: all five would not fit the registers
+        }
       }
-    }
+  }
   __syncthreads();
 
   keep_packed(row);
@@ -367,13 +389,13 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   if (w < H) {
     float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       const int j = lane + 64 * t;
       if (j < N) acc = fmaf(pd[(j * 8 + w) * 2], pd[(j * 8 + w) * 2 + 1], acc);
     }
     const float D = wave_sum_dpp(acc);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       const int j = lane + 64 * t;
       if (j < N) pd[(j * 8 + w) * 2 + 1] = pd[(j * 8 + w) * 2] * (pd[(j * 8 + w) * 2 + 1] - D);
     }
@@ -383,9 +405,12 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   // d LN(x_j) = sum_h p_jh (gamma dm_h) + ds_jh (gamma r_h), then the LayerNorm backward of the row
   // where the rows behind N and the lanes behind d store: this sequence's own partial row (written for real at the very end)
   E* const trash = reinterpret_cast<E*>(p.partial + (int64_t)f * 2 * d) + ((w * 16 + (lane & 15)) * 8) % (4 * d);
+  for (int ch = 0; ch < NC; ++ch) {
+  const int base = ch * NP;
+  if (NC > 1) { keep_packed(row); request(base); }
 #pragma unroll
   for (int g0 = 0; g0 < RPW; g0 += GR)
-    if (w + kWaves * g0 < N) {
+    if (base + w + kWaves * g0 < N) {
       f32x2 dn[GR][4];
 #pragma unroll
       for (int u = 0; u < GR; ++u)
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
         load8x2(dl + off, dd);
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
-          const int j = w + kWaves * (g0 + u);                 // zero coefficients behind N and behind H
+          const int j = base + w + kWaves * (g0 + u);          // zero coefficients behind N and behind H
           const f32x2 cf = *reinterpret_cast<const f32x2*>(pd + (j * 8 + h) * 2);
           const f32x2 cp = splat2(act ? cf[0] : 0.f), cs = splat2(act ? cf[1] : 0.f);
 #pragma unroll
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
       }
 #pragma unroll
       for (int u = 0; u < GR; ++u) {
-        const int j = w + kWaves * (g0 + u);
+        const int j = base + w + kWaves * (g0 + u);
         const float mu = st[2 * j], rs = st[2 * j + 1];
         f32x2 n[4];
         centred(row[g0 + u], mu, act, n);
@@ -431,6 +456,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
         if (u & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
 
   keep_packed(row);
   // G_h = sum_j ds_jh n_j
@@ -439,12 +465,15 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   for (int h = 0; h < kMaxH; ++h)
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[h][k] = splat2(0.f);
+  for (int ch = 0; ch < NC; ++ch) {
+  const int base = ch * NP;
+  if (NC > 1) { keep_packed(row); request(base); }
 #pragma unroll
   for (int g0 = 0; g0 < RPW; g0 += kGroup)
-    if (w + kWaves * g0 < N) {
+    if (base + w + kWaves * g0 < N) {
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
-        const int i = g0 + u, j = w + kWaves * i;
+        const int i = g0 + u, j = base + w + kWaves * i;
         const float mu = st[2 * j], rs = st[2 * j + 1];
         f32x2 n[4];
         centred(row[i], mu, act, n);
@@ -457,6 +486,7 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
         if (u & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
   __syncthreads();                                       // rl / dl are dead: the region becomes the waves' partial sums
   float* red = big;
   if (act) {
@@ -484,12 +514,17 @@ __global__ __launch_bounds__(kThreads) void attn_cls_bwd_kernel(ClsParams p) {
   }
 }
 
-constexpr int kRPW = 25;                                  // N <= 200 (197 tokens of a 224^2 frame at patch 16)
+constexpr int kRPW = 25;                                  // 200 rows per chunk (197 tokens of a 224^2 frame at patch 16)
+constexpr int kMaxChunks = 2;                             // N <= 400 (325 tokens of a 288^2 frame: two chunks)
 
-size_t cls_fwd_lds(int H, int d) { return sizeof(float) * ((size_t)(kRPW * kWaves + 1) * 10 + 6 + (size_t)kWaves * H * d); }
-size_t cls_bwd_lds(int H, int d) {
+size_t cls_fwd_lds(int N, int H, int d) {
+  const int nt = (N + kRPW * kWaves - 1) / (kRPW * kWaves) * (kRPW * kWaves);
+  return sizeof(float) * ((size_t)(nt + 1) * 10 + 6 + (size_t)kWaves * H * d);
+}
+size_t cls_bwd_lds(int N, int H, int d) {
+  const int nt = (N + kRPW * kWaves - 1) / (kRPW * kWaves) * (kRPW * kWaves);
   const size_t big = (size_t)kWaves * H * d > (size_t)2 * kMaxH * d ? (size_t)kWaves * H * d : (size_t)2 * kMaxH * d;
-  return sizeof(float) * ((size_t)(kRPW * kWaves + 1) * 18 + 2 + big);
+  return sizeof(float) * ((size_t)(nt + 1) * 18 + 2 + big);
 }
 
 int cls_check(const char* name, const dvt_attn_cls_desc* q, bool bwd) {
@@ -498,7 +533,7 @@ int cls_check(const char* name, const dvt_attn_cls_desc* q, bool bwd) {
   DVT_REQUIRE(q->S > 0 && q->N > 0 && q->d > 0 && q->H > 0, "%s: bad sizes", name);
   if (!dvt_attn_cls_supported(q))
     DVT_UNSUPPORTED("%s: needs a 16-bit dtype, d %% 8 == 0, d <= 512, H <= 8, N <= %d, strides %% 8 == 0 (got d = %lld, H = %lld, "
-                    "N = %lld)", name, kRPW * kWaves, (long long)q->d, (long long)q->H, (long long)q->N);
+                    "N = %lld)", name, kMaxChunks * kRPW * kWaves, (long long)q->d, (long long)q->H, (long long)q->N);
   DVT_REQUIRE(dvt_aligned16(q->x) && dvt_aligned16(q->gamma) && dvt_aligned16(q->beta) && dvt_aligned16(q->R) &&
                   dvt_aligned16(q->A), "%s: buffers must be 16-byte aligned", name);
   if (bwd) {
@@ -690,7 +725,7 @@ extern "C" {
 
 int dvt_attn_cls_supported(const dvt_attn_cls_desc* q) {
   if (!q) return 0;
-  return dvt_is_16bit(q->dtype) && q->d % 8 == 0 && q->d <= 512 && q->H <= kMaxH && q->N <= kRPW * kWaves &&
+  return dvt_is_16bit(q->dtype) && q->d % 8 == 0 && q->d <= 512 && q->H <= kMaxH && q->N <= kMaxChunks * kRPW * kWaves &&
          q->xs0 % 8 == 0 && q->xs1 % 8 == 0 && q->xs1 >= q->d;
 }
 
@@ -702,7 +737,7 @@ int dvt_attn_cls_fwd(const dvt_attn_cls_desc* q, dvt_stream_t stream) {
   int rc = cls_check("dvt_attn_cls_fwd", q, false);
   if (rc) return rc;
   const ClsParams p = cls_params(q);
-  const size_t lds = cls_fwd_lds(p.H, p.d);
+  const size_t lds = cls_fwd_lds(p.N, p.H, p.d);
   DVT_DISPATCH_16BIT(q->dtype, E, {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)attn_cls_fwd_kernel<E, kRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
@@ -716,7 +751,7 @@ int dvt_attn_cls_bwd(const dvt_attn_cls_desc* q, dvt_stream_t stream) {
   int rc = cls_check("dvt_attn_cls_bwd", q, true);
   if (rc) return rc;
   const ClsParams p = cls_params(q);
-  const size_t lds = cls_bwd_lds(p.H, p.d);
+  const size_t lds = cls_bwd_lds(p.N, p.H, p.d);
   DVT_DISPATCH_16BIT(q->dtype, E, {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)attn_cls_bwd_kernel<E, kRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }

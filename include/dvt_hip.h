@@ -327,7 +327,8 @@ int dvt_attention_bwd(const dvt_attn_desc* desc, dvt_stream_t stream);
  *         j at P[(s*N + j)*8 + h]; kept for the backward), mean / rstd [S*N]
  *   bwd:  dM (gradient of m) -> dx, G[s,h,:] = sum_j ds_jh n_j (so dr_h = gamma G_h), dgamma / dbeta (+= when the
  *         accumulate flags are set; workspace >= dvt_attn_cls_bwd_workspace_bytes holds one partial row per sequence).
- * 16-bit dtypes, d % 8 == 0, d <= 512, H <= 8, N <= 200; dvt_attn_cls_supported tells (callers keep the unfolded
+ * 16-bit dtypes, d % 8 == 0, d <= 512, H <= 8, N <= 400 (sequences of more than 200 rows -- the 325-token frames of a 288^2
+ * clip -- are walked in two chunks per pass); dvt_attn_cls_supported tells (callers keep the unfolded
  * dvt_layernorm_fwd -> dvt_gemm -> dvt_attention_fwd sequence otherwise). */
 typedef struct dvt_attn_cls_desc {
   const void* x;

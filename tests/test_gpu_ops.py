@@ -629,7 +629,8 @@ def test_attn_block_cls_equals_dense_block_row0(dvt, device, dtype, dim, heads, 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("dim,heads,dh,N,S", [(128, 2, 64, 17, 5), (512, 8, 64, 197, 6), (64, 2, 32, 10, 3),
-                                              (384, 6, 64, 197, 3), (512, 8, 64, 200, 2), (512, 3, 64, 1, 9)])
+                                              (384, 6, 64, 197, 3), (512, 8, 64, 200, 2), (512, 3, 64, 1, 9),
+                                              (512, 8, 64, 325, 2), (128, 2, 64, 201, 3)])
 def test_attn_block_cls_folded_equals_dense_block_row0(dvt, device, dtype, dim, heads, dh, N, S, monkeypatch):
     """The same contract with the K / V projections folded into the one query (csrc/attention_cls.hip: no LN(x), K, V
     of the rows that are never read again): values and every gradient against the dense block + slice of the oracle."""
@@ -659,7 +660,8 @@ def test_attn_block_cls_folded_equals_dense_block_row0(dvt, device, dtype, dim, 
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("S,N,d,H", [(4, 197, 512, 8), (3, 50, 384, 6), (2, 9, 64, 2), (5, 200, 512, 1)])
+@pytest.mark.parametrize("S,N,d,H", [(4, 197, 512, 8), (3, 50, 384, 6), (2, 9, 64, 2), (5, 200, 512, 1), (3, 325, 512, 8),
+                                     (2, 400, 512, 8), (2, 201, 128, 3)])
 def test_attn_cls_folded_kernels_against_float64(dvt, device, dtype, S, N, d, H):
     """dvt_attn_cls_fwd / _bwd on 16-bit rows: everything between the rows and the fp32 results is fp32, so the fp32
     outputs are held to 2e-5 against a float64 evaluation of the same formulas on the same inputs; dx (16-bit) to the
