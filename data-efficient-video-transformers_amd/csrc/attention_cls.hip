@@ -569,10 +569,6 @@ __global__ __launch_bounds__(256) void heads_expand_kernel(const E* __restrict__
   const int c = blockIdx.z * 128 + (tid & 63) * 2, fg = (tid >> 6) * 4;
   const bool cok = c < d;
   const int dhp = (dh + 63) & ~63;
-  for (int i = tid; i < 16 * dhp; i += 256) {
-    const int ee = i >> 4, ff = i & 15;
-    lds[i] = f0 + ff < S && ee < dh ? to_f32<E>(in[(int64_t)(f0 + ff) * ld_in + h * dh + ee]) : 0.f;
-  }
   f32x2 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x2{0.f, 0.f};
@@ -582,7 +578,13 @@ __global__ __launch_bounds__(256) void heads_expand_kernel(const E* __restrict__
 #pragma unroll
     for (int e = 0; e < 64; ++e) w[e] = *reinterpret_cast<const v2*>(Wh + (int64_t)min(e0 + e, dh - 1) * ldw);
     __builtin_amdgcn_sched_barrier(0);
-    if (e0 == 0) __syncthreads();
+    if (e0 == 0) {                                       // the activations' round trip runs under the weights'
+      for (int i = tid; i < 16 * dhp; i += 256) {
+        const int ee = i >> 4, ff = i & 15;
+        lds[i] = f0 + ff < S && ee < dh ? to_f32<E>(in[(int64_t)(f0 + ff) * ld_in + h * dh + ee]) : 0.f;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < 64; ++e) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(lds + (e0 + e) * 16 + fg);    // zero behind dh
@@ -616,6 +618,10 @@ __global__ __launch_bounds__(256) void heads_contract_kernel(const float* __rest
   for (int k = 0; k < 4; ++k) { g[k] = f32x2{1.f, 1.f}; b[k] = f32x2{0.f, 0.f}; }
   if (act && gamma) load8x2(gamma + c, g);
   if (act && beta) load8x2(beta + c, b);
+  v8 wr[16];                                             // the first 16 weight rows of this wave: requested with the operands
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    wr[i] = *reinterpret_cast<const v8*>(W + (int64_t)(h * dh + min(w + 4 * i, dh - 1)) * ldw + (act ? c : 0));
 #pragma unroll
   for (int ff = 0; ff < 8; ++ff)                         // unconditional requests (clamped), all in flight together
     load8x2(in + ((int64_t)min(f0 + ff, S - 1) * H + h) * d + (act ? c : 0), v[ff]);
@@ -625,11 +631,12 @@ __global__ __launch_bounds__(256) void heads_contract_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[ff][k] = act && f0 + ff < S ? __builtin_elementwise_fma(v[ff][k], g[k], b[k]) : f32x2{0.f, 0.f};
   for (int e0 = w; e0 < dh; e0 += 64) {
-    v8 wr[16];                                           // unconditional requests (clamped rows), all in flight together
+    if (e0 != w) {                                       // further rounds (dh > 64): unconditional requests, all in flight
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      wr[i] = *reinterpret_cast<const v8*>(W + (int64_t)(h * dh + min(e0 + 4 * i, dh - 1)) * ldw + (act ? c : 0));
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 16; ++i)
+        wr[i] = *reinterpret_cast<const v8*>(W + (int64_t)(h * dh + min(e0 + 4 * i, dh - 1)) * ldw + (act ? c : 0));
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       if (e0 + 4 * i < dh) {
