@@ -592,6 +592,14 @@ class _AttnBlockCls(torch.autograd.Function):
     slice: the rows that are dropped contribute exact zeros to every gradient.  Backward: dK / dV come
     from the one query; the gradient into LN(x) is ``dkv W_kv`` on all rows plus ``dq W_q`` on row 0,
     summed inside the LayerNorm backward kernel together with the residual path of row 0.
+
+    Folded form (16-bit dtypes, ``S * N >= CLS_FOLD_MIN_ROWS``, shapes ``ops.attn_cls_supported`` accepts: the space
+    stack): with one query per (sequence, head) the K / V projections commute with the attention sums --
+    ``s_jh = r_h . LN(x_j)`` with ``r_h = scale Wk_h^T q_h`` and ``o_h = Wv_h m_h`` with ``m_h = sum_j p_jh LN(x_j)`` -- so
+    LN(x), K and V of the rows 1 .. N-1 never exist: one pass over the raw rows forward (``ops.attn_cls_fwd``), one more
+    backward (``ops.attn_cls_bwd``, which also is those rows' LayerNorm backward), head-wise products over the S first
+    rows on either side, and a LayerNorm backward call on the S first rows for the query / residual paths of row 0.
+    Same values up to summation order (csrc/attention_cls.hip).
     """
 
     @staticmethod
