@@ -124,6 +124,10 @@ SIGNATURES = {
     "dvt_heads_expand": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     "dvt_heads_contract": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_p]),
     "dvt_heads_outer": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_int, c_int, c_p]),
+    "dvt_heads_expand_outer": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_i64, c_f, c_int,
+                                       c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "dvt_heads_contract_outer": (c_int, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_f, c_p, c_i64, c_p, c_i64, c_f, c_int,
+                                         c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
     "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 9 + [c_i64, c_int, c_p]),
     "dvt_col2im_nchw": (c_int, [c_p, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),

@@ -560,13 +560,12 @@ ClsParams cls_params(const dvt_attn_cls_desc* q) {
 // out[f, h, c] = alpha sum_e in[f, h dh + e] W[h dh + e, c]: 16 sequences x one head x 128 columns per workgroup; a thread
 // owns two columns of four sequences and holds its 64 weight pairs in registers.
 template <typename E>
-__global__ __launch_bounds__(256) void heads_expand_kernel(const E* __restrict__ in, int64_t ld_in, const E* __restrict__ W,
-                                                           int64_t ldw, float* __restrict__ out, int S, int H, int dh, int d,
-                                                           float alpha) {
+__device__ __forceinline__ void heads_expand_tile(const int bx, const int by, const int bz, float* lds /* [dh rounded up to 64][16] */,
+                                                  const E* __restrict__ in, int64_t ld_in, const E* __restrict__ W, int64_t ldw,
+                                                  float* __restrict__ out, int S, int H, int dh, int d, float alpha) {
   typedef E v2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [dh rounded up to 64][16]: a[e][f], zero rows behind dh
-  const int f0 = blockIdx.x * 16, h = blockIdx.y, tid = threadIdx.x;
-  const int c = blockIdx.z * 128 + (tid & 63) * 2, fg = (tid >> 6) * 4;
+  const int f0 = bx * 16, h = by, tid = threadIdx.x;              // lds: a[e][f], zero rows behind dh
+  const int c = bz * 128 + (tid & 63) * 2, fg = (tid >> 6) * 4;
   const bool cok = c < d;
   const int dhp = (dh + 63) & ~63;
   f32x2 acc[4];
@@ -604,12 +603,12 @@ __global__ __launch_bounds__(256) void heads_expand_kernel(const E* __restrict__
 // 8 sequences x one head per workgroup; a lane owns 8 columns of the 8 sequences (64 registers), a wave takes the output
 // columns e = wave, wave + 4, ... in rounds of 16 weight rows requested together.
 template <typename E>
-__global__ __launch_bounds__(256) void heads_contract_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const E* __restrict__ W,
-                                                             int64_t ldw, E* __restrict__ out, int64_t ld_out, int S, int H,
-                                                             int dh, int d, float alpha) {
+__device__ __forceinline__ void heads_contract_tile(const int bx, const int by, const float* __restrict__ in,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const E* __restrict__ W, int64_t ldw, E* __restrict__ out, int64_t ld_out, int S,
+                                                    int H, int dh, int d, float alpha) {
   typedef typename Row8<E>::type v8;
-  const int f0 = blockIdx.x * 8, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int f0 = bx * 8, h = by, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane * 8;
   const bool act = c < d;
   f32x2 v[8][4];
@@ -657,13 +656,12 @@ __global__ __launch_bounds__(256) void heads_contract_kernel(const float* __rest
 // One (head, 64 columns, 16 rows e) tile per workgroup (256 workgroups at the metric shape); sequences staged 128 at a
 // time through LDS, all of a chunk's requests in flight together; a thread owns one column of four rows.
 template <typename E>
-__global__ __launch_bounds__(256) void heads_outer_kernel(const E* __restrict__ a, int64_t lda, const float* __restrict__ b,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ dW, int64_t ldw, int S, int H, int dh, int d,
-                                                          float alpha, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float vt[128][64];
-  __shared__ __attribute__((aligned(16))) float at[128][16];
-  const int h = blockIdx.x, c0 = blockIdx.y * 64, e0 = blockIdx.z * 16, tid = threadIdx.x;
+__device__ __forceinline__ void heads_outer_tile(const int bx, const int by, const int bz, float (*vt)[64], float (*at)[16],
+                                                 const E* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* __restrict__ dW, int64_t ldw, int S, int H, int dh, int d, float alpha,
+                                                 int accumulate) {
+  const int h = bx, c0 = by * 64, e0 = bz * 16, tid = threadIdx.x;
   const int cl = tid & 63, eg = (tid >> 6) * 4;
   const int c4 = (tid & 15) * 4;                        // staging: this thread's four columns of rows tid / 16 + 16 k
   f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
@@ -715,6 +713,61 @@ __global__ __launch_bounds__(256) void heads_outer_kernel(const E* __restrict__ 
         float* o = dW + (int64_t)(h * dh + e0 + eg + i) * ldw + c0 + cl;
         *o = accumulate ? *o + alpha * acc[i] : alpha * acc[i];
       }
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void heads_expand_kernel(const E* in, int64_t ld_in, const E* W, int64_t ldw, float* out, int S, int H,
+                                                           int dh, int d, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  heads_expand_tile<E>(blockIdx.x, blockIdx.y, blockIdx.z, lds, in, ld_in, W, ldw, out, S, H, dh, d, alpha);
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void heads_contract_kernel(const float* in, const float* gamma, const float* beta, const E* W,
+                                                             int64_t ldw, E* out, int64_t ld_out, int S, int H, int dh, int d,
+                                                             float alpha) {
+  heads_contract_tile<E>(blockIdx.x, blockIdx.y, in, gamma, beta, W, ldw, out, ld_out, S, H, dh, d, alpha);
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void heads_outer_kernel(const E* a, int64_t lda, const float* b, const float* gamma,
+                                                          const float* beta, float* dW, int64_t ldw, int S, int H, int dh, int d,
+                                                          float alpha, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float vt[128][64];
+  __shared__ __attribute__((aligned(16))) float at[128][16];
+  heads_outer_tile<E>(blockIdx.x, blockIdx.y, blockIdx.z, vt, at, a, lda, b, gamma, beta, dW, ldw, S, H, dh, d, alpha, accumulate);
+}
+
+// The two products in front of the row pass of the backward (dm = expand(do, Wv), dWv (+)= outer(do, gamma A + beta)) and
+// the two behind it (dq = contract(gamma G, Wk), dWk (+)= outer(q, gamma G)) are independent of each other: one launch
+// per pair, the workgroups of the first member in front (a dependent launch costs ~2.7 us inside the replayed graph).
+struct HeadsPair {
+  // first member: expand (kind 0) or contract (kind 1)
+  const void* in16; int64_t ld_in; const float* vin; const float* gamma1; const float* beta1;
+  const void* W; int64_t ldw; void* out; int64_t ld_out; float alpha1;
+  int gx, gy, gz;                                        // its grid
+  // second member: outer
+  const void* a; int64_t lda; const float* v; const float* gamma2; const float* beta2; float* dW; int64_t ld_dw; float alpha2;
+  int accumulate; int ox, oy, oz;
+  int S, H, dh, d;
+};
+
+template <typename E, int KIND>
+__global__ __launch_bounds__(256) void heads_pair_kernel(const HeadsPair q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) float vt[128][64];
+  __shared__ __attribute__((aligned(16))) float at[128][16];
+  const int n1 = q.gx * q.gy * q.gz;
+  int b = blockIdx.x;
+  if (b < n1) {
+    const int bx = b % q.gx, by = (b / q.gx) % q.gy, bz = b / (q.gx * q.gy);
+    if (KIND == 0) heads_expand_tile<E>(bx, by, bz, lds, (const E*)q.in16, q.ld_in, (const E*)q.W, q.ldw, (float*)q.out, q.S, q.H, q.dh, q.d, q.alpha1);
+    else heads_contract_tile<E>(bx, by, q.vin, q.gamma1, q.beta1, (const E*)q.W, q.ldw, (E*)q.out, q.ld_out, q.S, q.H, q.dh, q.d, q.alpha1);
+  } else {
+    b -= n1;
+    const int bx = b % q.ox, by = (b / q.ox) % q.oy, bz = b / (q.ox * q.oy);
+    heads_outer_tile<E>(bx, by, bz, vt, at, (const E*)q.a, q.lda, q.v, q.gamma2, q.beta2, q.dW, q.ld_dw, q.S, q.H, q.dh, q.d, q.alpha2, q.accumulate);
   }
 }
 
@@ -812,6 +865,49 @@ int dvt_heads_outer(const void* a, int64_t lda, const float* b, const float* gam
                                                   (hipStream_t)stream, (const E*)a, lda, b, gamma, beta, dW, ldw, (int)S, (int)H,
                                                   (int)dh, (int)d, alpha, accumulate));
   DVT_LAUNCH_CHECK("dvt_heads_outer");
+  return DVT_OK;
+}
+
+int dvt_heads_expand_outer(const void* in, int64_t ld_in, const void* W, int64_t ldw, float* out, float alpha_out, const float* v,
+                           const float* gamma, const float* beta, float* dW, int64_t ld_dw, float alpha_dw, int accumulate,
+                           int64_t S, int64_t H, int64_t dh, int64_t d, int dtype, dvt_stream_t stream) {
+  int rc = heads_check("dvt_heads_expand_outer", in, W, out, S, H, dh, d, dtype);
+  if (rc) return rc;
+  DVT_REQUIRE(v && dW, "dvt_heads_expand_outer: null pointer");
+  DVT_REQUIRE(d % 4 == 0 && ldw % 2 == 0 && dvt_aligned16(v) && (reinterpret_cast<uintptr_t>(W) & 3u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && dh <= 512,
+              "dvt_heads_expand_outer: alignment (see dvt_heads_expand / dvt_heads_outer)");
+  HeadsPair q{};
+  q.in16 = in; q.ld_in = ld_in; q.W = W; q.ldw = ldw; q.out = out; q.alpha1 = alpha_out;
+  q.gx = (int)dvt_cdiv(S, 16); q.gy = (int)H; q.gz = (int)dvt_cdiv(d, 128);
+  q.a = in; q.lda = ld_in; q.v = v; q.gamma2 = gamma; q.beta2 = beta; q.dW = dW; q.ld_dw = ld_dw; q.alpha2 = alpha_dw;
+  q.accumulate = accumulate; q.ox = (int)H; q.oy = (int)dvt_cdiv(d, 64); q.oz = (int)dvt_cdiv(dh, 16);
+  q.S = (int)S; q.H = (int)H; q.dh = (int)dh; q.d = (int)d;
+  const unsigned grid = (unsigned)(q.gx * q.gy * q.gz + q.ox * q.oy * q.oz);
+  DVT_DISPATCH_16BIT(dtype, E, hipLaunchKernelGGL((heads_pair_kernel<E, 0>), dim3(grid), dim3(256),
+                                                  16 * (size_t)((dh + 63) / 64 * 64) * sizeof(float), (hipStream_t)stream, q));
+  DVT_LAUNCH_CHECK("dvt_heads_expand_outer");
+  return DVT_OK;
+}
+
+int dvt_heads_contract_outer(const float* v, const float* gamma, const void* W, int64_t ldw, void* out, int64_t ld_out,
+                             float alpha_out, const void* a, int64_t lda, float* dW, int64_t ld_dw, float alpha_dw,
+                             int accumulate, int64_t S, int64_t H, int64_t dh, int64_t d, int dtype, dvt_stream_t stream) {
+  int rc = heads_check("dvt_heads_contract_outer", v, W, out, S, H, dh, d, dtype);
+  if (rc) return rc;
+  DVT_REQUIRE(a && dW, "dvt_heads_contract_outer: null pointer");
+  DVT_REQUIRE(d % 8 == 0 && ldw % 8 == 0 && dvt_aligned16(W) && dvt_aligned16(v) && dvt_aligned16(gamma),
+              "dvt_heads_contract_outer: alignment (see dvt_heads_contract / dvt_heads_outer)");
+  if (d > 512) DVT_UNSUPPORTED("dvt_heads_contract_outer: d = %lld > 512", (long long)d);
+  HeadsPair q{};
+  q.vin = v; q.gamma1 = gamma; q.beta1 = nullptr; q.W = W; q.ldw = ldw; q.out = out; q.ld_out = ld_out; q.alpha1 = alpha_out;
+  q.gx = (int)dvt_cdiv(S, 8); q.gy = (int)H; q.gz = 1;
+  q.a = a; q.lda = lda; q.v = v; q.gamma2 = gamma; q.beta2 = nullptr; q.dW = dW; q.ld_dw = ld_dw; q.alpha2 = alpha_dw;
+  q.accumulate = accumulate; q.ox = (int)H; q.oy = (int)dvt_cdiv(d, 64); q.oz = (int)dvt_cdiv(dh, 16);
+  q.S = (int)S; q.H = (int)H; q.dh = (int)dh; q.d = (int)d;
+  const unsigned grid = (unsigned)(q.gx * q.gy * q.gz + q.ox * q.oy * q.oz);
+  DVT_DISPATCH_16BIT(dtype, E, hipLaunchKernelGGL((heads_pair_kernel<E, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q));
+  DVT_LAUNCH_CHECK("dvt_heads_contract_outer");
   return DVT_OK;
 }
 

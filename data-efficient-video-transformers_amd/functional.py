@@ -658,16 +658,16 @@ class _AttnBlockCls(torch.autograd.Function):
             buf, acc = torch.empty((3 * inner, d), dtype=torch.float32, device=x2.device), False
             dwqkv = buf
         w_q, w_k, w_v = wqkv[:inner], wqkv[inner:2 * inner], wqkv[2 * inner:]
-        dM = ops.heads_expand(do, w_v, heads, 1.0)                       # dm_h = Wv_h^T do_h
-        ops.heads_outer(do, A, buf[2 * inner:], 1.0, g, bb, accumulate=acc)          # dWv_h = do_h (x) m_h
+        # dm_h = Wv_h^T do_h and dWv_h = do_h (x) m_h: independent, one launch
+        dM = ops.heads_expand_outer(do, w_v, heads, A, buf[2 * inner:], gamma=g, beta=bb, accumulate=acc)
         if s_g is not None and s_b is not None:
             dx2, G, _, _ = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, P, mean, rstd, dM, dg=s_g.buf.view(-1),
                                             db=s_b.buf.view(-1), accumulate=not s_g.fresh, accumulate_beta=not s_b.fresh)
             dg, db = s_g.buf.view(-1), s_b.buf.view(-1)
         else:
             dx2, G, dg, db = ops.attn_cls_bwd(x2.view(S, N, d), g, bb, eps, R, A, lse, P, mean, rstd, dM)
-        dq = ops.heads_contract(G, w_k, scale, g)                        # dq_h = scale Wk_h (gamma G_h)
-        ops.heads_outer(q, G, buf[inner:2 * inner], scale, g, accumulate=acc)        # dWk_h = scale q_h (x) dr_h
+        # dq_h = scale Wk_h (gamma G_h) and dWk_h = scale q_h (x) (gamma G_h): independent, one launch
+        dq = ops.heads_contract_outer(G, g, w_k, q, buf[inner:2 * inner], alpha_out=scale, alpha_dw=scale, accumulate=acc)
         _, dxn0 = ops.linear_backward(dq, xn0, w_q, out=buf[:inner], accumulate=acc)   # dWq; dxn0 [S, d]: the query path into LN(x)[:, 0]
         if s_qkv is not None:
             s_qkv.mark_written()

@@ -701,6 +701,39 @@ def heads_outer(a: Tensor, v: Tensor, out: Tensor, alpha: float = 1.0, gamma: Op
     return out
 
 
+def heads_expand_outer(a: Tensor, W: Tensor, H: int, v: Tensor, dW: Tensor, *, alpha_out: float = 1.0, alpha_dw: float = 1.0,
+                       gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """One launch: ``heads_expand(a, W, H, alpha_out)`` (returned) and ``heads_outer(a, v, dW, alpha_dw, gamma, beta)``."""
+    _need_cuda(a, W, v, dW, gamma, beta)
+    S, inner = a.shape
+    d = W.shape[1]
+    assert W.shape[0] == inner and a.stride(1) == 1 and W.stride(1) == 1 and a.dtype == W.dtype and inner % H == 0
+    assert v.shape == (S, H, d) and v.is_contiguous() and v.dtype == torch.float32
+    assert dW.shape == (inner, d) and dW.stride(1) == 1 and dW.dtype == torch.float32
+    out = torch.empty((S, H, d), dtype=torch.float32, device=a.device)
+    L.check(L.load().dvt_heads_expand_outer(a.data_ptr(), a.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), alpha_out,
+                                            v.data_ptr(), _p(gamma), _p(beta), dW.data_ptr(), dW.stride(0), alpha_dw,
+                                            int(accumulate), S, H, inner // H, d, dt(a), _stream()), "dvt_heads_expand_outer")
+    return out
+
+
+def heads_contract_outer(v: Tensor, gamma: Tensor, W: Tensor, a: Tensor, dW: Tensor, *, alpha_out: float = 1.0,
+                         alpha_dw: float = 1.0, accumulate: bool = False) -> Tensor:
+    """One launch: ``heads_contract(v, W, alpha_out, gamma)`` (returned) and ``heads_outer(a, v, dW, alpha_dw, gamma)``."""
+    _need_cuda(v, gamma, W, a, dW)
+    S, H, d = v.shape
+    inner = W.shape[0]
+    assert W.shape[1] == d and W.stride(1) == 1 and v.is_contiguous() and v.dtype == torch.float32 and inner % H == 0
+    assert a.shape == (S, inner) and a.stride(1) == 1 and a.dtype == W.dtype
+    assert dW.shape == (inner, d) and dW.stride(1) == 1 and dW.dtype == torch.float32
+    out = torch.empty((S, inner), dtype=W.dtype, device=v.device)
+    L.check(L.load().dvt_heads_contract_outer(v.data_ptr(), gamma.data_ptr(), W.data_ptr(), W.stride(0), out.data_ptr(), inner,
+                                              alpha_out, a.data_ptr(), a.stride(0), dW.data_ptr(), dW.stride(0), alpha_dw,
+                                              int(accumulate), S, H, inner // H, d, dt(W), _stream()),
+            "dvt_heads_contract_outer")
+    return out
+
+
 # ------------------------------------------------------------------ losses / optimizer
 def bce_logits_fwd(z: Tensor, target: Tensor) -> Tensor:
     _need_cuda(z, target)

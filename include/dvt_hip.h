@@ -372,6 +372,15 @@ int dvt_heads_contract(const float* in, const float* gamma, const float* beta, c
 int dvt_heads_outer(const void* a, int64_t lda, const float* b, const float* gamma, const float* beta, float* dW,
                     int64_t ldw, int64_t S, int64_t H, int64_t dh, int64_t d, float alpha, int accumulate, int dtype,
                     dvt_stream_t stream);
+/* The backward runs them in two independent pairs, one launch each (workgroups of the first member in front):
+ *   expand_outer:    out = alpha_out expand(in, W);          dW (+)= alpha_dw outer(in, gamma v + beta)     (dm and dWv from do)
+ *   contract_outer:  out = alpha_out contract(gamma v, W);   dW (+)= alpha_dw outer(a, gamma v)             (dq and dWk from G) */
+int dvt_heads_expand_outer(const void* in, int64_t ld_in, const void* W, int64_t ldw, float* out, float alpha_out,
+                           const float* v, const float* gamma, const float* beta, float* dW, int64_t ld_dw, float alpha_dw,
+                           int accumulate, int64_t S, int64_t H, int64_t dh, int64_t d, int dtype, dvt_stream_t stream);
+int dvt_heads_contract_outer(const float* v, const float* gamma, const void* W, int64_t ldw, void* out, int64_t ld_out,
+                             float alpha_out, const void* a, int64_t lda, float* dW, int64_t ld_dw, float alpha_dw,
+                             int accumulate, int64_t S, int64_t H, int64_t dh, int64_t d, int dtype, dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- on-device input stage
  * transforms.Compose([Resize(resize), CenterCrop(crop), ToTensor(), Normalize(mean, std)]) of the reference's loader

@@ -733,6 +733,15 @@ def test_heads_products(dvt, device, dtype, S, H, dh, d):
     assert (buf[:inner] == 0.5).all() and (buf[2 * inner:] == 0.5).all()
     dvt.ops.heads_outer(a_d, v.cuda(), buf[inner:2 * inner], 1.0, gam.cuda())
     assert rel_l2(buf[inner:2 * inner], torch.einsum("she,shd->hed", a, v.double() * gam.double()).reshape(inner, d)) < 5e-6
+    # the pairs the backward launches together: bit-identical to their members
+    b1, b2 = torch.full((3 * inner, d), 0.5, device="cuda"), torch.full((3 * inner, d), 0.5, device="cuda")
+    e1 = dvt.ops.heads_expand_outer(a_d, W_d, H, v.cuda(), b1[inner:2 * inner], alpha_out=0.37, alpha_dw=0.9, gamma=gam.cuda(),
+                                    beta=bet.cuda(), accumulate=True)
+    dvt.ops.heads_outer(a_d, v.cuda(), b2[inner:2 * inner], 0.9, gam.cuda(), bet.cuda(), accumulate=True)
+    assert torch.equal(e1, dvt.ops.heads_expand(a_d, W_d, H, 0.37)) and torch.equal(b1, b2)
+    c1 = dvt.ops.heads_contract_outer(v.cuda(), gam.cuda(), W_d, a_d, b1[:inner], alpha_out=1.7, alpha_dw=0.3)
+    dvt.ops.heads_outer(a_d, v.cuda(), b2[:inner], 0.3, gam.cuda())
+    assert torch.equal(c1, dvt.ops.heads_contract(v.cuda(), W_d, 1.7, gam.cuda())) and torch.equal(b1, b2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
