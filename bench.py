@@ -48,6 +48,14 @@ def algorithmic_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch
     return fwd, 3 * fwd
 
 
+def cls_fold_flag(B, T, n_tok, d, heads, dh, cdt):
+    """Whether the space stack's last layer takes the folded single-query form: the predicate functional._AttnBlockCls uses
+    (rows >= CLS_FOLD_MIN_ROWS, 16-bit element type, shapes the folded kernels and their head-wise helpers accept)."""
+    from dvt_amd import functional as F
+    probe = torch.empty((B * T, n_tok, d), dtype=cdt, device="cuda")
+    return bool(F.cls_fold_taken(probe, heads, dh))
+
+
 def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, pool_cls=True, fold_kv=True):
     """FLOPs the build actually launches: the reference reads only row 0 of the space transformer's output
     (vit.py:119-120) and, under pool == 'cls', of the temporal one (:126), so in the last layer of each stack the query /
@@ -68,7 +76,7 @@ def executed_flops_per_clip(T, n_tok, d, heads, dh, depth, patch_dim, n_patch, p
         return kv + qp + 2 * qk + proj + ff
 
     fwd = 2 * T * n_patch * patch_dim * d
-    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1, folded=fold_kv and n_tok <= 400 and d <= 512 and heads <= 8)
+    fwd += (depth - 1) * layer(n_tok, T, n_tok) + layer(n_tok, T, 1, folded=fold_kv)
     fwd += (depth - 1) * layer(T + 1, 1, T + 1) + layer(T + 1, 1, 1 if pool_cls else T + 1)
     return fwd, 3 * fwd
 
@@ -422,6 +430,34 @@ def rebuild_communicator(comm):
 
 _LIVE = {"comm": None}      # the communicator main() destroys at exit (a rebuild replaces it)
 
+# Distributed watchdog: a collective that some rank never joins hangs every rank silently.  The limit counts time since the
+# last PROGRESS point (progress() re-arms it: after the rendezvous, each warm-up / timed block, each workload), not since
+# the start, so a long legitimate run (large --steps, the secondaries) is not killed; it is cancelled before the final print.
+_WATCHDOG = {"limit": 0.0, "rank": 0, "timer": None, "where": ""}
+
+
+def progress(where=""):
+    import threading
+    if _WATCHDOG["limit"] <= 0:
+        return
+    if _WATCHDOG["timer"] is not None:
+        _WATCHDOG["timer"].cancel()
+    _WATCHDOG["where"] = where
+    if where is None:                  # cancel only
+        _WATCHDOG["timer"] = None
+        return
+
+    def _give_up():
+        sys.stderr.write(f"[bench] rank {_WATCHDOG['rank']}: no progress for {_WATCHDOG['limit']:.0f} s after "
+                         f"'{_WATCHDOG['where']}' (a collective is stuck?) -- aborting\n")
+        sys.stderr.flush()
+        os._exit(124)
+
+    t = threading.Timer(_WATCHDOG["limit"], _give_up)
+    t.daemon = True
+    t.start()
+    _WATCHDOG["timer"] = t
+
 
 def timed_steps(run, steps, barrier):
     torch.cuda.synchronize()
@@ -495,9 +531,12 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
                 replay()
                 return static_loss
 
+    progress(f"{workload}: capture")
     for _ in range(warmup):
         run()
+    progress(f"{workload}: warm-up")
     elapsed, per_step, loss = timed_steps(run, steps, barrier)
+    progress(f"{workload}: timed steps")
     if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -513,6 +552,19 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             step()
         e_elapsed, _, _ = timed_steps(step, k, barrier)
         extra["eager_ms_per_step"] = round(e_elapsed / k * 1e3, 3)
+        progress(f"{workload}: eager steps")
+        if comm is not None:
+            # One traced eager step: when does each bucket's all-reduce start and end relative to the END of backward
+            # (negative start = launched while backward was still running, i.e. overlapped)?  Side-stream timing events.
+            comm.trace, comm.marks = [], {}
+            step()
+            torch.cuda.synchronize()
+            end_bwd = comm.marks.get("backward_end")
+            if end_bwd is not None:
+                extra["bucket_timeline"] = [{"wire_bytes": int(nb), "start_ms_after_backward_end": round(end_bwd.elapsed_time(e0), 3),
+                                             "end_ms_after_backward_end": round(end_bwd.elapsed_time(e1), 3),
+                                             "ms": round(e0.elapsed_time(e1), 3)} for nb, e0, e1 in comm.trace]
+            comm.trace, comm.marks = None, {}
         extra["graph_ms_per_step"] = round(elapsed / steps * 1e3, 3)
         if comm is not None and launch.startswith("hipGraph replay"):
             # exposed (un-overlapped) exchange time: the captured step with and without its collectives
@@ -614,6 +666,11 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
         fwd, tot = algorithmic_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
                                               3 * cfg["patch"] ** 2, n_tok - 1)
         is_ft = workload == "frametransformer"
+        exec_flops = 0.0
+        if workload in ("vivit", "longclip"):
+            fold = cls_fold_flag(B, cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cdt)
+            exec_flops = executed_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
+                                                 3 * cfg["patch"] ** 2, n_tok - 1, fold_kv=fold)[1]
         out = {
             "metric": f"clips/sec fwd+bwd, B=8 T=32 3x224x224 {args.dtype}" if workload == "vivit" else
                       ("samples/sec fwd+bwd [frametransformer workload], B=2 x 14 chunks x 12 x 3x112x112" if is_ft else
@@ -631,10 +688,10 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
             if workload in ("vivit", "longclip") else None,
             # model_tflops prices the step at the REFERENCE's algorithmic FLOPs (dense last layers); executed_tflops at
             # what is launched (last layer of each stack on the CLS rows only)
-            "executed_tflops": round(executed_flops_per_clip(cfg["T"], n_tok, cfg["d"], cfg["heads"], cfg["dh"], cfg["depth"],
-                                                             3 * cfg["patch"] ** 2, n_tok - 1,
-                                                             fold_kv=not getattr(args, "no_cls_fold", False))[1]
-                                     * B * world / (elapsed / steps) / 1e12, 1)
+            "executed_tflops": round(exec_flops * B * world / (elapsed / steps) / 1e12, 1)
+            if workload in ("vivit", "longclip") else None,
+            # the hardware fraction: launched FLOPs per second per GPU against the dense MFMA peak
+            "executed_mfma_frac": round(exec_flops * B / (elapsed / steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
             if workload in ("vivit", "longclip") else None,
             "final_loss": round(final_loss, 5),
             "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3)},
@@ -781,17 +838,8 @@ def main():
     if use_dist:
         # A collective that some rank never joins hangs every rank silently: a watchdog turns that into a loud exit (the
         # launcher / torchrun then ends the other ranks) instead of a run that never returns its line.
-        import threading
-        limit = float(os.environ.get("DVT_BENCH_TIMEOUT_S", "900"))
-
-        def _give_up():
-            sys.stderr.write(f"[bench] rank {rank}: no result after {limit:.0f} s (a collective is stuck?) -- aborting\n")
-            sys.stderr.flush()
-            os._exit(124)
-
-        wd = threading.Timer(limit, _give_up)
-        wd.daemon = True
-        wd.start()
+        _WATCHDOG.update(limit=float(os.environ.get("DVT_BENCH_TIMEOUT_S", "900")), rank=rank)
+        progress("process group")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -809,10 +857,16 @@ def main():
         from dvt_amd.dp import Communicator
         try:
             comm = Communicator.from_torch_distributed()
-        except Exception as e:      # the exchange then goes through torch.distributed's own RCCL group (launched eagerly)
-            if rank == 0:
-                print(f"[bench] dvt_comm_init failed ({type(e).__name__}: {e}); falling back to torch.distributed", file=sys.stderr)
-            comm = None
+        except Exception as e:
+            # No fallback: a run that exchanged its gradients through torch.distributed's eager collectives would measure a
+            # different design under the same metric name.  Fail loudly; the launcher ends the other ranks.
+            sys.stderr.write(f"[bench] rank {rank}: dvt_comm_init failed under --backend nccl ({type(e).__name__}: {e}); "
+                             "refusing to fall back to torch.distributed collectives\n")
+            sys.stderr.flush()
+            try:
+                dist.destroy_process_group()
+            finally:
+                raise SystemExit(3)
     _LIVE["comm"] = comm
 
     out = run_workload(args, args.workload, rank, world, use_dist, comm, steps=args.steps, warmup=args.warmup,
@@ -833,6 +887,7 @@ def main():
                 sec[wl] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if out is not None:
             out["secondary"] = sec
+    progress(None)                      # done: nothing collective left that could hang
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":
             out["cpu_baseline"] = cpu_baseline(dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64))

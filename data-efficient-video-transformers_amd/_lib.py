@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvt_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
+ABI_VERSION = 2            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_DGELU, EPI_DRELU = range(6)
 
 c_i64 = C.c_int64
@@ -215,8 +216,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.dvt_version() != 1:
-        raise RuntimeError(f"libdvt_hip.so ABI version {lib.dvt_version()} != 1; rebuild")
+    if lib.dvt_version() != ABI_VERSION:
+        raise RuntimeError(f"libdvt_hip.so ABI version {lib.dvt_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

@@ -62,16 +62,6 @@ struct AttnParams {
   uint64_t rng_off;
 };
 
-#ifdef DVT_ATTN_TIMING
-// dev build only (tools/attn_timing.sh): per-workgroup s_memtime stamps of the forward kernel, 8 slots per workgroup
-__device__ long long* g_attn_tb = nullptr;
-#define DVT_ASTAMP(i) do { if (threadIdx.x == 0 && g_attn_tb) g_attn_tb[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DVT_ASTAMP_ID() do { if (threadIdx.x == 0 && g_attn_tb) { g_attn_tb[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
-                                                                  g_attn_tb[(int64_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
-#else
-#define DVT_ASTAMP(i)
-#define DVT_ASTAMP_ID()
-#endif
 
 // dropout multiplier of probability (b, h, i, j): 0 or 1 / (1 - p); 1 when dropout is off
 __device__ __forceinline__ float attn_drop(const AttnParams& p, int b, int h, int i, int j) {
@@ -667,12 +657,9 @@ __global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel
     for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const V8*>(qb + (int64_t)qrow * p.q_sl + kk * 32 + g * 8);
   };
   V8 qf[2];
-  DVT_ASTAMP(0);
-  DVT_ASTAMP_ID();
   load_q(wid, qf);                                   // in flight while K / V are staged
   stage_images<E>(ks, kb, p.k_sl, vs, vb, p.v_sl, p.Lk, NKP * 32);
   __syncthreads();
-  DVT_ASTAMP(1);
 
   const float c2 = p.scale * kLog2e;
   char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
@@ -744,19 +731,11 @@ __global__ __launch_bounds__(NKP > 7 ? 768 : 1024) void attn_fwd_mfma_res_kernel
     const int qi = qt * 16 + li;
     consume(qf[0]);
     consume(qf[1]);
-    if (qt == wid) DVT_ASTAMP(2);
     store_tile<E>(patch, ob, p.o_sl, qt * 16, p.Lq, o, inv, lane);
     if (qi < p.Lq && g == 0) lse[qi] = (mn + __builtin_amdgcn_logf(l)) * kLn2;
-    if (qt == wid) DVT_ASTAMP(3);
   }
-  DVT_ASTAMP(4);
 }
 
-#ifdef DVT_ATTN_TIMING
-extern "C" int dvt_debug_attn_timing_buffer(void* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tb), &buf, sizeof(buf));
-}
-#endif
 
 // ---------------------------------------------------------------- backward: dq
 // Query on the lane.  dQ^T[d][q] = scale * sum_key K[key][d] * (P (dP - delta))^T[key][q].
@@ -907,14 +886,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
       vf[kk] = *reinterpret_cast<const V8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
     }
   };
-#ifdef DVT_ATTN_TIMING
-  long long* tbuf = reinterpret_cast<long long*>(p.delta + (((int64_t)p.B * p.H * p.Lq + 1) & ~1ll)) + (int64_t)blockIdx.x * 8;
-  if (threadIdx.x == 0) {
-    tbuf[0] = __builtin_amdgcn_s_memtime();
-    tbuf[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-    tbuf[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-  }
-#endif
   V8 kf[2], vf[2];
   load_rows(wid, kf, vf);                            // in flight while Q / dO are staged
   // per-row statistics: lse in log2 units and delta = rowsum(dO * O) (written by the dq kernel); 0 for padding rows.
@@ -932,16 +903,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
   }
   __syncthreads();
 
-#ifdef DVT_ATTN_TIMING
-  if (threadIdx.x == 0) tbuf[1] = __builtin_amdgcn_s_memtime();
-#endif
   const float c2 = p.scale * kLog2e;
   char* patch = p.patch_off >= 0 ? smem + p.patch_off + wid * 2048 : nullptr;
   for (int kt = wid; kt < nkt; kt += W) {
     asm volatile("" ::: "memory");                   // Q / dO fragments are loop-invariant: keep their LDS reads in the loop
-#ifdef DVT_ATTN_TIMING
-    if (threadIdx.x == 0) tbuf[kt == wid ? 2 : 4] = __builtin_amdgcn_s_memtime();
-#endif
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -998,9 +963,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
     if (kt + W < nkt) load_rows(kt + W, kf, vf);
     store_tile<E>(patch, dkb, p.k_sl, kt * 16, p.Lk, dk, p.scale, lane);
     store_tile<E>(patch, dvb, p.v_sl, kt * 16, p.Lk, dv, 1.0f, lane);
-#ifdef DVT_ATTN_TIMING
-    if (threadIdx.x == 0) tbuf[kt == wid ? 3 : 5] = __builtin_amdgcn_s_memtime();
-#endif
   }
 }
 
@@ -1095,9 +1057,6 @@ extern "C" {
 
 size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* d) {
   if (!d) return 0;
-#ifdef DVT_ATTN_TIMING
-  return ((size_t)d->B * (size_t)d->H * (size_t)d->Lq + 2) * sizeof(float) + (size_t)d->B * d->H * 64 + 256 * 128 * 8;
-#endif
   return (size_t)d->B * (size_t)d->H * (size_t)d->Lq * sizeof(float);
 }
 

@@ -875,8 +875,11 @@ int dvt_heads_expand_outer(const void* in, int64_t ld_in, const void* W, int64_t
   if (rc) return rc;
   DVT_REQUIRE(v && dW, "dvt_heads_expand_outer: null pointer");
   DVT_REQUIRE(d % 4 == 0 && ldw % 2 == 0 && dvt_aligned16(v) && (reinterpret_cast<uintptr_t>(W) & 3u) == 0 &&
-                  (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && dh <= 512,
+                  (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
               "dvt_heads_expand_outer: alignment (see dvt_heads_expand / dvt_heads_outer)");
+  // 40 KiB of static LDS (the outer-product tiles) + 16 * ceil64(dh) floats of dynamic LDS must stay inside the 64 KiB a
+  // kernel gets without the max-dynamic-LDS attribute
+  if (dh > 384) DVT_UNSUPPORTED("dvt_heads_expand_outer: dh = %lld > 384 (LDS budget of the paired launch)", (long long)dh);
   HeadsPair q{};
   q.in16 = in; q.ld_in = ld_in; q.W = W; q.ldw = ldw; q.out = out; q.alpha1 = alpha_out;
   q.gx = (int)dvt_cdiv(S, 16); q.gy = (int)H; q.gz = (int)dvt_cdiv(d, 128);

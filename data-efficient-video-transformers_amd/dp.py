@@ -65,6 +65,11 @@ class Communicator:
         self._h = _C.c_void_p()
         L.check(L.load().dvt_comm_init(_C.byref(self._h), unique_id, world, rank), "dvt_comm_init")
         self.stream = torch.cuda.Stream()
+        # Diagnostic trace (bench.py, eager launches only -- timing events cannot be captured in a hipGraph): when a list,
+        # every all_reduce_async appends (bytes on the wire, start event, end event) recorded on the side stream, and
+        # ``marks`` holds named timing events of the compute stream (FlatParameters records "backward_end").
+        self.trace = None
+        self.marks = {}
 
     @staticmethod
     def unique_id() -> bytes:
@@ -99,6 +104,9 @@ class Communicator:
         self._after_current()
         st = self.stream.cuda_stream
         n = t.numel()
+        if self.trace is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
         if via is None:
             L.check(lib.dvt_comm_allreduce(self._h, t.data_ptr(), n, ops._DT[t.dtype], st), "dvt_comm_allreduce")
         else:
@@ -106,6 +114,10 @@ class Communicator:
             L.check(lib.dvt_cast(t.data_ptr(), ops._DT[t.dtype], via.data_ptr(), ops._DT[via.dtype], n, st), "dvt_cast")
             L.check(lib.dvt_comm_allreduce(self._h, via.data_ptr(), n, ops._DT[via.dtype], st), "dvt_comm_allreduce")
             L.check(lib.dvt_cast(via.data_ptr(), ops._DT[via.dtype], t.data_ptr(), ops._DT[t.dtype], n, st), "dvt_cast")
+        if self.trace is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.stream)
+            self.trace.append((n * (t if via is None else via).element_size(), e0, e1))
         return self._done()
 
     def broadcast(self, t: torch.Tensor, root: int = 0) -> None:
@@ -316,6 +328,10 @@ class FlatParameters:
         """Call after loss.backward(): zero gradients nobody wrote (and exclude them from the optimizer step), flush
         remaining buckets, wait for the collectives (on the compute stream, not the host), fold in late writes.
         ``exchange=False`` (with ``defer_exchange``): local part only; ``exchange_all()`` follows."""
+        if self.comm is not None and self.comm.trace is not None:      # end of backward on the compute stream
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self.comm.marks["backward_end"] = ev
         unwritten = []
         for s in self.sinks:
             if s._fresh:

@@ -617,7 +617,7 @@ class _AttnBlockCls(torch.autograd.Function):
         ctx.cfg = (S, N, d, heads, dh, inner, b_out is not None, eps)
         ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
         x3 = x2.view(S, N, d)
-        ctx.folded = S * N >= CLS_FOLD_MIN_ROWS and ops.attn_cls_supported(x3, heads)
+        ctx.folded = cls_fold_taken(x3, heads, dh)
         if ctx.folded:
             # K / V projections folded into the query (csrc/attention_cls.hip): LN(x), K and V of the rows 1 .. N-1 never exist
             xn0, mean0, rstd0 = ops.layernorm_fwd(x2, g, bb, eps, rows=(S, 1, N * d, 0))          # [S, d]: row 0 only
@@ -721,6 +721,12 @@ class _AttnBlockCls(torch.autograd.Function):
 # Sequences x rows from which the last layer's single-query attention runs with the K / V projections folded into the query
 # (csrc/attention_cls.hip); below it (the 33-token temporal stack) the unfolded form has fewer launches.
 CLS_FOLD_MIN_ROWS = 4096
+
+
+def cls_fold_taken(x3: Tensor, heads: int, dh: int) -> bool:
+    """The predicate ``_AttnBlockCls`` uses to take the folded form (bench.py prices ``executed_tflops`` with it)."""
+    S, N, _ = x3.shape
+    return S * N >= CLS_FOLD_MIN_ROWS and ops.attn_cls_supported(x3, heads, dh)
 
 
 def attn_block_cls(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, eps=1e-5):

@@ -86,6 +86,23 @@ def workspace(nbytes: int, device, slot: str = "main") -> Optional[Tensor]:
     return buf
 
 
+_live_deferred = {}      # (device, stream) -> the SplitKPending whose slabs occupy the "deferred" scratch slot
+
+
+def _deferred_workspace(nbytes: int, device, pending) -> Optional[Tensor]:
+    """Scratch slot for the slabs of a deferred split-K reduce.  One slot per (device, stream): a second deferral while an
+    earlier pending reduce is still outstanding would overwrite that one's slabs -- refuse it instead of producing a
+    silently wrong weight gradient (callers resolve a pending reduce -- ``carry=`` / ``splitk_reduce_pending`` -- before
+    they defer the next)."""
+    key = (str(device), _stream())
+    prev = _live_deferred.get(key)
+    if prev is not None and prev.valid:
+        raise RuntimeError("a deferred split-K reduce is still pending on this stream: carry it (carry=) or call "
+                           "ops.splitk_reduce_pending before deferring another one")
+    _live_deferred[key] = pending
+    return workspace(nbytes, device, slot="deferred")
+
+
 # ------------------------------------------------------------------ elementwise
 def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
     _need_cuda(src)
@@ -430,7 +447,8 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
         d.carry = C.pointer(carry)
     lib = L.load()
     # the slabs of a deferred reduce must survive the next call: they get a scratch slot of their own
-    ws = workspace(lib.dvt_gemm_workspace_bytes(C.byref(d)), A.device, slot="deferred" if defer_reduce else "main")
+    nws = lib.dvt_gemm_workspace_bytes(C.byref(d))
+    ws = _deferred_workspace(nws, A.device, pending) if defer_reduce else workspace(nws, A.device)
     d.workspace = _p(ws)
     if defer_reduce:
         pending._keep += (ws,)
@@ -603,9 +621,13 @@ def _attn_cls_desc(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, H: int) -
     return q
 
 
-def attn_cls_supported(x: Tensor, H: int) -> bool:
-    """Shape / dtype test of the folded single-query kernels (no launch)."""
+def attn_cls_supported(x: Tensor, H: int, dh: Optional[int] = None) -> bool:
+    """Shape / dtype test of the folded single-query path (no launch): the row-pass kernels (dvt_attn_cls_supported) and,
+    when ``dh`` is given, the head-wise products on either side of them (dvt_heads_expand_outer: dh <= 384;
+    dvt_heads_contract*: d % 8 == 0, d <= 512) -- so that a shape accepted here cannot fail later inside backward."""
     if not x.is_cuda or x.dim() != 3 or x.stride(2) != 1:
+        return False
+    if dh is not None and not (0 < dh <= 384 and x.shape[2] % 8 == 0 and x.shape[2] <= 512):
         return False
     q = L.AttnClsDesc()
     q.xs0, q.xs1 = x.stride(0), x.stride(1)
@@ -1183,12 +1205,11 @@ def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int
     out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
     d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad, trim_w)
     lib = L.load()
-    ws = workspace(lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d)), x.device,
-                   slot="deferred" if defer_reduce else "main")
+    pending = L.SplitKPending() if defer_reduce else None
+    nws = lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d))
+    ws = _deferred_workspace(nws, x.device, pending) if defer_reduce else workspace(nws, x.device)
     d.workspace = _p(ws)
-    pending = None
     if defer_reduce:
-        pending = L.SplitKPending()
         pending._keep = (out, ws)
         d.defer_reduce = 1
         d.pending = C.addressof(pending)

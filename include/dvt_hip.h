@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define DVT_ABI_VERSION 1
+/* Bumped whenever a descriptor struct changes layout (fields are only ever appended) or an entry point changes
+ * signature.  v2: dvt_gemm_desc / dvt_conv_desc gained defer_reduce / pending / carry, dvt_splitk_pending and the
+ * head-wise / folded-attention descriptors were added.  Callers MUST zero-initialise every descriptor (memset / = {0})
+ * before filling it: a zero in a field this header adds later means "feature off". */
+#define DVT_ABI_VERSION 2
 
 typedef void* dvt_stream_t; /* hipStream_t */
 

@@ -465,6 +465,29 @@ def test_deferred_split_k_reduce_rides_in_the_data_gradient_launch(dvt, device, 
     assert torch.equal(dw4, dw_ref) and rel_l2(small, dx_ref[:264]) < 1e-2      # (another kernel: another summation order)
 
 
+def test_second_deferred_reduce_while_one_is_pending_is_refused(dvt, device):
+    """The slabs of a deferred split-K reduce sit in ONE scratch slot per stream: deferring a second reduce
+    while the first is still pending would overwrite them, so it must raise instead of yielding a wrong dW; once the first
+    is resolved (carried or flushed) deferring works again."""
+    g = torch.Generator().manual_seed(34)
+    M, N, K = 50432, 512, 512
+    dy_d, _ = _rnd((M, N), torch.bfloat16, g)
+    x_d, _ = _rnd((M, K), torch.bfloat16, g)
+    ops = dvt.ops
+    ref = ops.linear_wgrad(dy_d, x_d)
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    _, pend = ops.linear_wgrad(dy_d, x_d, out=dw, defer_reduce=True)
+    assert pend.valid                                           # this shape does split K
+    with pytest.raises(RuntimeError, match="still pending"):
+        ops.linear_wgrad(dy_d, x_d, defer_reduce=True)
+    ops.splitk_reduce_pending(pend)                             # the first one's slabs were not touched by the refusal
+    assert torch.equal(dw, ref)
+    dw2 = torch.full((N, K), float("nan"), device="cuda")
+    _, pend2 = ops.linear_wgrad(dy_d, x_d, out=dw2, defer_reduce=True)
+    ops.splitk_reduce_pending(pend2)
+    assert torch.equal(dw2, ref)
+
+
 def test_wgrad_deep_k_fused_bias_with_exact_workspace(dvt, device):
     """Reference-default ViViT (dim 192) at batch 32: the to_out weight gradient is M = N = 192 with K = 100,864 token
     rows -> one 256x256 tile, 197 K slices, bias gradient fused (one scratch row of M floats per slice).  A C-ABI caller
