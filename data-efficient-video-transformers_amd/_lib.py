@@ -137,8 +137,8 @@ SIGNATURES = {
     "dvt_bn_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
     "dvt_bn_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_int, c_p]),
     "dvt_bn_eval_invstd": (c_int, [c_p, c_p, c_int, c_f, c_p]),
-    "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
-    "dvt_bn_bwd": (c_int, [c_p] * 12 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
+    "dvt_bn_bwd": (c_int, [c_p] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_bn_relu_maxpool_fwd": (c_int, [c_p] * 7 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_bn_bwd_pooled": (c_int, [c_p] * 11 + [c_i64] + [c_int] * 7 + [c_p]),

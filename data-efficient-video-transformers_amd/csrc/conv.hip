@@ -218,6 +218,46 @@ __global__ void weight_pack_dgrad_kernel(const float* __restrict__ w, D* __restr
   }
 }
 
+// ---- row-streaming BatchNorm kernels.  A thread owns ONE 8-channel group for its whole life (cg = thread % (C/8)) and walks
+// the rows lane, lane + lanes, ...: the per-channel constants are loaded and folded ONCE (reloading six parameter vectors
+// per 16 bytes of payload kept the CU's L1 / address pipeline four times busier with parameters than with data), and
+// kBnU rows are requested before the first is consumed.
+constexpr int kBnU = 4;
+
+struct RowMap { int cg; int64_t row, lanes; };
+__device__ __forceinline__ RowMap bn_row_map(int cv) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+  RowMap m;
+  m.lanes = nth / cv;                    // whole rows per sweep; the last nth % cv threads idle
+  m.cg = (int)(gtid % cv);
+  m.row = gtid / cv;
+  return m;
+}
+
+// The affine part y = (x - mean) * invstd * gamma + beta of 8 channels.  16-bit maps: folded to one fma (x * s + t); the fp32
+// parity mode keeps the reference's operation order.  EVERY kernel that decides a ReLU mask (forward, the pooled stem
+// forward, the backward passes that recompute the mask from z) goes through apply(): one formula, identical decisions.
+template <typename T>
+struct BnAffine {
+  float mu[8], is[8], g[8], b[8], s[8], t[8];
+  __device__ __forceinline__ void init(const float* mean, const float* invstd, const float* gamma, const float* beta, int c) {
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g);
+    if (beta) load8<float>(beta + c, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (!beta) b[k] = 0.f;
+      s[k] = is[k] * g[k];
+      t[k] = fmaf(-mu[k], s[k], b[k]);
+    }
+  }
+  __device__ __forceinline__ float apply(float x, int k) const {
+    if (sizeof(T) == 4) return fmaf((x - mu[k]) * is[k], g[k], b[k]);
+    return fmaf(x, s[k], t[k]);
+  }
+  __device__ __forceinline__ float xhat(float x, int k) const { return (x - mu[k]) * is[k]; }
+};
+
 // ------------------------------------------------------------------ BatchNorm (columns of [rows, C])
 // partial[b][0][c] = sum x, partial[b][1][c] = sum x^2 over the block's rows  (MODE 0)
 // partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat                 (MODE 1), dz = dy * (y > 0 if relu)
@@ -234,43 +274,60 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
                                                           float* __restrict__ partial,
                                                           const float* __restrict__ gamma = nullptr,
                                                           const float* __restrict__ beta = nullptr,
-                                                          PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0}) {
+                                                          PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0},
+                                                          const unsigned char* __restrict__ mask = nullptr) {
   // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
-  // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.
+  // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.  Four rows are requested before the first is
+  // consumed.  ReLU mask of MODE 1: the forward's mask bytes, else the stored output y, else recomputed from x.
   __shared__ float red[2][256][8];
+  constexpr int U = POOL ? 1 : 4;
   const int vc = 1 << vc_log2, nrl = 256 >> vc_log2;
   const int cl = threadIdx.x & (vc - 1), rl = threadIdx.x >> vc_log2;
   const int c = (blockIdx.x * vc + cl) * 8;
+  const int cv = C >> 3;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c < C) {
-    float mu[8], is[8], ga[8], be[8];
-    if (MODE == 1) { load8<float>(mean + c, mu); load8<float>(invstd + c, is); }
-    const bool remask = MODE == 1 && relu && y == nullptr;      // no stored output: recompute the ReLU mask from x
-    if (remask) { load8<float>(gamma + c, ga); load8<float>(beta + c, be); }
-    for (int64_t r = r0 + rl; r < r1; r += nrl) {
-      float xv[8];
-      load8<T>(x + r * C + c, xv);
-      if (MODE == 0) {
+  if (c < C && r0 < r1) {
+    BnAffine<T> af;
+    if (MODE == 1) af.init(mean, invstd, gamma, (relu && y == nullptr && mask == nullptr) ? beta : nullptr, c);
+    const int msrc = !relu ? 3 : (mask ? 2 : (y ? 1 : 0));      // block-uniform
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * nrl) {
+      float xv[U][8], dv[U][8], yv[U][8];
+      unsigned mb[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a[k] += xv[k]; b[k] = fmaf(xv[k], xv[k], b[k]); }
-      } else {
-        float dv[8], yv[8];
-        if (POOL) {
-          const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
-          pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
-        } else {
-          load8<T>(dy + r * C + c, dv);
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = min(rb + (int64_t)u * nrl, r1 - 1);      // clamped; surplus rows are dropped below
+        load8<T>(x + r * C + c, xv[u]);
+        if (MODE == 1) {
+          if (POOL) {
+            const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
+            pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv[u]);
+          } else {
+            load8<T>(dy + r * C + c, dv[u]);
+          }
+          if (msrc == 1) load8<T>(y + r * C + c, yv[u]);
+          if (msrc == 2) mb[u] = mask[r * cv + (c >> 3)];
         }
-        if (relu && !remask) load8<T>(y + r * C + c, yv);
+      }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float xh = (xv[k] - mu[k]) * is[k];
-          if (remask) yv[k] = fmaf(xh, ga[k], be[k]);
-          const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
-          a[k] += dz;
-          b[k] = fmaf(dz, xh, b[k]);
+      for (int u = 0; u < U; ++u) {
+        if (rb + (int64_t)u * nrl >= r1) break;
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { a[k] += xv[u][k]; b[k] = fmaf(xv[u][k], xv[u][k], b[k]); }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float xh = af.xhat(xv[u][k], k);
+            bool on = true;
+            if (msrc == 2) on = ((mb[u] >> k) & 1u) != 0u;
+            else if (msrc == 1) on = yv[u][k] > 0.f;
+            else if (msrc == 0) on = af.apply(xv[u][k], k) > 0.f;
+            const float dz = on ? dv[u][k] : 0.f;
+            a[k] += dz;
+            b[k] = fmaf(dz, xh, b[k]);
+          }
         }
       }
     }
@@ -280,11 +337,11 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
   __syncthreads();
   // thread t < 2*vc*8 sums one (stat, column) over the row lanes in a fixed order
   for (int t = threadIdx.x; t < 2 * vc * 8; t += 256) {
-    const int st = t / (vc * 8), col = t % (vc * 8), cv = col >> 3, k = col & 7;
-    const int cc = (blockIdx.x * vc + cv) * 8 + k;
+    const int st = t / (vc * 8), col = t % (vc * 8), cvi = col >> 3, k = col & 7;
+    const int cc = (blockIdx.x * vc + cvi) * 8 + k;
     if (cc < C) {
       float acc = 0.f;
-      for (int r = 0; r < nrl; ++r) acc += red[st][(r << vc_log2) + cv][k];
+      for (int r = 0; r < nrl; ++r) acc += red[st][(r << vc_log2) + cvi][k];
       partial[((int64_t)blockIdx.y * 2 + st) * C + cc] = acc;
     }
   }
@@ -393,69 +450,136 @@ __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restric
   if (c < C) out[c] = rsqrtf(var[c] + eps);
 }
 
-// y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
-template <typename T>
-__global__ void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const T* __restrict__ residual,
-                                    T* __restrict__ y, int64_t rows, int C, int relu) {
+// y = relu?( BN(x) (+ residual) ).  MASK: also leaves one byte per (row, channel group) whose bit k says y[.., c + k] > 0 --
+// the ReLU mask the backward of a residual layer needs (its output cannot be recomputed from z alone), 1/16 of re-reading y.
+template <typename T, bool RES, bool MASK>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const T* __restrict__ residual,
+                                                           T* __restrict__ y, unsigned char* __restrict__ mask, int64_t rows,
+                                                           int C, int relu) {
   const int cv = C >> 3;
-  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
-    const int c = (int)(it % cv) << 3;
-    const int64_t off = (it / cv) * C + c;
-    float xv[8], mu[8], is[8], g[8], b[8], rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    load8<T>(x + off, xv);
-    load8<float>(mean + c, mu); load8<float>(invstd + c, is);
-    load8<float>(gamma + c, g); load8<float>(beta + c, b);
-    if (residual) load8<T>(residual + off, rv);
+  const RowMap m = bn_row_map(cv);
+  if (m.row >= m.lanes) return;
+  const int c = m.cg << 3;
+  BnAffine<T> af;
+  af.init(mean, invstd, gamma, beta, c);
+  for (int64_t r0 = m.row; r0 < rows; r0 += kBnU * m.lanes) {
+    float xv[kBnU][8], rv[kBnU][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float v = fmaf((xv[k] - mu[k]) * is[k], g[k], b[k]) + rv[k];
-      xv[k] = relu ? fmaxf(v, 0.f) : v;
+    for (int u = 0; u < kBnU; ++u) {
+      const int64_t r = min(r0 + u * m.lanes, rows - 1);       // clamped: loaded unconditionally, stored only when live
+      load8<T>(x + r * C + c, xv[u]);
+      if (RES) load8<T>(residual + r * C + c, rv[u]);
     }
-    store8<T>(y + off, xv);
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int64_t r = r0 + u * m.lanes;
+      if (r >= rows) break;
+      unsigned bits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float v = af.apply(xv[u][k], k);
+        if (RES) v += rv[u][k];
+        if (relu) v = fmaxf(v, 0.f);
+        xv[u][k] = v;
+        if (MASK) bits |= (to_f32<T>(from_f32<T>(v)) > 0.f ? 1u : 0u) << k;   // the stored (rounded) value decides
+      }
+      store8<T>(y + r * C + c, xv[u]);
+      if (MASK) mask[r * cv + m.cg] = (unsigned char)bits;
+    }
   }
 }
 
-// dz = dy * (y > 0 if relu);  dres = dz (if wanted);
+// dz = dy * (relu mask);  dres = dz (if wanted);
 // train: dx = gamma*invstd*(dz - sum_dz/rows - xhat*sum_dzxhat/rows);  eval: dx = gamma*invstd*dz
-template <typename T, bool POOL = false>
-__global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
-                                    int64_t rows, int C, int relu, int training, float inv_rows,
-                                    const float* __restrict__ beta = nullptr, PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0}) {
+// The ReLU mask comes from (in this order) the mask bytes of the forward (MSRC 2), the stored output y (MSRC 1), or is
+// recomputed from z (MSRC 0, layers without a residual branch).
+template <typename T, int MSRC, bool DRES>
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                           const unsigned char* __restrict__ mask,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t rows, int C,
+                                                           int relu, int training, float inv_rows) {
+  const int cv = C >> 3;
+  const RowMap m = bn_row_map(cv);
+  if (m.row >= m.lanes) return;
+  const int c = m.cg << 3;
+  BnAffine<T> af;
+  af.init(mean, invstd, gamma, MSRC == 0 ? beta : nullptr, c);
+  float gi[8], kb[8], kg[8];
+  {
+    float dg[8], db[8];
+    load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gi[k] = af.g[k] * af.is[k];
+      kb[k] = training ? db[k] * inv_rows : 0.f;
+      kg[k] = training ? dg[k] * inv_rows : 0.f;
+    }
+  }
+  for (int64_t r0 = m.row; r0 < rows; r0 += kBnU * m.lanes) {
+    float dv[kBnU][8], xv[kBnU][8], yv[kBnU][8];
+    unsigned mb[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int64_t r = min(r0 + u * m.lanes, rows - 1);
+      load8<T>(dy + r * C + c, dv[u]);
+      load8<T>(x + r * C + c, xv[u]);
+      if (MSRC == 1) load8<T>(y + r * C + c, yv[u]);
+      if (MSRC == 2) mb[u] = mask[r * cv + m.cg];
+    }
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int64_t r = r0 + u * m.lanes;
+      if (r >= rows) break;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = af.xhat(xv[u][k], k);
+        bool on = true;
+        if (relu) on = MSRC == 2 ? ((mb[u] >> k) & 1u) != 0u : (MSRC == 1 ? yv[u][k] > 0.f : af.apply(xv[u][k], k) > 0.f);
+        const float dz = on ? dv[u][k] : 0.f;
+        dv[u][k] = dz;
+        o[k] = gi[k] * (dz - kb[k] - xh * kg[k]);
+      }
+      store8<T>(dx + r * C + c, o);
+      if (DRES) store8<T>(dres + r * C + c, dv[u]);
+    }
+  }
+}
+
+// The same for the layer in front of a 3x3 / 2 / 1 max-pool, generic geometry (odd H or W): the incoming gradient is
+// gathered from the pooled gradient (pooled_dy8_k3s2p1); the mask is recomputed from z.
+template <typename T>
+__global__ void bn_apply_bwd_pool_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                         const float* __restrict__ dbeta, T* __restrict__ dx,
+                                         int64_t rows, int C, int relu, int training, float inv_rows,
+                                         const float* __restrict__ beta, PoolGeom pg) {
   const int cv = C >> 3;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < rows * cv; it += gs) {
     const int c = (int)(it % cv) << 3;
     const int64_t off = (it / cv) * C + c;
-    float dv[8], xv[8], yv[8], mu[8], is[8], g[8], dg[8], db[8], o[8], be[8];
-    if (POOL) {
-      const int64_t r = it / cv;
-      const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
-      pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
-    } else {
-      load8<T>(dy + off, dv);
-    }
+    float dv[8], xv[8], dg[8], db[8], o[8];
+    const int64_t r = it / cv;
+    const int w = (int)(r % pg.W), h = (int)((r / pg.W) % pg.H);
+    pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
     load8<T>(x + off, xv);
-    const bool remask = relu && y == nullptr;
-    if (relu && !remask) load8<T>(y + off, yv);
-    if (remask) load8<float>(beta + c, be);
-    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g);
+    BnAffine<T> af;
+    af.init(mean, invstd, gamma, beta, c);
     load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float xh = (xv[k] - mu[k]) * is[k];
-      if (remask) yv[k] = fmaf(xh, g[k], be[k]);
-      const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : dv[k];
-      dv[k] = dz;
-      o[k] = training ? g[k] * is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : g[k] * is[k] * dz;
+      const float xh = af.xhat(xv[k], k);
+      const float dz = (relu && !(af.apply(xv[k], k) > 0.f)) ? 0.f : dv[k];
+      o[k] = training ? af.g[k] * af.is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : af.g[k] * af.is[k] * dz;
     }
     store8<T>(dx + off, o);
-    if (dres) store8<T>(dres + off, dv);
   }
 }
 
@@ -463,17 +587,31 @@ __global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
 // can have selected any of them -- (qh, qw) .. (qh+1, qw+1) -- are loaded once for the quad instead of four (clamped)
 // windows per pixel; an even row can only be tap row 1 of window qh, an odd row tap row 2 of qh or tap row 0 of qh+1.
 template <typename T>
-__global__ void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T* __restrict__ x,
                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                               T* __restrict__ dx, int64_t N, int C, int relu, int training, float inv_rows,
                                               PoolGeom pg) {
   const int cv = C >> 3, H2 = pg.H >> 1, W2 = pg.W >> 1;
-  const int64_t items = N * H2 * W2 * cv;
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(it % cv) << 3;
-    const int64_t q = it / cv;
+  const int64_t quads = N * H2 * W2;
+  const RowMap m = bn_row_map(cv);                       // "row" = one 2 x 2 quad of input pixels
+  if (m.row >= m.lanes) return;
+  const int c = m.cg << 3;
+  BnAffine<T> af;
+  af.init(mean, invstd, gamma, beta, c);
+  float gi[8], kb[8], kg[8];
+  {
+    float dg[8], db[8];
+    load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gi[k] = af.g[k] * af.is[k];
+      kb[k] = training ? db[k] * inv_rows : 0.f;
+      kg[k] = training ? dg[k] * inv_rows : 0.f;
+    }
+  }
+  for (int64_t q = m.row; q < quads; q += m.lanes) {
     const int qw = (int)(q % W2), qh = (int)((q / W2) % H2);
     const int64_t n = q / ((int64_t)W2 * H2);
     unsigned long long pk[2][2];
@@ -493,9 +631,6 @@ __global__ void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T
 #pragma unroll
       for (int pw = 0; pw < 2; ++pw)
         load8<T>(x + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, xv[ph][pw]);
-    float mu[8], is[8], g[8], be[8], dg[8], db[8];
-    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g); load8<float>(beta + c, be);
-    load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
     const bool va[2] = {true, qh + 1 < pg.Ho}, vb[2] = {true, qw + 1 < pg.Wo};
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
@@ -516,9 +651,9 @@ __global__ void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T
         float o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float xh = (xv[ph][pw][k] - mu[k]) * is[k];
-          const float dz = (relu && !(fmaf(xh, g[k], be[k]) > 0.f)) ? 0.f : dv[k];
-          o[k] = training ? g[k] * is[k] * (dz - db[k] * inv_rows - xh * dg[k] * inv_rows) : g[k] * is[k] * dz;
+          const float xh = af.xhat(xv[ph][pw][k], k);
+          const float dz = (relu && !(af.apply(xv[ph][pw][k], k) > 0.f)) ? 0.f : dv[k];
+          o[k] = gi[k] * (dz - kb[k] - xh * kg[k]);
         }
         store8<T>(dx + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, o);
       }
@@ -806,43 +941,48 @@ __global__ void maxpool_bwd_k3s2p1_kernel(const T* __restrict__ dy, const unsign
 // the normalised map (411 MB at 256 frames of 224^2) is neither written nor read back.  Values are rounded to T before the
 // comparison, ties go to the first tap: the same output and argmax as bn_apply_fwd followed by maxpool_fwd.
 template <typename T>
-__global__ void bn_relu_maxpool_k3s2p1_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_relu_maxpool_k3s2p1_kernel(const T* __restrict__ z, const float* __restrict__ mean,
                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, T* __restrict__ y,
                                               unsigned char* __restrict__ idx, int N, int C, int H, int W, int Ho, int Wo,
                                               int relu) {
   const int cv = C >> 3;
-  const int64_t items = (int64_t)N * Ho * Wo * cv;
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(it % cv) << 3;
-    const int64_t r = it / cv;
+  const int64_t outs = (int64_t)N * Ho * Wo;
+  const RowMap m = bn_row_map(cv);                       // "row" = one pooled output pixel
+  if (m.row >= m.lanes) return;
+  const int c = m.cg << 3;
+  BnAffine<T> af;
+  af.init(mean, invstd, gamma, beta, c);
+  for (int64_t r = m.row; r < outs; r += m.lanes) {
     const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
     const int64_t n = r / ((int64_t)Wo * Ho);
-    float mu[8], is[8], g[8], b[8];
-    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g); load8<float>(beta + c, b);
+    // all nine taps in flight at once (clamped coordinates; out-of-image taps are skipped below)
+    float v[9][8];
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj) {
+        const int h = min(max(ho * 2 - 1 + ki, 0), H - 1), w = min(max(wo * 2 - 1 + kj, 0), W - 1);
+        load8<T>(z + ((n * H + h) * W + w) * C + c, v[ki * 3 + kj]);
+      }
     float best[8];
     int bi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
 #pragma unroll
-    for (int ki = 0; ki < 3; ++ki) {
-      const int h = ho * 2 - 1 + ki;
-      if (h < 0 || h >= H) continue;
+    for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
       for (int kj = 0; kj < 3; ++kj) {
-        const int w = wo * 2 - 1 + kj;
-        if (w < 0 || w >= W) continue;
-        float v[8];
-        load8<T>(z + ((n * H + h) * W + w) * C + c, v);
+        const int h = ho * 2 - 1 + ki, w = wo * 2 - 1 + kj;
+        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float t = fmaf((v[e] - mu[e]) * is[e], g[e], b[e]);
+          float t = af.apply(v[ki * 3 + kj][e], e);
           if (relu) t = fmaxf(t, 0.f);
           t = to_f32<T>(from_f32<T>(t));
-          if (bi[e] < 0 || t > best[e]) { best[e] = t; bi[e] = ki * 3 + kj; }
+          if (ok && (bi[e] < 0 || t > best[e])) { best[e] = t; bi[e] = ki * 3 + kj; }
         }
       }
-    }
     store8<T>(y + r * C + c, best);
     unsigned long long packed = 0;
 #pragma unroll
@@ -1167,17 +1307,27 @@ int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps
   return DVT_OK;
 }
 
+// grid of a row-streaming kernel: a multiple of C/8 threads is not needed (bn_row_map idles the remainder), 8 workgroups/CU
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream) {
+                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int relu, int dtype,
+                     dvt_stream_t stream) {
   DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0, "dvt_bn_apply_fwd: bad arguments");
   if (rows == 0) return DVT_OK;
   hipStream_t st = (hipStream_t)stream;
   if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(residual) && dvt_aligned16(mean) &&
       dvt_aligned16(invstd) && dvt_aligned16(gamma) && dvt_aligned16(beta)) {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                    (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
-                                                    rows, C, relu));
+    const dim3 grid(cgrid(dvt_cdiv(rows, kBnU) * (C >> 3)));
+#define DVT_BN_FWD(RES, MASK)                                                                                      \
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, RES, MASK>), grid, dim3(kB), 0, st, (const T*)x, mean, \
+                                                  invstd, gamma, beta, (const T*)residual, (T*)y, (unsigned char*)relu_mask, \
+                                                  rows, C, relu))
+    if (residual && relu_mask) DVT_BN_FWD(true, true);
+    else if (residual) DVT_BN_FWD(true, false);
+    else if (relu_mask) DVT_BN_FWD(false, true);
+    else DVT_BN_FWD(false, false);
+#undef DVT_BN_FWD
   } else {
+    if (relu_mask) DVT_UNSUPPORTED("dvt_bn_apply_fwd: the ReLU mask output needs C %% 8 == 0 and 16-byte aligned buffers");
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
                                                     (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
                                                     rows, C, relu));
@@ -1186,7 +1336,7 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
   return DVT_OK;
 }
 
-int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
                int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
   DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
@@ -1194,8 +1344,9 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   const bool cvec = C % 8 == 0 && dvt_aligned16(dy) && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(dx) &&
                     dvt_aligned16(dres) && dvt_aligned16(mean) && dvt_aligned16(invstd) && dvt_aligned16(gamma) &&
                     dvt_aligned16(workspace);
-  DVT_REQUIRE(!relu || y || (beta && !dres),
-              "dvt_bn_bwd: relu needs the forward output y, or beta to recompute the mask (no residual branch)");
+  DVT_REQUIRE(!relu || y || relu_mask || (beta && !dres),
+              "dvt_bn_bwd: relu needs the forward's mask bytes or output y, or beta to recompute the mask (no residual branch)");
+  if (relu_mask && !cvec) DVT_UNSUPPORTED("dvt_bn_bwd: the ReLU mask input needs C %% 8 == 0 and 16-byte aligned buffers");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
@@ -1206,7 +1357,8 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
   float* part = (float*)workspace;
   if (cvec) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma, beta));
+                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma,
+                                                    beta, PoolGeom{nullptr, 0, 0, 0, 0}, (const unsigned char*)relu_mask));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid_s, dim3(256), 0, st, (const T*)x,
                                                     (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part,
@@ -1220,10 +1372,20 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, 
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                    (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
-                                                    loc + C, (T*)dx, (T*)dres, rows, C, relu, training,
-                                                    1.0f / (float)rows, beta));
+    const dim3 agrid(cgrid(dvt_cdiv(rows, kBnU) * (C >> 3)));
+    const int msrc = !relu ? 0 : (relu_mask ? 2 : (y ? 1 : 0));
+#define DVT_BN_BWD(MSRC, DRES)                                                                                               \
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, MSRC, DRES>), agrid, dim3(kB), 0, st, (const T*)dy,  \
+                                                  (const T*)x, (const T*)y, (const unsigned char*)relu_mask, mean, invstd,   \
+                                                  gamma, beta, loc, loc + C, (T*)dx, (T*)dres, rows, C, relu, training,      \
+                                                  1.0f / (float)rows))
+    if (msrc == 2 && dres) DVT_BN_BWD(2, true);
+    else if (msrc == 2) DVT_BN_BWD(2, false);
+    else if (msrc == 1 && dres) DVT_BN_BWD(1, true);
+    else if (msrc == 1) DVT_BN_BWD(1, false);
+    else if (dres) DVT_BN_BWD(0, true);
+    else DVT_BN_BWD(0, false);
+#undef DVT_BN_BWD
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
                                                     (const T*)dy, (const T*)x, (const T*)y, mean, invstd, gamma, loc,
@@ -1280,10 +1442,9 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
                                                     st, (const T*)dy_pool, (const T*)x, mean, invstd, gamma, beta, loc, loc + C,
                                                     (T*)dx, N, C, relu, training, 1.0f / (float)rows, pg));
   } else {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, true>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
-                                                    (const T*)dy_pool, (const T*)x, (const T*)nullptr, mean, invstd, gamma, loc,
-                                                    loc + C, (T*)dx, (T*)nullptr, rows, C, relu, training, 1.0f / (float)rows,
-                                                    beta, pg));
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_pool_kernel<T>), dim3(cgrid(rows * (C >> 3))), dim3(kB), 0, st,
+                                                    (const T*)dy_pool, (const T*)x, mean, invstd, gamma, loc, loc + C, (T*)dx,
+                                                    rows, C, relu, training, 1.0f / (float)rows, beta, pg));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(apply)");
   return DVT_OK;

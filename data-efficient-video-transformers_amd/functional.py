@@ -1246,8 +1246,13 @@ class _ConvBnAct(torch.autograd.Function):
         if pool and not pooled:
             raise ValueError("pool=True needs a layer without a residual branch and a multiple of 8 output channels")
         pidx = None
+        # a ReLU layer with a residual branch cannot recompute its mask from z alone: the forward leaves one bit per element
+        # (1/16 of re-reading y in both passes of the BatchNorm backward)
+        rmask = None
         if pooled:
             y, pidx = ops.bn_relu_maxpool_fwd(z, mean, invstd, g32, b32, N, Cout, Ho, Wo, relu)
+        elif relu and res is not None and Cout % 8 == 0 and any(ctx.needs_input_grad):
+            y, rmask = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu, want_mask=True)
         else:
             y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
         # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
@@ -1258,8 +1263,8 @@ class _ConvBnAct(torch.autograd.Function):
         keep_col = SAVE_CONV_COLUMNS and not direct and col is not None and not wg_implicit
         # a ReLU layer without a residual branch recomputes its mask from z in backward (saves two passes over y)
         keep_y = relu and residual is not None
-        ctx.save_for_backward(None if keep_col else xc, wp, z, y if keep_y else None, mean, invstd, g32,
-                              col if keep_col else None, b32 if ((relu and not keep_y) or pooled) else None, pidx)
+        ctx.save_for_backward(None if keep_col else xc, wp, z, y if (keep_y and rmask is None) else None, mean, invstd, g32,
+                              col if keep_col else None, b32 if ((relu and not keep_y) or pooled) else None, pidx, rmask)
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
@@ -1271,7 +1276,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wp, z, y, mean, invstd, g32, col, b32, pidx = ctx.saved_tensors
+        xc, wp, z, y, mean, invstd, g32, col, b32, pidx, rmask = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l, padded = ctx.logical
@@ -1284,7 +1289,7 @@ class _ConvBnAct(torch.autograd.Function):
             if pidx is not None:       # dy is the pooled gradient
                 dz_, dg_, db_ = ops.bn_bwd_pooled(dy, pidx, z, mean, invstd, g32, b32, N, Ho, Wo, relu, training, **kw)
                 return dz_, None, dg_, db_
-            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, **kw)
+            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, **kw)
 
         if sg is not None and sb is not None and Cout == Cout_l and sg.fresh != sb.fresh:
             dz, dres, dgam, dbet = bn_backward()

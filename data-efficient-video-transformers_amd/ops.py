@@ -1306,20 +1306,24 @@ def bn_eval_invstd(running_var: Tensor, eps: float) -> Tensor:
 
 
 def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, residual: Optional[Tensor],
-                 relu: bool) -> Tensor:
+                 relu: bool, want_mask: bool = False):
+    """want_mask: -> (y, mask) with mask uint8 [rows, C/8], the ReLU mask bits for bn_bwd (layers with a residual branch)."""
     rows, Cc = z.shape
     y = torch.empty_like(z)
-    with _timed(("hbm", "bn_apply_fwd", rows * Cc), z.numel() * z.element_size() * (2 + (residual is not None))):
+    mask = torch.empty((rows, Cc // 8), dtype=torch.uint8, device=z.device) if want_mask else None
+    nb = z.numel() * z.element_size() * (2 + (residual is not None)) + (rows * (Cc // 8) if want_mask else 0)
+    with _timed(("hbm", "bn_apply_fwd", rows * Cc), nb):
         L.check(L.load().dvt_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                          beta.data_ptr(), _p(residual), y.data_ptr(), rows, Cc, int(relu), dt(z),
+                                          beta.data_ptr(), _p(residual), y.data_ptr(), _p(mask), rows, Cc, int(relu), dt(z),
                                           _stream()), "dvt_bn_apply_fwd")
-    return y
+    return (y, mask) if want_mask else y
 
 
 def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
            training: bool, want_dres: bool, *, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-           accumulate: bool = False, beta: Optional[Tensor] = None):
-    """y may be None for a ReLU layer without a residual branch when ``beta`` is given (mask recomputed from z)."""
+           accumulate: bool = False, beta: Optional[Tensor] = None, mask: Optional[Tensor] = None):
+    """ReLU mask: ``mask`` (bn_apply_fwd(want_mask=True)) if given, else ``y``, else recomputed from z (``beta`` given, no
+    residual branch)."""
     rows, Cc = z.shape
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
@@ -1327,13 +1331,19 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
         assert not accumulate
         dgamma = torch.empty((Cc,), dtype=torch.float32, device=z.device)
         dbeta = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == rows * (Cc // 8)
+        y = None
     lib = L.load()
     ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
     # train-mode BatchNorm backward is two passes by construction (the sums over the batch, then the input gradient):
-    # each reads dy and z (and y for a ReLU mask that cannot be recomputed), the second writes dz (and the shortcut's gradient)
-    nb = z.numel() * z.element_size() * (2 * (2 + (y is not None)) + 1 + int(want_dres))
+    # each reads dy and z (and the mask bytes, or y when the mask cannot be recomputed), the second writes dz (and the
+    # shortcut's gradient)
+    esz = z.element_size()
+    per_pass = z.numel() * esz * (2 + (y is not None)) + (mask.numel() if mask is not None else 0)
+    nb = 2 * per_pass + z.numel() * esz * (1 + int(want_dres))
     with _timed(("hbm", "bn_bwd", rows * Cc), nb):
-        L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+        L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), _p(mask), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
                                int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
     return dz, dres, dgamma, dbeta

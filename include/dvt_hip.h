@@ -550,13 +550,18 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
 int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
                                float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream);
 int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream);
-/* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52). */
+/* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52).
+ * relu_mask (optional, C % 8 == 0): uint8 [rows][C/8], bit k of byte (r, g) = y[r, 8g + k] > 0 -- the ReLU mask the backward
+ * of a layer WITH a residual branch needs (its output cannot be recomputed from x alone); dvt_bn_bwd reads these bytes
+ * (1/16 of the traffic) instead of the output y in both of its passes. */
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, void* y, int64_t rows, int C, int relu, int dtype, dvt_stream_t stream);
-/* dz = dy*(y>0 if relu); dres = dz (if dres != NULL); dgamma/dbeta (+)=; dx by the batch-statistics
- * formula (training) or gamma*invstd*dz (eval).  y may be NULL for a ReLU layer without a residual branch: the mask
- * is then recomputed from x as (x - mean)*invstd*gamma + beta > 0 (beta required), which saves two passes over y. */
-int dvt_bn_bwd(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int relu, int dtype,
+                     dvt_stream_t stream);
+/* dz = dy*(relu mask); dres = dz (if dres != NULL); dgamma/dbeta (+)=; dx by the batch-statistics formula (training) or
+ * gamma*invstd*dz (eval).  The ReLU mask comes from relu_mask (dvt_bn_apply_fwd's bytes) when given, else from the
+ * forward output y, else -- a ReLU layer without a residual branch -- it is recomputed from x as
+ * (x - mean)*invstd*gamma + beta > 0 (beta required). */
+int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
                int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
 /* The ResNet stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) without the normalised map in HBM:

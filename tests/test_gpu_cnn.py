@@ -125,6 +125,53 @@ def test_maxpool_fwd_bwd_matches_torch(dvt, device, H, W, k, stride, pad):
     assert torch.allclose(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, C), atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,C", [(37, 8), (4099, 48), (70001, 64), (9000, 512)])
+def test_batchnorm_row_streaming_kernels_and_relu_mask(dvt, device, dtype, rows, C):
+    """BatchNorm + residual + ReLU of a BasicBlock's second layer (custom_resnet.py:48-52) and its backward against plain
+    fp64 arithmetic on the same rounded operands -- row counts that are not multiples of the kernels' row sweep, a channel
+    group count (48 / 8 = 6) that does not divide the thread count --, and the ReLU mask bytes of the forward: bit k of
+    byte (r, g) is y[r, 8g + k] > 0, and the backward fed with them is BIT-identical to the backward fed with y."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    z = torch.randn(rows, C, generator=g).to(dtype)
+    res = torch.randn(rows, C, generator=g).to(dtype)
+    dy = torch.randn(rows, C, generator=g).to(dtype)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    zd, rd, dyd, gd, bd = (t.cuda() for t in (z, res, dy, gamma, beta))
+    mean, invstd = ops.bn_stats(zd, None, None, 1e-5, 0.1)
+    z64 = z.double()
+    mu, var = z64.mean(0), z64.var(0, unbiased=False)
+    assert torch.allclose(mean.cpu().double(), mu, atol=1e-4) and rel_l2(invstd.cpu().double(), (var + 1e-5).rsqrt()) < 1e-4
+    y, mask = ops.bn_apply_fwd(zd, mean, invstd, gd, bd, rd, True, want_mask=True)
+    y_plain = ops.bn_apply_fwd(zd, mean, invstd, gd, bd, rd, True)
+    assert torch.equal(y, y_plain)
+    xh = (z64 - mean.cpu().double()) * invstd.cpu().double()
+    ref = torch.relu(xh * gamma.double() + beta.double() + res.double())
+    tol = 1e-5 if dtype == torch.float32 else (6e-3 if dtype == torch.bfloat16 else 8e-4)
+    assert rel_l2(y.float().cpu().double(), ref) < tol
+    bits = (y.float() > 0).view(rows, C // 8, 8).to(torch.int32)
+    want = (bits << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(mask, want)
+    # backward: mask-fed == y-fed, bit for bit; and both against float64
+    dz_m, dres_m, dg_m, db_m = ops.bn_bwd(dyd, zd, None, mean, invstd, gd, True, True, True, mask=mask)
+    dz_y, dres_y, dg_y, db_y = ops.bn_bwd(dyd, zd, y, mean, invstd, gd, True, True, True)
+    assert torch.equal(dz_m, dz_y) and torch.equal(dres_m, dres_y) and torch.equal(dg_m, dg_y) and torch.equal(db_m, db_y)
+    on = (y.float().cpu() > 0).double()
+    dzr = dy.double() * on
+    dg_ref, db_ref = (dzr * xh).sum(0), dzr.sum(0)
+    dx_ref = gamma.double() * invstd.cpu().double() * (dzr - db_ref / rows - xh * dg_ref / rows)
+    assert rel_l2(dg_m.cpu().double(), dg_ref) < 20 * tol and rel_l2(db_m.cpu().double(), db_ref) < 20 * tol
+    assert rel_l2(dz_m.float().cpu().double(), dx_ref) < tol and torch.equal(dres_m.float().cpu().double(), dzr)
+    # a ReLU layer without a residual branch: the mask is recomputed from z with the forward's own formula
+    y2 = ops.bn_apply_fwd(zd, mean, invstd, gd, bd, None, True)
+    dz_r, _, dg_r, db_r = ops.bn_bwd(dyd, zd, None, mean, invstd, gd, True, True, False, beta=bd)
+    dz_s, _, dg_s, db_s = ops.bn_bwd(dyd, zd, y2, mean, invstd, gd, True, True, False)
+    # (identical unless an activation is positive in fp32 and rounds to zero in 16 bits: a handful of elements at most)
+    assert rel_l2(dz_r.float(), dz_s.float()) < 1e-4 and rel_l2(dg_r, dg_s) < 1e-5 and rel_l2(db_r, db_s) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(9, 11), (12, 16)])
 def test_bn_relu_maxpool_in_one_pass_matches_the_three_ops(dvt, device, dtype, H, W):
