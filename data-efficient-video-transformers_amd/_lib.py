@@ -28,6 +28,7 @@ class SplitKPending(C.Structure):
         ("M", c_i64), ("N", c_i64), ("C", c_p), ("ldc", c_i64),
         ("accumulate", C.c_int32), ("cs_accumulate", C.c_int32),
         ("cs_slab", c_p), ("cs_out", c_p),
+        ("conv_cin", C.c_int32), ("conv_taps", C.c_int32),
     ]
 
 
@@ -52,7 +53,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int64)] + \
                [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")] + \
                [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32),
-                ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p)]
+                ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p),
+                ("residual", C.c_void_p), ("wgrad_master_layout", C.c_int32), ("wgrad_accumulate", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -130,7 +132,7 @@ SIGNATURES = {
     "dvt_heads_contract_outer": (c_int, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_f, c_p, c_i64, c_p, c_i64, c_f, c_int,
                                          c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "dvt_im2col": (c_int, [c_p, c_int, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
-    "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 9 + [c_i64, c_int, c_p]),
+    "dvt_col2im": (c_int, [c_p, c_p, c_i64] + [c_int] * 9 + [c_i64, c_p, c_int, c_int, c_p]),
     "dvt_col2im_nchw": (c_int, [c_p, c_int, c_p, c_int, c_i64] + [c_int] * 9 + [c_i64, c_p]),
     "dvt_conv_weight_pack": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_i64, c_p]),
     "dvt_conv_weight_unpack_grad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p]),
@@ -176,7 +178,7 @@ SIGNATURES = {
     "dvt_nchw_to_nhwc_pad": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv3x3_c64_supported": (c_int, [c_i64, c_int, c_int, c_int]),
     "dvt_conv3x3_c64_stats_parts": (c_i64, [c_i64, c_int, c_int]),
-    "dvt_conv3x3_c64": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
+    "dvt_conv3x3_c64": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_conv_weight_pairs": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv_weight_pairs_bwd": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),

@@ -104,7 +104,7 @@ __global__ void im2col_nhwc_vec_kernel(const T* __restrict__ x, T* __restrict__ 
 template <typename T>
 __global__ void col2im_nhwc_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int C, int H,
                                    int W, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
-                                   int64_t ld) {
+                                   int64_t ld, const T* __restrict__ add = nullptr, int add_stride = 0) {
   const int cv = C >> 3;
   const int64_t items = (int64_t)N * H * W * cv;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
@@ -114,6 +114,14 @@ __global__ void col2im_nhwc_kernel(const T* __restrict__ dcol, T* __restrict__ d
     const int w = (int)(px % W), h = (int)((px / W) % H);
     const int64_t n = px / ((int64_t)W * H);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (add) {                                    // a second gradient path into the same pixel (see dvt_col2im)
+      if (add_stride == 0) {
+        load8<T>(add + px * C + c, acc);
+      } else if (h % add_stride == 0 && w % add_stride == 0) {
+        const int Hs = (H + add_stride - 1) / add_stride, Ws = (W + add_stride - 1) / add_stride;
+        load8<T>(add + ((n * Hs + h / add_stride) * Ws + w / add_stride) * C + c, acc);
+      }
+    }
     for (int ki = 0; ki < kh; ++ki) {
       const int hh = h + ph - ki;
       if (hh < 0 || hh % sh) continue;
@@ -266,7 +274,7 @@ struct BnAffine {
 struct PoolGeom { const unsigned char* idx; int H, W, Ho, Wo; };
 template <typename T> __device__ __forceinline__ void pooled_dy8_k3s2p1(const T*, const unsigned char*, int64_t, int, int, int, int, int, int, float*);
 
-template <typename T, int MODE, bool POOL = false>
+template <typename T, int MODE, bool POOL = false, int MSRC = 0>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int64_t rows, int C,
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
                                                           const unsigned char* __restrict__ mask = nullptr) {
   // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
   // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.  Four rows are requested before the first is
-  // consumed.  ReLU mask of MODE 1: the forward's mask bytes, else the stored output y, else recomputed from x.
+  // consumed.  ReLU mask of MODE 1 (MSRC): 2 = the forward's mask bytes, 1 = the stored output y, 0 = recomputed from x.
   __shared__ float red[2][256][8];
   constexpr int U = POOL ? 1 : 4;
   const int vc = 1 << vc_log2, nrl = 256 >> vc_log2;
@@ -290,8 +298,8 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C && r0 < r1) {
     BnAffine<T> af;
-    if (MODE == 1) af.init(mean, invstd, gamma, (relu && y == nullptr && mask == nullptr) ? beta : nullptr, c);
-    const int msrc = !relu ? 3 : (mask ? 2 : (y ? 1 : 0));      // block-uniform
+    if (MODE == 1) af.init(mean, invstd, gamma, (relu && MSRC == 0) ? beta : nullptr, c);
+    constexpr int msrc = MSRC;
     for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * nrl) {
       float xv[U][8], dv[U][8], yv[U][8];
       unsigned mb[U];
@@ -321,9 +329,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
           for (int k = 0; k < 8; ++k) {
             const float xh = af.xhat(xv[u][k], k);
             bool on = true;
-            if (msrc == 2) on = ((mb[u] >> k) & 1u) != 0u;
-            else if (msrc == 1) on = yv[u][k] > 0.f;
-            else if (msrc == 0) on = af.apply(xv[u][k], k) > 0.f;
+            if (relu) on = msrc == 2 ? ((mb[u] >> k) & 1u) != 0u : (msrc == 1 ? yv[u][k] > 0.f : af.apply(xv[u][k], k) > 0.f);
             const float dz = on ? dv[u][k] : 0.f;
             a[k] += dz;
             b[k] = fmaf(dz, xh, b[k]);
@@ -348,35 +354,38 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
 }
 
 // MODE 0: mean, invstd (biased var), running stats update.  MODE 1: dgamma = sum dz*xhat, dbeta = sum dz.
-template <int MODE>
+template <int MODE, int CL = 32>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
                                                            float inv_rows, float eps, float* __restrict__ o0,
                                                            float* __restrict__ o1, float* __restrict__ run_mean,
                                                            float* __restrict__ run_var, float momentum, float unbias,
                                                            int accumulate, float* __restrict__ pub0 = nullptr,
                                                            float* __restrict__ pub1 = nullptr) {
-  // block = 32 columns x 32 part lanes; fixed summation order (lane-strided partial sums, then a lane tree)
+  // block = CL columns x PL = 1024 / CL part lanes; fixed summation order (lane-strided partial sums, then a lane tree).
+  // CL = 8 for narrow maps: a 64-channel layer then runs on 8 CUs instead of 2 (the launch is bound by what ONE CU can pull
+  // in -- up to 1 MB of partial rows -- not by arithmetic).
   // The partial sums are added in double and the variance is formed in double: the one-pass form E[x^2] - mu^2 in fp32
   // loses the variance of channels whose |mean| is large against their spread to the rounding of sums over 10^5..10^7
   // rows; with double accumulation of the (fp32, <= 128-row) partials what is left is the rounding inside one partial.
-  __shared__ double red[2][32][33];
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int PL = 1024 / CL;
+  __shared__ double red[2][PL][CL + 1];
+  const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+  const int c = blockIdx.x * CL + cl;
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
     // four partial rows per round trip (a rolled loop waits for each before it requests the next); same order of additions
     int p = pl;
-    for (; p + 96 < nparts; p += 128) {
+    for (; p + 3 * PL < nparts; p += 4 * PL) {
       float a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        a[u] = partial[((int64_t)(p + 32 * u) * 2 + 0) * C + c];
-        b[u] = partial[((int64_t)(p + 32 * u) * 2 + 1) * C + c];
+        a[u] = partial[((int64_t)(p + PL * u) * 2 + 0) * C + c];
+        b[u] = partial[((int64_t)(p + PL * u) * 2 + 1) * C + c];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
     }
-    for (; p < nparts; p += 32) {
+    for (; p < nparts; p += PL) {
       s0 += (double)partial[((int64_t)p * 2 + 0) * C + c];
       s1 += (double)partial[((int64_t)p * 2 + 1) * C + c];
     }
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   __syncthreads();
   if (pl != 0 || c >= C) return;
   s0 = 0.0; s1 = 0.0;
-  for (int p = 0; p < 32; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
+  for (int p = 0; p < PL; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
   if (MODE == 0) {
     const double mud = s0 * (double)inv_rows;
     const double vard = s1 * (double)inv_rows - mud * mud;
@@ -410,6 +419,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       o1[c] = accumulate ? o1[c] + d0 : d0;   // dbeta
     }
   }
+}
+
+// launch of the finalize kernel with the column-lane count that suits C
+template <int MODE>
+static void bn_finalize_launch(hipStream_t st, const float* partial, int nparts, int C, float inv_rows, float eps, float* o0,
+                               float* o1, float* run_mean, float* run_var, float momentum, float unbias, int accumulate,
+                               float* pub0 = nullptr, float* pub1 = nullptr) {
+  if (C <= 256)
+    hipLaunchKernelGGL((bn_finalize_kernel<MODE, 8>), dim3((unsigned)dvt_cdiv(C, 8)), dim3(1024), 0, st, partial, nparts, C,
+                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<MODE, 32>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, partial, nparts, C,
+                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1);
 }
 
 // Fold many partial rows (one per 128 output rows of a convolution: thousands) into gridDim.y rows that bn_finalize can
@@ -586,6 +608,105 @@ __global__ void bn_apply_bwd_pool_kernel(const T* __restrict__ dy, const T* __re
 // bn_apply_bwd<POOL> for even H and W, one thread per 2 x 2 input pixels (and 8 channels): the four pooling windows that
 // can have selected any of them -- (qh, qw) .. (qh+1, qw+1) -- are loaded once for the quad instead of four (clamped)
 // windows per pixel; an even row can only be tap row 1 of window qh, an odd row tap row 2 of qh or tap row 0 of qh+1.
+// One 2 x 2 quad of input pixels (2qh + ph, 2qw + pw) of a 3x3 / 2 / 1 max-pool (even H and W): the four pooling windows
+// that can have selected any of them are (qh + a, qw + b), a, b in {0, 1} -- loaded once for the quad; an even row can only
+// be tap row 1 of window qh, an odd row tap row 2 of window qh or tap row 0 of window qh + 1 (columns alike).
+template <typename T>
+struct PoolQuad {
+  unsigned long long pk[2][2];
+  float v[2][2][8];
+  bool va[2], vb[2];
+  __device__ __forceinline__ void load(const T* __restrict__ dyp, const PoolGeom& pg, int64_t n, int qh, int qw, int c, int C) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int hc = min(qh + a, pg.Ho - 1), wc = min(qw + b, pg.Wo - 1);
+        const int64_t o = ((n * pg.Ho + hc) * pg.Wo + wc) * C + c;
+        pk[a][b] = *reinterpret_cast<const unsigned long long*>(pg.idx + o);
+        load8<T>(dyp + o, v[a][b]);
+      }
+    va[0] = true; va[1] = qh + 1 < pg.Ho;
+    vb[0] = true; vb[1] = qw + 1 < pg.Wo;
+  }
+  // gradient of pixel (ph, pw) of the quad
+  template <int PH, int PW>
+  __device__ __forceinline__ void grad(float (&dv)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a <= PH; ++a)
+#pragma unroll
+      for (int b = 0; b <= PW; ++b) {
+        if (!(va[a] && vb[b])) continue;
+        const unsigned ki = PH == 0 ? 1u : (a == 0 ? 2u : 0u), kj = PW == 0 ? 1u : (b == 0 ? 2u : 0u);
+        const unsigned tap = ki * 3 + kj;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((pk[a][b] >> (8 * e)) & 0xffu) == tap) dv[e] += v[a][b][e];
+      }
+  }
+};
+
+// bn_colstats<MODE 1, POOL> for even H and W in the quad form: partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat over
+// the block's quads (dz = the gathered pool gradient under the recomputed ReLU mask).  Same block shape as bn_colstats_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_colstats_pool_quad_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    int64_t quads, int C, int quads_per_block, int relu, int vc_log2,
+                                                                    float* __restrict__ partial, PoolGeom pg) {
+  __shared__ float red[2][256][8];
+  const int vc = 1 << vc_log2, nrl = 256 >> vc_log2;
+  const int cl = threadIdx.x & (vc - 1), rl = threadIdx.x >> vc_log2;
+  const int c = (blockIdx.x * vc + cl) * 8;
+  const int H2 = pg.H >> 1, W2 = pg.W >> 1;
+  const int64_t q0 = (int64_t)blockIdx.y * quads_per_block, q1 = min(quads, q0 + quads_per_block);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C) {
+    BnAffine<T> af;
+    af.init(mean, invstd, gamma, beta, c);
+    for (int64_t q = q0 + rl; q < q1; q += nrl) {
+      const int qw = (int)(q % W2), qh = (int)((q / W2) % H2);
+      const int64_t n = q / ((int64_t)W2 * H2);
+      PoolQuad<T> pq;
+      pq.load(dyp, pg, n, qh, qw, c, C);
+      float xv[2][2][8];
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+          load8<T>(x + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, xv[ph][pw]);
+      auto acc = [&](const float (&dv)[8], const float (&xq)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = af.xhat(xq[k], k);
+          const float dz = (relu && !(af.apply(xq[k], k) > 0.f)) ? 0.f : dv[k];
+          a[k] += dz;
+          b[k] = fmaf(dz, xh, b[k]);
+        }
+      };
+      float dv[8];
+      pq.template grad<0, 0>(dv); acc(dv, xv[0][0]);
+      pq.template grad<0, 1>(dv); acc(dv, xv[0][1]);
+      pq.template grad<1, 0>(dv); acc(dv, xv[1][0]);
+      pq.template grad<1, 1>(dv); acc(dv, xv[1][1]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = a[k]; red[1][threadIdx.x][k] = b[k]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * vc * 8; t += 256) {
+    const int st = t / (vc * 8), col = t % (vc * 8), cvi = col >> 3, k = col & 7;
+    const int cc = (blockIdx.x * vc + cvi) * 8 + k;
+    if (cc < C) {
+      float acc2 = 0.f;
+      for (int r = 0; r < nrl; ++r) acc2 += red[st][(r << vc_log2) + cvi][k];
+      partial[((int64_t)blockIdx.y * 2 + st) * C + cc] = acc2;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_bwd_pool_quad_kernel(const T* __restrict__ dyp, const T* __restrict__ x,
                                               const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -614,49 +735,29 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_pool_quad_kernel(const T* __
   for (int64_t q = m.row; q < quads; q += m.lanes) {
     const int qw = (int)(q % W2), qh = (int)((q / W2) % H2);
     const int64_t n = q / ((int64_t)W2 * H2);
-    unsigned long long pk[2][2];
-    float v[2][2][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int hc = min(qh + a, pg.Ho - 1), wc = min(qw + b, pg.Wo - 1);
-        const int64_t o = ((n * pg.Ho + hc) * pg.Wo + wc) * C + c;
-        pk[a][b] = *reinterpret_cast<const unsigned long long*>(pg.idx + o);
-        load8<T>(dyp + o, v[a][b]);
-      }
+    PoolQuad<T> pq;
+    pq.load(dyp, pg, n, qh, qw, c, C);
     float xv[2][2][8];
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
       for (int pw = 0; pw < 2; ++pw)
         load8<T>(x + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, xv[ph][pw]);
-    const bool va[2] = {true, qh + 1 < pg.Ho}, vb[2] = {true, qw + 1 < pg.Wo};
+    auto emit = [&](const float (&dv)[8], const float (&xq)[8], int ph, int pw) {
+      float o[8];
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-      for (int pw = 0; pw < 2; ++pw) {
-        float dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int a = 0; a <= ph; ++a)            // even row: window qh only (tap row 1); odd: qh (tap row 2), qh+1 (tap row 0)
-#pragma unroll
-          for (int b = 0; b <= pw; ++b) {
-            if (!(va[a] && vb[b])) continue;
-            const unsigned ki = ph == 0 ? 1u : (a == 0 ? 2u : 0u), kj = pw == 0 ? 1u : (b == 0 ? 2u : 0u);
-            const unsigned tap = ki * 3 + kj;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (((pk[a][b] >> (8 * e)) & 0xffu) == tap) dv[e] += v[a][b][e];
-          }
-        float o[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float xh = af.xhat(xv[ph][pw][k], k);
-          const float dz = (relu && !(af.apply(xv[ph][pw][k], k) > 0.f)) ? 0.f : dv[k];
-          o[k] = gi[k] * (dz - kb[k] - xh * kg[k]);
-        }
-        store8<T>(dx + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, o);
+      for (int k = 0; k < 8; ++k) {
+        const float xh = af.xhat(xq[k], k);
+        const float dz = (relu && !(af.apply(xq[k], k) > 0.f)) ? 0.f : dv[k];
+        o[k] = gi[k] * (dz - kb[k] - xh * kg[k]);
       }
+      store8<T>(dx + ((n * pg.H + 2 * qh + ph) * pg.W + 2 * qw + pw) * C + c, o);
+    };
+    float dv[8];
+    pq.template grad<0, 0>(dv); emit(dv, xv[0][0], 0, 0);
+    pq.template grad<0, 1>(dv); emit(dv, xv[0][1], 0, 1);
+    pq.template grad<1, 0>(dv); emit(dv, xv[1][0], 1, 0);
+    pq.template grad<1, 1>(dv); emit(dv, xv[1][1], 1, 1);
   }
 }
 
@@ -1149,9 +1250,10 @@ int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t
 }
 
 int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
-               int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0, "dvt_col2im: bad arguments");
-  const bool cvec = C % 8 == 0 && ld % 8 == 0 && dvt_aligned16(dcol) && dvt_aligned16(dx);
+               int ph, int pw, int64_t ld, const void* add, int add_stride, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dcol && dx && N >= 0 && C > 0 && add_stride >= 0, "dvt_col2im: bad arguments");
+  const bool cvec = C % 8 == 0 && ld % 8 == 0 && dvt_aligned16(dcol) && dvt_aligned16(dx) && dvt_aligned16(add);
+  if (add && !cvec) DVT_UNSUPPORTED("dvt_col2im: the fused second gradient path needs C %% 8 == 0 and 16-byte aligned buffers");
   DVT_REQUIRE(sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "dvt_col2im: bad stride / padding");
   const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   if (N == 0) return DVT_OK;
@@ -1159,7 +1261,7 @@ int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int k
   if (cvec) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_nhwc_kernel<T>), dim3(cgrid(N * H * W * (C >> 3))), dim3(kB), 0,
                                                     st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, sh, sw, ph, pw,
-                                                    Ho, Wo, ld));
+                                                    Ho, Wo, ld, (const T*)add, add_stride));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im_scalar_kernel<T, T, false>), dim3(cgrid(N * H * W * C)), dim3(kB), 0,
                                                     st, (const T*)dcol, (T*)dx, (int)N, C, H, W, kh, kw, sh, sw, ph, pw,
@@ -1266,8 +1368,7 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
   }
   DVT_LAUNCH_CHECK("dvt_bn_stats");
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st,
-                     (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
+  bn_finalize_launch<0>(st, (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
                      running_var, momentum, unbias, 0);
   DVT_LAUNCH_CHECK("dvt_bn_stats(finalize)");
   return DVT_OK;
@@ -1293,7 +1394,7 @@ int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float
     src = folded;
     np = folds;
   }
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, src, np, C,
+  bn_finalize_launch<0>(st, src, np, C,
                      1.0f / (float)rows, eps, mean, invstd, running_mean, running_var, momentum, unbias, 0);
   DVT_LAUNCH_CHECK("dvt_bn_stats_from_partials");
   return DVT_OK;
@@ -1356,9 +1457,14 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
   // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
   float* part = (float*)workspace;
   if (cvec) {
-    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma,
-                                                    beta, PoolGeom{nullptr, 0, 0, 0, 0}, (const unsigned char*)relu_mask));
+#define DVT_BN_CS(MSRC)                                                                                                      \
+  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, false, MSRC>), grid, dim3(256), 0, st, (const T*)x, \
+                                                  (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma, \
+                                                  beta, PoolGeom{nullptr, 0, 0, 0, 0}, (const unsigned char*)relu_mask))
+    if (relu && relu_mask) DVT_BN_CS(2);
+    else if (relu && y) DVT_BN_CS(1);
+    else DVT_BN_CS(0);
+#undef DVT_BN_CS
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 1>), grid_s, dim3(256), 0, st, (const T*)x,
                                                     (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, part,
@@ -1368,7 +1474,7 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
   // keep the local dgamma/dbeta 16-byte aligned behind the partials
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
   // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
+  bn_finalize_launch<1>(st, (const float*)part,
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {
@@ -1428,16 +1534,23 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
   const int vcl = bn_vc_log2(C);
   const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
   float* part = (float*)workspace;
-  DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, true>), grid, dim3(256), 0, st, (const T*)x,
-                                                  (const T*)dy_pool, (const T*)nullptr, mean, invstd, rows, C, rpb, relu, vcl,
-                                                  part, gamma, beta, pg));
+  const bool quad = H % 2 == 0 && W % 2 == 0;
+  if (quad) {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_pool_quad_kernel<T>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)dy_pool, mean, invstd, gamma, beta, rows / 4, C, (int)dvt_cdiv(rpb, 4), relu,
+                                                    vcl, part, pg));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, true>), grid, dim3(256), 0, st, (const T*)x,
+                                                    (const T*)dy_pool, (const T*)nullptr, mean, invstd, rows, C, rpb, relu, vcl,
+                                                    part, gamma, beta, pg));
+  }
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(stats)");
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
   // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, (const float*)part,
+  bn_finalize_launch<1>(st, (const float*)part,
                      parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(finalize)");
-  if (H % 2 == 0 && W % 2 == 0) {
+  if (quad) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_pool_quad_kernel<T>), dim3(cgrid(rows / 4 * (C >> 3))), dim3(kB), 0,
                                                     st, (const T*)dy_pool, (const T*)x, mean, invstd, gamma, beta, loc, loc + C,
                                                     (T*)dx, N, C, relu, training, 1.0f / (float)rows, pg));

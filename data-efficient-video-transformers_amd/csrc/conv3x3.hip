@@ -31,6 +31,7 @@ struct Conv3Params {
   const void* w;        // [64][576] k-major, k = tap * 64 + c
   void* y;              // [N, H, W, 64]
   float* bn_partial;    // [grid * 8][2][64] or nullptr
+  const void* residual; // [N, H, W, 64] added to the output rows, or nullptr
   int N, H, W, R, tiles_per_img, ntiles, patch_bytes;
 };
 
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
     const int rows_ok = min(p.R, p.H - h0);
     const int valid = rows_ok * p.W;             // pixels of this tile that exist
     E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * kC;
+    const E* rt = p.residual ? (const E*)p.residual + ((int64_t)(n * p.H + h0) * p.W) * kC : nullptr;
     char* stg = const_cast<char*>(cur) + wid * 2048;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -174,8 +176,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int r = ps * 8 + (lane >> 3), c = lane & 7;
-        const V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
         if (m0 + r < valid) {
+          if (rt) {                               // a second gradient path joining this one (dvt_conv3x3_c64's residual)
+            const V8 rv = *reinterpret_cast<const V8*>(rt + (int64_t)(m0 + r) * kC + c * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (E)((float)v[k] + (float)rv[k]);
+          }
           *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * kC + c * 8) = v;
           if (p.bn_partial) {
 #pragma unroll
@@ -241,17 +248,17 @@ int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W) {
   return (ntiles < dvt_num_cus() ? ntiles : dvt_num_cus()) * 8;      // one partial row per wave of the persistent grid
 }
 
-int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, int64_t N, int H, int W, int dtype,
-                    dvt_stream_t stream) {
+int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
+                    int dtype, dvt_stream_t stream) {
   DVT_REQUIRE(x && w && y && N >= 0 && H > 0 && W > 0, "dvt_conv3x3_c64: bad arguments");
-  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y) && dvt_aligned16(stats_partial),
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y) && dvt_aligned16(stats_partial) && dvt_aligned16(residual),
               "dvt_conv3x3_c64: buffers must be 16-byte aligned");
   if (N == 0) return DVT_OK;
   Conv3Params p;
   if (!dvt_conv3x3_c64_supported(N, H, W, dtype))
     DVT_UNSUPPORTED("dvt_conv3x3_c64: needs a 16-bit dtype and (R + 2)(W + 2) * 128 B <= 44 KiB with R = 256 / W rows per tile");
   plan(H, W, &p.R, &p.patch_bytes);
-  p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial;
+  p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.residual = residual;
   p.N = (int)N; p.H = H; p.W = W;
   p.tiles_per_img = (int)dvt_cdiv(H, p.R);
   p.ntiles = (int)(N * p.tiles_per_img);

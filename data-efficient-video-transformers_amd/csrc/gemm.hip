@@ -685,12 +685,22 @@ static GemmRoute route_gemm(const dvt_gemm_desc* d) {
   return r;
 }
 
+// the pending reduce as a launch of its own, any form of it (plain, fused bias gradient, convolution scatter)
+__global__ void splitk_reduce_pending_kernel(const dvt_splitk_pending q) {
+  splitk_reduce_f32_part(q, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
 static int launch_pending_reduce(const dvt_splitk_pending* q, hipStream_t st) {
   if (!q || !q->valid) return DVT_OK;
   const int64_t nvec = q->M * q->N / 8;
   int64_t blocks = dvt_cdiv(nvec, 256);
   const int64_t cap = (int64_t)dvt_num_cus() * 8;
   if (blocks > cap) blocks = cap;
+  if (q->conv_taps > 0) {
+    hipLaunchKernelGGL(splitk_reduce_pending_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *q);
+    DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce, convolution scatter)");
+    return DVT_OK;
+  }
   hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, q->slab, q->splits, (int)q->M,
                      (int)q->N, q->C, q->ldc, q->accumulate, q->cs_slab, q->cs_out, q->cs_accumulate);
   DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce)");
@@ -875,6 +885,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
         q->slab = p.slab; q->splits = split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->C; q->ldc = d->ldc;
         q->accumulate = d->accumulate; q->cs_accumulate = d->colsum_accumulate;
         q->cs_slab = p.colsum_slab; q->cs_out = d->colsum_out;
+        q->conv_cin = 0; q->conv_taps = 0;
         return DVT_OK;
       }
       else if (p.out_f32)
@@ -988,11 +999,13 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.A = (const bf16*)d->x; p.B = (const bf16*)d->w; p.C = d->y;
   p.M = (int)(d->N * Ho * Wo); p.N = d->Cout; p.K = (int)dvt_conv2d_implicit_k(d);
   p.lda = 0; p.ldb = p.K; p.ldc = d->Cout;
-  p.epilogue = DVT_EPI_NONE; p.out_f32 = 0; p.accumulate = 0;
-  p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0;
+  p.epilogue = d->residual ? DVT_EPI_RESIDUAL : DVT_EPI_NONE; p.out_f32 = 0; p.accumulate = 0;
+  p.bias = nullptr; p.residual = d->residual; p.ldr = d->Cout; p.aux = nullptr; p.ldaux = 0;
   p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = p.K; p.slab = nullptr; p.tiles_n = 0; p.colsum_slab = nullptr;
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
+  DVT_REQUIRE(!(d->residual && d->stats_partial), "dvt_conv2d_implicit: residual and stats_partial are exclusive");
+  DVT_REQUIRE(dvt_aligned16(d->residual), "dvt_conv2d_implicit: residual must be 16-byte aligned");
   p.bn_partial = d->stats_partial;
   if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
     const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
@@ -1086,7 +1099,15 @@ int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
     dvt_splitk_pending* q = d->pending;
     q->slab = p.slab; q->splits = pl.split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->y; q->ldc = d->Cout;
     q->accumulate = 0; q->cs_accumulate = 0; q->cs_slab = nullptr; q->cs_out = nullptr;
+    q->conv_cin = 0; q->conv_taps = 0;
+    if (d->wgrad_master_layout) { q->conv_cin = d->C; q->conv_taps = d->kh * d->kw; q->accumulate = d->wgrad_accumulate; }
     return DVT_OK;
+  }
+  if (d->wgrad_master_layout) {
+    dvt_splitk_pending q{};
+    q.slab = p.slab; q.splits = pl.split; q.valid = 1; q.M = p.M; q.N = p.N; q.C = (float*)d->y; q.ldc = d->Cout;
+    q.accumulate = d->wgrad_accumulate; q.conv_cin = d->C; q.conv_taps = d->kh * d->kw;
+    return launch_pending_reduce(&q, st);
   }
   const int64_t nvec = (int64_t)p.M * p.N / 8;
   int64_t blocks = dvt_cdiv(nvec, 256);

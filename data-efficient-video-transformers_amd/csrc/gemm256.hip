@@ -683,6 +683,17 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n + p.pig_blocks), 1, 1), block(C::NW * 64);   // + a carried split-K reduce
+  if (p.epilogue == DVT_EPI_RESIDUAL) {             // data gradient joined by the shortcut's gradient (dvt_conv_desc.residual)
+    static bool attr_set_r = false;
+    if (!attr_set_r) {
+      (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+      attr_set_r = true;
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true>), grid, block, kSmem, st, p);
+    DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma, residual)");
+    return DVT_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>,

@@ -87,6 +87,16 @@ __device__ __forceinline__ void splitk_reduce_f32_part(const dvt_splitk_pending&
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += v[k];
     }
+    if (q.conv_taps > 0) {
+      // convolution weight gradient: (m = tap * Cin + ci, n = co) goes to the parameter's own layout C[co][ci][tap]
+      const int64_t tap = m / q.conv_cin, ci = m - tap * q.conv_cin;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float* o = q.C + ((n + k) * q.conv_cin + ci) * q.conv_taps + tap;
+        *o = q.accumulate ? *o + acc[k] : acc[k];
+      }
+      continue;
+    }
     float* o = q.C + m * q.ldc + n;
     if (q.accumulate) {
       float old[8];

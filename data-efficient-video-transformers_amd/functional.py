@@ -1138,7 +1138,13 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
-                cpad=0, dx_frames=None, pool=False):
+                cpad=0, dx_frames=None, pool=False, fork=None):
+        # fork: the layer's input has a second consumer, the block's shortcut (custom_resnet.py:38-54), handed out by THIS
+        # Function as a second output so that its gradient arrives here and joins the data gradient inside the kernel that
+        # produces it (residual epilogue of the implicit / halo convolution, second operand of col2im) instead of in an add
+        # kernel behind it.  "alias": the second output is x itself; an int s: x subsampled with stride s, i.e. the input of
+        # a strided 1x1 downsample convolution, whose gradient then comes back COMPACT (no zero-filled full-size map).
+        ctx.fork = fork
         # pool: the layer is followed by MaxPool2d(3, 2, 1) (the ResNet stem, custom_resnet.py:100-105): BatchNorm, ReLU and
         # the pooling run as one pass over the convolution output and the pooled map is returned; backward gathers the
         # layer's gradient from the pooled gradient inside the BatchNorm backward (neither full-resolution map exists).
@@ -1186,6 +1192,11 @@ class _ConvBnAct(torch.autograd.Function):
             raise ValueError("input has fewer channels than the convolution weight")
         K = kh * kw * Cin
         direct = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and not nchw and K % 8 == 0 and x.dtype == dtype)
+        # (a 1x1 / stride-1 layer the implicit kernels accept goes through them as well: the BatchNorm statistics come out of
+        # their epilogue and the weight gradient's reduce rides in the data gradient, like every other layer)
+        if direct and IMPLICIT_CONV and dtype in (torch.bfloat16, torch.float16) and Cout % 8 == 0 and \
+                Cin % (32 if Cout <= 128 else 64) == 0 and (N * H * W) % 64 == 0:
+            direct = False
         ld = K if direct else (ops.conv2d_implicit_k(Cin, Cout, k) if stem8 else _kpad(K, dtype))
         if pair is not None:
             kh_o, kw_o, pw_o, _ = pair
@@ -1272,10 +1283,16 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.w4 = w4.detach() if implicit else None
         ctx.wg_implicit = wg_implicit
         ctx.logical = (Cout_l, Cin_l, padded)
-        return y
+        if fork is None:
+            return y
+        if nchw or stem8:
+            raise ValueError("fork is for NHWC feature maps (residual blocks), not the stem")
+        if fork == "alias":
+            return y, x.view(x.shape)
+        return y, ops.im2col(xc, False, N, Cin, H, W, 1, int(fork), 0, Cin, xc.dtype)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dshort=None):
         xc, wp, z, y, mean, invstd, g32, col, b32, pidx, rmask = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
@@ -1312,7 +1329,15 @@ class _ConvBnAct(torch.autograd.Function):
                     dbet = ops.unpad3_f32(dbet, Cout_l, 1, 1, 1).view(-1)
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
-        if ctx.wg_implicit:
+        # the common case: the split-K reduce scatters straight into the parameter's own gradient layout (no packed dWt, no
+        # scatter launch); the pixel-pair stem and channel-padded layers post-process the packed form instead
+        direct_dw = ctx.wg_implicit and ctx.pair is None and not padded
+        if direct_dw:
+            dw_master = sw.buf.view(wshape) if sw is not None else torch.empty(wshape, dtype=torch.float32, device=dz.device)
+            _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
+                                                master=dw_master, accumulate=(not sw.fresh) if sw is not None else False)
+            unpack = dwp = None
+        elif ctx.wg_implicit:
             dwt, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim,
                                                   defer_reduce=True)                        # [kh*kw*Cin, Cout] fp32
             unpack, dwp = ops.conv_weight_unpack_grad_t, dwt
@@ -1326,7 +1351,12 @@ class _ConvBnAct(torch.autograd.Function):
         def emit_dw():
             """Unpack / scatter the reduced weight gradient into the parameter layout (and the sink).  Runs BEHIND the data
             gradient: the implicit weight gradient leaves its split-K reduce to that launch's grid tail (``pend``)."""
-            if ctx.pair is not None:                                         # pixel-pair stem: adjoint of dvt_conv_weight_pairs
+            if direct_dw:                                                    # the reduce wrote it in place
+                if sw is not None:
+                    sw.mark_written()
+                else:
+                    dw_box[0] = dw_master
+            elif ctx.pair is not None:                                         # pixel-pair stem: adjoint of dvt_conv_weight_pairs
                 kh_o, kw_o, pw_o, kwp = ctx.pair
                 dw_pairs = unpack(dwp, w4)                                   # [Cout, 8, kh, kwp]
                 if sw is not None and Cout == Cout_l:
@@ -1359,15 +1389,27 @@ class _ConvBnAct(torch.autograd.Function):
         dx = None
         (sh_, sw_), (ph_, pw_) = ops._pair(stride), ops._pair(pad)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+        # the shortcut's gradient (ctx.fork): joins the data gradient inside the kernel that writes it, where that kernel can
+        joined = [dshort is None or not ctx.x_needs]
+        if dshort is not None:
+            dshort = _as(dshort.contiguous(), dz.dtype)
+
+        def join_alias():
+            """The full-size second gradient path for a kernel that adds it in its epilogue (None: nothing to add / compact)."""
+            if joined[0] or ctx.fork != "alias":
+                return None
+            joined[0] = True
+            return dshort.view(N * H * W, Cin)
         if (ctx.x_needs and ctx.w4 is not None and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0 and kw - 1 - pw_ >= 0
                 and (Ho, Wo) == (H + 2 * ph_ - kh + 1, W + 2 * pw_ - kw + 1)):
             wd = ops.conv_weight_pack_dgrad(ctx.w4, dtype)               # [Cin, kh*kw*Cout]
             pd = (kh - 1 - ph_, kw - 1 - pw_)
             if (HALO_CONV and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and pd == (1, 1)
                     and ops.conv3x3_c64_supported(dz, wd, N, Ho, Wo)):
-                dx = ops.conv3x3_c64(dz, wd, N, Ho, Wo)
+                dx = ops.conv3x3_c64(dz, wd, N, Ho, Wo, residual=join_alias())
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
-                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend)   # [N*H*W, Cin], no dcol / col2im
+                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
+                                         residual=join_alias())           # [N*H*W, Cin], no dcol / col2im
         if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
             dx = ops.zeros(ctx.x_shape, ctx.x_dtype, dz.device).view(N, Cin, H, W)
             hw = Ho * Wo
@@ -1381,34 +1423,48 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = dcol
             elif nchw:      # gradient w.r.t. the raw NCHW frames (pixel-space CLS clip, frame_transformer.py:105)
                 dx = ops.col2im_nchw(dcol, N, Cin, H, W, k, stride, pad, ctx.x_dtype).view(ctx.x_shape)
+            elif not joined[0] and Cin % 8 == 0 and ld % 8 == 0:          # the shortcut's gradient joins inside col2im
+                joined[0] = True
+                if ctx.fork == "alias":
+                    dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad, add=dshort.view(N * H * W, Cin))
+                else:
+                    dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad, add=dshort, add_stride=int(ctx.fork))
             else:
                 dx = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
+        if not joined[0]:                        # a path without a fused form (1x1 / stride-1 layers, the fp32 parity mode)
+            dfull = dshort.view(dx.shape) if ctx.fork == "alias" else ops.col2im(dshort, N, Cin, H, W, 1, int(ctx.fork), 0)
+            dx = ops.add(dx.contiguous(), dfull.view(dx.shape))
         ops.splitk_reduce_pending(pend)          # nobody carried it (no data gradient wanted, or the halo kernel computed it)
         emit_dw()
         dw = dw_box[0]
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
-                dtype=torch.bfloat16, pool: bool = False):
+                dtype=torch.bfloat16, pool: bool = False, fork=None, stride=None):
     """geom = (N, Cin, H, W, nchw).  Kernel size / stride / padding come from ``conv``.  pool: the layer is followed by
     MaxPool2d(3, 2, 1); the pooled map is returned (see _ConvBnAct)."""
     N, Cin, H, W, nchw = geom
     assert conv.bias is None and conv.groups == 1
-    return conv_bn_act_raw(x, conv.weight, bn, geom, tuple(conv.kernel_size), tuple(conv.stride),
-                           tuple(conv.padding), relu=relu, residual=residual, dtype=dtype, pool=pool)
+    return conv_bn_act_raw(x, conv.weight, bn, geom, tuple(conv.kernel_size), tuple(conv.stride) if stride is None else stride,
+                           tuple(conv.padding), relu=relu, residual=residual, dtype=dtype, pool=pool, fork=fork)
 
 
 def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16,
-                    cpad: int = 0, dx_frames=None, pool: bool = False):
+                    cpad: int = 0, dx_frames=None, pool: bool = False, fork=None):
     """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
     Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
     (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
     N, Cin, H, W, nchw = geom
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    if fork is not None and not (torch.is_grad_enabled() and x.requires_grad):       # nothing to join: hand the shortcut its input
+        y = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                             (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool)
+        return y, (x if fork == "alias" else subsample_nhwc(x, N, Cin, H, W, int(fork)))
     return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool)
+                            (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool,
+                            fork)
 
 
 class _Subsample(torch.autograd.Function):

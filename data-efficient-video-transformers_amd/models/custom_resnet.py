@@ -40,10 +40,16 @@ def _out_hw(conv: nn.Conv2d, H: int, W: int):
     return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
 
-def _cba(fm: FMap, conv, bn, relu, residual=None, dtype=torch.bfloat16) -> FMap:
+def _cba(fm: FMap, conv, bn, relu, residual=None, dtype=torch.bfloat16, fork=None, stride=None):
+    """conv -> bn (-> + residual) (-> relu) on an NHWC map.  fork: the map has a second consumer (the block's shortcut) and the
+    layer hands it out as a second result (see F._ConvBnAct): -> (FMap, second).  stride: overrides the module's (a strided
+    1x1 downsample convolution applied to an already subsampled map runs with stride 1)."""
     x, N, H, W = fm
-    y = F.conv_bn_act(x, conv, bn, (N, conv.in_channels, H, W, False), relu=relu, residual=residual, dtype=dtype)
-    Ho, Wo = _out_hw(conv, H, W)
+    y = F.conv_bn_act(x, conv, bn, (N, conv.in_channels, H, W, False), relu=relu, residual=residual, dtype=dtype, fork=fork,
+                      stride=stride)
+    Ho, Wo = _out_hw(conv, H, W) if stride is None else (H, W)
+    if fork is not None:
+        return (y[0], N, Ho, Wo), y[1]
     return (y, N, Ho, Wo)
 
 
@@ -66,12 +72,27 @@ class _ResidualBlock(nn.Module):
         self.stride = stride
 
     def forward_nhwc(self, fm: FMap, dtype) -> FMap:
-        x_main, shortcut = F.fork(fm[0])                       # two consumers: their gradients are summed by dvt_add
-        fm = (x_main,) + tuple(fm[1:])
-        if self.downsample is not None:
-            shortcut = _cba((shortcut,) + tuple(fm[1:]), self.downsample[0], self.downsample[1], False, dtype=dtype)[0]
-        out = fm
-        for i in range(1, self.depth):
+        # The block input has two consumers, conv1 and the shortcut.  conv1's Function hands the shortcut its input as a second
+        # result, so that the shortcut's gradient comes back to it and joins conv1's data gradient inside the kernel that writes
+        # it (no add kernel).  A strided 1x1 downsample convolution gets the SUBSAMPLED map (its own gather) and runs with
+        # stride 1 on it: its input gradient then returns compact instead of as a zero-filled full-size map.
+        ds = self.downsample
+        fork = "alias"
+        if ds is not None:
+            dconv = ds[0]
+            s_ = dconv.stride[0]
+            if dconv.kernel_size == (1, 1) and dconv.padding == (0, 0) and dconv.stride == (s_, s_) and s_ > 1:
+                fork = s_
+        out, second = _cba(fm, self.conv1, self.bn1, True, dtype=dtype, fork=fork)
+        _, N, H, W = fm
+        if ds is None:
+            shortcut = second
+        elif fork == "alias":
+            shortcut = _cba((second, N, H, W), ds[0], ds[1], False, dtype=dtype)[0]
+        else:
+            Hs, Ws = (H + fork - 1) // fork, (W + fork - 1) // fork
+            shortcut = _cba((second, N, Hs, Ws), ds[0], ds[1], False, dtype=dtype, stride=(1, 1))[0]
+        for i in range(2, self.depth):
             out = _cba(out, getattr(self, f"conv{i}"), getattr(self, f"bn{i}"), True, dtype=dtype)
         last = self.depth                                     # out += residual; relu  (fused into the BatchNorm pass)
         return _cba(out, getattr(self, f"conv{last}"), getattr(self, f"bn{last}"), True, residual=shortcut, dtype=dtype)

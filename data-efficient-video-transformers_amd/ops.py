@@ -1040,13 +1040,20 @@ def im2col(x: Tensor, nchw: bool, N: int, Cc: int, H: int, W: int, k, stride, pa
     return out
 
 
-def col2im(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad) -> Tensor:
-    _need_cuda(dcol)
+def col2im(dcol: Tensor, N: int, Cc: int, H: int, W: int, k, stride, pad, *, add: Optional[Tensor] = None,
+           add_stride: int = 0) -> Tensor:
+    """add: a second gradient path into the same map, summed in the same pass -- [N*H*W, C] (add_stride 0), or the compact
+    gradient of the map's stride-``add_stride`` subsampling, added at the pixels that subsampling reads."""
+    _need_cuda(dcol, add)
     assert dcol.is_contiguous()
     (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     dx = torch.empty((N * H * W, Cc), dtype=dcol.dtype, device=dcol.device)
+    if add is not None:
+        s_ = add_stride
+        rows = N * H * W if s_ == 0 else N * ((H + s_ - 1) // s_) * ((W + s_ - 1) // s_)
+        assert add.is_contiguous() and add.dtype == dcol.dtype and tuple(add.shape) == (rows, Cc)
     L.check(L.load().dvt_col2im(dcol.data_ptr(), dx.data_ptr(), N, Cc, H, W, kh, kw, sh, sw, ph, pw, dcol.shape[1],
-                                dt(dcol), _stream()), "dvt_col2im")
+                                _p(add), add_stride, dt(dcol), _stream()), "dvt_col2im")
     return dx
 
 
@@ -1133,24 +1140,26 @@ def conv3x3_c64_supported(x: Tensor, wp: Tensor, N: int, H: int, W: int) -> bool
     return bool(L.load().dvt_conv3x3_c64_supported(N, H, W, dt(x)))
 
 
-def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool = False):
+def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool = False, residual: Optional[Tensor] = None):
     """3x3 / 1 / 1 convolution, 64 -> 64 channels, from an LDS-resident halo patch (dvt_conv3x3_c64); same contract as
-    conv2d_implicit."""
-    _need_cuda(x, wp)
+    conv2d_implicit (residual: added to the output)."""
+    _need_cuda(x, wp, residual)
     y = torch.empty((N * H * W, 64), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == y.shape
     lib = L.load()
     partial, parts = None, 0
     if want_stats:
         parts = int(lib.dvt_conv3x3_c64_stats_parts(N, H, W))
         partial = workspace((parts + 64) * 2 * 64 * 4, x.device, slot="bn_partial")
     with _timed(("conv", "halo3x3_c64", N * H * W, 64, 576, (2 * x.numel() + wp.numel()) * x.element_size()), 2.0 * N * H * W * 64 * 576):
-        L.check(lib.dvt_conv3x3_c64(x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(partial), N, H, W, dt(x), _stream()),
-                "dvt_conv3x3_c64")
+        L.check(lib.dvt_conv3x3_c64(x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(partial), _p(residual), N, H, W, dt(x),
+                                    _stream()), "dvt_conv3x3_c64")
     return (y, partial, parts) if want_stats else y
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                    want_stats: bool = False, trim_w: int = 0, carry=None):
+                    want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
     want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
     epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
@@ -1159,6 +1168,9 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
     Wo -= trim_w                                  # columns dropped at the right edge (dvt_conv_desc.trim_w)
     y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
     d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad, trim_w)
+    if residual is not None:                          # a second gradient path joining this one: added on the accumulators
+        assert residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == y.shape and not want_stats
+        d.residual = residual.data_ptr()
     lib = L.load()
     partial, parts = None, 0
     if want_stats:
@@ -1166,7 +1178,7 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         partial = workspace(lib.dvt_conv2d_implicit_stats_bytes(C.byref(d)), x.device, slot="bn_partial")
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
-    nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
+    nb = (x.numel() + wp.numel() + y.numel() * (2 if residual is not None else 1)) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
     if carry is not None and carry.valid:             # the layer's weight-gradient reduce rides in this launch's grid tail
         d.carry = C.addressof(carry)
     with _timed(("conv", "implicit", N * Ho * Wo, Cout, kh * kw * Cc, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
@@ -1196,14 +1208,23 @@ def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k,
 
 
 def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                          trim_w: int = 0, defer_reduce: bool = False):
+                          trim_w: int = 0, defer_reduce: bool = False, master: Optional[Tensor] = None,
+                          accumulate: bool = False):
     """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised.
     defer_reduce: -> (dWt, pending): the split-K reduce is left to the data-gradient launch of the same layer
-    (``conv2d_implicit(..., carry=pending)`` / ``linear_dgrad(..., carry=pending)``) or ``splitk_reduce_pending``."""
-    _need_cuda(x, dz)
+    (``conv2d_implicit(..., carry=pending)`` / ``linear_dgrad(..., carry=pending)``) or ``splitk_reduce_pending``.
+    master: the parameter's own gradient f32 [Cout, C, kh, kw] (+= when accumulate): the reduce scatters into it directly
+    and it is what is returned in dWt's place (no packed intermediate, no scatter launch)."""
+    _need_cuda(x, dz, master)
     (kh, kw) = _pair(k)
-    out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
+    if master is not None:
+        assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == Cout * Cc * kh * kw
+        out = master
+    else:
+        assert not accumulate
+        out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
     d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad, trim_w)
+    d.wgrad_master_layout, d.wgrad_accumulate = int(master is not None), int(accumulate)
     lib = L.load()
     pending = L.SplitKPending() if defer_reduce else None
     nws = lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d))

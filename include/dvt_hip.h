@@ -224,6 +224,10 @@ typedef struct dvt_splitk_pending {
   int32_t cs_accumulate;
   const float* cs_slab;    /* [splits][M] f32 or NULL */
   float* cs_out;           /* [M] f32 */
+  /* conv_taps > 0: the product is the weight gradient of a convolution, rows m = tap * conv_cin + ci, columns n = co, and
+   * the reduce scatters it straight into the parameter's own layout C[co][ci][tap] (f32 [N][conv_cin][conv_taps], ldc
+   * unused): no packed intermediate, no scatter launch behind the reduce. */
+  int32_t conv_cin, conv_taps;
 } dvt_splitk_pending;
 
 typedef struct dvt_gemm_desc {
@@ -457,9 +461,12 @@ int dvt_nchw_to_nhwc_pad(const void* x, int x_dtype, void* y, int y_dtype, int64
 int dvt_conv_weight_pairs(const float* w, float* wp, int Cout, int Cin, int kh, int kw, int pw, int kwp, dvt_stream_t stream);
 int dvt_conv_weight_pairs_bwd(const float* dwp, float* dw, int Cout, int Cin, int kh, int kw, int pw, int kwp, int accumulate,
                               dvt_stream_t stream);
-/* Adjoint gather (data gradient of the convolution), NHWC, C % 8 == 0. */
+/* Adjoint gather (data gradient of the convolution), NHWC.  Optional second gradient path into the same map, summed in
+ * the same pass (a residual block's shortcut joining its first convolution's data gradient, custom_resnet.py:38-54):
+ * add [N*H*W, C] when add_stride == 0; else the COMPACT gradient [N*ceil(H/s)*ceil(W/s), C] of the map's stride-s
+ * subsampling (the input of a strided 1x1 downsample convolution), added at the pixels with h % s == 0 and w % s == 0. */
 int dvt_col2im(const void* dcol, void* dx, int64_t N, int C, int H, int W, int kh, int kw, int sh, int sw,
-               int ph, int pw, int64_t ld, int dtype, dvt_stream_t stream);
+               int ph, int pw, int64_t ld, const void* add, int add_stride, int dtype, dvt_stream_t stream);
 /* Same adjoint written in NCHW order and in the clip's own dtype: the gradient of the stem w.r.t. the raw
  * frames (needed by the learnable pixel-space CLS clip, frame_transformer.py:105,195). */
 int dvt_col2im_nchw(const void* dcol, int dtype, void* dx, int dx_dtype, int64_t N, int C, int H, int W, int kh,
@@ -504,6 +511,12 @@ typedef struct dvt_conv_desc {
   int32_t defer_reduce;
   dvt_splitk_pending* pending;
   const dvt_splitk_pending* carry;
+  /* forward / data gradient, optional: y = conv(x) + residual, residual [N*Ho*Wo, Cout] in the map's dtype, added on the fp32
+   * accumulators (the shortcut's gradient joining a block input's gradient, custom_resnet.py:38-54: no add kernel). */
+  const void* residual;
+  /* weight gradient, optional: y is the parameter's own gradient f32 [Cout][C][kh][kw] (+= when wgrad_accumulate) instead
+   * of the packed dWt -- the split-K reduce scatters into it (dvt_splitk_pending.conv_taps). */
+  int32_t wgrad_master_layout, wgrad_accumulate;
 } dvt_conv_desc;
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
  * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a
@@ -514,8 +527,8 @@ typedef struct dvt_conv_desc {
  * must fit beside the weights in 160 KiB); callers fall back to dvt_conv2d_implicit otherwise. */
 int dvt_conv3x3_c64_supported(int64_t N, int H, int W, int dtype);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
-int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, int64_t N, int H, int W, int dtype,
-                    dvt_stream_t stream);
+int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
+                    int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */

@@ -221,6 +221,9 @@ def test_conv3x3_c64_from_an_lds_halo_patch(dvt, device, dtype, N, H, W):
     assert rel_l2(invstd.cpu().double(), 1.0 / torch.sqrt(zf.var(0, unbiased=False) + 1e-5)) < 2e-3
     z2 = ops.conv3x3_c64(xd, wp, N, H, W)                            # no statistics: same values
     assert torch.equal(z, z2)
+    res = torch.randn(N * H * W, 64, generator=g).to(dtype).cuda()     # the shortcut's gradient joining a data gradient
+    z3 = ops.conv3x3_c64(xd, wp, N, H, W, residual=res)
+    assert torch.equal(z3, (z.float() + res.float()).to(dtype))
 
 
 def test_maxpool_first_max_and_eval_bn(dvt, device):
@@ -577,6 +580,14 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
         dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw))
         dref = ops.col2im(ops.linear_dgrad(dz, wp), N, Cin, H, W, k, stride, pad)
         assert dx.shape == dref.shape and rel_l2(dx, dref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+        # a second gradient path (the block's shortcut) added on the accumulators: == the plain result + the operand, to one
+        # rounding of the element type; the same operand through col2im's second input
+        res = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
+        dx_r = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw), residual=res)
+        eps16 = 8e-3 if dtype == torch.bfloat16 else 1e-3
+        assert float((dx_r.float() - (dx.float() + res.float())).abs().max()) <= eps16 * float((dx.float().abs() + res.float().abs()).max())
+        dref_r = ops.col2im(ops.linear_dgrad(dz, wp), N, Cin, H, W, k, stride, pad, add=res)
+        assert float((dref_r.float() - (dref.float() + res.float())).abs().max()) <= eps16 * float((dref.float().abs() + res.float().abs()).max())
     # unsupported geometry is reported, not mis-computed
     x45 = torch.zeros(4 * 8 * 8, 40, dtype=dtype, device="cuda")
     assert not ops.conv2d_implicit_supported(x45, ops.conv_weight_pack(torch.zeros(64, 40, 3, 3, device="cuda"), 360, dtype),
@@ -612,6 +623,47 @@ def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype,
     acc = torch.ones_like(dw)
     ops.conv_weight_unpack_grad_t(dwt, (Cout, Cin, kh, kw), out=acc, accumulate=True)
     assert rel_l2(acc - 1.0, dw) < 1e-5
+    # the split-K reduce scattering straight into the parameter's own layout: same sums, bit for bit -- stand-alone,
+    # deferred + flushed, deferred + carried by the data-gradient launch, and accumulating into an existing gradient
+    m1 = torch.full((Cout, Cin, kh, kw), float("nan"), device="cuda")
+    ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad, master=m1)
+    assert torch.equal(m1, dw)
+    m2 = torch.full((Cout, Cin, kh, kw), float("nan"), device="cuda")
+    _, pend = ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad, master=m2, defer_reduce=True)
+    ops.splitk_reduce_pending(pend)
+    assert torch.equal(m2, dw)
+    m3 = torch.ones((Cout, Cin, kh, kw), device="cuda")
+    _, pend = ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad, master=m3, defer_reduce=True, accumulate=True)
+    if ops._pair(stride) == (1, 1) and Cin % 32 == 0:
+        wd = ops.conv_weight_pack_dgrad(torch.randn(Cout, Cin, kh, kw, generator=g).cuda() * 0.05, dtype)
+        (ph, pw) = ops._pair(pad)
+        if ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw)):
+            ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw), carry=pend)
+    ops.splitk_reduce_pending(pend)                      # (no-op when the data gradient carried it)
+    assert rel_l2(m3 - 1.0, dw) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
+def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
+    """The first block of a ResNet stage (custom_resnet.py:121-136): its input feeds a 3x3 / 2 convolution and a 1x1 / 2
+    downsample convolution.  dvt_col2im sums the 3x3 path's adjoint gather and the downsample's COMPACT input gradient
+    (added at the pixels the stride-2 subsampling reads) in one pass == col2im + zero-filled col2im + add."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(5)
+    N, C = 3, 16
+    Ho, Wo = ops.conv_out_hw(H, W, 3, 2, 1)
+    dcol = torch.randn(N * Ho * Wo, 9 * C, generator=g).to(dtype).cuda()
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    dsub = torch.randn(N * Hs * Ws, C, generator=g).to(dtype).cuda()
+    got = ops.col2im(dcol, N, C, H, W, 3, 2, 1, add=dsub, add_stride=2)
+    a, b = ops.col2im(dcol, N, C, H, W, 3, 2, 1), ops.col2im(dsub, N, C, H, W, 1, 2, 0)
+    want = a.float() + b.float()
+    assert float((got.float() - want).abs().max()) <= (1e-6 if dtype == torch.float32 else 8e-3) * float(want.abs().max())
+    full = torch.randn(N * H * W, C, generator=g).to(dtype).cuda()
+    got2 = ops.col2im(dcol, N, C, H, W, 3, 2, 1, add=full)
+    want2 = a.float() + full.float()
+    assert float((got2.float() - want2).abs().max()) <= (1e-6 if dtype == torch.float32 else 8e-3) * float(want2.abs().max())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

@@ -1,0 +1,53 @@
+"""Per-STEP kernel table from a rocprofv3 kernel trace: steps are the intervals between consecutive optimizer launches
+(`adamw_fused_kernel`), so one-time set-up work (parameter copies, warm-up allocations) is not smeared over the steps.
+The last <keep> full steps are averaged, split by (kernel, grid, block).
+
+    python3 tools/dev/trace_steps.py <kernel_trace.csv> [keep=3] [top=60]
+"""
+import collections
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", n)
+    n = re.sub(r"^void ", "", n)
+    return n[:72]
+
+
+marks = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+# a step = the kernels after one optimizer launch up to and including the next, if there are enough of them
+steps = [(a + 1, b + 1) for a, b in zip(marks, marks[1:]) if b - a > 20]
+steps = steps[-keep:]
+if not steps:
+    sys.exit("no steps found (no adamw launches?)")
+agg = collections.defaultdict(lambda: [0, 0.0])
+span = 0.0
+for a, b in steps:
+    span += (int(rows[b - 1]["End_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6
+    for r in rows[a:b]:
+        g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        k = (short(r["Kernel_Name"]), g, int(r["Workgroup_Size_X"]))
+        agg[k][0] += 1
+        agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+n = len(steps)
+tot = sum(v[1] for v in agg.values()) / n
+print(f"# {n} steps; kernel time {tot / 1e3:.3f} ms/step, wall span {span / n:.3f} ms/step, {sum(v[0] for v in agg.values()) / n:.0f} launches/step")
+print("| kernel | grid | block | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|---|---|")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    print(f"| `{k[0]}` | {k[1]} | {k[2]} | {v[0] / n:.2f} | {v[1] / n / 1e3:.4f} | {v[1] / v[0]:.1f} | {100 * v[1] / n / tot:.1f} |")
+# by kernel name only
+byname = collections.defaultdict(lambda: [0, 0.0])
+for k, v in agg.items():
+    byname[k[0]][0] += v[0]
+    byname[k[0]][1] += v[1]
+print("\n# by kernel name")
+for k, v in sorted(byname.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{v[1] / n / 1e3:8.4f} ms {v[0] / n:7.2f} calls  {k}")
