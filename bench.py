@@ -809,6 +809,8 @@ def main():
                     "without folding the K / V projections into the query (functional.CLS_FOLD_MIN_ROWS)")
     ap.add_argument("--no-pair-launch", action="store_true", help="A/B switch: weight and data gradient of the launch-bound "
                     "Linears as two launches (ops.PAIR_LAUNCH)")
+    ap.add_argument("--attn-two-pass", action="store_true", help="A/B switch: attention backward as the dq + dk/dv kernel pair "
+                    "instead of the one-pass kernel (ops.ATTN_BWD_TWO_PASS)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test (runs without a GPU): every rank joins "
                     "the process group, sums its rank over the group and rank 0 prints a JSON line with n_gpus = world")
     args = ap.parse_args()
@@ -853,6 +855,8 @@ def main():
         dvt_amd.functional.CLS_FOLD_MIN_ROWS = 1 << 62
     if args.no_pair_launch:
         dvt_amd.ops.PAIR_LAUNCH = False
+    if args.attn_two_pass:
+        dvt_amd.ops.ATTN_BWD_TWO_PASS = True
     if use_dist and args.backend == "nccl":
         from dvt_amd.dp import Communicator
         try:

@@ -69,6 +69,7 @@ class AttnDesc(C.Structure):
         ("scale", c_f), ("dtype", C.c_int32),
         ("workspace", c_p),
         ("dropout_p", c_f), ("rng_state", c_p), ("rng_offset", C.c_uint64),
+        ("bwd_two_pass", C.c_int32),
     ]
 
 

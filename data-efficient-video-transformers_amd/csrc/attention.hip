@@ -966,6 +966,262 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(const AttnParam
   }
 }
 
+// ---------------------------------------------------------------- backward in ONE pass (Lq, Lk <= 224, equal 32-row padding)
+// One workgroup per (batch, head).  Q, dO and K are staged once as LDS images, P comes from the saved lse (no row
+// reductions), delta = rowsum(dO * O) is taken while dO is staged: 5 MFMA products per (query, key) block instead of the 7 of
+// the dq / dkdv pair, every operand through the CU's memory pipeline once (8 u of traffic per layer instead of 13 u).
+//   * compute waves (one per 32 keys): the wave keeps the K and V rows of its two 16-key tiles in registers (B operands) and
+//     dK^T / dV^T of those keys in accumulators for the whole kernel; per 32-query step it forms S and dP for its keys
+//     (A = Q / dO row fragments of the images), P and dS, and adds dO^T P and Q^T dS to its accumulators -- the dkdv kernel's
+//     step on two key tiles at once, so every Q / dO fragment read from LDS feeds two MFMAs;
+//   * dQ needs the sum over ALL keys, i.e. over the waves.  Instead of reducing 32 x 64 fp32 partials per wave, the waves
+//     write their dS blocks (16-bit, [key][32 queries], the layout their accumulators have) into a strip of 18 KiB; behind
+//     the step's barrier ONE wave -- a dedicated dQ wave -- multiplies the whole strip (A = K^T from the K image, B = dS^T by
+//     the transposing LDS read) and owns the complete sum over the keys: fixed order, no atomics, bitwise reproducible.  The
+//     strip is double-buffered, so the dQ wave works on step s while the compute waves run step s + 1: one barrier per step.
+constexpr int kStripRow = 80;        // bytes per key row of a strip: 32 queries x 2 B + 16 B of padding (bank spread)
+
+template <typename E>
+__device__ __forceinline__ typename Elem16<E>::v8 strip_tr_frag(const char* strip, int ta, int tb, int col0, int g, int li) {
+  // element j of lane (g, li) = strip[16 * (j < 4 ? ta : tb) + 4 g + (j & 3)][col0 + li]   (col0 = 0 or 16)
+  const int qq = li >> 2, pp = li & 3;
+  typename Elem16<E>::v4 half[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int r = 16 * (hf ? tb : ta) + 4 * g + qq;
+    half[hf] = Elem16<E>::tr_read(strip + r * kStripRow + col0 * 2 + 8 * pp);
+  }
+  return __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Prologue of the one-pass backward: Q, dO and K into their images (rows >= L zero) and, from the dO / O chunks of the same
+// loads, -delta[r] = -sum_e dO[r][e] * O[r][e] (the 8 chunks of a row sit on 8 consecutive lanes: blockDim is a multiple of
+// 8).  EVERY load of the workgroup -- NCH chunks per thread and matrix -- is issued before the first LDS write: one memory
+// round trip under full-chip load costs ~5 k clocks, and three staging loops in sequence paid it three times.
+template <typename E, int NCH>
+__device__ __forceinline__ void stage_bwd_operands(char* qs, const E* q, int64_t q_sl, char* gs, const E* g, const E* o, int64_t o_sl,
+                                                   char* ks, const E* k, int64_t k_sl, int Lq, int Lk, int rows_pad, float* dls) {
+  using V8 = typename Elem16<E>::v8;
+  const int total = rows_pad * 8, nt = blockDim.x;
+  V8 vq[NCH], vg[NCH], vo[NCH], vk[NCH];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int idx = min((int)threadIdx.x + u * nt, total - 1);      // past the end: the last chunk again (same data, same slot)
+    const int r = idx >> 3, c = idx & 7;
+    const int rq = r < Lq ? r : 0, rk = r < Lk ? r : 0;
+    vq[u] = *reinterpret_cast<const V8*>(q + (int64_t)rq * q_sl + c * 8);
+    vg[u] = *reinterpret_cast<const V8*>(g + (int64_t)rq * o_sl + c * 8);
+    vo[u] = *reinterpret_cast<const V8*>(o + (int64_t)rq * o_sl + c * 8);
+    vk[u] = *reinterpret_cast<const V8*>(k + (int64_t)rk * k_sl + c * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const V8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int idx = min((int)threadIdx.x + u * nt, total - 1);
+    const int r = idx >> 3, off = img_off(r, idx & 7);
+    const bool lq = r < Lq, lk = r < Lk;
+    *reinterpret_cast<V8*>(qs + off) = lq ? vq[u] : zero;
+    *reinterpret_cast<V8*>(gs + off) = lq ? vg[u] : zero;
+    *reinterpret_cast<V8*>(ks + off) = lk ? vk[u] : zero;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d = fmaf((float)vg[u][j], (float)vo[u][j], d);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if ((idx & 7) == 0) dls[r] = lq ? -d : 0.f;
+  }
+}
+
+template <typename E, int NP>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  using V4 = typename Elem16<E>::v4;
+  constexpr int LP = 32 * NP;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockDim.x >> 6, WC = W - 1;              // WC compute waves (32 keys each) + the dQ wave
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const E* qb = (const E*)p.q + b * p.q_sb + h * p.q_sh;
+  const E* kb = (const E*)p.k + b * p.k_sb + h * p.k_sh;
+  const E* vb = (const E*)p.v + b * p.v_sb + h * p.v_sh;
+  const E* ob = (const E*)p.o + b * p.o_sb + h * p.o_sh;
+  const E* gb = (const E*)p.d_o + b * p.o_sb + h * p.o_sh;
+  E* dqb = (E*)p.dq + b * p.q_sb + h * p.q_sh;
+  E* dkb = (E*)p.dk + b * p.k_sb + h * p.k_sh;
+  E* dvb = (E*)p.dv + b * p.v_sb + h * p.v_sh;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  char* qs = smem;
+  char* gs = qs + LP * kRowBytes;
+  char* ks = gs + LP * kRowBytes;
+  char* strip0 = ks + LP * kRowBytes;
+  float* l2s = reinterpret_cast<float*>(strip0 + 2 * LP * kStripRow);   // -lse * log2e, [LP]
+  float* dls = l2s + LP;                                                // -delta, [LP]
+  char* patch = reinterpret_cast<char*>(dls + LP) + wid * 2048;
+
+  // phase: start
+  // ---- prologue: the compute waves' K / V rows (in flight while the images are staged), images, per-row statistics
+  V8 kf[2][2], vf[2][2];
+  if (wid < WC) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kj = (2 * wid + j) * 16 + li;
+      const int krow = kj < p.Lk ? kj : p.Lk - 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        kf[j][kk] = *reinterpret_cast<const V8*>(kb + (int64_t)krow * p.k_sl + kk * 32 + g * 8);
+        vf[j][kk] = *reinterpret_cast<const V8*>(vb + (int64_t)krow * p.v_sl + kk * 32 + g * 8);
+      }
+    }
+  }
+  {
+    const int r = threadIdx.x;                       // (blockDim >= LP: one row statistic per thread, in the same round trip)
+    const float l = lse[r < p.Lq ? r : 0];
+    // NCH chunks per thread cover an image: LP * 8 = 256 NP <= NCH * blockDim = 256 (NP + 1)
+    stage_bwd_operands<E, 4>(qs, qb, p.q_sl, gs, gb, ob, p.o_sl, ks, kb, p.k_sl, p.Lq, p.Lk, LP, dls);
+    if (r < LP) l2s[r] = r < p.Lq ? -l * kLog2e : 0.f;
+  }
+  __syncthreads();
+  // phase: staged
+  const float c2 = p.scale * kLog2e;
+  if (wid < WC) {
+    // ------------------------------------------------------------ compute wave: keys [32 wid, 32 wid + 32)
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    const f32x2 c2v = {c2, c2};
+    const bool kvalid[2] = {(2 * wid) * 16 + li < p.Lk, (2 * wid + 1) * 16 + li < p.Lk};
+    char* myrow[2] = {strip0 + ((2 * wid) * 16 + li) * kStripRow + g * 8, strip0 + ((2 * wid + 1) * 16 + li) * kStripRow + g * 8};
+#pragma unroll
+    for (int qp = 0; qp < NP; ++qp) {
+      asm volatile("" ::: "memory");                 // image fragments are loop-invariant in form: keep their reads in the step
+      V8 qfr[2][2], gfr[2][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          qfr[tt][kk] = img_row_frag<E>(qs, (2 * qp + tt) * 16, kk, g, li);
+          gfr[tt][kk] = img_row_frag<E>(gs, (2 * qp + tt) * 16, kk, g, li);
+        }
+      f32x4 l2[2], dl[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        l2[tt] = *reinterpret_cast<const f32x4*>(l2s + (2 * qp + tt) * 16 + 4 * g);
+        dl[tt] = *reinterpret_cast<const f32x4*>(dls + (2 * qp + tt) * 16 + 4 * g);
+      }
+      V8 pf[2], dsf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            // D[row = query 4g + r][col = key li]
+            s[tt] = Elem16<E>::mma(qfr[tt][kk], kf[j][kk], s[tt]);
+            dp[tt] = Elem16<E>::mma(gfr[tt][kk], vf[j][kk], dp[tt]);
+          }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 x = __builtin_elementwise_fma(f32x2{s[tt][r], s[tt][r + 1]}, c2v, f32x2{l2[tt][r], l2[tt][r + 1]});
+            const f32x2 d = f32x2{dp[tt][r], dp[tt][r + 1]} + f32x2{dl[tt][r], dl[tt][r + 1]};
+            f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            if (!kvalid[j]) pr = f32x2{0.f, 0.f};    // keys >= Lk: their K / V rows are clamped copies
+            const f32x2 ds = pr * d;
+            s[tt][r] = pr[0];
+            s[tt][r + 1] = pr[1];
+            dp[tt][r] = ds[0];
+            dp[tt][r + 1] = ds[1];
+          }
+        pf[j] = pack_pair<E>(s[0], s[1]);
+        dsf[j] = pack_pair<E>(dp[0], dp[1]);
+      }
+      // dS^T of this step for the dQ wave: row = key, 32 queries of the step (this lane: queries 4g .. 4g+3 of either tile)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        char* row = myrow[j] + (qp & 1) * (LP * kStripRow);
+        *reinterpret_cast<V4*>(row) = __builtin_shufflevector(dsf[j], dsf[j], 0, 1, 2, 3);
+        *reinterpret_cast<V4*>(row + 32) = __builtin_shufflevector(dsf[j], dsf[j], 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const V8 gt = img_tr_frag<E>(gs, 2 * qp, 2 * qp + 1, dt * 16, g, li);
+        const V8 qt = img_tr_frag<E>(qs, 2 * qp, 2 * qp + 1, dt * 16, g, li);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          dv[j][dt] = Elem16<E>::mma(gt, pf[j], dv[j][dt]);
+          dk[j][dt] = Elem16<E>::mma(qt, dsf[j], dk[j][dt]);
+        }
+      }
+      // phase: work
+      __syncthreads();                                // strip (qp & 1) complete; the dQ wave takes it from here
+      // phase: step
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k0 = (2 * wid + j) * 16;
+      if (k0 < p.Lk) {                                // wave-uniform
+        store_tile<E>(patch, dkb, p.k_sl, k0, p.Lk, dk[j], p.scale, lane);
+        store_tile<E>(patch, dvb, p.v_sl, k0, p.Lk, dv[j], 1.0f, lane);
+      }
+    }
+    // phase: stored
+  } else {
+    // ------------------------------------------------------------ dQ wave: dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
+    // The K^T fragments (A operands) do not change from step to step: all 4 NP of them are read once and stay in registers
+    // (112 at NP = 7; this wave holds no dK / dV accumulators), so a step costs 2 NP strip reads and 8 NP MFMAs.
+    V8 ka[NP][4];
+#pragma unroll
+    for (int kp = 0; kp < NP; ++kp)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ka[kp][dt] = img_tr_frag<E>(ks, 2 * kp, 2 * kp + 1, dt * 16, g, li);
+#pragma unroll 1
+    for (int qp = 0; qp < NP; ++qp) {
+      __syncthreads();
+      const char* strip = strip0 + (qp & 1) * (LP * kStripRow);
+      V8 bq[NP][2];
+#pragma unroll
+      for (int kp = 0; kp < NP; ++kp) {
+        bq[kp][0] = strip_tr_frag<E>(strip, 2 * kp, 2 * kp + 1, 0, g, li);
+        bq[kp][1] = strip_tr_frag<E>(strip, 2 * kp, 2 * kp + 1, 16, g, li);
+      }
+      // phase: dq read
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[tt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kp = 0; kp < NP; ++kp)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          acc[0][dt] = Elem16<E>::mma(ka[kp][dt], bq[kp][0], acc[0][dt]);
+          acc[1][dt] = Elem16<E>::mma(ka[kp][dt], bq[kp][1], acc[1][dt]);
+        }
+      // phase: dq mfma
+      // this wave is the critical path of a step: its tiles go out as per-lane 8-byte stores straight from the accumulators
+      // (the whole-row form through the LDS patch costs the wave two more LDS round trips per tile)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        if ((2 * qp + tt) * 16 < p.Lq) store_tile<E>(nullptr, dqb, p.q_sl, (2 * qp + tt) * 16, p.Lq, acc[tt], p.scale, lane);
+      // phase: dq unit
+    }
+  }
+}
+
 // ======================================================================= host
 constexpr int kMaxLds = 160 * 1024;
 
@@ -995,6 +1251,7 @@ int fill_params(const dvt_attn_desc* d, AttnParams& p, bool bwd, const char* nam
   p.Lkp = (p.Lk + 31) & ~31;
   p.Lqp = (p.Lq + 31) & ~31;
   p.patch_off = -1;
+
   return DVT_OK;
 }
 
@@ -1022,6 +1279,13 @@ bool q1_ok(const dvt_attn_desc* d, const AttnParams& p) {
 bool mfma_bwd_ok(const dvt_attn_desc* d, const AttnParams& p) {
   return mfma_fwd_ok(d, p) && dvt_aligned16(d->d_o) && dvt_aligned16(d->dq) && dvt_aligned16(d->dk) &&
          dvt_aligned16(d->dv) && 2 * p.Lqp * kRowBytes + 2 * p.Lqp * 4 <= kMaxLds;
+}
+
+// the one-pass backward: both lengths padded to the same multiple of 32, at most 224 (three 28 KiB images + two strips)
+bool fused_bwd_ok(const AttnParams& p) { return p.Lqp == p.Lkp && p.Lkp <= 224; }
+size_t fused_bwd_lds(int NP, int waves) {
+  const size_t LP = 32 * (size_t)NP;
+  return 3 * LP * kRowBytes + 2 * LP * kStripRow + 2 * LP * sizeof(float) + (size_t)waves * 2048;
 }
 
 // waves per block so that the tile count splits evenly over as few rounds as possible.  When the staged images
@@ -1131,6 +1395,26 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)dvt_cdiv((int64_t)p.B * p.H, 4)), block(256);
     DVT_DISPATCH_16BIT(d->dtype, E, hipLaunchKernelGGL((attn_bwd_q1_kernel<E>), grid, block, 0, st, p));
     DVT_LAUNCH_CHECK("dvt_attention_bwd(q1)");
+    return DVT_OK;
+  }
+  if (mfma_bwd_ok(d, p) && fused_bwd_ok(p) && !d->bwd_two_pass) {      // one pass: Q, dO, K staged once, dK / dV in registers, dQ through LDS strips
+    const int NP = p.Lkp >> 5;
+    const int waves = NP + 1;                      // one compute wave per 32 keys + the dQ wave
+    const size_t lds = fused_bwd_lds(NP, waves);
+    const dim3 grid((unsigned)(p.B * p.H)), block(64 * waves);
+#define DVT_ATTN_BWD_FUSED(N)                                                               \
+  case N:                                                                                   \
+    set_lds(attn_bwd_fused_kernel<E, N>, lds);                                              \
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<E, N>), grid, block, lds, st, p);             \
+    break
+    DVT_DISPATCH_16BIT(d->dtype, E, {
+      switch (NP) {
+        DVT_ATTN_BWD_FUSED(1); DVT_ATTN_BWD_FUSED(2); DVT_ATTN_BWD_FUSED(3); DVT_ATTN_BWD_FUSED(4);
+        DVT_ATTN_BWD_FUSED(5); DVT_ATTN_BWD_FUSED(6); DVT_ATTN_BWD_FUSED(7);
+      }
+    });
+#undef DVT_ATTN_BWD_FUSED
+    DVT_LAUNCH_CHECK("dvt_attention_bwd(fused)");
     return DVT_OK;
   }
   if (mfma_bwd_ok(d, p)) {

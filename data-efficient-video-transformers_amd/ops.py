@@ -590,8 +590,11 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, scale: float, drop
     return lse
 
 
+ATTN_BWD_TWO_PASS = False      # A/B switch (bench.py --attn-two-pass): the dq + dk/dv kernel pair instead of the one-pass backward
+
+
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: Tensor, dq: Tensor,
-                  dk: Tensor, dv: Tensor, scale: float, dropout=None) -> None:
+                  dk: Tensor, dv: Tensor, scale: float, dropout=None, two_pass: Optional[bool] = None) -> None:
     """do must share o's strides; dq/dk/dv must share q/k/v's strides (views of
     caller-owned memory, fully overwritten)."""
     _need_cuda(q, k, v, o, do, dq, dk, dv)
@@ -600,11 +603,13 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: T
             "gradient views must share the layout of their primal"
     d = _attn_desc(q, k, v, o, lse, scale, dropout)
     d.d_o, d.dq, d.dk, d.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.bwd_two_pass = int(ATTN_BWD_TWO_PASS if two_pass is None else two_pass)
     lib = L.load()
     ws = workspace(lib.dvt_attention_bwd_workspace_bytes(C.byref(d)), q.device)
     d.workspace = _p(ws)
-    # two kernels: dq reads q,k,v,o,dO writes dq; dkdv reads q,k,v,o,dO writes dk,dv
-    nb = (7 * q.numel() + 3 * k.numel() + 3 * v.numel()) * q.element_size()
+    # algorithmic bytes: q, k, v, o, dO read once, dq, dk, dv written once (the one-pass form moves exactly that; the
+    # two-kernel form re-reads q, k, v, dO: 13 units through the memory pipeline for these 8)
+    nb = (4 * q.numel() + 2 * k.numel() + 2 * v.numel()) * q.element_size()
     with _timed(("hbm", "attention_bwd", q.numel(), 10.0 * q.numel() * k.shape[2]), nb):  # 5 products of 2*L*L*dh
         L.check(lib.dvt_attention_bwd(C.byref(d), _stream()), "dvt_attention_bwd")
 

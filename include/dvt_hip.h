@@ -314,6 +314,11 @@ typedef struct dvt_attn_desc {
   float dropout_p;
   const uint64_t* rng_state;
   uint64_t rng_offset;
+  /* bwd, 16-bit dh = 64 kernels: sequences whose two lengths pad to the same multiple of 32 <= 224 (the 197-token frames,
+   * the 33-token clips) run as ONE pass -- Q, dO, K staged once, dK / dV kept in registers by key-owner waves, dQ formed by
+   * a dedicated wave from 16-bit dS strips in LDS (5 MFMA products and 8 units of traffic instead of the 7 and 13 of the
+   * dq + dk/dv pair).  bwd_two_pass != 0 forces the pair (longer sequences always use it). */
+  int32_t bwd_two_pass;
 } dvt_attn_desc;
 
 size_t dvt_attention_bwd_workspace_bytes(const dvt_attn_desc* desc);

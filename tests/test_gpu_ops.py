@@ -566,6 +566,50 @@ def test_attention_core(dvt, device, dtype, B, H, Lq, Lk, dh):
     assert rel_l2(vd.grad, vr.grad) < 2 * tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(3, 8, 197, 197), (2, 8, 33, 33), (1, 2, 193, 224), (1, 1, 16, 5), (2, 2, 96, 70)])
+def test_attention_backward_one_pass_matches_the_kernel_pair(dvt, device, dtype, B, H, Lq, Lk):
+    """vit.py:51-55 backward.  Sequences whose lengths pad to the same multiple of 32 (<= 224) run the backward as ONE pass
+    (Q, dO, K staged once; dK / dV in registers of key-owner waves; dQ by a dedicated wave from 16-bit dS strips in LDS);
+    the dq + dk/dv kernel pair stays reachable through dvt_attn_desc.bwd_two_pass.  Both against float64 on the same 16-bit
+    operands, on the packed [tokens, 3 h dh] layout the blocks use (strided q / k / v views), and the one-pass form twice:
+    bitwise reproducible (fixed summation order, no atomics)."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(77)
+    dh = 64
+    L = max(Lq, Lk)
+    qkv = (torch.randn(B, L, 3, H, dh, generator=g) * 0.7).to(dtype).cuda()
+    q = qkv[:, :Lq, 0].permute(0, 2, 1, 3)
+    k = qkv[:, :Lk, 1].permute(0, 2, 1, 3)
+    v = qkv[:, :Lk, 2].permute(0, 2, 1, 3)
+    o_mem = torch.empty(B, Lq, H, dh, dtype=dtype, device="cuda")
+    o = o_mem.permute(0, 2, 1, 3)
+    scale = dh ** -0.5
+    lse = ops.attention_fwd(q, k, v, o, scale)
+    do_mem = torch.randn(B, Lq, H, dh, generator=g).to(dtype).cuda()
+    do = do_mem.permute(0, 2, 1, 3)
+
+    def run(two_pass):
+        dqkv = torch.full_like(qkv, float("nan"))
+        dq = dqkv[:, :Lq, 0].permute(0, 2, 1, 3)
+        dk = dqkv[:, :Lk, 1].permute(0, 2, 1, 3)
+        dv = dqkv[:, :Lk, 2].permute(0, 2, 1, 3)
+        ops.attention_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, two_pass=two_pass)
+        return dq.clone(), dk.clone(), dv.clone()
+
+    one, again, pair = run(False), run(False), run(True)
+    for a, b in zip(one, again):
+        assert torch.equal(a, b)
+    q64, k64, v64, do64 = (t.double().cpu().requires_grad_(t is not do) for t in (q, k, v, do))
+    p64 = torch.softmax(q64 @ k64.transpose(-1, -2) * scale, -1)
+    (p64 @ v64).backward(do64)
+    tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-3
+    for got, got2, ref in zip(one, pair, (q64.grad, k64.grad, v64.grad)):
+        assert torch.isfinite(got).all()
+        assert rel_l2(got.double().cpu(), ref) < tol and rel_l2(got2.double().cpu(), ref) < tol
+        assert rel_l2(got.float(), got2.float()) < tol
+
+
 def test_attention_softmax_spike(dvt, device):
     """Online-softmax rescale path: one key dominates late in the sequence."""
     g = torch.Generator().manual_seed(10)
