@@ -32,6 +32,22 @@ class SplitKPending(C.Structure):
     ]
 
 
+class LnPending(C.Structure):
+    _fields_ = [("partial", c_p), ("nparts", C.c_int32), ("d", C.c_int32), ("dgamma", c_p), ("dbeta", c_p),
+                ("accumulate", C.c_int32), ("valid", C.c_int32)]
+
+
+class LnBwdDesc(C.Structure):
+    _fields_ = [("dy", c_p), ("dy_dtype", C.c_int32), ("x", c_p), ("x_dtype", C.c_int32),
+                ("gamma", c_p), ("mean", c_p), ("rstd", c_p), ("dx_add", c_p),
+                ("dx", c_p), ("dx_dtype", C.c_int32), ("dx_lp", c_p), ("dx_lp_dtype", C.c_int32),
+                ("dgamma", c_p), ("dbeta", c_p), ("workspace", c_p),
+                ("n0", c_i64), ("n1", c_i64), ("d", c_i64), ("xs0", c_i64), ("xs1", c_i64), ("ys0", c_i64), ("ys1", c_i64),
+                ("dy_first", c_p), ("dy_first_stride", c_i64), ("dx_first", c_p), ("dx_first_stride", c_i64),
+                ("accumulate_gamma", C.c_int32), ("accumulate_beta", C.c_int32),
+                ("defer_reduce", C.c_int32), ("pending", C.POINTER(LnPending))]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", c_p), ("B", c_p), ("C", c_p),
@@ -46,6 +62,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_p),
         ("colsum_out", c_p), ("colsum_accumulate", C.c_int32),
         ("defer_reduce", C.c_int32), ("pending", C.POINTER(SplitKPending)), ("carry", C.POINTER(SplitKPending)),
+        ("residual_f32", C.c_int32),
     ]
 
 
@@ -108,11 +125,16 @@ SIGNATURES = {
     "dvt_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                   c_i64, c_f, c_int, c_p]),
     "dvt_layernorm_bwd_workspace_bytes": (C.c_size_t, [c_i64]),
+    "dvt_layernorm_fwd_mixed": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p] + [c_i64] * 7 + [c_f, c_p]),
+    "dvt_layernorm_bwd_partial_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "dvt_layernorm_bwd_ex": (c_int, [C.POINTER(LnBwdDesc), c_p]),
+    "dvt_layernorm_reduce_group": (c_int, [c_p, c_int, c_p]),
     "dvt_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_layernorm_bwd_first": (c_int, [c_p] * 10 + [c_i64] * 7 + [c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dvt_gemm": (c_int, [C.POINTER(GemmDesc), c_p]),
+    "dvt_gemm_route": (c_int, [C.POINTER(GemmDesc)]),
     "dvt_splitk_reduce_pending": (c_int, [C.POINTER(SplitKPending), c_p]),
     "dvt_gemm_pair_fused": (c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc)]),
     "dvt_gemm_pair": (c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), c_p]),

@@ -727,6 +727,7 @@ static GemmParams small_params(const dvt_gemm_desc* d) {
   p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr; p.aux = d->aux; p.ldaux = d->ldaux;
   p.alpha = d->alpha; p.elem = d->in_dtype; p.k_per_split = (int)d->K; p.slab = nullptr;
   p.colsum_slab = d->colsum_out; p.accumulate_colsum = d->colsum_accumulate;
+  p.res_f32 = d->residual_f32 && d->epilogue == DVT_EPI_RESIDUAL;
   return p;
 }
 
@@ -740,6 +741,9 @@ static bool pair_fusable(const dvt_gemm_desc* w, const dvt_gemm_desc* g) {
   if (w->M == 0 || w->N == 0 || g->M == 0 || g->N == 0) return false;
   return route_gemm(w).kind == ROUTE_SMALL && route_gemm(g).kind == ROUTE_SMALL;
 }
+
+// 0 = panel-streaming kernel (launch-bound shapes), 1 = LDS-DMA / register-staged MFMA kernels, 2 = generic fp32 kernel
+int dvt_gemm_route(const dvt_gemm_desc* d) { return d ? (int)route_gemm(d).kind : 2; }
 
 int dvt_gemm_pair_fused(const dvt_gemm_desc* wgrad, const dvt_gemm_desc* dgrad) { return pair_fusable(wgrad, dgrad) ? 1 : 0; }
 
@@ -793,6 +797,12 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     rc = launch_pending_reduce(carry, st);
     if (rc) return rc;
     carry = nullptr;
+  }
+  if (d->residual_f32 && d->epilogue == DVT_EPI_RESIDUAL) {
+    DVT_REQUIRE(d->out_dtype == DVT_F32 && d->ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 15u) == 0,
+                "dvt_gemm: an fp32 residual needs an fp32 output, ldr %% 4 == 0 and a 16-byte aligned buffer");
+    if (route.kind != ROUTE_SMALL)
+      DVT_UNSUPPORTED("dvt_gemm: the fp32 residual epilogue is served for launch-bound shapes only (M = %lld)", (long long)d->M);
   }
   if (route.kind == ROUTE_SMALL) {
     const GemmParams p = small_params(d);

@@ -12,6 +12,7 @@ struct GemmParams {
   const float* bias;
   const void* residual;
   int64_t ldr;
+  int res_f32;          // gemm_small.hip only: the residual operand is fp32 (fp32 residual stream of the launch-bound zone)
   void* aux;
   int64_t ldaux;
   float alpha;

@@ -138,7 +138,7 @@ __device__ __forceinline__ void gemm_small_tile(const GemmParams& p, const int b
   const bool want_ld = p.epilogue == DVT_EPI_RESIDUAL || p.epilogue == DVT_EPI_DGELU || p.epilogue == DVT_EPI_DRELU;
   const bool want_old = p.out_f32 && p.accumulate;
   f32x4 pre_bias[NU], pre_old[2][NU];
-  V4 pre_ld[2][NU];
+  f32x4 pre_ld[2][NU];                              // residual / derivative operand as fp32 (16-bit or, residual only, fp32 in memory)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int n = min(n0 + wn * WCOLS + u * 16 + 4 * g, p.N - 4);
@@ -146,12 +146,16 @@ __device__ __forceinline__ void gemm_small_tile(const GemmParams& p, const int b
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m = min(m0 + wm * 32 + t * 16 + li, p.M - 1);
-      pre_ld[t][u] = V4{0, 0, 0, 0};
+      pre_ld[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
       pre_old[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (want_ld) {
+      if (want_ld && p.epilogue == DVT_EPI_RESIDUAL && p.res_f32) {
+        pre_ld[t][u] = *reinterpret_cast<const f32x4*>((const float*)p.residual + (int64_t)m * p.ldr + n);
+      } else if (want_ld) {
         const E* src = p.epilogue == DVT_EPI_RESIDUAL ? (const E*)p.residual + (int64_t)m * p.ldr + n
                                                       : (const E*)p.aux + (int64_t)m * p.ldaux + n;
-        pre_ld[t][u] = *reinterpret_cast<const V4*>(src);
+        const V4 h = *reinterpret_cast<const V4*>(src);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre_ld[t][u][r] = (float)h[r];
       }
       if (want_old) pre_old[t][u] = *reinterpret_cast<const f32x4*>((const float*)p.C + (int64_t)m * p.ldc + n);
     }
@@ -218,7 +222,7 @@ __device__ __forceinline__ void gemm_small_tile(const GemmParams& p, const int b
   _Pragma("unroll") for (int t = 0; t < 2; ++t)              \
   _Pragma("unroll") for (int u = 0; u < NU; ++u)             \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) {            \
-    const float bi = pre_bias[u][r], ld = (float)pre_ld[t][u][r]; \
+    const float bi = pre_bias[u][r], ld = pre_ld[t][u][r]; \
     float& x = v[t][u][r];                                   \
     (void)bi; (void)ld;                                      \
     EXPR;                                                    \

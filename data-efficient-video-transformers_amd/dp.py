@@ -328,6 +328,8 @@ class FlatParameters:
         """Call after loss.backward(): zero gradients nobody wrote (and exclude them from the optimizer step), flush
         remaining buckets, wait for the collectives (on the compute stream, not the host), fold in late writes.
         ``exchange=False`` (with ``defer_exchange``): local part only; ``exchange_all()`` follows."""
+        from . import functional as F       # dgamma / dbeta reduces still deferred: one launch, then their sinks are written
+        F.ln_flush(end_of_step=True)
         if self.comm is not None and self.comm.trace is not None:      # end of backward on the compute stream
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream())

@@ -114,16 +114,43 @@ def _emit_colsum(sink, dy2: Tensor):
     return None
 
 
+# dgamma / dbeta of a LayerNorm whose gradients go into sinks: the reduce of the per-workgroup partial rows is deferred and
+# performed for many layers by ONE launch (ops.layernorm_flush: at the end of every full-size attention block's backward, and
+# in dp.FlatParameters.finish_backward) -- the sinks are marked written only then.
+LN_DEFER = True
+_ln_pending_sinks = set()
+
+
+def ln_flush(end_of_step: bool = False):
+    ops.layernorm_flush()
+    _ln_pending_sinks.clear()
+    if end_of_step:
+        _lp_hand.clear()
+
+
 def _ln_bwd(dy, x, g, mean, rstd, sg, sb, **kw):
-    """LayerNorm backward with optional sinks for dgamma / dbeta."""
+    """LayerNorm backward with optional sinks for dgamma / dbeta -> (dx, dgamma, dbeta[, dx_lp])."""
     if sg is None or sb is None:
         return ops.layernorm_bwd(dy, x, g, mean, rstd, **kw)
+    defer = None
+    if LN_DEFER:
+        if id(sg) in _ln_pending_sinks or id(sb) in _ln_pending_sinks:     # a second write to a sink still pending: in order
+            ln_flush()
+        # only a FIRST write is deferred: an accumulating one must be enqueued before its bucket's exchange can start, and
+        # the bucket logic counts first writes only
+        if sg.fresh and sb.fresh:
+            _ln_pending_sinks.update((id(sg), id(sb)))
+
+            def defer():
+                sg.mark_written()
+                sb.mark_written()
     # one flag per sink: gamma and beta may sit in different gradient buckets (dp.GradSink late-write redirect)
-    dx, _, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dg=sg.buf.view(-1), db=sb.buf.view(-1),
-                                 accumulate=not sg.fresh, accumulate_beta=not sb.fresh, **kw)
-    sg.mark_written()
-    sb.mark_written()
-    return dx, None, None
+    r = ops.layernorm_bwd(dy, x, g, mean, rstd, dg=sg.buf.view(-1), db=sb.buf.view(-1),
+                          accumulate=not sg.fresh, accumulate_beta=not sb.fresh, defer=defer, **kw)
+    if defer is None:
+        sg.mark_written()
+        sb.mark_written()
+    return (r[0], None, None) + tuple(r[3:])
 
 
 def _emit_into(sink, t: Tensor):
@@ -131,6 +158,26 @@ def _emit_into(sink, t: Tensor):
     accumulate flag for two destinations whose sinks disagree (one of them redirected to its late buffer)."""
     ops.axpby_f32_(sink.buf.view(-1), t.reshape(-1).contiguous(), 1.0, 0.0 if sink.fresh else 1.0)
     sink.mark_written()
+
+
+# ---- fp32 residual stream of the launch-bound zone (the 33-token temporal encoder, vit.py:122-128: 264 rows at B = 8).
+# There single rows carry whole gradients and nothing averages the rounding of 16-bit storage, while fp32 storage of 264 rows
+# costs no bandwidth: the blocks of that stack take and return an fp32 map (x fp32 -> LN -> 16-bit GEMM operands -> fp32
+# residual add in the GEMM epilogue), and their gradients likewise.  A block's backward needs the incoming fp32 gradient as a
+# 16-bit GEMM operand as well: the LayerNorm backward that produced it wrote that copy in the same pass and leaves it here,
+# keyed by the gradient's address (a miss -- autograd handed a different tensor on -- costs one cast launch, not correctness).
+_lp_hand = {}
+
+
+def _lp_put(t32: Tensor, lp: Tensor) -> None:
+    _lp_hand[t32.data_ptr()] = (tuple(t32.shape), lp)
+
+
+def _lp_take(t32: Tensor, T: torch.dtype) -> Tensor:
+    e = _lp_hand.pop(t32.data_ptr(), None)
+    if e is not None and e[0] == tuple(t32.shape) and e[1].dtype == T:
+        return e[1]
+    return ops.cast(t32, T)
 
 
 def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -370,16 +417,18 @@ class _ClsNormConcat(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, b, tok, B, T, eps):
+    def forward(ctx, x, w, b, tok, B, T, eps, out_dtype=None):
+        # out_dtype float32 (x 16-bit): the sequence enters the fp32 residual stream of the temporal stack
         S, N, d = x.shape
         xc = x.contiguous()
         g, bb = _f32(w), _f32(b)
         rows = (S, 1, N * d, 0)
-        cls_rows, mean, rstd = ops.layernorm_fwd(xc, g, bb, eps, rows=rows)      # [S, d]
+        cls_rows, mean, rstd = ops.layernorm_fwd(xc, g, bb, eps, rows=rows, out_dtype=out_dtype)      # [S, d]
         tok32 = _f32(tok).reshape(-1) if tok is not None else None
         seq = ops.rows_gather_fwd(cls_rows, d, tok32, B, T, d)
         ctx.save_for_backward(xc, g, mean, rstd)
         ctx.dims = (B, T, S, N, d)
+        ctx.seq_dtype = seq.dtype
         ctx.tok_shape = tuple(tok.shape) if tok is not None else None
         ctx.sinks = (_sink(w), _sink(b), _sink(tok))
         return seq
@@ -388,8 +437,9 @@ class _ClsNormConcat(torch.autograd.Function):
     def backward(ctx, dseq):
         xc, g, mean, rstd = ctx.saved_tensors
         B, T, S, N, d = ctx.dims
-        dseq = _as(dseq.contiguous(), xc.dtype)
-        drows = torch.empty((S, d), dtype=xc.dtype, device=xc.device)
+        gdt = ctx.seq_dtype                               # the sequence's type: xc's, or fp32 (then dy fp32 -> dx 16-bit)
+        dseq = _as(dseq.contiguous(), gdt)
+        drows = torch.empty((S, d), dtype=gdt, device=xc.device)
         sg, sb, st = ctx.sinks
         if st is not None:
             ops.rows_gather_bwd(dseq, drows, d, True, B, T, d, dtok=st.buf.view(-1), accumulate=not st.fresh)
@@ -401,12 +451,12 @@ class _ClsNormConcat(torch.autograd.Function):
         _, dg, db = _ln_bwd(drows, xc, g, mean, rstd, sg, sb, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
         if dtok is not None:
             dtok = dtok.view(ctx.tok_shape)
-        return dx, dg, db, dtok, None, None, None
+        return dx, dg, db, dtok, None, None, None, None
 
 
 def cls_norm_concat(x: Tensor, w: Tensor, b: Tensor, tok: Optional[Tensor], B: int, T: int,
-                    eps: float = 1e-5) -> Tensor:
-    return _ClsNormConcat.apply(x, w, b, tok, B, T, eps)
+                    eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    return _ClsNormConcat.apply(x, w, b, tok, B, T, eps, out_dtype)
 
 
 class _RowsSelect(torch.autograd.Function):
@@ -498,8 +548,9 @@ class _AttnBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv=None,
-                seq_first=False, attn_dropout=0.0):
+                seq_first=False, attn_dropout=0.0, cdt=None):
         # seq_first: x is [L, B, E] (torch nn.MultiheadAttention layout, frame_transformer.py:204-207)
+        # cdt: element type of the GEMM operands when x is an fp32 stream (see _lp_hand); None: x's own
         shp = x.shape
         d = shp[-1]
         if seq_first:
@@ -510,10 +561,13 @@ class _AttnBlock(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         M = x2.shape[0]
-        T = x.dtype
+        T = x.dtype if cdt is None else cdt
+        ctx.mixed = mixed = T != x.dtype
+        if mixed and not (x.dtype == torch.float32 and prenorm and residual and w_out is not None and attn_dropout == 0.0):
+            raise ValueError("the fp32 stream form is the pre-norm residual block with an output projection")
         if prenorm:
             g, bb = _f32(ln_w), _f32(ln_b)
-            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps, out_dtype=T)
         else:
             g = mean = rstd = None
             xn = x2
@@ -532,7 +586,8 @@ class _AttnBlock(torch.autograd.Function):
         if w_out is not None:
             wo = _wc(w_out, T)
             if residual:
-                y = ops.linear_fwd(o2, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2)
+                y = ops.linear_fwd(o2, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x2,
+                                   out_dtype=torch.float32 if mixed else None)
             else:
                 y = ops.linear_fwd(o2, wo, _f32(b_out))
         else:
@@ -550,10 +605,14 @@ class _AttnBlock(torch.autograd.Function):
         x2, g, mean, rstd, xn, wq, wo, qkv, o_mem, lse = ctx.saved_tensors
         S, N, heads, dh, inner, prenorm, residual, has_out, has_bias, has_qkv_bias, seq_first = ctx.cfg
         M = x2.shape[0]
-        T = x2.dtype
+        T = qkv.dtype
         if xn is None:
             xn = x2
-        dy2 = _as(dy.reshape(M, -1).contiguous(), T)
+        if ctx.mixed:                                    # fp32 gradient stream: its 16-bit copy is the GEMM operand
+            dy32 = dy.reshape(M, -1).contiguous()
+            dy2 = _lp_take(dy32, T)
+        else:
+            dy2 = _as(dy.reshape(M, -1).contiguous(), T)
         dwo = dbo = None
         if has_out:
             dwo, dbo, do2 = _linear_bwd(ctx.sinks[3], ctx.sinks[4], dy2, o_mem.view(M, inner), wo, has_bias)   # do2 [M, inner]
@@ -566,19 +625,26 @@ class _AttnBlock(torch.autograd.Function):
                           _heads_view(do2.view(o_mem.shape), seq_first), dq, dk, dv, dh ** -0.5, ctx.drop)
         dwq, dbq, dxn = _linear_bwd(ctx.sinks[2], ctx.sinks[5], dqkv, xn, wq, has_qkv_bias)                    # dxn [M, d]
         dg = db = None
-        if prenorm:
+        if ctx.mixed:
+            dx, dg, db, dx_lp = _ln_bwd(dxn, x2, g, mean, rstd, ctx.sinks[0], ctx.sinks[1], dx_add=dy32,
+                                        dx_dtype=torch.float32, dx_lp=T)
+            _lp_put(dx, dx_lp)
+        elif prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, ctx.sinks[0], ctx.sinks[1],
                                  dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
-        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None, dbq, None, None
+        if M >= 4096:                                    # a full-size layer: its two LayerNorms' reduces (and whatever the
+            ln_flush()                                   # launch-bound zone left pending) in one launch
+        return dx.view(ctx.xshape), dg, db, dwq, dwo, dbo, None, None, None, None, dbq, None, None, None
 
 
 def attn_block(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, prenorm=True, residual=True, eps=1e-5,
-               b_qkv=None, seq_first=False, attn_dropout=0.0):
-    """attn_dropout > 0: dropout on the attention probabilities (training mode of nn.MultiheadAttention)."""
+               b_qkv=None, seq_first=False, attn_dropout=0.0, cdt=None):
+    """attn_dropout > 0: dropout on the attention probabilities (training mode of nn.MultiheadAttention).
+    cdt: GEMM operand type when x is an fp32 residual stream (the launch-bound zone)."""
     return _AttnBlock.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, prenorm, residual, eps, b_qkv, seq_first,
-                            float(attn_dropout))
+                            float(attn_dropout), cdt)
 
 
 class _AttnBlockCls(torch.autograd.Function):
@@ -603,9 +669,10 @@ class _AttnBlockCls(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps):
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps, cdt=None):
         S, N, d = x.shape
-        T = x.dtype
+        T = x.dtype if cdt is None else cdt
+        ctx.mixed = mixed = T != x.dtype                 # fp32 residual stream (the temporal stack): unfolded form only
         x2 = x.reshape(S * N, d)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -617,7 +684,7 @@ class _AttnBlockCls(torch.autograd.Function):
         ctx.cfg = (S, N, d, heads, dh, inner, b_out is not None, eps)
         ctx.sinks = tuple(_sink(t) for t in (ln_w, ln_b, w_qkv, w_out, b_out))
         x3 = x2.view(S, N, d)
-        ctx.folded = cls_fold_taken(x3, heads, dh)
+        ctx.folded = (not mixed) and cls_fold_taken(x3, heads, dh)
         if ctx.folded:
             # K / V projections folded into the query (csrc/attention_cls.hip): LN(x), K and V of the rows 1 .. N-1 never exist
             xn0, mean0, rstd0 = ops.layernorm_fwd(x2, g, bb, eps, rows=(S, 1, N * d, 0))          # [S, d]: row 0 only
@@ -628,7 +695,7 @@ class _AttnBlockCls(torch.autograd.Function):
             y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0])
             ctx.save_for_backward(x2, g, bb, mean0, rstd0, xn0, wqkv, wo, q, o, R, A, lse, P, mean, rstd)
             return y
-        xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+        xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps, out_dtype=T)
         w_q, w_kv = wqkv[:inner], wqkv[inner:]                          # row slices of the packed weight, no copies
         kv = ops.linear_fwd(xn, w_kv)                                    # [S*N, 2*inner]
         xn0 = xn.view(S, N, d)[:, 0]                                     # [S, d], row stride N*d
@@ -638,7 +705,8 @@ class _AttnBlockCls(torch.autograd.Function):
         o = torch.empty((S, inner), dtype=T, device=x.device)
         lse = ops.attention_fwd(q.view(S, 1, heads, dh).permute(0, 2, 1, 3), k4, v4,
                                 o.view(S, 1, heads, dh).permute(0, 2, 1, 3), dh ** -0.5)
-        y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0])
+        y = ops.linear_fwd(o, wo, _f32(b_out), epilogue=L.EPI_RESIDUAL, residual=x3[:, 0],
+                           out_dtype=torch.float32 if mixed else None)
         ctx.save_for_backward(x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse)
         return y
 
@@ -679,7 +747,7 @@ class _AttnBlockCls(torch.autograd.Function):
             s_g.mark_written()
             s_b.mark_written()
             dg = db = None
-        return dx2.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None
+        return dx2.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None, None
 
     @staticmethod
     def backward(ctx, dy):
@@ -687,9 +755,10 @@ class _AttnBlockCls(torch.autograd.Function):
             return _AttnBlockCls._backward_folded(ctx, dy)
         x2, g, mean, rstd, xn, wqkv, wo, q, kv, o, lse = ctx.saved_tensors
         S, N, d, heads, dh, inner, has_bias, _ = ctx.cfg
-        T = x2.dtype
+        T = kv.dtype
         s_g, s_b, s_qkv, s_o, s_bo = ctx.sinks
-        dy2 = _as(dy.reshape(S, d).contiguous(), T)
+        dy_s = dy.reshape(S, d).contiguous()             # the stream's own type (fp32 in the mixed form): row 0's residual path
+        dy2 = _lp_take(dy_s, T) if ctx.mixed else _as(dy_s, T)
         dwo, dbo, do = _linear_bwd(s_o, s_bo, dy2, o, wo, has_bias)      # do [S, inner]
         kv5 = kv.view(S, N, 2, heads, dh)
         k4, v4 = kv5[:, :, 0].permute(0, 2, 1, 3), kv5[:, :, 1].permute(0, 2, 1, 3)
@@ -713,9 +782,14 @@ class _AttnBlockCls(torch.autograd.Function):
         if s_qkv is not None:
             s_qkv.mark_written()
         dxn0 = ops.linear_dgrad(dq, w_q)                                 # [S, d]: the Q path, row 0
-        dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d),
-                             dy_first=dxn0, dx_first=dy2)
-        return dx.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None
+        if ctx.mixed:
+            dx, dg, db, dx_lp = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d), dy_first=dxn0,
+                                        dx_first=dy_s, dx_dtype=torch.float32, dx_lp=T)
+            _lp_put(dx.view(S * N, d), dx_lp.view(S * N, d))
+        else:
+            dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, s_g, s_b, rows=(S, N, N * d, d),
+                                 dy_first=dxn0, dx_first=dy2)
+        return dx.view(S, N, d), dg, db, dwqkv, dwo, dbo, None, None, None
 
 
 # Sequences x rows from which the last layer's single-query attention runs with the K / V projections folded into the query
@@ -729,9 +803,9 @@ def cls_fold_taken(x3: Tensor, heads: int, dh: int) -> bool:
     return S * N >= CLS_FOLD_MIN_ROWS and ops.attn_cls_supported(x3, heads, dh)
 
 
-def attn_block_cls(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, eps=1e-5):
+def attn_block_cls(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, *, eps=1e-5, cdt=None):
     """``attn_block(x, ...)[:, 0]`` for x [S, N, d] without the rows that are never read."""
-    return _AttnBlockCls.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps)
+    return _AttnBlockCls.apply(x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps, cdt)
 
 
 class _CrossAttnBlock(torch.autograd.Function):
@@ -803,16 +877,19 @@ class _MlpBlock(torch.autograd.Function):
     (vit.py:17-28,73-74).  act: 'gelu' (exact erf) or 'relu'."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps, cdt=None):
         shp = x.shape
         d = shp[-1]
         x2 = x.reshape(-1, d)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        T = x.dtype
+        T = x.dtype if cdt is None else cdt
+        ctx.mixed = mixed = T != x.dtype                 # fp32 residual stream, 16-bit GEMM operands (see _lp_hand)
+        if mixed and not (x.dtype == torch.float32 and prenorm and residual):
+            raise ValueError("the fp32 stream form is the pre-norm residual block")
         if prenorm:
             g, bb = _f32(ln_w), _f32(ln_b)
-            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps)
+            xn, mean, rstd = ops.layernorm_fwd(x2, g, bb, eps, out_dtype=T)
         else:
             g = mean = rstd = None
             xn = x2
@@ -825,7 +902,8 @@ class _MlpBlock(torch.autograd.Function):
             u = None
             h = ops.linear_fwd(xn, w1c, _f32(b1), epilogue=L.EPI_RELU)
         if residual:
-            y = ops.linear_fwd(h, w2c, _f32(b2), epilogue=L.EPI_RESIDUAL, residual=x2)
+            y = ops.linear_fwd(h, w2c, _f32(b2), epilogue=L.EPI_RESIDUAL, residual=x2,
+                               out_dtype=torch.float32 if mixed else None)
         else:
             y = ops.linear_fwd(h, w2c, _f32(b2))
         ctx.save_for_backward(x2, g, mean, rstd, xn if prenorm else None, w1c, w2c, u, h)
@@ -838,10 +916,14 @@ class _MlpBlock(torch.autograd.Function):
     def backward(ctx, dy):
         x2, g, mean, rstd, xn, w1c, w2c, u, h = ctx.saved_tensors
         act, prenorm, residual, has_b1, has_b2 = ctx.cfg
-        T = x2.dtype
+        T = h.dtype
         if xn is None:
             xn = x2
-        dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
+        if ctx.mixed:
+            dy32 = dy.reshape(x2.shape).contiguous()
+            dy2 = _lp_take(dy32, T)
+        else:
+            dy2 = _as(dy.reshape(x2.shape).contiguous(), T)
         sk = ctx.sinks
         # full-size shapes: each weight gradient's split-K reduce rides in the tail of the data-gradient launch behind it;
         # launch-bound shapes: weight and data gradient of a Linear in one launch
@@ -851,15 +933,18 @@ class _MlpBlock(torch.autograd.Function):
             dw2, db2, du = _linear_bwd(sk[4], sk[5], dy2, h, w2c, has_b2, epilogue=L.EPI_DRELU, aux=h)
         dw1, db1, dxn = _linear_bwd(sk[2], sk[3], du, xn, w1c, has_b1)
         dg = db = None
-        if prenorm:
+        if ctx.mixed:
+            dx, dg, db, dx_lp = _ln_bwd(dxn, x2, g, mean, rstd, sk[0], sk[1], dx_add=dy32, dx_dtype=torch.float32, dx_lp=T)
+            _lp_put(dx, dx_lp)
+        elif prenorm:
             dx, dg, db = _ln_bwd(dxn, x2, g, mean, rstd, sk[0], sk[1], dx_add=dy2 if residual else None)
         else:
             dx = ops.add(dxn, dy2) if residual else dxn
-        return dx.view(ctx.xshape), dg, db, dw1, db1, dw2, db2, None, None, None, None
+        return dx.view(ctx.xshape), dg, db, dw1, db1, dw2, db2, None, None, None, None, None
 
 
-def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, *, act="gelu", prenorm=True, residual=True, eps=1e-5):
-    return _MlpBlock.apply(x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps)
+def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, *, act="gelu", prenorm=True, residual=True, eps=1e-5, cdt=None):
+    return _MlpBlock.apply(x, ln_w, ln_b, w1, b1, w2, b2, act, prenorm, residual, eps, cdt)
 
 
 # ---------------------------------------------------------------------------

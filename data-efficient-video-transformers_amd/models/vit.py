@@ -72,7 +72,8 @@ class FeedForward(nn.Module):
         )
         self.dropout_p = dropout
 
-    def forward(self, x, _norm=None, _residual=False):
+    def forward(self, x, _norm=None, _residual=False, _cdt=None):
+        # _cdt: GEMM operand type when x is an fp32 residual stream (the launch-bound temporal stack, see ViViT.forward)
         l1, l2 = self.net[0], self.net[3]
         if self.training and self.dropout_p > 0.0:         # unfused: Linear - GELU - Dropout - Linear - Dropout (:20-26)
             h = F.layernorm(x, _norm.weight, _norm.bias, _norm.eps) if _norm is not None else x
@@ -83,7 +84,7 @@ class FeedForward(nn.Module):
                            _norm.bias if _norm is not None else None,
                            l1.weight, l1.bias, l2.weight, l2.bias, act="gelu",
                            prenorm=_norm is not None, residual=_residual,
-                           eps=_norm.eps if _norm is not None else 1e-5)
+                           eps=_norm.eps if _norm is not None else 1e-5, cdt=_cdt)
 
 
 class Attention(nn.Module):
@@ -103,7 +104,7 @@ class Attention(nn.Module):
         self.project_out = project_out
         self.dropout_p = dropout
 
-    def forward(self, x, _norm=None, _residual=False):
+    def forward(self, x, _norm=None, _residual=False, _cdt=None):
         w_out = self.to_out[0].weight if self.project_out else None
         b_out = self.to_out[0].bias if self.project_out else None
         if self.training and self.dropout_p > 0.0 and self.project_out:     # to_out = Linear + Dropout (:41-44)
@@ -116,7 +117,7 @@ class Attention(nn.Module):
                             _norm.bias if _norm is not None else None,
                             self.to_qkv.weight, w_out, b_out, self.heads,
                             prenorm=_norm is not None, residual=_residual,
-                            eps=_norm.eps if _norm is not None else 1e-5)
+                            eps=_norm.eps if _norm is not None else 1e-5, cdt=_cdt)
 
 
 class Transformer(nn.Module):
@@ -133,17 +134,30 @@ class Transformer(nn.Module):
                 PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout)),
             ]))
 
-    def forward_layers(self, x):
-        """All residual blocks, without the final norm."""
+    def stream_f32_ok(self, rows: int, cdt: torch.dtype) -> bool:
+        """May this stack run on an fp32 residual stream with ``cdt`` GEMM operands for ``rows`` rows?  (The launch-bound
+        zone: 16-bit kernels, no active dropout, and every residual GEMM of a block a launch-bound shape -- the fp32
+        residual epilogue is the panel-streaming kernel's.)"""
+        if cdt not in (torch.bfloat16, torch.float16) or len(self.layers) == 0:
+            return False
+        attn, ff = self.layers[0][0].fn, self.layers[0][1].fn
+        if not attn.project_out or (self.training and (attn.dropout_p > 0.0 or ff.dropout_p > 0.0)):
+            return False
+        d, inner, hidden = attn.to_out[0].weight.shape[0], attn.to_out[0].weight.shape[1], ff.net[0].weight.shape[0]
+        from .. import ops
+        return ops.gemm_is_launch_bound(rows, d, inner, cdt) and ops.gemm_is_launch_bound(rows, d, hidden, cdt)
+
+    def forward_layers(self, x, cdt=None):
+        """All residual blocks, without the final norm.  cdt: GEMM operand type when x is an fp32 stream."""
         for attn, ff in self.layers:
             if self.checkpoint and self.training and torch.is_grad_enabled():
                 def block(t, attn=attn, ff=ff):
-                    t = attn.fn(t, _norm=attn.norm, _residual=True)
-                    return ff.fn(t, _norm=ff.norm, _residual=True)
+                    t = attn.fn(t, _norm=attn.norm, _residual=True, _cdt=cdt)
+                    return ff.fn(t, _norm=ff.norm, _residual=True, _cdt=cdt)
                 x = F.checkpoint(block, x, tuple(attn.parameters()) + tuple(ff.parameters()))
             else:
-                x = attn.fn(x, _norm=attn.norm, _residual=True)
-                x = ff.fn(x, _norm=ff.norm, _residual=True)
+                x = attn.fn(x, _norm=attn.norm, _residual=True, _cdt=cdt)
+                x = ff.fn(x, _norm=ff.norm, _residual=True, _cdt=cdt)
         return x
 
     def cls_prunable(self) -> bool:
@@ -154,7 +168,7 @@ class Transformer(nn.Module):
         dropping = self.training and (attn.dropout_p > 0.0 or self.layers[-1][1].fn.dropout_p > 0.0)
         return attn.project_out and not dropping
 
-    def forward_layers_cls(self, x):
+    def forward_layers_cls(self, x, cdt=None):
         """``forward_layers(x)[:, 0]`` for x [S, N, d] -> [S, d]: what the reference reads of the space
         transformer (vit.py:119-120) and, under pool == 'cls', of the temporal one (:126).  In the last
         layer only the keys and values are computed for all rows; query, attention, output projection and
@@ -163,25 +177,25 @@ class Transformer(nn.Module):
         for a, f in head:
             if self.checkpoint and self.training and torch.is_grad_enabled():
                 def block(t, a=a, f=f):
-                    t = a.fn(t, _norm=a.norm, _residual=True)
-                    return f.fn(t, _norm=f.norm, _residual=True)
+                    t = a.fn(t, _norm=a.norm, _residual=True, _cdt=cdt)
+                    return f.fn(t, _norm=f.norm, _residual=True, _cdt=cdt)
                 x = F.checkpoint(block, x, tuple(a.parameters()) + tuple(f.parameters()))
             else:
-                x = a.fn(x, _norm=a.norm, _residual=True)
-                x = f.fn(x, _norm=f.norm, _residual=True)
+                x = a.fn(x, _norm=a.norm, _residual=True, _cdt=cdt)
+                x = f.fn(x, _norm=f.norm, _residual=True, _cdt=cdt)
 
         def last(t):
             an, af = attn.norm, attn.fn
             c = F.attn_block_cls(t, an.weight, an.bias, af.to_qkv.weight, af.to_out[0].weight, af.to_out[0].bias,
-                                 af.heads, eps=an.eps)
-            return ff.fn(c, _norm=ff.norm, _residual=True)
+                                 af.heads, eps=an.eps, cdt=cdt)
+            return ff.fn(c, _norm=ff.norm, _residual=True, _cdt=cdt)
 
         if self.checkpoint and self.training and torch.is_grad_enabled():
             return F.checkpoint(last, x, tuple(attn.parameters()) + tuple(ff.parameters()))
         return last(x)
 
-    def forward(self, x):
-        x = self.forward_layers(x)
+    def forward(self, x, cdt=None):
+        x = self.forward_layers(x, cdt)
         return F.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
@@ -216,6 +230,7 @@ class ViViT(nn.Module):
         self.num_frames = num_frames
         self.emb_dropout_p = emb_dropout
         self.compute_dtype = compute_dtype
+        self.zone_f32 = True          # fp32 residual stream in the temporal stack / heads under 16-bit kernels (see forward)
         self.space_transformer.checkpoint = activation_checkpointing
         self.temporal_transformer.checkpoint = activation_checkpointing
 
@@ -238,11 +253,17 @@ class ViViT(nn.Module):
             s = st.forward_layers_cls(tok).view(b * t, 1, -1)
         else:
             s = st.forward_layers(tok)                                              # :118-119
-        seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps)  # :119-123
+        # The temporal stack and the heads are the launch-bound zone of the step (b (t + 1) rows: 264 at the metric shape):
+        # single rows carry whole gradients there and nothing averages the rounding of 16-bit storage, while fp32 storage
+        # of so few rows costs no bandwidth -- its residual stream and row gradients are kept in fp32 (GEMM operands stay T).
+        zone32 = self.zone_f32 and tt.stream_f32_ok(b * (t + 1), T)
+        cdt = T if zone32 else None
+        seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps,
+                                out_dtype=torch.float32 if zone32 else None)       # :119-123
         if self.pool == 'cls' and tt.cls_prunable():                                # only x[:, 0] is read (:126)
-            pooled = F.layernorm(tt.forward_layers_cls(seq), tt.norm.weight, tt.norm.bias, tt.norm.eps)
+            pooled = F.layernorm(tt.forward_layers_cls(seq, cdt), tt.norm.weight, tt.norm.bias, tt.norm.eps)
         else:
-            z = tt(seq)                                                             # :125
+            z = tt(seq, cdt)                                                        # :125
             pooled = F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)  # :126
         hn, hl = self.mlp_head[0], self.mlp_head[1]
         h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)

@@ -321,41 +321,69 @@ def mean_rows_bwd(dout: Tensor, Ln: int, scale: Optional[float] = None) -> Tenso
 
 # ------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, *, rows=None,
-                  out: Optional[Tensor] = None, out_rows=None) -> Tuple[Tensor, Tensor, Tensor]:
+                  out: Optional[Tensor] = None, out_rows=None, out_dtype: Optional[torch.dtype] = None
+                  ) -> Tuple[Tensor, Tensor, Tensor]:
     """Dense (rows is None): x [..., d] contiguous -> y like x.
     Strided: rows = (n0, n1, xs0, xs1) selects row (i0,i1) of ``x`` at element
     i0*xs0 + i1*xs1; the output row goes to ``out`` at i0*ys0 + i1*ys1 with
-    out_rows = (ys0, ys1) (default: a dense [n0*n1, d] tensor)."""
+    out_rows = (ys0, ys1) (default: a dense [n0*n1, d] tensor).
+    out_dtype: element type of y when it differs from x's (fp32 stream <-> 16-bit GEMM operand, see dvt_layernorm_fwd_mixed)."""
     _need_cuda(x, gamma, beta)
     d = x.shape[-1]
+    ydt = x.dtype if out_dtype is None else out_dtype
     if rows is None:
         assert x.is_contiguous()
         n0, n1, xs0, xs1 = x.numel() // d, 1, d, 0
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(x.shape, dtype=ydt, device=x.device)
         ys0, ys1 = d, 0
     else:
         n0, n1, xs0, xs1 = rows
         if out is None:
-            out = torch.empty((n0 * n1, d), dtype=x.dtype, device=x.device)
+            out = torch.empty((n0 * n1, d), dtype=ydt, device=x.device)
         ys0, ys1 = out_rows if out_rows is not None else (n1 * d, d)
+    assert out.dtype == ydt
     nrows = n0 * n1
     mean = torch.empty((nrows,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((nrows,), dtype=torch.float32, device=x.device)
-    with _timed(("hbm", "layernorm_fwd", nrows), nrows * (2 * d * x.element_size() + 8)):
-        L.check(L.load().dvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                           mean.data_ptr(), rstd.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1, eps,
-                                           dt(x), _stream()), "dvt_layernorm_fwd")
+    with _timed(("hbm", "layernorm_fwd", nrows), nrows * (d * (x.element_size() + out.element_size()) + 8)):
+        L.check(L.load().dvt_layernorm_fwd_mixed(x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                 dt(out), mean.data_ptr(), rstd.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1,
+                                                 eps, _stream()), "dvt_layernorm_fwd")
     return out, mean, rstd
+
+
+# dgamma / dbeta reduces left undone by layernorm_bwd(defer=...): (pending descriptor, callback) pairs, performed by ONE
+# launch in layernorm_flush() -- the launch-bound zone of the step has a dozen LayerNorms whose reduces were a launch each
+_ln_deferred = []
+LN_DEFER_MAX = 24
+
+
+def layernorm_flush() -> None:
+    """Perform every deferred dgamma / dbeta reduce (one launch per 32) and run their completion callbacks."""
+    global _ln_deferred
+    if not _ln_deferred:
+        return
+    todo, _ln_deferred = _ln_deferred, []
+    arr = (L.LnPending * len(todo))(*[pn for pn, _ in todo])
+    L.check(L.load().dvt_layernorm_reduce_group(C.cast(arr, C.c_void_p), len(todo), _stream()), "dvt_layernorm_reduce_group")
+    for pn, done in todo:
+        pn.valid = 0
+        if done is not None:
+            done()
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, *,
                   dx_add: Optional[Tensor] = None, rows=None, dy_rows=None,
                   dx: Optional[Tensor] = None, dg: Optional[Tensor] = None, db: Optional[Tensor] = None,
                   accumulate: bool = False, accumulate_beta: Optional[bool] = None,
-                  dy_first: Optional[Tensor] = None, dx_first: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                  dy_first: Optional[Tensor] = None, dx_first: Optional[Tensor] = None,
+                  dx_dtype: Optional[torch.dtype] = None, dx_lp: Optional[torch.dtype] = None, defer=None):
     """``accumulate`` applies to dgamma (and to dbeta unless ``accumulate_beta`` is given).
-    ``dy_first`` / ``dx_first`` [n0, d] (row stride free): added to dy / dx of row (i0, 0) only."""
+    ``dy_first`` / ``dx_first`` [n0, d] (row stride free): added to dy / dx of row (i0, 0) only.
+    Element types: dy's, x's and dx's (``dx_dtype``, default x's) may differ as dvt_layernorm_bwd_ex allows; ``dx_lp``: also
+    return a copy of dx in that 16-bit type (-> (dx, dg, db, dx_copy)).  ``defer``: a callable (or True): the dgamma / dbeta
+    reduce is left to ``layernorm_flush()`` (one launch for many layers), which calls it when dg / db are final."""
     _need_cuda(dy, x, gamma, mean, rstd, dx_add, dy_first, dx_first)
     d = x.shape[-1]
     if rows is None:
@@ -365,25 +393,49 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     else:
         n0, n1, xs0, xs1 = rows
         ys0, ys1 = dy_rows if dy_rows is not None else (d * n1, d)
-    for f in (dy_first, dx_first):
-        assert f is None or (f.dim() == 2 and f.shape == (n0, d) and f.stride(1) == 1 and f.dtype == x.dtype)
+    dxt = x.dtype if dx_dtype is None else dx_dtype
+    assert dy_first is None or (dy_first.dim() == 2 and dy_first.shape == (n0, d) and dy_first.stride(1) == 1 and dy_first.dtype == dy.dtype)
+    assert dx_first is None or (dx_first.dim() == 2 and dx_first.shape == (n0, d) and dx_first.stride(1) == 1 and dx_first.dtype == dxt)
     if dx is None:
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, dtype=dxt, device=x.device)
+    assert dx.dtype == dxt and (dx_add is None or dx_add.dtype == dxt)
     if dg is None or db is None:
         assert not accumulate and not accumulate_beta and dg is None and db is None
         dg = torch.empty((d,), dtype=torch.float32, device=x.device)
         db = torch.empty((d,), dtype=torch.float32, device=x.device)
     acc_b = accumulate if accumulate_beta is None else accumulate_beta
     lib = L.load()
-    ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
-    with _timed(("hbm", "layernorm_bwd", n0 * n1), n0 * n1 * ((3 + (dx_add is not None)) * d * x.element_size() + 8)):
-        L.check(lib.dvt_layernorm_bwd_first(
-            dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
-            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), n0, n1, d, xs0, xs1, ys0, ys1,
-            _p(dy_first), dy_first.stride(0) if dy_first is not None else 0,
-            _p(dx_first), dx_first.stride(0) if dx_first is not None else 0,
-            dt(x), int(accumulate), int(acc_b), _stream()), "dvt_layernorm_bwd")
-    return dx, dg, db
+    q = L.LnBwdDesc()
+    q.dy, q.dy_dtype, q.x, q.x_dtype = dy.data_ptr(), dt(dy), x.data_ptr(), dt(x)
+    q.gamma, q.mean, q.rstd = gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    q.dx_add, q.dx, q.dx_dtype = _p(dx_add), dx.data_ptr(), _DT[dxt]
+    lp = None
+    if dx_lp is not None:
+        lp = torch.empty(x.shape, dtype=dx_lp, device=x.device)
+        q.dx_lp, q.dx_lp_dtype = lp.data_ptr(), _DT[dx_lp]
+    q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
+    q.n0, q.n1, q.d, q.xs0, q.xs1, q.ys0, q.ys1 = n0, n1, d, xs0, xs1, ys0, ys1
+    q.dy_first, q.dy_first_stride = _p(dy_first), dy_first.stride(0) if dy_first is not None else 0
+    q.dx_first, q.dx_first_stride = _p(dx_first), dx_first.stride(0) if dx_first is not None else 0
+    q.accumulate_gamma, q.accumulate_beta = int(accumulate), int(acc_b)
+    pending = None
+    if defer:
+        # the partial rows must outlive this call: a buffer of their own, kept alive by the pending record
+        ws = torch.empty((lib.dvt_layernorm_bwd_partial_bytes(n0 * n1, d),), dtype=torch.uint8, device=x.device)
+        pending = L.LnPending()
+        pending._keep = (ws, dg, db)
+        q.defer_reduce, q.pending = 1, C.pointer(pending)
+    else:
+        ws = workspace(lib.dvt_layernorm_bwd_workspace_bytes(d), x.device)
+    q.workspace = ws.data_ptr()
+    nb = n0 * n1 * (d * (dy.element_size() + x.element_size() + dx.element_size() * (1 + (dx_add is not None))) + 8)
+    with _timed(("hbm", "layernorm_bwd", n0 * n1), nb):
+        L.check(lib.dvt_layernorm_bwd_ex(C.byref(q), _stream()), "dvt_layernorm_bwd")
+    if defer:
+        _ln_deferred.append((pending, defer if callable(defer) else None))
+        if len(_ln_deferred) >= LN_DEFER_MAX:
+            layernorm_flush()
+    return (dx, dg, db) if dx_lp is None else (dx, dg, db, lp)
 
 
 # ------------------------------------------------------------------ GEMM family
@@ -404,6 +456,9 @@ def _gemm_desc(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, 
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
     d = L.GemmDesc()
+    if residual is not None and residual.dtype != A.dtype:      # fp32 residual stream behind 16-bit operands (dvt_gemm_desc.residual_f32)
+        assert residual.dtype == torch.float32 and out_dtype == torch.float32 and epilogue == L.EPI_RESIDUAL
+        d.residual_f32 = 1
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, out.stride(0) if out.dim() == 2 else N
@@ -467,6 +522,20 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmaj
     return (out, pending) if defer_reduce else out
 
 
+def gemm_is_launch_bound(M: int, N: int, K: int, dtype: torch.dtype, *, a_kmajor: bool = True, b_kmajor: bool = True) -> bool:
+    """Does dvt_gemm take the panel-streaming kernel of the launch-bound shapes for this product (no launch)?"""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    d = L.GemmDesc()
+    d.A = d.B = d.C = 16                              # (non-null, aligned: the route depends on shapes and layouts only)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = (K if a_kmajor else M), (K if b_kmajor else N), N
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype = d.out_dtype = _DT[dtype]
+    d.alpha = 1.0
+    return L.load().dvt_gemm_route(C.byref(d)) == 0
+
+
 def splitk_reduce_pending(pending) -> None:
     """Perform a deferred split-K reduce as a launch of its own (no data-gradient launch followed to carry it)."""
     if pending is not None and pending.valid:
@@ -475,13 +544,14 @@ def splitk_reduce_pending(pending) -> None:
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, epilogue: int = L.EPI_NONE,
-               residual: Optional[Tensor] = None, aux: Optional[Tensor] = None) -> Tensor:
-    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias)."""
+               residual: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+               out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """y[M,N] = epi(x[M,K] @ w[N,K]^T + bias).  out_dtype float32 with an fp32 residual: the fp32 residual stream."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.is_contiguous()
     return gemm(x, w, M, N, K, a_kmajor=True, b_kmajor=True, lda=x.stride(0), ldb=K, epilogue=epilogue,
-                bias=bias, residual=residual, aux=aux)
+                bias=bias, residual=residual, aux=aux, out_dtype=out_dtype)
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, *, epilogue: int = L.EPI_NONE, aux: Optional[Tensor] = None,

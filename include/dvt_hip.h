@@ -188,6 +188,45 @@ int dvt_layernorm_bwd_first(const void* dy, const void* x, const float* gamma, c
                             const void* dx_first, int64_t dx_first_stride, int dtype,
                             int accumulate_gamma, int accumulate_beta, dvt_stream_t stream);
 
+/* The general forms.  _fwd_mixed: x and y may differ in element type -- fp32 on exactly one side, a 16-bit type on the
+ * other: the launch-bound zone of the path (the 33-token temporal encoder of vit.py:122-128, 264 rows at B = 8) keeps its
+ * residual stream and its row gradients in fp32 (there single rows carry whole gradients; storage there costs no
+ * bandwidth), while the GEMM operands stay 16-bit.  _bwd_ex: dy / x / dx element types separately (all equal; or dy 16-bit,
+ * x and dx fp32, plus dx_lp, a 16-bit copy of dx for the GEMMs behind; or dy fp32, x and dx 16-bit: the seam where the fp32
+ * stream meets the space stack's rows); defer_reduce leaves the dgamma / dbeta reduce of the per-workgroup partial rows
+ * undone and describes it in *pending -- dvt_layernorm_reduce_group then performs up to 32 of them in ONE launch (the zone
+ * has a dozen LayerNorms whose reduces were a launch of ~5 us each).  The partial rows live in `workspace`
+ * (>= dvt_layernorm_bwd_partial_bytes(rows, d)), which must stay untouched until that launch. */
+typedef struct dvt_ln_pending {
+  const float* partial;   /* [nparts][2][d] */
+  int32_t nparts, d;
+  float* dgamma;
+  float* dbeta;
+  int32_t accumulate;     /* bit 0: dgamma +=, bit 1: dbeta += */
+  int32_t valid;
+} dvt_ln_pending;
+typedef struct dvt_ln_bwd_desc {
+  const void* dy; int32_t dy_dtype;
+  const void* x; int32_t x_dtype;
+  const float* gamma; const float* mean; const float* rstd;
+  const void* dx_add;                    /* dx_dtype, x strides; may be NULL */
+  void* dx; int32_t dx_dtype;
+  void* dx_lp; int32_t dx_lp_dtype;      /* optional second copy of dx, x strides */
+  float* dgamma; float* dbeta; void* workspace;
+  int64_t n0, n1, d, xs0, xs1, ys0, ys1;
+  const void* dy_first; int64_t dy_first_stride;   /* dy_dtype */
+  const void* dx_first; int64_t dx_first_stride;   /* dx_dtype */
+  int32_t accumulate_gamma, accumulate_beta;
+  int32_t defer_reduce;
+  dvt_ln_pending* pending;
+} dvt_ln_bwd_desc;
+int dvt_layernorm_fwd_mixed(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                            float* rstd, int64_t n0, int64_t n1, int64_t d, int64_t xs0, int64_t xs1,
+                            int64_t ys0, int64_t ys1, float eps, dvt_stream_t stream);
+size_t dvt_layernorm_bwd_partial_bytes(int64_t rows, int64_t d);
+int dvt_layernorm_bwd_ex(const dvt_ln_bwd_desc* desc, dvt_stream_t stream);
+int dvt_layernorm_reduce_group(const dvt_ln_pending* list, int count, dvt_stream_t stream);
+
 /* ---------------------------------------------------------------- GEMM family
  * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).  One kernel family serves
  *   forward  Linear        y = x W^T          (A k-major, B = W[N,K] k-major)
@@ -260,10 +299,17 @@ typedef struct dvt_gemm_desc {
   int32_t defer_reduce;
   dvt_splitk_pending* pending;
   const dvt_splitk_pending* carry;
+  /* RESIDUAL epilogue with an fp32 residual [M, ldr] (and out_dtype DVT_F32): y32 = x W^T + b + r32 -- the residual stream of
+   * the launch-bound zone (the 33-token temporal encoder) is kept in fp32 while the GEMM operands stay 16-bit.  Served by
+   * the panel-streaming kernel (launch-bound shapes) only; other shapes report DVT_ERR_UNSUPPORTED. */
+  int32_t residual_f32;
 } dvt_gemm_desc;
 
 size_t dvt_gemm_workspace_bytes(const dvt_gemm_desc* desc);
 int dvt_gemm(const dvt_gemm_desc* desc, dvt_stream_t stream);
+/* Which kernel family dvt_gemm would take for desc (no launch): 0 = the panel-streaming kernel of the launch-bound shapes
+ * (the only one that serves residual_f32), 1 = the LDS-DMA / register-staged MFMA kernels, 2 = the generic fp32 kernel. */
+int dvt_gemm_route(const dvt_gemm_desc* desc);
 /* The two products of one Linear's backward (src/models/vit.py:20-25,39-43: dW = dy^T x with both operands mn-major,
  * dx = dy W with A k-major / B mn-major) as ONE launch when both are launch-bound shapes (the 33-token temporal encoder,
  * the CLS-row layers: a few hundred rows): they are independent, each fills a fraction of the chip, and between dependent

@@ -69,7 +69,7 @@ def test_vivit_matches_reference_golden(device, mode, case):
         return
     ref_out, ref_errs = reference_lowprec_yardstick(g, golden(f"vivit_{case}_lowprec.npz"), mode)
     w = assert_within_reference_lowprec(f"{case}/{mode}", e_out, grad_digest_errors(g, grads), ref_out, ref_errs,
-                                        out_cap=1e-2)
+                                        out_cap=1e-2, grad_cap={"bf16": 5e-2, "fp16": 1e-2}[mode])
     print(f"[{case}/{mode}] reference's own {mode}: logits {ref_out:.2e}; worst gradient ratio ours/reference {w[0][1]:.2f} "
           f"({w[0][0]}); median ratio {w[1]:.2f}")
 
@@ -108,7 +108,8 @@ def test_vivit_large_configs_match_reference_digest(device, tag, mode):
     wk = max(errs, key=errs.get)
     print(f"[{tag}/{mode}] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} worst grad digest "
           f"{wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
-    w = assert_within_reference_lowprec(f"{tag}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=1e-2)
+    w = assert_within_reference_lowprec(f"{tag}/{mode}", e_out, errs, ref_out, ref_errs, out_cap=1e-2,
+                                        grad_cap={"bf16": 5e-2, "fp16": 1e-2}[mode])
     print(f"[{tag}/{mode}] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); median ratio {w[1]:.2f}")
 
 
@@ -145,7 +146,7 @@ def test_longclip_config_composed_matches_reference_digest(device):
     print(f"[longclip/fp16+scaling+ckpt] logits rel {e_out:.2e} (reference's own {ref_out:.2e}) loss abs {e_loss:.2e} "
           f"worst grad digest {wk} {errs[wk]:.2e} (reference's own {ref_errs[wk]:.2e})")
     assert e_loss < 1e-3
-    w = assert_within_reference_lowprec("longclip/fp16", e_out, errs, ref_out, ref_errs, out_cap=4e-3)
+    w = assert_within_reference_lowprec("longclip/fp16", e_out, errs, ref_out, ref_errs, out_cap=4e-3, grad_cap=1e-2)
     print(f"[longclip/fp16+scaling+ckpt] worst gradient ratio ours/reference {w[0][1]:.2f} ({w[0][0]}); median ratio "
           f"{w[1]:.2f}")
     # the optimizer consumes the scaled gradients: one AdamW step must not overflow-skip and must move the weights

@@ -111,8 +111,8 @@ def check_grad_digest(npz, grads, tol, label=""):
     worst = ("", 0.0)
     for k in [f[3:] for f in npz.files if f.startswith("gs:")]:
         g = grads[k].detach().float().cpu().reshape(-1)
-        idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
         ref_s, ref_n = torch.from_numpy(npz["gs:" + k]), float(npz["gn:" + k])
+        idx = digest_idx(tuple(grads[k].shape), stored=ref_s.numel())
         e_s = float((g[torch.from_numpy(idx)] - ref_s).norm() / (ref_s.norm() + 1e-30))
         e_n = abs(float(g.double().norm()) - ref_n) / (ref_n + 1e-30)
         e = max(e_s, e_n)
@@ -122,8 +122,25 @@ def check_grad_digest(npz, grads, tol, label=""):
     return worst
 
 
+def digest_idx(shape, stored=None):
+    """Flat indices of the entries a gradient digest keeps (the SAME rule in tools/gen_golden.py and in the checks).
+    Default: 256 evenly spaced entries.  A 4-D gradient [1, T, rows, d] -- ``pos_embedding`` -- is, at one clip, the raw
+    gradient of the token map, and its energy sits in the T CLS rows (row 0 of every frame: > 95 %; the patch rows only
+    receive what attention routes back from a CLS query): 256 evenly spaced entries catch one or two CLS-row entries, so
+    the digest error of that one parameter was a coin toss (ratios between 0.9 and 4.0 from run to run on the same
+    kernels).  Its digest therefore holds all T * d CLS-row entries followed by the 256 spaced ones.  ``stored``: the
+    entry count of an existing fixture -- older ones (256 entries for every tensor) keep their rule."""
+    n = int(np.prod(shape))
+    base = np.linspace(0, n - 1, num=min(256, n)).astype(np.int64)
+    if len(shape) != 4 or shape[0] != 1 or (stored is not None and stored == base.size):
+        return base
+    _, T, R, d = shape
+    cls = (np.arange(T)[:, None] * (R * d) + np.arange(d)[None, :]).reshape(-1).astype(np.int64)
+    return np.concatenate([cls, base])
+
+
 def _digest_idx(n):
-    return np.linspace(0, n - 1, num=min(256, n)).astype(np.int64)
+    return digest_idx((n,))
 
 
 def grad_digest_errors(npz, grads, prefix=""):
@@ -136,14 +153,15 @@ def grad_digest_errors(npz, grads, prefix=""):
         if "gs:" + k in npz.files:
             ref_s, ref_n = torch.from_numpy(npz["gs:" + k]).double(), float(npz["gn:" + k])
         else:
-            full = torch.from_numpy(npz["g:" + k]).double().reshape(-1)
-            ref_s, ref_n = full[torch.from_numpy(_digest_idx(full.numel()))], float(full.norm())
+            full = torch.from_numpy(npz["g:" + k]).double()
+            stored_lp = grads[k][0].size if isinstance(grads[k], tuple) else None      # a stored low-precision digest decides the rule
+            ref_s, ref_n = full.reshape(-1)[torch.from_numpy(digest_idx(tuple(full.shape), stored=stored_lp))], float(full.norm())
         got = grads[k]
         if isinstance(got, tuple):                       # (digest entries, norm) of a stored low-precision run
             g_s, g_n = torch.from_numpy(got[0]).double(), float(got[1])
         else:
             g = got.detach().double().cpu().reshape(-1)
-            g_s, g_n = g[torch.from_numpy(_digest_idx(g.numel()))], float(g.norm())
+            g_s, g_n = g[torch.from_numpy(digest_idx(tuple(got.shape), stored=ref_s.numel()))], float(g.norm())
         e_s = float((g_s - ref_s).norm() / (ref_s.norm() + 1e-30))
         e_n = abs(g_n - ref_n) / (ref_n + 1e-30)
         out[k] = max(e_s, e_n)
@@ -171,20 +189,18 @@ def reference_lowprec_yardstick(npz, lp, prec):
     return max(a_out, p_out), {k: max(a[k], p[k]) for k in a}
 
 
-def assert_within_reference_lowprec(tag, e_out, errs, ref_out, ref_errs, factor=2.0, out_cap=None, floor=2e-4):
+def assert_within_reference_lowprec(tag, e_out, errs, ref_out, ref_errs, factor=2.0, out_cap=None, floor=2e-4, grad_cap=None):
     """The parity protocol of SURVEY section 7 / BASELINE.md section 2 for the 16-bit kernels: "<= 2x the reference's own
     low-precision error on the same inputs", against ``reference_lowprec_yardstick`` (``ref_*``):
       * logits: under ``out_cap`` and within ``factor`` (2x) of the yardstick;
       * gradients as a population: the median deviation within ``factor`` of the yardsticks' median;
-      * every single gradient: within ``factor`` (2x) of max(that parameter's yardstick, the MEDIAN yardstick).
-    The median enters the single-parameter bound because one parameter's deviation is ONE realisation of rounding noise:
-    the reference's own value for ``pos_embedding`` is 3.6e-3 / 5.4e-3 (autocast / cast) at configs[1] and 8.7e-3 /
-    2.3e-2 at the metric shape, 1.4e-2 / 9.3e-3 at configs[4], while its median parameter sits at 0.9-1.4e-2 throughout;
-    the HIP path's is 1.6-2.2e-2 at all of them (tests/probes/grad_stream_probe.py: that deviation is born in the
-    33-token temporal encoder, where at one clip single rows carry the whole gradient and nothing averages; fp16 shows
-    1/8 of it).  A parameter for which the reference happened to draw less than its typical deviation is held to 2x the
-    typical one.  ``floor`` (2e-4) keeps quantities whose reference deviation is at fp32 round-off from dividing by ~0.
-    Returns (worst (name, ratio) against the bound's yardstick, median ratio)."""
+      * EVERY single gradient: within ``factor`` (2x) of ITS OWN like-for-like yardstick, and under the absolute
+        ``grad_cap`` when one is given (a bound that does not move with the reference's noisier run: drift shows).
+    Round 4 removed the floor that let a parameter be measured against the MEDIAN yardstick instead of its own: the one
+    parameter that needed it, ``pos_embedding``, was a measurement artefact of the digest (256 evenly spaced entries of a
+    tensor whose energy sits in 1 row of 197, see ``digest_idx``), not a property of the kernels.
+    ``floor`` (2e-4) keeps quantities whose reference deviation is at fp32 round-off from dividing by ~0.
+    Returns (worst (name, ratio) against its own yardstick, median ratio)."""
     assert e_out <= factor * ref_out + floor, (tag, "logits", e_out, ref_out)
     if out_cap is not None:
         assert e_out <= out_cap, (tag, "logits", e_out)
@@ -193,8 +209,10 @@ def assert_within_reference_lowprec(tag, e_out, errs, ref_out, ref_errs, factor=
     assert med <= factor * med_ref + floor, (tag, "median gradient deviation", med, med_ref)
     worst = ("", 0.0)
     for k, e in errs.items():
-        yard = max(ref_errs[k], med_ref)
-        if e / (yard + 1e-30) > worst[1]:
-            worst = (k, e / (yard + 1e-30))
+        yard = ref_errs[k]
+        if e / (yard + floor) > worst[1]:
+            worst = (k, e / (yard + floor))
         assert e <= factor * yard + floor, (tag, k, e, ref_errs[k], med_ref)
+        if grad_cap is not None:
+            assert e <= grad_cap, (tag, k, "absolute cap", e, grad_cap)
     return worst, med / (med_ref + 1e-30)

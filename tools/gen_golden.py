@@ -29,6 +29,9 @@ import types
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import digest_idx      # the one rule for which entries of a gradient a digest keeps  # noqa: E402
+
 REF = "/root/reference/src/models"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 SEED = 1130  # src/main.py:25
@@ -297,8 +300,8 @@ def vivit_digest_case(vit, tag, cfg, batch, seed):
     for k, v in cfg.items():
         out["cfg_" + k] = np.array(v)
     for name, p in net.named_parameters():
+        idx = digest_idx(tuple(p.grad.shape))            # tests/util.py: 256 spaced entries; pos_embedding: + its CLS rows
         g = p.grad.detach().reshape(-1)
-        idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
         out["gn:" + name] = np.array(float(g.double().norm()))
         out["gs:" + name] = g[torch.from_numpy(idx)].numpy()
     np.savez_compressed(os.path.join(OUT, f"vivit_{tag}.npz"), **out)
@@ -343,8 +346,8 @@ def vivit_lowprec_case(vit, tag, cfg, batch, seed, modes):
         out[f"{mode}:logits"] = logits.numpy()
         out[f"{mode}:loss"] = loss.numpy()[None]
         for name, g in grads.items():
+            idx = digest_idx(tuple(g.shape))
             g = g.reshape(-1)
-            idx = np.linspace(0, g.numel() - 1, num=min(256, g.numel())).astype(np.int64)
             out[f"{mode}:gn:{name}"] = np.array(float(g.double().norm()))
             out[f"{mode}:gs:{name}"] = g[torch.from_numpy(idx)].numpy()
         print(f"vivit_{tag}_lowprec[{mode}]: loss {float(loss):.6f}")
