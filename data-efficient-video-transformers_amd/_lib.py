@@ -28,7 +28,7 @@ class SplitKPending(C.Structure):
         ("M", c_i64), ("N", c_i64), ("C", c_p), ("ldc", c_i64),
         ("accumulate", C.c_int32), ("cs_accumulate", C.c_int32),
         ("cs_slab", c_p), ("cs_out", c_p),
-        ("conv_cin", C.c_int32), ("conv_taps", C.c_int32),
+        ("conv_cin", C.c_int32), ("conv_taps", C.c_int32), ("conv_cin_l", C.c_int32), ("conv_cout_l", C.c_int32),
     ]
 
 
@@ -71,7 +71,13 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ("H", "W", "C", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "dtype")] + \
                [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32),
                 ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p),
-                ("residual", C.c_void_p), ("wgrad_master_layout", C.c_int32), ("wgrad_accumulate", C.c_int32)]
+                ("residual", C.c_void_p), ("wgrad_master_layout", C.c_int32), ("wgrad_accumulate", C.c_int32),
+                ("wgrad_cout_l", C.c_int32), ("wgrad_cin_l", C.c_int32)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("cout_l", "cin_l", "kh", "kw", "cout_p", "cin_p", "ld", "kind", "dtype")]
 
 
 class AttnDesc(C.Structure):
@@ -129,6 +135,7 @@ SIGNATURES = {
     "dvt_layernorm_bwd_partial_bytes": (C.c_size_t, [c_i64, c_i64]),
     "dvt_layernorm_bwd_ex": (c_int, [C.POINTER(LnBwdDesc), c_p]),
     "dvt_layernorm_reduce_group": (c_int, [c_p, c_int, c_p]),
+    "dvt_conv_weight_pack_group": (c_int, [c_p, c_int, c_p]),
     "dvt_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "dvt_layernorm_bwd_first": (c_int, [c_p] * 10 + [c_i64] * 7 + [c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_p]),
@@ -160,10 +167,10 @@ SIGNATURES = {
     "dvt_conv_weight_pack": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_i64, c_p]),
     "dvt_conv_weight_unpack_grad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p]),
     "dvt_bn_workspace_bytes": (C.c_size_t, [c_i64, c_int]),
-    "dvt_bn_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_int, c_p]),
+    "dvt_bn_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_f, c_f, c_int, c_p]),
     "dvt_bn_eval_invstd": (c_int, [c_p, c_p, c_int, c_f, c_p]),
-    "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
-    "dvt_bn_bwd": (c_int, [c_p] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_bn_bwd": (c_int, [c_p] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_bn_relu_maxpool_fwd": (c_int, [c_p] * 7 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_bn_bwd_pooled": (c_int, [c_p] * 11 + [c_i64] + [c_int] * 7 + [c_p]),
@@ -207,7 +214,7 @@ SIGNATURES = {
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
     "dvt_conv2d_implicit_stats_parts": (c_i64, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_stats_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
-    "dvt_bn_stats_from_partials": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_f, c_p]),
+    "dvt_bn_stats_from_partials": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_f, c_f, c_p]),
     "dvt_conv2d_implicit_wgrad_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad": (c_int, [C.POINTER(ConvDesc), c_p]),

@@ -226,6 +226,48 @@ __global__ void weight_pack_dgrad_kernel(const float* __restrict__ w, D* __restr
   }
 }
 
+// Both packed forms of MANY convolution weights in one launch (once per optimizer step: the weights only change there), with
+// the zero extension of channel-padded layers folded in.  A workgroup packs 2048 consecutive destination elements of the
+// entry its index falls into (entries carry their first workgroup).
+constexpr int kPackGroup = 40;
+struct PackGroup { dvt_pack_entry e[kPackGroup]; int begin[kPackGroup + 1]; int n; };
+
+template <typename D>
+__device__ __forceinline__ void pack_elems(const dvt_pack_entry& q, int64_t i0) {
+  const int taps = q.kh * q.kw;
+  const float* __restrict__ w = q.src;
+  D* __restrict__ dst = (D*)q.dst;
+  if (q.kind == 0) {                               // forward operand [cout_p][ld], column = tap * cin_p + ci
+    const int64_t total = (int64_t)q.cout_p * q.ld;
+    for (int64_t i = i0 + threadIdx.x; i < min(total, i0 + 2048); i += 256) {
+      const int col = (int)(i % q.ld), co = (int)(i / q.ld);
+      const int ci = col % q.cin_p, tap = col / q.cin_p;
+      float v = 0.f;
+      if (co < q.cout_l && ci < q.cin_l && tap < taps) v = w[((int64_t)co * q.cin_l + ci) * taps + tap];
+      dst[i] = from_f32<D>(v);
+    }
+  } else {                                         // data-gradient operand [cin_p][taps * cout_p]: rotated taps, transposed channels
+    const int64_t K = (int64_t)taps * q.cout_p, total = (int64_t)q.cin_p * K;
+    for (int64_t i = i0 + threadIdx.x; i < min(total, i0 + 2048); i += 256) {
+      const int ci = (int)(i / K), col = (int)(i % K);
+      const int co = col % q.cout_p, tap = taps - 1 - col / q.cout_p;
+      float v = 0.f;
+      if (co < q.cout_l && ci < q.cin_l) v = w[((int64_t)co * q.cin_l + ci) * taps + tap];
+      dst[i] = from_f32<D>(v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_pack_group_kernel(const PackGroup g) {
+  int e = 0;
+  while (e + 1 < g.n && (int)blockIdx.x >= g.begin[e + 1]) ++e;
+  const dvt_pack_entry& q = g.e[e];
+  const int64_t i0 = (int64_t)((int)blockIdx.x - g.begin[e]) * 2048;
+  if (q.dtype == DVT_BF16) pack_elems<bf16>(q, i0);
+  else if (q.dtype == DVT_F16) pack_elems<f16>(q, i0);
+  else pack_elems<float>(q, i0);
+}
+
 // ---- row-streaming BatchNorm kernels.  A thread owns ONE 8-channel group for its whole life (cg = thread % (C/8)) and walks
 // the rows lane, lane + lanes, ...: the per-channel constants are loaded and folded ONCE (reloading six parameter vectors
 // per 16 bytes of payload kept the CU's L1 / address pipeline four times busier with parameters than with data), and
@@ -249,9 +291,21 @@ __device__ __forceinline__ RowMap bn_row_map(int cv) {
 template <typename T>
 struct BnAffine {
   float mu[8], is[8], g[8], b[8], s[8], t[8];
-  __device__ __forceinline__ void init(const float* mean, const float* invstd, const float* gamma, const float* beta, int c) {
-    load8<float>(mean + c, mu); load8<float>(invstd + c, is); load8<float>(gamma + c, g);
-    if (beta) load8<float>(beta + c, b);
+  // cv: number of channels gamma / beta really have (channel-padded layers: the channels beyond are gamma = beta = 0, i.e.
+  // exact zeros through BatchNorm, ReLU and back); mean / invstd are internal arrays of the padded width
+  __device__ __forceinline__ void init(const float* mean, const float* invstd, const float* gamma, const float* beta, int c,
+                                       int cv) {
+    load8<float>(mean + c, mu); load8<float>(invstd + c, is);
+    if (c + 8 <= cv) {
+      load8<float>(gamma + c, g);
+      if (beta) load8<float>(beta + c, b);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        g[k] = c + k < cv ? gamma[c + k] : 0.f;
+        b[k] = (beta && c + k < cv) ? beta[c + k] : 0.f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (!beta) b[k] = 0.f;
@@ -283,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
                                                           const float* __restrict__ gamma = nullptr,
                                                           const float* __restrict__ beta = nullptr,
                                                           PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0},
-                                                          const unsigned char* __restrict__ mask = nullptr) {
+                                                          const unsigned char* __restrict__ mask = nullptr, int c_valid = 1 << 30) {
   // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
   // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.  Four rows are requested before the first is
   // consumed.  ReLU mask of MODE 1 (MSRC): 2 = the forward's mask bytes, 1 = the stored output y, 0 = recomputed from x.
@@ -298,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C && r0 < r1) {
     BnAffine<T> af;
-    if (MODE == 1) af.init(mean, invstd, gamma, (relu && MSRC == 0) ? beta : nullptr, c);
+    if (MODE == 1) af.init(mean, invstd, gamma, (relu && MSRC == 0) ? beta : nullptr, c, c_valid);
     constexpr int msrc = MSRC;
     for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * nrl) {
       float xv[U][8], dv[U][8], yv[U][8];
@@ -360,7 +414,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ o1, float* __restrict__ run_mean,
                                                            float* __restrict__ run_var, float momentum, float unbias,
                                                            int accumulate, float* __restrict__ pub0 = nullptr,
-                                                           float* __restrict__ pub1 = nullptr) {
+                                                           float* __restrict__ pub1 = nullptr, int c_valid = 1 << 30) {
+  // c_valid: the channels the CALLER's arrays (running statistics; published dgamma / dbeta) have -- a channel-padded layer's
+  // padded channels exist in the internal arrays (o0 / o1) only.
   // block = CL columns x PL = 1024 / CL part lanes; fixed summation order (lane-strided partial sums, then a lane tree).
   // CL = 8 for narrow maps: a 64-channel layer then runs on 8 CUs instead of 2 (the launch is bound by what ONE CU can pull
   // in -- up to 1 MB of partial rows -- not by arithmetic).
@@ -403,7 +459,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const float var = vard > 0.0 ? (float)vard : 0.f;
     o0[c] = mu;
     o1[c] = rsqrtf(var + eps);
-    if (run_mean) {
+    if (run_mean && c < c_valid) {
       run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
       run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
     }
@@ -412,8 +468,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     if (pub0) {                             // this launch's own sums for the apply pass; the caller's (accumulated) result
       o0[c] = d1;
       o1[c] = d0;
-      pub0[c] = accumulate ? pub0[c] + d1 : d1;   // dgamma
-      pub1[c] = accumulate ? pub1[c] + d0 : d0;   // dbeta
+      if (c < c_valid) {
+        pub0[c] = accumulate ? pub0[c] + d1 : d1;   // dgamma
+        pub1[c] = accumulate ? pub1[c] + d0 : d0;   // dbeta
+      }
     } else {
       o0[c] = accumulate ? o0[c] + d1 : d1;   // dgamma
       o1[c] = accumulate ? o1[c] + d0 : d0;   // dbeta
@@ -425,13 +483,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 template <int MODE>
 static void bn_finalize_launch(hipStream_t st, const float* partial, int nparts, int C, float inv_rows, float eps, float* o0,
                                float* o1, float* run_mean, float* run_var, float momentum, float unbias, int accumulate,
-                               float* pub0 = nullptr, float* pub1 = nullptr) {
+                               float* pub0 = nullptr, float* pub1 = nullptr, int c_valid = 1 << 30) {
   if (C <= 256)
     hipLaunchKernelGGL((bn_finalize_kernel<MODE, 8>), dim3((unsigned)dvt_cdiv(C, 8)), dim3(1024), 0, st, partial, nparts, C,
-                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1);
+                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1, c_valid);
   else
     hipLaunchKernelGGL((bn_finalize_kernel<MODE, 32>), dim3((unsigned)dvt_cdiv(C, 32)), dim3(1024), 0, st, partial, nparts, C,
-                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1);
+                       inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1, c_valid);
 }
 
 // Fold many partial rows (one per 128 output rows of a convolution: thousands) into gridDim.y rows that bn_finalize can
@@ -479,13 +537,13 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const T* __restrict__ residual,
                                                            T* __restrict__ y, unsigned char* __restrict__ mask, int64_t rows,
-                                                           int C, int relu) {
+                                                           int C, int relu, int c_valid) {
   const int cv = C >> 3;
   const RowMap m = bn_row_map(cv);
   if (m.row >= m.lanes) return;
   const int c = m.cg << 3;
   BnAffine<T> af;
-  af.init(mean, invstd, gamma, beta, c);
+  af.init(mean, invstd, gamma, beta, c, c_valid);
   for (int64_t r0 = m.row; r0 < rows; r0 += kBnU * m.lanes) {
     float xv[kBnU][8], rv[kBnU][8];
 #pragma unroll
@@ -524,13 +582,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            T* __restrict__ dx, T* __restrict__ dres, int64_t rows, int C,
-                                                           int relu, int training, float inv_rows) {
+                                                           int relu, int training, float inv_rows, int c_valid) {
   const int cv = C >> 3;
   const RowMap m = bn_row_map(cv);
   if (m.row >= m.lanes) return;
   const int c = m.cg << 3;
   BnAffine<T> af;
-  af.init(mean, invstd, gamma, MSRC == 0 ? beta : nullptr, c);
+  af.init(mean, invstd, gamma, MSRC == 0 ? beta : nullptr, c, c_valid);
   float gi[8], kb[8], kg[8];
   {
     float dg[8], db[8];
@@ -593,7 +651,7 @@ __global__ void bn_apply_bwd_pool_kernel(const T* __restrict__ dy, const T* __re
     pooled_dy8_k3s2p1<T>(dy, pg.idx, r / ((int64_t)pg.W * pg.H), h, w, c, C, pg.Ho, pg.Wo, dv);
     load8<T>(x + off, xv);
     BnAffine<T> af;
-    af.init(mean, invstd, gamma, beta, c);
+    af.init(mean, invstd, gamma, beta, c, C);
     load8<float>(dgamma + c, dg); load8<float>(dbeta + c, db);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -665,7 +723,7 @@ __global__ __launch_bounds__(256) void bn_colstats_pool_quad_kernel(const T* __r
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
     BnAffine<T> af;
-    af.init(mean, invstd, gamma, beta, c);
+    af.init(mean, invstd, gamma, beta, c, C);
     for (int64_t q = q0 + rl; q < q1; q += nrl) {
       const int qw = (int)(q % W2), qh = (int)((q / W2) % H2);
       const int64_t n = q / ((int64_t)W2 * H2);
@@ -720,7 +778,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_pool_quad_kernel(const T* __
   if (m.row >= m.lanes) return;
   const int c = m.cg << 3;
   BnAffine<T> af;
-  af.init(mean, invstd, gamma, beta, c);
+  af.init(mean, invstd, gamma, beta, c, C);
   float gi[8], kb[8], kg[8];
   {
     float dg[8], db[8];
@@ -1053,7 +1111,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_k3s2p1_kernel(const T* __
   if (m.row >= m.lanes) return;
   const int c = m.cg << 3;
   BnAffine<T> af;
-  af.init(mean, invstd, gamma, beta, c);
+  af.init(mean, invstd, gamma, beta, c, C);
   for (int64_t r = m.row; r < outs; r += m.lanes) {
     const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
     const int64_t n = r / ((int64_t)Wo * Ho);
@@ -1281,6 +1339,30 @@ int dvt_conv_weight_pack(const float* w, void* dst, int dst_dtype, int Cout, int
   return DVT_OK;
 }
 
+int dvt_conv_weight_pack_group(const dvt_pack_entry* entries, int count, dvt_stream_t stream) {
+  DVT_REQUIRE(count >= 0 && (count == 0 || entries), "dvt_conv_weight_pack_group: bad arguments");
+  for (int base = 0; base < count; base += kPackGroup) {
+    PackGroup g{};
+    int blocks = 0;
+    g.n = count - base < kPackGroup ? count - base : kPackGroup;
+    for (int i = 0; i < g.n; ++i) {
+      const dvt_pack_entry& q = entries[base + i];
+      DVT_REQUIRE(q.src && q.dst && q.cout_l > 0 && q.cin_l > 0 && q.kh > 0 && q.kw > 0 && q.cout_p >= q.cout_l &&
+                      q.cin_p >= q.cin_l && (q.kind == 0 || q.kind == 1) && (q.kind == 1 || q.ld >= q.kh * q.kw * q.cin_p) &&
+                      (q.dtype == DVT_F32 || dvt_is_16bit(q.dtype)),
+                  "dvt_conv_weight_pack_group: bad entry %d", base + i);
+      g.e[i] = q;
+      g.begin[i] = blocks;
+      const int64_t total = q.kind == 0 ? (int64_t)q.cout_p * q.ld : (int64_t)q.cin_p * q.kh * q.kw * q.cout_p;
+      blocks += (int)dvt_cdiv(total, 2048);
+    }
+    g.begin[g.n] = blocks;
+    hipLaunchKernelGGL(weight_pack_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    DVT_LAUNCH_CHECK("dvt_conv_weight_pack_group");
+  }
+  return DVT_OK;
+}
+
 int dvt_pad3_f32(const float* src, float* dst, int A, int B, int K, int Ap, int Bp, dvt_stream_t stream) {
   DVT_REQUIRE(src && dst && A > 0 && B > 0 && K > 0 && Ap >= A && Bp >= B, "dvt_pad3_f32: bad arguments");
   hipLaunchKernelGGL(pad3_kernel, dim3(cgrid((int64_t)Ap * Bp * K)), dim3(kB), 0, (hipStream_t)stream, src, dst, A, B, K, Ap, Bp);
@@ -1349,8 +1431,9 @@ static int bn_parts(int64_t rows, int C, int* rpb) {
 }
 
 int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                 void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0, "dvt_bn_stats: bad arguments");
+                 void* workspace, int64_t rows, int C, int c_valid, float eps, float momentum, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && mean && invstd && workspace && rows > 0 && C > 0 && c_valid <= C, "dvt_bn_stats: bad arguments");
+  if (c_valid <= 0) c_valid = C;
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
@@ -1369,15 +1452,17 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
   DVT_LAUNCH_CHECK("dvt_bn_stats");
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
   bn_finalize_launch<0>(st, (const float*)workspace, parts, C, 1.0f / (float)rows, eps, mean, invstd, running_mean,
-                     running_var, momentum, unbias, 0);
+                     running_var, momentum, unbias, 0, nullptr, nullptr, c_valid);
   DVT_LAUNCH_CHECK("dvt_bn_stats(finalize)");
   return DVT_OK;
 }
 
 int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
-                               float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream) {
-  DVT_REQUIRE(partial && mean && invstd && parts > 0 && parts < (1ll << 31) && rows > 0 && C > 0,
+                               float* running_var, int64_t rows, int C, int c_valid, float eps, float momentum,
+                               dvt_stream_t stream) {
+  DVT_REQUIRE(partial && mean && invstd && parts > 0 && parts < (1ll << 31) && rows > 0 && C > 0 && c_valid <= C,
               "dvt_bn_stats_from_partials: bad arguments");
+  if (c_valid <= 0) c_valid = C;
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
   hipStream_t st = (hipStream_t)stream;
   const float* src = partial;
@@ -1395,7 +1480,8 @@ int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float
     np = folds;
   }
   bn_finalize_launch<0>(st, src, np, C,
-                     1.0f / (float)rows, eps, mean, invstd, running_mean, running_var, momentum, unbias, 0);
+                     1.0f / (float)rows, eps, mean, invstd, running_mean, running_var, momentum, unbias, 0, nullptr, nullptr,
+                     c_valid);
   DVT_LAUNCH_CHECK("dvt_bn_stats_from_partials");
   return DVT_OK;
 }
@@ -1410,10 +1496,11 @@ int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps
 
 // grid of a row-streaming kernel: a multiple of C/8 threads is not needed (bn_row_map idles the remainder), 8 workgroups/CU
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int relu, int dtype,
+                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int c_valid, int relu, int dtype,
                      dvt_stream_t stream) {
-  DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0, "dvt_bn_apply_fwd: bad arguments");
+  DVT_REQUIRE(x && mean && invstd && gamma && beta && y && rows >= 0 && C > 0 && c_valid <= C, "dvt_bn_apply_fwd: bad arguments");
   if (rows == 0) return DVT_OK;
+  if (c_valid <= 0) c_valid = C;
   hipStream_t st = (hipStream_t)stream;
   if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(residual) && dvt_aligned16(mean) &&
       dvt_aligned16(invstd) && dvt_aligned16(gamma) && dvt_aligned16(beta)) {
@@ -1421,14 +1508,14 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 #define DVT_BN_FWD(RES, MASK)                                                                                      \
   DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, RES, MASK>), grid, dim3(kB), 0, st, (const T*)x, mean, \
                                                   invstd, gamma, beta, (const T*)residual, (T*)y, (unsigned char*)relu_mask, \
-                                                  rows, C, relu))
+                                                  rows, C, relu, c_valid))
     if (residual && relu_mask) DVT_BN_FWD(true, true);
     else if (residual) DVT_BN_FWD(true, false);
     else if (relu_mask) DVT_BN_FWD(false, true);
     else DVT_BN_FWD(false, false);
 #undef DVT_BN_FWD
   } else {
-    if (relu_mask) DVT_UNSUPPORTED("dvt_bn_apply_fwd: the ReLU mask output needs C %% 8 == 0 and 16-byte aligned buffers");
+    if (relu_mask || c_valid != C) DVT_UNSUPPORTED("dvt_bn_apply_fwd: the ReLU mask output / channel padding need C %% 8 == 0 and 16-byte aligned buffers");
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_fwd_scalar_kernel<T>), dim3(cgrid(rows * C)), dim3(kB), 0, st,
                                                     (const T*)x, mean, invstd, gamma, beta, (const T*)residual, (T*)y,
                                                     rows, C, relu));
@@ -1439,15 +1526,17 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
-               int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
+               int64_t rows, int C, int c_valid, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && c_valid <= C,
               "dvt_bn_bwd: bad arguments");
+  if (c_valid <= 0) c_valid = C;
   const bool cvec = C % 8 == 0 && dvt_aligned16(dy) && dvt_aligned16(x) && dvt_aligned16(y) && dvt_aligned16(dx) &&
                     dvt_aligned16(dres) && dvt_aligned16(mean) && dvt_aligned16(invstd) && dvt_aligned16(gamma) &&
                     dvt_aligned16(workspace);
   DVT_REQUIRE(!relu || y || relu_mask || (beta && !dres),
               "dvt_bn_bwd: relu needs the forward's mask bytes or output y, or beta to recompute the mask (no residual branch)");
-  if (relu_mask && !cvec) DVT_UNSUPPORTED("dvt_bn_bwd: the ReLU mask input needs C %% 8 == 0 and 16-byte aligned buffers");
+  if ((relu_mask || c_valid != C) && !cvec)
+    DVT_UNSUPPORTED("dvt_bn_bwd: the ReLU mask input / channel padding need C %% 8 == 0 and 16-byte aligned buffers");
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
@@ -1460,7 +1549,7 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
 #define DVT_BN_CS(MSRC)                                                                                                      \
   DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, false, MSRC>), grid, dim3(256), 0, st, (const T*)x, \
                                                   (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma, \
-                                                  beta, PoolGeom{nullptr, 0, 0, 0, 0}, (const unsigned char*)relu_mask))
+                                                  beta, PoolGeom{nullptr, 0, 0, 0, 0}, (const unsigned char*)relu_mask, c_valid))
     if (relu && relu_mask) DVT_BN_CS(2);
     else if (relu && y) DVT_BN_CS(1);
     else DVT_BN_CS(0);
@@ -1475,7 +1564,8 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
   // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
   bn_finalize_launch<1>(st, (const float*)part,
-                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta);
+                     parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta,
+                     c_valid);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {
     const dim3 agrid(cgrid(dvt_cdiv(rows, kBnU) * (C >> 3)));
@@ -1484,7 +1574,7 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
   DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, MSRC, DRES>), agrid, dim3(kB), 0, st, (const T*)dy,  \
                                                   (const T*)x, (const T*)y, (const unsigned char*)relu_mask, mean, invstd,   \
                                                   gamma, beta, loc, loc + C, (T*)dx, (T*)dres, rows, C, relu, training,      \
-                                                  1.0f / (float)rows))
+                                                  1.0f / (float)rows, c_valid))
     if (msrc == 2 && dres) DVT_BN_BWD(2, true);
     else if (msrc == 2) DVT_BN_BWD(2, false);
     else if (msrc == 1 && dres) DVT_BN_BWD(1, true);

@@ -895,7 +895,7 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
         q->slab = p.slab; q->splits = split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->C; q->ldc = d->ldc;
         q->accumulate = d->accumulate; q->cs_accumulate = d->colsum_accumulate;
         q->cs_slab = p.colsum_slab; q->cs_out = d->colsum_out;
-        q->conv_cin = 0; q->conv_taps = 0;
+        q->conv_cin = 0; q->conv_taps = 0; q->conv_cin_l = 0; q->conv_cout_l = 0;
         return DVT_OK;
       }
       else if (p.out_f32)
@@ -1109,14 +1109,18 @@ int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
     dvt_splitk_pending* q = d->pending;
     q->slab = p.slab; q->splits = pl.split; q->valid = 1; q->M = p.M; q->N = p.N; q->C = (float*)d->y; q->ldc = d->Cout;
     q->accumulate = 0; q->cs_accumulate = 0; q->cs_slab = nullptr; q->cs_out = nullptr;
-    q->conv_cin = 0; q->conv_taps = 0;
-    if (d->wgrad_master_layout) { q->conv_cin = d->C; q->conv_taps = d->kh * d->kw; q->accumulate = d->wgrad_accumulate; }
+    q->conv_cin = 0; q->conv_taps = 0; q->conv_cin_l = 0; q->conv_cout_l = 0;
+    if (d->wgrad_master_layout) {
+      q->conv_cin = d->C; q->conv_taps = d->kh * d->kw; q->accumulate = d->wgrad_accumulate;
+      q->conv_cin_l = d->wgrad_cin_l; q->conv_cout_l = d->wgrad_cout_l;
+    }
     return DVT_OK;
   }
   if (d->wgrad_master_layout) {
     dvt_splitk_pending q{};
     q.slab = p.slab; q.splits = pl.split; q.valid = 1; q.M = p.M; q.N = p.N; q.C = (float*)d->y; q.ldc = d->Cout;
     q.accumulate = d->wgrad_accumulate; q.conv_cin = d->C; q.conv_taps = d->kh * d->kw;
+    q.conv_cin_l = d->wgrad_cin_l; q.conv_cout_l = d->wgrad_cout_l;
     return launch_pending_reduce(&q, st);
   }
   const int64_t nvec = (int64_t)p.M * p.N / 8;

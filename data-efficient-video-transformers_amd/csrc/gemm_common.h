@@ -91,10 +91,15 @@ __device__ __forceinline__ void splitk_reduce_f32_part(const dvt_splitk_pending&
     if (q.conv_taps > 0) {
       // convolution weight gradient: (m = tap * Cin + ci, n = co) goes to the parameter's own layout C[co][ci][tap]
       const int64_t tap = m / q.conv_cin, ci = m - tap * q.conv_cin;
+      const int64_t cin_l = q.conv_cin_l > 0 ? q.conv_cin_l : q.conv_cin, cout_l = q.conv_cout_l > 0 ? q.conv_cout_l : q.N;
+      if (ci < cin_l) {                            // (padded input channels have no parameter entries)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float* o = q.C + ((n + k) * q.conv_cin + ci) * q.conv_taps + tap;
-        *o = q.accumulate ? *o + acc[k] : acc[k];
+        for (int k = 0; k < 8; ++k) {
+          if (n + k < cout_l) {
+            float* o = q.C + ((n + k) * cin_l + ci) * q.conv_taps + tap;
+            *o = q.accumulate ? *o + acc[k] : acc[k];
+          }
+        }
       }
       continue;
     }

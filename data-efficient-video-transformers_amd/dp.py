@@ -267,11 +267,14 @@ class FlatParameters:
         # (every parameter slice is 64-element aligned), rebuilt only when the set of unwritten parameters changes.
         self.skip_mask = None
         self._skip_sig = ()
+        self._packed = {}              # (parameter index, form, padded shape, dtype) -> (packed tensor, pack entry)
+        self._packed_valid = False
 
     # ------------------------------------------------------------------ compute copy
     def _after_step(self) -> None:
         from . import functional as F       # dropout generator: move past this step's sites (device-side add)
         F.next_step()
+        self._packed_valid = False          # the packed convolution weights are stale from here on
 
     def sync_compute_copy(self) -> None:
         """One cast launch: fp32 masters -> bf16 copy used by the GEMMs."""
@@ -283,6 +286,22 @@ class FlatParameters:
 
     def invalidate_compute_copy(self) -> None:
         self.compute_valid = False
+        self._packed_valid = False
+
+    def packed_weight(self, key, make):
+        """GEMM-operand forms of convolution weights (functional._packed_weight): kept here per (parameter, form) and ALL
+        refreshed by ONE launch at their first use after the weights changed (an optimizer step, a broadcast, a loaded
+        checkpoint) -- a training step then packs its convolution weights once instead of twice per layer."""
+        e = self._packed.get(key)
+        if e is None:
+            dst, entry = make()
+            self._packed[key] = (dst, entry)
+            ops.conv_weight_pack_group([entry])
+            return dst
+        if not self._packed_valid:
+            ops.conv_weight_pack_group([en for _, en in self._packed.values()])
+            self._packed_valid = True
+        return e[0]
 
     # ------------------------------------------------------------------ per-step protocol
     def zero_grad(self) -> None:
@@ -415,6 +434,7 @@ class FlatParameters:
                               mirror=self.compute)
         if self.compute is not None:
             self.compute_valid = True
+        self._packed_valid = False
         self._after_step()
 
     def sgd_step(self, lr: float, momentum: float = 0.0, weight_decay: float = 0.0) -> None:

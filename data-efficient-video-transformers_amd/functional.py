@@ -1212,6 +1212,26 @@ FUSE_BN_STATS = True
 HALO_CONV = True          # 64 -> 64 channel 3x3 / 1 / 1 convolutions from an LDS-resident halo patch (dvt_conv3x3_c64)
 
 
+def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: int, cout_p: int, cin_p: int, ld: int,
+                   dtype: torch.dtype) -> Tensor:
+    """The GEMM operand form of a convolution weight f32 [cout_l, cin_l, (1,) kh, kw]: kind 0 = forward [cout_p, ld] (column
+    (ki*kw + kj) * cin_p + ci), kind 1 = data gradient [cin_p, kh*kw*cout_p] (rotated taps, transposed channels); channels
+    beyond the parameter's own are zero (channel-padded layers).  A parameter that lives in a ``dp.FlatParameters`` store keeps
+    its packed forms there and ALL of them are refreshed by one launch per optimizer step (the weights only change there);
+    any other tensor is packed on the spot."""
+    def make():
+        src = w.detach().contiguous()
+        shape = (cout_p, ld) if kind == 0 else (cin_p, kh * kw * cout_p)
+        dst = torch.empty(shape, dtype=dtype, device=w.device)
+        return dst, (src, dst, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind)
+    sink = _sink(w)
+    if sink is None or w.dtype != torch.float32:
+        dst, entry = make()
+        ops.conv_weight_pack_group([entry])
+        return dst
+    return sink.owner.packed_weight((sink.index, kind, cout_p, cin_p, ld, dtype), make)
+
+
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
     clip frames [N, Cin, H, W] for the stem.  Returns the NHWC matrix [N*Ho*Wo, Cout].
@@ -1289,11 +1309,9 @@ class _ConvBnAct(torch.autograd.Function):
             if Cout != Cout_l:
                 w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh_o * kw_o, Cout, Cin_l)
             w4 = ops.conv_weight_pairs(w4, Cout, Cin_l, kh_o, kw_o, pw_o, kwp)          # [Cout, 8, kh, kwp]
-        else:
-            w4 = w.reshape(Cout_l, Cin_l, kh, kw)
-            if padded:
-                w4 = ops.pad3_f32(w4, Cout_l, Cin_l, kh * kw, Cout, Cin).view(Cout, Cin, kh, kw)
-        wp = ops.conv_weight_pack(w4, ld, dtype)
+            wp = ops.conv_weight_pack(w4, ld, dtype)
+        else:                                      # packed once per optimizer step for all layers (zero extension included)
+            wp = _packed_weight(w, 0, Cout_l, Cin_l, kh, kw, Cout, Cin, ld, dtype)
         implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8) and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad, ctx.trim))
         if ctx.trim and not implicit:
@@ -1317,24 +1335,22 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             col = xc if direct else ops.im2col(xc, nchw, N, Cin, H, W, k, stride, pad, ld, dtype)
             z = ops.linear_fwd(col, wp)                                 # [N*Ho*Wo, Cout]
+        # BatchNorm vectors keep the parameter's own length; the kernels take it as c_valid and treat the padded channels as
+        # gamma = beta = 0 (no padded copies, no slices of the statistics or of dgamma / dbeta)
         g32, b32 = _f32(gamma), _f32(beta)
         rm, rv = run_mean, run_var
-        if Cout != Cout_l:
-            g32 = ops.pad3_f32(g32, Cout_l, 1, 1, Cout, 1).view(-1)
-            b32 = ops.pad3_f32(b32, Cout_l, 1, 1, Cout, 1).view(-1)
-            if rm is not None:
-                rm = ops.pad3_f32(rm.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
-                rv = ops.pad3_f32(rv.detach().float(), Cout_l, 1, 1, Cout, 1).view(-1)
+        cval = Cout_l if Cout != Cout_l else 0
         if training:
             if stats_partial is not None:
-                mean, invstd = ops.bn_stats_from_partials(stats_partial, stats_parts, z.shape[0], Cout, rm, rv, eps, momentum)
+                mean, invstd = ops.bn_stats_from_partials(stats_partial, stats_parts, z.shape[0], Cout, rm, rv, eps, momentum,
+                                                          c_valid=cval)
             else:
-                mean, invstd = ops.bn_stats(z, rm, rv, eps, momentum)
-            if Cout != Cout_l and run_mean is not None:             # running statistics back into the module buffers
-                ops.unpad3_f32(rm, Cout_l, 1, 1, 1, out=run_mean)
-                ops.unpad3_f32(rv, Cout_l, 1, 1, 1, out=run_var)
+                mean, invstd = ops.bn_stats(z, rm, rv, eps, momentum, c_valid=cval)
         else:
             mean, invstd = rm.detach().float(), ops.bn_eval_invstd(rv.detach().float(), eps)
+            if cval:                               # (mean / invstd are internal arrays of the padded width)
+                mean = ops.pad3_f32(mean, Cout_l, 1, 1, Cout, 1).view(-1)
+                invstd = ops.pad3_f32(invstd, Cout_l, 1, 1, Cout, 1).view(-1)
         res = None if residual is None else residual.contiguous()
         if res is not None and res.shape[1] != Cout:
             raise ValueError("residual width must equal the (padded) output width")
@@ -1346,11 +1362,13 @@ class _ConvBnAct(torch.autograd.Function):
         # (1/16 of re-reading y in both passes of the BatchNorm backward)
         rmask = None
         if pooled:
+            if cval:
+                raise ValueError("pool=True is for layers without channel padding")
             y, pidx = ops.bn_relu_maxpool_fwd(z, mean, invstd, g32, b32, N, Cout, Ho, Wo, relu)
         elif relu and res is not None and Cout % 8 == 0 and any(ctx.needs_input_grad):
-            y, rmask = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu, want_mask=True)
+            y, rmask = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu, want_mask=True, c_valid=cval)
         else:
-            y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu)
+            y = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu, c_valid=cval)
         # weight gradient straight from x (column matrix gathered inside the GEMM): nothing to keep but x
         wg_implicit = (IMPLICIT_CONV and not direct and not nchw and xc.dtype == dtype and
                        ops.conv2d_implicit_wgrad_supported(xc, z, N, Cin, H, W, Cout, k, stride, pad, ctx.trim))
@@ -1365,7 +1383,9 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
         ctx.x_needs = x.requires_grad
         ctx.x_shape, ctx.x_dtype = tuple(x.shape), x.dtype
-        ctx.w4 = w4.detach() if implicit else None
+        ctx.implicit = implicit
+        ctx.w_ref = w if pair is None else None           # the parameter itself: backward asks for its data-gradient form
+        ctx.w4 = w4.detach() if (implicit and pair is not None) else None
         ctx.wg_implicit = wg_implicit
         ctx.logical = (Cout_l, Cin_l, padded)
         if fork is None:
@@ -1387,40 +1407,35 @@ class _ConvBnAct(torch.autograd.Function):
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         Wo -= ctx.trim
 
+        cval = Cout_l if Cout != Cout_l else 0           # channel-padded layer: dgamma / dbeta have the parameter's own length
+
         def bn_backward(**kw):
             if pidx is not None:       # dy is the pooled gradient
                 dz_, dg_, db_ = ops.bn_bwd_pooled(dy, pidx, z, mean, invstd, g32, b32, N, Ho, Wo, relu, training, **kw)
                 return dz_, None, dg_, db_
-            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, **kw)
+            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, c_valid=cval, **kw)
 
-        if sg is not None and sb is not None and Cout == Cout_l and sg.fresh != sb.fresh:
+        if sg is not None and sb is not None and sg.fresh != sb.fresh:
             dz, dres, dgam, dbet = bn_backward()
             _emit_into(sg, dgam); _emit_into(sb, dbet)
             dgam = dbet = None
-        elif sg is not None and sb is not None and Cout == Cout_l:
+        elif sg is not None and sb is not None:
             dz, dres, _, _ = bn_backward(dgamma=sg.buf.view(-1), dbeta=sb.buf.view(-1), accumulate=not sg.fresh)
             sg.mark_written(); sb.mark_written()
             dgam = dbet = None
         else:
             dz, dres, dgam, dbet = bn_backward()
-            if Cout != Cout_l:                                           # drop the padded channels
-                if sg is not None and sb is not None:
-                    ops.unpad3_f32(dgam, Cout_l, 1, 1, 1, out=sg.buf.view(-1), accumulate=not sg.fresh)
-                    ops.unpad3_f32(dbet, Cout_l, 1, 1, 1, out=sb.buf.view(-1), accumulate=not sb.fresh)
-                    sg.mark_written(); sb.mark_written()
-                    dgam = dbet = None
-                else:
-                    dgam = ops.unpad3_f32(dgam, Cout_l, 1, 1, 1).view(-1)
-                    dbet = ops.unpad3_f32(dbet, Cout_l, 1, 1, 1).view(-1)
         (kh, kw) = ops._pair(k)
         w4 = (Cout, Cin, kh, kw)
         # the common case: the split-K reduce scatters straight into the parameter's own gradient layout (no packed dWt, no
-        # scatter launch); the pixel-pair stem and channel-padded layers post-process the packed form instead
-        direct_dw = ctx.wg_implicit and ctx.pair is None and not padded
+        # scatter launch; channel-padded layers: only the entries the parameter has); the pixel-pair stem post-processes the
+        # packed form instead
+        direct_dw = ctx.wg_implicit and ctx.pair is None
         if direct_dw:
             dw_master = sw.buf.view(wshape) if sw is not None else torch.empty(wshape, dtype=torch.float32, device=dz.device)
             _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
-                                                master=dw_master, accumulate=(not sw.fresh) if sw is not None else False)
+                                                master=dw_master, accumulate=(not sw.fresh) if sw is not None else False,
+                                                logical=(Cout_l, Cin_l))
             unpack = dwp = None
         elif ctx.wg_implicit:
             dwt, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim,
@@ -1485,9 +1500,12 @@ class _ConvBnAct(torch.autograd.Function):
                 return None
             joined[0] = True
             return dshort.view(N * H * W, Cin)
-        if (ctx.x_needs and ctx.w4 is not None and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0 and kw - 1 - pw_ >= 0
+        if (ctx.x_needs and ctx.implicit and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0 and kw - 1 - pw_ >= 0
                 and (Ho, Wo) == (H + 2 * ph_ - kh + 1, W + 2 * pw_ - kw + 1)):
-            wd = ops.conv_weight_pack_dgrad(ctx.w4, dtype)               # [Cin, kh*kw*Cout]
+            if ctx.w_ref is not None:                                    # [Cin, kh*kw*Cout], refreshed once per optimizer step
+                wd = _packed_weight(ctx.w_ref, 1, Cout_l, Cin_l, kh, kw, Cout, Cin, 0, dtype)
+            else:
+                wd = ops.conv_weight_pack_dgrad(ctx.w4, dtype)
             pd = (kh - 1 - ph_, kw - 1 - pw_)
             if (HALO_CONV and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and pd == (1, 1)
                     and ops.conv3x3_c64_supported(dz, wd, N, Ho, Wo)):

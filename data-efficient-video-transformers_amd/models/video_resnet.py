@@ -38,13 +38,17 @@ class Conv2Plus1D(nn.Sequential):
 CPAD = 64     # mid-plane counts 45 / 230 / 460 / 921 are zero-padded to multiples of 64 (MFMA / LDS-DMA tile widths)
 
 
-def _spatial(fm, conv, bn, relu, dtype):
-    """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames."""
+def _spatial(fm, conv, bn, relu, dtype, fork=None):
+    """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames.  fork="alias": the map has a second consumer
+    (the block's shortcut); the layer hands it out as a second result so that the shortcut's gradient joins this layer's
+    data gradient inside the kernel that writes it (F._ConvBnAct) -> (fm, alias)."""
     y, N, T, H, W = fm
     k, s, p = conv.kernel_size[1:], conv.stride[1:], conv.padding[1:]
     out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
-                            cpad=CPAD)
+                            cpad=CPAD, fork=fork)
     Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    if fork is not None:
+        return (out[0], N, T, Ho, Wo), out[1]
     return (out, N, T, Ho, Wo)
 
 
@@ -74,7 +78,7 @@ class BasicBlock(nn.Module):
     def forward_ndhwc(self, fm, dtype):
         y, N, T, H, W = fm
         c1, c2 = self.conv1[0], self.conv2[0]
-        out = _spatial(fm, c1[0], c1[1], True, dtype)
+        out, y = _spatial(fm, c1[0], c1[1], True, dtype, fork="alias")      # y: the block input again, for the shortcut
         out = _temporal(out, c1[3], self.conv1[1], True, dtype)
         residual = y
         if self.downsample is not None:

@@ -1264,13 +1264,14 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
 
 
 def bn_stats_from_partials(partial: Tensor, parts: int, rows: int, Cc: int, running_mean: Optional[Tensor],
-                           running_var: Optional[Tensor], eps: float, momentum: float):
-    """mean / invstd (and the running statistics update) from the partial sums of conv2d_implicit(want_stats=True)."""
+                           running_var: Optional[Tensor], eps: float, momentum: float, c_valid: int = 0):
+    """mean / invstd (and the running statistics update) from the partial sums of conv2d_implicit(want_stats=True).
+    c_valid: channels the running statistics really have (channel-padded layers; 0 = Cc)."""
     mean = torch.empty((Cc,), dtype=torch.float32, device=partial.device)
     invstd = torch.empty((Cc,), dtype=torch.float32, device=partial.device)
     L.check(L.load().dvt_bn_stats_from_partials(partial.data_ptr(), parts, mean.data_ptr(), invstd.data_ptr(),
-                                               _p(running_mean), _p(running_var), rows, Cc, eps, momentum, _stream()),
-            "dvt_bn_stats_from_partials")
+                                               _p(running_mean), _p(running_var), rows, Cc, c_valid, eps, momentum,
+                                               _stream()), "dvt_bn_stats_from_partials")
     return mean, invstd
 
 
@@ -1284,7 +1285,7 @@ def conv2d_implicit_wgrad_supported(x: Tensor, dz: Tensor, N, Cc, H, W, Cout, k,
 
 def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
                           trim_w: int = 0, defer_reduce: bool = False, master: Optional[Tensor] = None,
-                          accumulate: bool = False):
+                          accumulate: bool = False, logical: Optional[Tuple[int, int]] = None):
     """-> dWt f32 [kh*kw*C, Cout] = gather(x)^T dz, the column matrix never materialised.
     defer_reduce: -> (dWt, pending): the split-K reduce is left to the data-gradient launch of the same layer
     (``conv2d_implicit(..., carry=pending)`` / ``linear_dgrad(..., carry=pending)``) or ``splitk_reduce_pending``.
@@ -1292,14 +1293,17 @@ def conv2d_implicit_wgrad(x: Tensor, dz: Tensor, N: int, Cc: int, H: int, W: int
     and it is what is returned in dWt's place (no packed intermediate, no scatter launch)."""
     _need_cuda(x, dz, master)
     (kh, kw) = _pair(k)
+    cout_l, cin_l = logical if logical is not None else (Cout, Cc)       # channel-padded layers: the parameter's own counts
     if master is not None:
-        assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == Cout * Cc * kh * kw
+        assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == cout_l * cin_l * kh * kw
+        assert cout_l <= Cout and cin_l <= Cc
         out = master
     else:
         assert not accumulate
         out = torch.empty((kh * kw * Cc, Cout), dtype=torch.float32, device=x.device)
     d = _conv_desc(x, dz, out, N, Cc, H, W, Cout, k, stride, pad, trim_w)
     d.wgrad_master_layout, d.wgrad_accumulate = int(master is not None), int(accumulate)
+    d.wgrad_cout_l, d.wgrad_cin_l = (cout_l, cin_l) if master is not None else (0, 0)
     lib = L.load()
     pending = L.SplitKPending() if defer_reduce else None
     nws = lib.dvt_conv2d_implicit_wgrad_workspace_bytes(C.byref(d))
@@ -1347,6 +1351,23 @@ def unpad3_f32(src: Tensor, A: int, B: int, K: int, Bp: int, *, out: Optional[Te
     return out
 
 
+def conv_weight_pack_group(entries) -> None:
+    """Both packed forms of many convolution weights in one launch.  entries: (src f32 [cout_l, cin_l, kh*kw] contiguous,
+    dst tensor, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind) with kind 0 = forward operand [cout_p, ld], 1 = data-gradient
+    operand [cin_p, kh*kw*cout_p]."""
+    if not entries:
+        return
+    arr = (L.PackEntry * len(entries))()
+    for i, (src, dst, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind) in enumerate(entries):
+        _need_cuda(src, dst)
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == cout_l * cin_l * kh * kw
+        assert dst.is_contiguous() and dst.numel() == (cout_p * ld if kind == 0 else cin_p * kh * kw * cout_p)
+        e = arr[i]
+        e.src, e.dst = src.data_ptr(), dst.data_ptr()
+        e.cout_l, e.cin_l, e.kh, e.kw, e.cout_p, e.cin_p, e.ld, e.kind, e.dtype = cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind, dt(dst)
+    L.check(L.load().dvt_conv_weight_pack_group(C.cast(arr, C.c_void_p), len(entries), _stream()), "dvt_conv_weight_pack_group")
+
+
 def conv_weight_pack(w: Tensor, ld: int, dtype: torch.dtype) -> Tensor:
     _need_cuda(w)
     w = w.detach().contiguous()
@@ -1381,7 +1402,7 @@ def conv_weight_unpack_grad(g: Tensor, shape, *, out: Optional[Tensor] = None, a
 
 
 def bn_stats(z: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float,
-             momentum: float) -> Tuple[Tensor, Tensor]:
+             momentum: float, c_valid: int = 0) -> Tuple[Tensor, Tensor]:
     _need_cuda(z)
     rows, Cc = z.shape
     mean = torch.empty((Cc,), dtype=torch.float32, device=z.device)
@@ -1390,7 +1411,7 @@ def bn_stats(z: Tensor, running_mean: Optional[Tensor], running_var: Optional[Te
     ws = workspace(lib.dvt_bn_workspace_bytes(rows, Cc), z.device)
     with _timed(("hbm", "bn_stats", rows * Cc), z.numel() * z.element_size()):
         L.check(lib.dvt_bn_stats(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
-                                 ws.data_ptr(), rows, Cc, eps, momentum, dt(z), _stream()), "dvt_bn_stats")
+                                 ws.data_ptr(), rows, Cc, c_valid, eps, momentum, dt(z), _stream()), "dvt_bn_stats")
     return mean, invstd
 
 
@@ -1402,7 +1423,7 @@ def bn_eval_invstd(running_var: Tensor, eps: float) -> Tensor:
 
 
 def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, residual: Optional[Tensor],
-                 relu: bool, want_mask: bool = False):
+                 relu: bool, want_mask: bool = False, c_valid: int = 0):
     """want_mask: -> (y, mask) with mask uint8 [rows, C/8], the ReLU mask bits for bn_bwd (layers with a residual branch)."""
     rows, Cc = z.shape
     y = torch.empty_like(z)
@@ -1410,14 +1431,14 @@ def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: T
     nb = z.numel() * z.element_size() * (2 + (residual is not None)) + (rows * (Cc // 8) if want_mask else 0)
     with _timed(("hbm", "bn_apply_fwd", rows * Cc), nb):
         L.check(L.load().dvt_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                          beta.data_ptr(), _p(residual), y.data_ptr(), _p(mask), rows, Cc, int(relu), dt(z),
-                                          _stream()), "dvt_bn_apply_fwd")
+                                          beta.data_ptr(), _p(residual), y.data_ptr(), _p(mask), rows, Cc, c_valid, int(relu),
+                                          dt(z), _stream()), "dvt_bn_apply_fwd")
     return (y, mask) if want_mask else y
 
 
 def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
            training: bool, want_dres: bool, *, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-           accumulate: bool = False, beta: Optional[Tensor] = None, mask: Optional[Tensor] = None):
+           accumulate: bool = False, beta: Optional[Tensor] = None, mask: Optional[Tensor] = None, c_valid: int = 0):
     """ReLU mask: ``mask`` (bn_apply_fwd(want_mask=True)) if given, else ``y``, else recomputed from z (``beta`` given, no
     residual branch)."""
     rows, Cc = z.shape
@@ -1425,8 +1446,8 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
     dres = torch.empty_like(z) if want_dres else None
     if dgamma is None:
         assert not accumulate
-        dgamma = torch.empty((Cc,), dtype=torch.float32, device=z.device)
-        dbeta = torch.empty((Cc,), dtype=torch.float32, device=z.device)
+        dgamma = torch.empty((c_valid or Cc,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((c_valid or Cc,), dtype=torch.float32, device=z.device)
     if mask is not None:
         assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == rows * (Cc // 8)
         y = None
@@ -1441,7 +1462,7 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
     with _timed(("hbm", "bn_bwd", rows * Cc), nb):
         L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), _p(mask), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), rows, Cc,
-                               int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
+                               c_valid, int(relu), int(training), int(accumulate), dt(z), _stream()), "dvt_bn_bwd")
     return dz, dres, dgamma, dbeta
 
 

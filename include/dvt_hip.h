@@ -267,6 +267,9 @@ typedef struct dvt_splitk_pending {
    * the reduce scatters it straight into the parameter's own layout C[co][ci][tap] (f32 [N][conv_cin][conv_taps], ldc
    * unused): no packed intermediate, no scatter launch behind the reduce. */
   int32_t conv_cin, conv_taps;
+  /* channel-padded layers: only n < conv_cout_l and ci < conv_cin_l exist in the parameter f32 [conv_cout_l][conv_cin_l]
+   * [conv_taps] (0: the GEMM's own N / conv_cin) */
+  int32_t conv_cin_l, conv_cout_l;
 } dvt_splitk_pending;
 
 typedef struct dvt_gemm_desc {
@@ -538,6 +541,16 @@ int dvt_unpad3_f32(const float* src, float* dst, int A, int B, int K, int Bp, in
  * operand of the data-gradient convolution, see dvt_conv2d_implicit). */
 int dvt_conv_weight_pack_dgrad(const float* w, void* dst, int dst_dtype, int Cout, int Cin, int kh, int kw,
                                dvt_stream_t stream);
+/* Both packed forms of many convolution weights in ONE launch -- the weights change once per optimizer step, so a training
+ * step needs one such launch instead of two per layer -- with the zero extension of channel-padded layers (cout_p >= cout_l,
+ * cin_p >= cin_l) folded in.  kind 0: dvt_conv_weight_pack's layout dst[cout_p][ld] (column (ki*kw+kj)*cin_p + ci, zeros
+ * beyond); kind 1: dvt_conv_weight_pack_dgrad's dst[cin_p][kh*kw*cout_p] (rotated taps, transposed channels). */
+typedef struct dvt_pack_entry {
+  const float* src;      /* f32 [cout_l][cin_l][kh*kw] */
+  void* dst;
+  int32_t cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind, dtype;
+} dvt_pack_entry;
+int dvt_conv_weight_pack_group(const dvt_pack_entry* entries, int count, dvt_stream_t stream);
 typedef struct dvt_conv_desc {
   const void* x;
   const void* w;
@@ -568,6 +581,7 @@ typedef struct dvt_conv_desc {
   /* weight gradient, optional: y is the parameter's own gradient f32 [Cout][C][kh][kw] (+= when wgrad_accumulate) instead
    * of the packed dWt -- the split-K reduce scatters into it (dvt_splitk_pending.conv_taps). */
   int32_t wgrad_master_layout, wgrad_accumulate;
+  int32_t wgrad_cout_l, wgrad_cin_l;   /* channel-padded layers: the parameter's own channel counts (0: Cout / C) */
 } dvt_conv_desc;
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
  * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a
@@ -606,20 +620,25 @@ int dvt_conv_weight_unpack_grad(const float* g, float* dw, int Cout, int Cin, in
  * biased variance -> mean / invstd, running statistics updated with `momentum` (unbiased variance),
  * as torch does.  Eval: dvt_bn_eval_invstd from running_var.  workspace >= dvt_bn_workspace_bytes. */
 size_t dvt_bn_workspace_bytes(int64_t rows, int C);
+/* c_valid (every BatchNorm entry that takes it): the channels the parameter-side arrays really have -- gamma, beta, the
+ * running statistics, dgamma, dbeta are [c_valid]; mean / invstd and the maps are [C] wide, C >= c_valid.  The layers of
+ * R(2+1)D whose plane counts (45, 230, 460, 921) are zero-extended to multiples of 64 run at the padded width without
+ * padded copies of their BatchNorm vectors: channels >= c_valid behave as gamma = beta = 0.  c_valid <= 0 means C. */
 int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                 void* workspace, int64_t rows, int C, float eps, float momentum, int dtype, dvt_stream_t stream);
+                 void* workspace, int64_t rows, int C, int c_valid, float eps, float momentum, int dtype, dvt_stream_t stream);
 /* Same result from the per-block partial sums a convolution left behind (dvt_conv_desc.stats_partial, a buffer of
  * dvt_conv2d_implicit_stats_bytes = parts + 64 rows of 2 * C floats: with more than 256 partial rows the call WRITES
  * the 64-row tail -- it folds the partial rows into it before the final sum, hence the non-const pointer). */
 int dvt_bn_stats_from_partials(float* partial, int64_t parts, float* mean, float* invstd, float* running_mean,
-                               float* running_var, int64_t rows, int C, float eps, float momentum, dvt_stream_t stream);
+                               float* running_var, int64_t rows, int C, int c_valid, float eps, float momentum,
+                               dvt_stream_t stream);
 int dvt_bn_eval_invstd(const float* running_var, float* invstd, int C, float eps, dvt_stream_t stream);
 /* y = relu?((x-mean)*invstd*gamma + beta (+ residual)): `out += residual; relu` fused (custom_resnet.py:51-52).
  * relu_mask (optional, C % 8 == 0): uint8 [rows][C/8], bit k of byte (r, g) = y[r, 8g + k] > 0 -- the ReLU mask the backward
  * of a layer WITH a residual branch needs (its output cannot be recomputed from x alone); dvt_bn_bwd reads these bytes
  * (1/16 of the traffic) instead of the output y in both of its passes. */
 int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int relu, int dtype,
+                     const void* residual, void* y, void* relu_mask, int64_t rows, int C, int c_valid, int relu, int dtype,
                      dvt_stream_t stream);
 /* dz = dy*(relu mask); dres = dz (if dres != NULL); dgamma/dbeta (+)=; dx by the batch-statistics formula (training) or
  * gamma*invstd*dz (eval).  The ReLU mask comes from relu_mask (dvt_bn_apply_fwd's bytes) when given, else from the
@@ -627,7 +646,7 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
  * (x - mean)*invstd*gamma + beta > 0 (beta required). */
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
-               int64_t rows, int C, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
+               int64_t rows, int C, int c_valid, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
 /* The ResNet stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) without the normalised map in HBM:
  * _fwd reads the convolution output z once and writes the pooled map y[N*Ho*Wo, C] and the argmax taps idx (same values
  * and taps as dvt_bn_apply_fwd followed by dvt_maxpool_fwd); dvt_bn_bwd_pooled is dvt_bn_bwd whose incoming gradient

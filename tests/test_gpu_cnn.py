@@ -433,7 +433,7 @@ def test_r2plus1d_18_matches_conv3d_restatement(dvt, device, mode):
     errs = {k: rel_l2(Pn[k].grad.double() / scale, tg[k]) for k in tg}
     e_out = rel_l2(out, truth)
     w = assert_within_reference_lowprec(f"r2plus1d/{mode}", e_out, errs, yard_out, yard,
-                                        floor=1e-4 if mode == "fp32" else 2e-4)
+                                        floor=1e-4 if mode == "fp32" else 2e-4, flip_noise=True)
     print(f"[r2plus1d/{mode}] features rel {e_out:.2e} (restatement's own {yard_out:.2e}); {len(errs)} gradients: median "
           f"{float(np.median(list(errs.values()))):.2e} (own {float(np.median(list(yard.values()))):.2e}); worst ratio "
           f"{w[0][1]:.2f} ({w[0][0]})")
