@@ -1054,10 +1054,9 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   if (Ho <= 0 || Wo <= 0) return false;
   const int64_t rows = d->N * Ho * Wo;
   pl->cfg = conv_cfg(d->Cout, d->C, true);
-  if (pl->cfg == 6 && rows % 64) pl->cfg = 4;
-  if (pl->cfg == 7 && rows % 64) pl->cfg = 1;
   pl->tk = conv_tk(pl->cfg);
-  if (rows % pl->tk || rows >= ((int64_t)1 << 31) || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
+  // (any pixel count: rows past the end of the last k-tile are read as zeros by both operand gathers)
+  if (rows >= ((int64_t)1 << 31) - 64 || d->N * d->H * d->W >= ((int64_t)1 << 31)) return false;
   pl->K = d->kh * d->kw * d->C;
   pl->rows = rows; pl->Ho = (int)Ho; pl->Wo = (int)Wo;
   const int tn = pl->cfg == 4 || pl->cfg == 6 ? 64 : pl->cfg ? 128 : 256;
@@ -1066,7 +1065,7 @@ static bool conv_wgrad_plan(const dvt_conv_desc* d, ConvWgradPlan* pl) {
   const int64_t target = (int64_t)dvt_num_cus() * (two_per_cu ? 2 : 1);
   int64_t split = target / tiles;
   if (split < 1) split = 1;
-  const int64_t ktiles = rows / pl->tk;
+  const int64_t ktiles = dvt_cdiv(rows, pl->tk);
   if (split > ktiles / 4) split = ktiles / 4 > 0 ? ktiles / 4 : 1;          // at least 4 k-tiles per slice
   pl->kps = (int)(dvt_cdiv(ktiles, split) * pl->tk);
   pl->split = (int)dvt_cdiv(rows, pl->kps);
@@ -1088,8 +1087,7 @@ size_t dvt_conv2d_implicit_wgrad_workspace_bytes(const dvt_conv_desc* d) {
 int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* d, dvt_stream_t stream) {
   ConvWgradPlan pl;
   if (!conv_wgrad_plan(d, &pl))
-    DVT_UNSUPPORTED("dvt_conv2d_implicit_wgrad: needs a 16-bit dtype, C %% 8 == 0, Cout %% 8 == 0 and N*Ho*Wo a multiple of "
-                    "the k-tile (32 for Cout <= 128, else 64)");
+    DVT_UNSUPPORTED("dvt_conv2d_implicit_wgrad: needs a 16-bit dtype, C %% 8 == 0 and Cout %% 8 == 0");
   DVT_REQUIRE(d->workspace, "dvt_conv2d_implicit_wgrad: workspace (dvt_conv2d_implicit_wgrad_workspace_bytes) required");
   hipStream_t st = (hipStream_t)stream;
   GemmParams p{};

@@ -69,12 +69,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 16-byte-chunk swizzle of a k-major image row (XOR involution, also used on the read side)
 template <int TK> __device__ __forceinline__ int swz_k(int row) { return TK == 64 ? (row & 7) : ((row >> 1) & 3); }
 
+// 16 zero bytes in global memory: the DMA source of every padded (out-of-image) tap of the implicit convolution
+static __device__ __attribute__((aligned(16))) unsigned int dvt_zero16[4] = {0u, 0u, 0u, 0u};
+
 // DMA one operand tile into LDS in 1 KiB pieces (one wave-instruction each).
 //   k-major : image [ROWS][TK],  row = TK*2 bytes
 //   mn-major: image [TK][ROWS],  row = ROWS*2 bytes, 32-byte units XOR-swizzled by swz_mn(k)
-template <bool KMAJOR, int ROWS, int TK, int NW>
+// KLIM (mn-major images only): k rows >= k_lim read the zero page -- the weight gradient of a convolution whose pixel
+// count is not a multiple of the k-tile (the last k-tile of the last slice is ragged).
+template <bool KMAJOR, int ROWS, int TK, int NW, bool KLIM = false>
 __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t ld, int mn0, int mn_lim,
-                                         int k0, char* tile, int wid, int lane) {
+                                         int k0, char* tile, int wid, int lane, int k_lim = 0) {
   constexpr int PIECES = ROWS * TK * 2 / 1024;
   constexpr int PPW = (PIECES + NW - 1) / NW;        // (224-row tiles: 28 pieces, 4 each for waves 0 .. 6)
 #pragma unroll
@@ -99,13 +104,12 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
       int gmn = mn0 + c * 8;
       gmn = gmn < mn_lim ? gmn : mn_lim - 8;
       src = base + (int64_t)(k0 + k) * ld + gmn;
+      if (KLIM && k0 + k >= k_lim) src = reinterpret_cast<const bf16*>(dvt_zero16);
     }
     dvt_dma16(src, tile + piece * 1024);
   }
 }
 
-// 16 zero bytes in global memory: the DMA source of every padded (out-of-image) tap of the implicit convolution
-static __device__ __attribute__((aligned(16))) unsigned int dvt_zero16[4] = {0u, 0u, 0u, 0u};
 
 // Implicit-GEMM A operand: row = output pixel (n, ho, wo), k = (ki, kj, c) of an NHWC map x[N, H, W, C].
 // C % TK == 0, so a whole k-tile lies inside one filter tap: per k-tile a lane only adds the tap's (ki, kj) to the
@@ -169,6 +173,7 @@ template <int ROWS, int TK, int NW>
 struct ConvColsMN {
   enum { PIECES = ROWS * TK * 2 / 1024, PPW = PIECES / NW, CPR = ROWS / 8, RPP = 64 / CPR };
   int wo[PPW], ho[PPW], nb[PPW], tc[PPW];   // tc = channel | kj << 16 | ki << 24
+  int krow[PPW];                            // the pixel row this lane's chunk of the NEXT k-tile names (rows >= p.K: zeros)
   int dr, dqr, dqq;
   __device__ __forceinline__ void init(const GemmParams& p, int m0, int kbeg, int wid, int lane) {
     const int dq = TK / p.cWo;
@@ -187,6 +192,7 @@ struct ConvColsMN {
       const int ki = tap / p.ckw, kj = tap - ki * p.ckw;
       tc[i] = (gmn - tap * p.cC) | (kj << 16) | (ki << 24);
       const int row = kbeg + k;
+      krow[i] = row;
       const int n = row / hw, r = row - n * hw;
       ho[i] = r / p.cWo;
       wo[i] = r - ho[i] * p.cWo;
@@ -198,10 +204,11 @@ struct ConvColsMN {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int hi = ho[i] * p.csh - p.cph + (tc[i] >> 24), wi = wo[i] * p.csw - p.cpw + ((tc[i] >> 16) & 0xff);
-      const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+      const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW && krow[i] < p.K;
       const bf16* src = ok ? p.A + ((int64_t)(nb[i] + hi * p.cW + wi) * p.cC + (tc[i] & 0xffff))
                            : reinterpret_cast<const bf16*>(dvt_zero16);
       dvt_dma16(src, tile + (wid * PPW + i) * 1024);
+      krow[i] += TK;
       wo[i] += dr;
       ho[i] += dqr;
       nb[i] += dqq * p.cH * p.cW;
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   constexpr int TM = C::TM, TN = C::TN, TK = C::TK, NW = C::NW, WN = C::WN, NSTG = C::NSTG;
   constexpr int kATile = TM * TK * 2, kBTile = TN * TK * 2, kStage = kATile + kBTile;
   constexpr int kPPT = (kATile + kBTile) / 1024 / NW;   // DMA instructions per thread per k-tile
+  constexpr bool kKLim = A_CONV && !A_KMAJOR && !B_KMAJOR;   // convolution weight gradient: K = output pixels, any count
   constexpr int WROWS = TM / (NW / WN);                 // rows of the tile owned by one wave (x 64 columns)
   constexpr int MT = WROWS / 16, NTH = MT / 4;          // m sub-tiles per wave, 64-row halves per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   const int n0 = (tile % p.tiles_n) * TN;
   const int kbeg = zsl * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / TK;
+  const int nk = (kend - kbeg + TK - 1) / TK;      // (a multiple of TK except in the ragged last slice of a convolution weight gradient)
 
   f32x4 acc[4][MT];  // [u: n sub-tile][t: m sub-tile]
 #pragma unroll
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + kt * TK, st, wid);
       else if (A_CONV) cvm.dma(p, st, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + kt * TK, st, wid, lane);
-      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + kt * TK, st + kATile, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW, kKLim>(p.B, p.ldb, n0, p.N, kbeg + kt * TK, st + kATile, wid, lane, p.K);
     };
     if (nk > 0) issue(0);
     wait_vm<0>();
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       if (A_CONV && A_KMAJOR) cv.dma(p, kbeg + s * TK, smem + s * kStage, wid);
       else if (A_CONV) cvm.dma(p, smem + s * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, kbeg + s * TK, smem + s * kStage, wid, lane);
-      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW, kKLim>(p.B, p.ldb, n0, p.N, kbeg + s * TK, smem + s * kStage + kATile, wid, lane, p.K);
     }
   int st_cur = 0, st_nxt = NSTG - 1;           // ring positions of k-tile kt and kt+NSTG-1
   constexpr int NB = NTH * (TK / 32);
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       if (A_CONV && A_KMAJOR) cv.dma(p, k0, smem + st_nxt * kStage, wid);
       else if (A_CONV) cvm.dma(p, smem + st_nxt * kStage, wid);
       else dma_tile<A_KMAJOR, TM, TK, NW>(p.A, p.lda, m0, p.M, k0, smem + st_nxt * kStage, wid, lane);
-      dma_tile<B_KMAJOR, TN, TK, NW>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane);
+      dma_tile<B_KMAJOR, TN, TK, NW, kKLim>(p.B, p.ldb, n0, p.N, k0, smem + st_nxt * kStage + kATile, wid, lane, p.K);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

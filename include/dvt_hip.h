@@ -603,8 +603,9 @@ int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* desc);
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* desc);
 /* Weight gradient without a column matrix: with x = the layer input (NHWC), w = dz [N*Ho*Wo, Cout] and
  * y = dWt f32 [kh*kw*C, Cout] (overwritten): dWt[(ki*kw+kj)*C + c, co] = sum_rows gather(x)[row, .] * dz[row, co];
- * split-K over the rows with a fixed-order reduction (reproducible).  C % 8 == 0, Cout % 8 == 0, N*Ho*Wo a multiple
- * of 64 (32 when Cout <= 128).  dvt_conv_weight_unpack_grad_t scatters dWt into the [Cout, Cin, kh, kw] master. */
+ * split-K over the rows with a fixed-order reduction (reproducible).  C % 8 == 0, Cout % 8 == 0, any number of output
+ * pixels (rows past the end of the last k-tile are read as zeros).  dvt_conv_weight_unpack_grad_t scatters dWt into the
+ * [Cout, Cin, kh, kw] master; or see wgrad_master_layout below. */
 int dvt_conv2d_implicit_wgrad_supported(const dvt_conv_desc* desc);
 size_t dvt_conv2d_implicit_wgrad_workspace_bytes(const dvt_conv_desc* desc);
 int dvt_conv2d_implicit_wgrad(const dvt_conv_desc* desc, dvt_stream_t stream);

@@ -601,6 +601,9 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
     (4, 128, 8, 8, 256, 3, 1, 1),          # cfg 256x256x64
     (4, 64, 16, 16, 128, 1, 2, 0),         # 1x1 stride-2 downsample
     (2, 24, 8, 8, 72, 3, 1, 1),            # C % 8 only (tap boundaries inside a tile)
+    (3, 256, 7, 7, 512, 3, 1, 1),          # 147 pixels: not a multiple of the k-tile (ragged last k-tile: zeros past the end)
+    (7, 64, 6, 6, 64, 3, 1, 1),            # 252 pixels, 64-deep k-tiles
+    (5, 128, 9, 5, 128, (3, 1), (2, 1), (1, 0)),   # temporal (3,1,1) / 2 of R(2+1)D over a [T, H*W] view: 125 output rows
 ])
 def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype, geom):
     ops = dvt.ops
@@ -608,10 +611,16 @@ def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype,
     g = torch.Generator().manual_seed(321)
     (kh, kw) = ops._pair(k)
     Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-    x = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
-    dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
+    # both operands sit in front of NaN-filled memory: a gather that reads past the last pixel row (the ragged k-tile of a
+    # pixel count that is not a multiple of the k-tile) would poison the result
+    xb = torch.full((N * H * W + 96, Cin), float("nan"), dtype=dtype, device="cuda")
+    zb = torch.full((N * Ho * Wo + 96, Cout), float("nan"), dtype=dtype, device="cuda")
+    x, dz = xb[: N * H * W], zb[: N * Ho * Wo]
+    x.copy_(torch.randn(N * H * W, Cin, generator=g).to(dtype))
+    dz.copy_(torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype))
     assert ops.conv2d_implicit_wgrad_supported(x, dz, N, Cin, H, W, Cout, k, stride, pad)
     dwt = ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad)
+    assert torch.isfinite(dwt).all()
     assert torch.equal(dwt, ops.conv2d_implicit_wgrad(x, dz, N, Cin, H, W, Cout, k, stride, pad))   # reproducible
     K = kh * kw * Cin
     col = ops.im2col(x, False, N, Cin, H, W, k, stride, pad, K, dtype)
