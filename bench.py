@@ -590,9 +590,9 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
     roof = None
-    if roofline and workload in ("pyramid", "crossmodal"):      # the per-frame CNN encoder's kernels
+    if roofline and workload in ("pyramid", "crossmodal", "frametransformer"):      # the CNN encoder's kernels
         summ, nprof, _ = profile_pass(ops, step, elapsed / steps * 1e3, steps)
-        roof = cnn_roofline(summ, nprof, "pyramid")
+        roof = cnn_roofline(summ, nprof, "frametransformer" if workload == "frametransformer" else "pyramid")
     elif roofline:
         summ, nprof, bracket_us = profile_pass(ops, step, elapsed / steps * 1e3, steps)
         fam, hbm, big = {}, {}, {}
@@ -782,7 +782,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bounded secondary workloads (pyramid, crossmodal, "
-                    "longclip: 3 timed steps each) that the default single-GPU run appends under \"secondary\"")
+                    "longclip, frametransformer: 3 timed steps each) that the default single-GPU run appends under \"secondary\"")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--grad-dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="element type of the gradient buckets on "
                     "the wire (bf16: 57.7 MB instead of 115 MB per step for the d=512 model; the sum stays fp32 on either side)")
@@ -877,13 +877,14 @@ def main():
                        roofline=not args.no_roofline)
     if world == 1 and not use_dist and args.workload == "vivit" and not args.no_secondary:
         # BASELINE configs[2..4] -- the per-frame CNN encoder + pyramid, the cross-modal attention + distillation head, the
-        # long-clip stress -- timed in the same driver-visible line, bounded (3 timed steps each, no roofline pass)
+        # long-clip stress -- and the reference's default FrameTransformer(model='vid') (R(2+1)D-18 encoder), timed in the same
+        # driver-visible line, bounded (3 timed steps each; the two CNN workloads carry their conv / BatchNorm roofline)
         sec = {}
-        for wl in ("pyramid", "crossmodal", "longclip"):
+        for wl in ("pyramid", "crossmodal", "longclip", "frametransformer"):
             release_gpu_memory()
             try:
                 r = run_workload(args, wl, rank, world, False, None, steps=3, warmup=1,
-                                 roofline=wl == "pyramid" and not args.no_roofline, secondary=True)
+                                 roofline=wl in ("pyramid", "frametransformer") and not args.no_roofline, secondary=True)
                 sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "launch", "peak_hbm_GiB",
                                              "final_loss", "roofline") if k in r}
                 sec[wl]["workload"] = r["config"]["workload"]

@@ -227,45 +227,113 @@ __global__ void weight_pack_dgrad_kernel(const float* __restrict__ w, D* __restr
 }
 
 // Both packed forms of MANY convolution weights in one launch (once per optimizer step: the weights only change there), with
-// the zero extension of channel-padded layers folded in.  A workgroup packs 2048 consecutive destination elements of the
-// entry its index falls into (entries carry their first workgroup).
+// the zero extension of channel-padded layers folded in.  Both forms are transposes of the parameter's [cout][cin * taps]
+// rows, so both go through LDS with coalesced accesses on either side (an element-per-thread gather read one 4-byte word per
+// 64-byte line for the data-gradient form and paid two 64-bit divisions per element):
+//   kind 0 (forward operand [cout_p][ld], column = tap * cin_p + ci): a workgroup stages R whole parameter rows (one
+//           contiguous read) and writes R destination rows, reading LDS with stride `taps`;
+//   kind 1 (data-gradient operand [cin_p][taps * cout_p], rotated taps): a workgroup transposes a 64 (cout) x 64 (cin * taps)
+//           tile: 256-byte reads along the parameter row, 128-byte writes along cout.
+// Rows longer than kPackRowMax words (none in the path's models) keep the element-per-thread form.
 constexpr int kPackGroup = 40;
+constexpr int kPackRowMax = 8192;
 struct PackGroup { dvt_pack_entry e[kPackGroup]; int begin[kPackGroup + 1]; int n; };
 
+// workgroups of an entry and, for kind 0, the rows each one packs (host and device agree through this one function)
+__host__ __device__ inline int pack_plan(const dvt_pack_entry& q, int* rows_per_block) {
+  const int taps = q.kh * q.kw;
+  const int64_t rowlen = (int64_t)q.cin_l * taps;
+  *rows_per_block = 0;
+  if (q.kind == 0) {
+    if (rowlen > kPackRowMax || q.ld > 4 * kPackRowMax)
+      return (int)(((int64_t)q.cout_p * q.ld + 2047) / 2048);
+    const int R = q.ld >= 2048 ? 1 : 2048 / q.ld;
+    *rows_per_block = R;
+    return (q.cout_p + R - 1) / R;
+  }
+  return ((q.cout_p + 63) / 64) * (int)(((int64_t)q.cin_p * taps + 63) / 64);
+}
+
 template <typename D>
-__device__ __forceinline__ void pack_elems(const dvt_pack_entry& q, int64_t i0) {
+__device__ __forceinline__ void pack_elems(const dvt_pack_entry& q, int64_t i0) {          // fallback for very long rows
   const int taps = q.kh * q.kw;
   const float* __restrict__ w = q.src;
   D* __restrict__ dst = (D*)q.dst;
-  if (q.kind == 0) {                               // forward operand [cout_p][ld], column = tap * cin_p + ci
-    const int64_t total = (int64_t)q.cout_p * q.ld;
-    for (int64_t i = i0 + threadIdx.x; i < min(total, i0 + 2048); i += 256) {
-      const int col = (int)(i % q.ld), co = (int)(i / q.ld);
-      const int ci = col % q.cin_p, tap = col / q.cin_p;
-      float v = 0.f;
-      if (co < q.cout_l && ci < q.cin_l && tap < taps) v = w[((int64_t)co * q.cin_l + ci) * taps + tap];
-      dst[i] = from_f32<D>(v);
-    }
-  } else {                                         // data-gradient operand [cin_p][taps * cout_p]: rotated taps, transposed channels
-    const int64_t K = (int64_t)taps * q.cout_p, total = (int64_t)q.cin_p * K;
-    for (int64_t i = i0 + threadIdx.x; i < min(total, i0 + 2048); i += 256) {
-      const int ci = (int)(i / K), col = (int)(i % K);
-      const int co = col % q.cout_p, tap = taps - 1 - col / q.cout_p;
-      float v = 0.f;
-      if (co < q.cout_l && ci < q.cin_l) v = w[((int64_t)co * q.cin_l + ci) * taps + tap];
-      dst[i] = from_f32<D>(v);
-    }
+  const int64_t total = (int64_t)q.cout_p * q.ld;
+  for (int64_t i = i0 + threadIdx.x; i < min(total, i0 + 2048); i += 256) {
+    const int col = (int)(i % q.ld), co = (int)(i / q.ld);
+    const int ci = col % q.cin_p, tap = col / q.cin_p;
+    float v = 0.f;
+    if (co < q.cout_l && ci < q.cin_l && tap < taps) v = w[((int64_t)co * q.cin_l + ci) * taps + tap];
+    dst[i] = from_f32<D>(v);
+  }
+}
+
+template <typename D>
+__device__ __forceinline__ void pack_rows(const dvt_pack_entry& q, int blk, int R, float* lds) {
+  const int taps = q.kh * q.kw, rowlen = q.cin_l * taps;
+  const int co0 = blk * R;
+  const int64_t src0 = (int64_t)co0 * rowlen, src_end = (int64_t)q.cout_l * rowlen;
+  for (int i = threadIdx.x; i < R * rowlen; i += 256) lds[i] = src0 + i < src_end ? q.src[src0 + i] : 0.f;
+  __syncthreads();
+  D* __restrict__ dst = (D*)q.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int body = taps * q.cin_p;
+  for (int p = ty; p < R * taps; p += 4) {                     // (row, tap) pairs, one per wave at a time
+    const int r = p / taps, tap = p - r * taps;
+    if (co0 + r >= q.cout_p) break;
+    D* __restrict__ d = dst + (int64_t)(co0 + r) * q.ld + tap * q.cin_p;
+    const float* l = lds + r * rowlen + tap;
+    for (int ci = tx; ci < q.cin_p; ci += 64) d[ci] = from_f32<D>(ci < q.cin_l ? l[ci * taps] : 0.f);
+  }
+  if (q.ld > body)                                             // K padding of the row
+    for (int r = 0; r < R && co0 + r < q.cout_p; ++r)
+      for (int j = body + threadIdx.x; j < q.ld; j += 256) dst[(int64_t)(co0 + r) * q.ld + j] = from_f32<D>(0.f);
+}
+
+template <typename D>
+__device__ __forceinline__ void pack_tile_t(const dvt_pack_entry& q, int blk, float* lds) {
+  const int taps = q.kh * q.kw, rowlen = q.cin_l * taps, cols = q.cin_p * taps;
+  const int tiles_co = (q.cout_p + 63) / 64;
+  const int co0 = (blk % tiles_co) * 64, c0 = (blk / tiles_co) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int co = co0 + r, c = c0 + tx;
+    lds[r * 65 + tx] = (co < q.cout_l && c < rowlen) ? q.src[(int64_t)co * rowlen + c] : 0.f;
+  }
+  __syncthreads();
+  D* __restrict__ dst = (D*)q.dst;
+  const int co = co0 + tx;
+  if (co >= q.cout_p) return;
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc;
+    if (c >= cols) break;
+    const int ci = c / taps, tap = c - ci * taps;
+    dst[((int64_t)ci * taps + (taps - 1 - tap)) * q.cout_p + co] = from_f32<D>(lds[tx * 65 + cc]);
   }
 }
 
 __global__ __launch_bounds__(256) void weight_pack_group_kernel(const PackGroup g) {
+  __shared__ float lds[kPackRowMax];
   int e = 0;
   while (e + 1 < g.n && (int)blockIdx.x >= g.begin[e + 1]) ++e;
   const dvt_pack_entry& q = g.e[e];
-  const int64_t i0 = (int64_t)((int)blockIdx.x - g.begin[e]) * 2048;
-  if (q.dtype == DVT_BF16) pack_elems<bf16>(q, i0);
-  else if (q.dtype == DVT_F16) pack_elems<f16>(q, i0);
-  else pack_elems<float>(q, i0);
+  const int blk = (int)blockIdx.x - g.begin[e];
+  int R;
+  pack_plan(q, &R);
+  if (q.kind == 1) {
+    if (q.dtype == DVT_BF16) pack_tile_t<bf16>(q, blk, lds);
+    else if (q.dtype == DVT_F16) pack_tile_t<f16>(q, blk, lds);
+    else pack_tile_t<float>(q, blk, lds);
+  } else if (R > 0) {
+    if (q.dtype == DVT_BF16) pack_rows<bf16>(q, blk, R, lds);
+    else if (q.dtype == DVT_F16) pack_rows<f16>(q, blk, R, lds);
+    else pack_rows<float>(q, blk, R, lds);
+  } else {
+    if (q.dtype == DVT_BF16) pack_elems<bf16>(q, (int64_t)blk * 2048);
+    else if (q.dtype == DVT_F16) pack_elems<f16>(q, (int64_t)blk * 2048);
+    else pack_elems<float>(q, (int64_t)blk * 2048);
+  }
 }
 
 // ---- row-streaming BatchNorm kernels.  A thread owns ONE 8-channel group for its whole life (cg = thread % (C/8)) and walks
@@ -1353,8 +1421,8 @@ int dvt_conv_weight_pack_group(const dvt_pack_entry* entries, int count, dvt_str
                   "dvt_conv_weight_pack_group: bad entry %d", base + i);
       g.e[i] = q;
       g.begin[i] = blocks;
-      const int64_t total = q.kind == 0 ? (int64_t)q.cout_p * q.ld : (int64_t)q.cin_p * q.kh * q.kw * q.cout_p;
-      blocks += (int)dvt_cdiv(total, 2048);
+      int rows_per_block;
+      blocks += pack_plan(q, &rows_per_block);
     }
     g.begin[g.n] = blocks;
     hipLaunchKernelGGL(weight_pack_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);

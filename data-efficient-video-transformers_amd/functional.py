@@ -1264,14 +1264,20 @@ class _ConvBnAct(torch.autograd.Function):
         xc = x.contiguous()
         ctx.pair = pair = None
         ctx.trim = 0
-        stem8 = (IMPLICIT_CONV and nchw and Cin <= 8 and not x.requires_grad and dtype in (torch.bfloat16, torch.float16)
-                 and Cout % 8 == 0 and (N * Ho * Wo) % 32 == 0)
+        # (frames that need a gradient: theirs is an explicit dcol GEMM + NCHW col2im over the rows of the dx_frames hint --
+        # all frames without one -- and everything else about the layer stays implicit)
+        stem8 = (IMPLICIT_CONV and nchw and Cin <= 8 and dtype in (torch.bfloat16, torch.float16) and Cout % 8 == 0
+                 and (N * Ho * Wo) % 32 == 0)
+        ctx.geom0 = None
         if stem8:
+            ctx.geom0 = (N, Cin, H, W, k, stride, pad)
+            ctx.w_stem = w if x.requires_grad else None
+            if x.requires_grad and not dx_frames:
+                ctx.dx_frames = [(0, N)]
             # The stem (custom_resnet.py:100: 7x7 / 2 on the 3-channel frames) as an implicit GEMM: the frames become an
             # NHWC map with the channels zero-extended to 8 (one 16-byte chunk per pixel and tap), the weights carry the
             # matching zero planes, and from here on it is an ordinary NHWC convolution with Cin = 8 -- no column matrix
-            # (0.94 GB at 256 frames of 224^2) in forward or in the weight gradient.  Not taken when the frames need a
-            # gradient (the pixel-space CLS clip of FrameTransformer): that path keeps the explicit gather.
+            # (0.94 GB at 256 frames of 224^2) in forward or in the weight gradient.
             (ph, pw) = ops._pair(pad)
             off = pw & 1
             kwp = (kw + off + 1) // 2                      # pairs that cover the taps: (-1,0) (1,2) (3,4) (5,6) for 7 / pad 3
@@ -1500,7 +1506,8 @@ class _ConvBnAct(torch.autograd.Function):
                 return None
             joined[0] = True
             return dshort.view(N * H * W, Cin)
-        if (ctx.x_needs and ctx.implicit and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0 and kw - 1 - pw_ >= 0
+        if (ctx.x_needs and ctx.implicit and ctx.geom0 is None and sh_ == 1 and sw_ == 1 and kh - 1 - ph_ >= 0
+                and kw - 1 - pw_ >= 0
                 and (Ho, Wo) == (H + 2 * ph_ - kh + 1, W + 2 * pw_ - kw + 1)):
             if ctx.w_ref is not None:                                    # [Cin, kh*kw*Cout], refreshed once per optimizer step
                 wd = _packed_weight(ctx.w_ref, 1, Cout_l, Cin_l, kh, kw, Cout, Cin, 0, dtype)
@@ -1513,12 +1520,19 @@ class _ConvBnAct(torch.autograd.Function):
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
                                          residual=join_alias())           # [N*H*W, Cin], no dcol / col2im
-        if ctx.x_needs and dx is None and nchw and ctx.dx_frames:
-            dx = ops.zeros(ctx.x_shape, ctx.x_dtype, dz.device).view(N, Cin, H, W)
-            hw = Ho * Wo
+        if ctx.x_needs and dx is None and (nchw or ctx.geom0 is not None) and ctx.dx_frames:
+            if ctx.geom0 is not None:            # implicit stem: the frames' own geometry and the plain [Cout, taps * Cin] pack
+                N0, C0, H0, W0, k0, s0, p0 = ctx.geom0
+                (kh0, kw0) = ops._pair(k0)
+                wq = _packed_weight(ctx.w_stem, 0, Cout_l, Cin_l, kh0, kw0, Cout, C0, _kpad(kh0 * kw0 * C0, dtype), dtype)
+            else:
+                (N0, C0, H0, W0, k0, s0, p0), wq = (N, Cin, H, W, k, stride, pad), wp
+            Ho0, Wo0 = ops.conv_out_hw(H0, W0, k0, s0, p0)
+            dx = ops.zeros(ctx.x_shape, ctx.x_dtype, dz.device).view(N0, C0, H0, W0)
+            hw = Ho0 * Wo0
             for f0, cnt in ctx.dx_frames:                                # only the frames whose gradient is read
-                dcol = ops.linear_dgrad(dz[f0 * hw:(f0 + cnt) * hw], wp)
-                ops.copy_(dx[f0:f0 + cnt], ops.col2im_nchw(dcol, cnt, Cin, H, W, k, stride, pad, ctx.x_dtype))
+                dcol = ops.linear_dgrad(dz[f0 * hw:(f0 + cnt) * hw], wq)
+                ops.copy_(dx[f0:f0 + cnt], ops.col2im_nchw(dcol, cnt, C0, H0, W0, k0, s0, p0, ctx.x_dtype))
             dx = dx.view(ctx.x_shape)
         if ctx.x_needs and dx is None:
             dcol = ops.linear_dgrad(dz, wp, carry=pend)                  # [rows, ld]

@@ -652,6 +652,40 @@ def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype,
     assert rel_l2(m3 - 1.0, dw) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_grouped_weight_pack_is_the_two_transposes(dvt, device, dtype):
+    """dvt_conv_weight_pack_group (once per optimizer step for every convolution of the encoder): kind 0 = forward operand
+    [cout_p, ld] with column tap * cin_p + ci, kind 1 = data-gradient operand [cin_p, taps * cout_p] with rotated taps; the
+    zero extension of channel-padded layers (R(2+1)D mid planes 45 / 230 / 921) and the K padding folded in.  Exact (a
+    rounding of the fp32 parameter) against the index arithmetic written out in torch; shapes cover several rows per
+    workgroup, one row per workgroup, ragged 64 x 64 tiles, a 7 x 7 stem and more entries than one launch holds."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(17)
+    shapes = [(64, 64, 3, 3, 64, 64, 576), (45, 3, 7, 7, 48, 3, 192), (230, 128, 3, 3, 240, 128, 1152),
+              (128, 230, 3, 1, 128, 240, 720), (512, 512, 3, 3, 512, 512, 4608), (921, 512, 1, 1, 928, 512, 512),
+              (70, 33, 2, 3, 80, 40, 256), (8, 8, 1, 1, 8, 8, 64)] * 6        # 96 entries: three launches
+    entries, want = [], []
+    for i, (co, ci, kh, kw, cop, cip, ld) in enumerate(shapes):
+        w = torch.randn(co, ci, kh * kw, generator=g).cuda()
+        taps = kh * kw
+        wz = torch.zeros(cop, cip, taps, device="cuda")
+        wz[:co, :ci] = w
+        kind = (i // 8) % 2 if i >= 8 else i % 2
+        for kd in ((0, 1) if i < 8 else (kind,)):
+            if kd == 0:
+                dst = torch.full((cop, ld), float("nan"), dtype=dtype, device="cuda")
+                ref = torch.zeros(cop, ld, device="cuda")
+                ref[:, :taps * cip] = wz.permute(0, 2, 1).reshape(cop, taps * cip)
+            else:
+                dst = torch.full((cip, taps * cop), float("nan"), dtype=dtype, device="cuda")
+                ref = wz.flip(2).permute(1, 2, 0).reshape(cip, taps * cop)
+            entries.append((w, dst, co, ci, kh, kw, cop, cip, ld, kd))
+            want.append(ref.to(dtype))
+    ops.conv_weight_pack_group(entries)
+    for e, ref in zip(entries, want):
+        assert torch.equal(e[1], ref), e[2:]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
 def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
