@@ -289,7 +289,7 @@ def build_workload(args, workload, rank, comm):
     def fwd_bwd():
         flat.zero_grad()
         if workload in ("vivit", "longclip"):
-            loss = F.bce_with_logits(net(x), y)
+            loss, _ = net.loss(x, y)                    # BCEWithLogits(net(x), y), head + loss in one launch
         elif workload == "frametransformer":
             loss = net.training_step((y, None, x), 0)
         else:

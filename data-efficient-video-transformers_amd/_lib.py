@@ -80,6 +80,16 @@ class PackEntry(C.Structure):
                [(n, C.c_int32) for n in ("cout_l", "cin_l", "kh", "kw", "cout_p", "cin_p", "ld", "kind", "dtype")]
 
 
+class HeadBceDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "g1", "b1", "g2", "b2", "w", "c", "target", "logits", "loss", "grads")] + \
+               [(n, C.c_int32) for n in ("rows", "d", "classes", "x_dtype")] + [("eps1", C.c_float), ("eps2", C.c_float)]
+
+
+class EmitEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_lp", C.c_void_p), ("n", C.c_int64),
+                ("accumulate", C.c_int32), ("lp_dtype", C.c_int32)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p),
@@ -176,6 +186,10 @@ SIGNATURES = {
     "dvt_bn_bwd_pooled": (c_int, [c_p] * 11 + [c_i64] + [c_int] * 7 + [c_p]),
     "dvt_maxpool_bwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_transpose_last2": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
+    "dvt_head_bce_supported": (c_int, [c_int, c_int, c_int]),
+    "dvt_head_bce_grads_elems": (c_i64, [c_int, c_int, c_int]),
+    "dvt_head_bce_fwd": (c_int, [c_p, c_p]),
+    "dvt_scaled_emit_group": (c_int, [c_p, c_p, c_int, c_p]),
     "dvt_bce_logits_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_bce_logits_bwd": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
     "dvt_ce_argmax_fwd": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_int, c_p]),

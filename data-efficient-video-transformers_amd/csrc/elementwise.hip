@@ -370,10 +370,10 @@ __global__ void tokens_bwd_pos_kernel(const T* __restrict__ dout, float* __restr
 
 // out[c] (+)= sum_{r < R} src[r * row_stride + c]; one block per 8-column chunk.
 template <typename T>
-__global__ void strided_rows_sum_kernel(const T* __restrict__ src, int64_t row_stride, int64_t R,
-                                        float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void strided_rows_sum_block(const T* __restrict__ src, int64_t row_stride, int64_t R,
+                                                       float* __restrict__ out, int accumulate, int64_t blk) {
   __shared__ float red[8][kBlock / 64];
-  const int64_t c = (int64_t)blockIdx.x << 3;
+  const int64_t c = blk << 3;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t r = threadIdx.x; r < R; r += blockDim.x) {
     float v[8];
@@ -393,6 +393,12 @@ __global__ void strided_rows_sum_kernel(const T* __restrict__ src, int64_t row_s
     float* o = out + c + threadIdx.x;
     *o = accumulate ? *o + t : t;
   }
+}
+
+template <typename T>
+__global__ void strided_rows_sum_kernel(const T* __restrict__ src, int64_t row_stride, int64_t R,
+                                        float* __restrict__ out, int accumulate) {
+  strided_rows_sum_block<T>(src, row_stride, R, out, accumulate, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ CLS row gather
@@ -415,13 +421,20 @@ __global__ void rows_gather_fwd_kernel(const T* __restrict__ src, int64_t src_ro
   }
 }
 
+// The last `tok_blocks` workgroups of the grid sum the token rows (row 0 of every sequence) into dtok instead -- the token
+// parameter's gradient in the same launch as the scatter of the other rows.
 template <typename T>
 __global__ void rows_gather_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dsrc,
                                        int64_t src_row_stride, int64_t B, int64_t Tn, int64_t d,
-                                       int lead) {
+                                       int lead, float* __restrict__ dtok, int accumulate, int tok_blocks) {
   const int64_t dv = d >> 3;
   const int64_t items = B * Tn * dv;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int gather_blocks = (int)gridDim.x - tok_blocks;
+  if ((int)blockIdx.x >= gather_blocks) {
+    strided_rows_sum_block<T>(dout, (Tn + 1) * d, B, dtok, accumulate, (int)blockIdx.x - gather_blocks);
+    return;
+  }
+  const int64_t stride = (int64_t)gather_blocks * blockDim.x;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
     const int64_t c = (it % dv) << 3;
     const int64_t row = it / dv;  // b*T + t
@@ -1027,9 +1040,10 @@ int dvt_rows_gather_bwd(const void* dout, void* dsrc, int64_t src_row_stride, fl
   const int64_t dv = d >> 3;
   DVT_DISPATCH_DTYPE(dtype, Tt, {
     if (T > 0)
-      hipLaunchKernelGGL((rows_gather_bwd_kernel<Tt>), dim3(grid_for(B * T * dv)), dim3(kBlock), 0, st,
-                         (const Tt*)dout, (Tt*)dsrc, src_row_stride, B, T, d, lead);
-    if (dtok)
+      hipLaunchKernelGGL((rows_gather_bwd_kernel<Tt>), dim3(grid_for(B * T * dv) + (dtok ? (unsigned)dv : 0u)), dim3(kBlock),
+                         0, st, (const Tt*)dout, (Tt*)dsrc, src_row_stride, B, T, d, lead, dtok, accumulate,
+                         dtok ? (int)dv : 0);
+    else if (dtok)
       hipLaunchKernelGGL((strided_rows_sum_kernel<Tt>), dim3((unsigned)dv), dim3(kBlock), 0, st,
                          (const Tt*)dout, (T + 1) * d, B, dtok, accumulate);
   });

@@ -447,7 +447,8 @@ class _ClsNormConcat(torch.autograd.Function):
             dtok = None
         else:
             dtok = ops.rows_gather_bwd(dseq, drows, d, ctx.tok_shape is not None, B, T, d)
-        dx = ops.zeros(xc.shape, xc.dtype, xc.device)   # rows other than CLS receive no gradient
+        # rows other than CLS receive no gradient (N == 1, the folded last layer: there are none, nothing to clear)
+        dx = ops.zeros(xc.shape, xc.dtype, xc.device) if N > 1 else torch.empty_like(xc)
         _, dg, db = _ln_bwd(drows, xc, g, mean, rstd, sg, sb, rows=(S, 1, N * d, 0), dy_rows=(d, 0), dx=dx)
         if dtok is not None:
             dtok = dtok.view(ctx.tok_shape)
@@ -968,6 +969,71 @@ class _BceLogits(torch.autograd.Function):
 def bce_with_logits(z: Tensor, target: Tensor) -> Tensor:
     """nn.BCEWithLogitsLoss() (mean)."""
     return _BceLogits.apply(z, target)
+
+
+class _HeadBce(torch.autograd.Function):
+    """loss = mean BCE(Linear(LN2(LN1(x))), target): the classification head of vit.py:97-100,126-128 (LN1 = the temporal
+    Transformer's final norm on the pooled row, None when the caller applied it) with the caller's BCEWithLogitsLoss, one
+    launch forward (which also leaves every gradient for an upstream gradient of 1) and one launch backward (scaling by the
+    incoming gradient and the stores into the gradient buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, g2, b2, w, c, target, eps1, eps2, lp_dtype):
+        x2 = x.contiguous()
+        loss, logits, grads = ops.head_bce_fwd(x2, _f32(g1), _f32(b1), eps1, _f32(g2), _f32(b2), eps2, _f32(w), _f32(c),
+                                               _f32(target))
+        ctx.grads = grads
+        ctx.sinks = tuple(_sink(p) for p in (g1, b1, g2, b2, w, c))
+        ctx.shapes = tuple(None if p is None else tuple(p.shape) for p in (g1, b1, g2, b2, w, c))
+        ctx.x_dtype, ctx.lp_dtype = x.dtype, lp_dtype
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)             # (no zero tensor for the logits' absent gradient)
+        return loss.view(()), logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        G = ctx.grads
+        g = _f32(gloss).reshape(1)
+        entries, outs, marks = [], [], []
+        dx = dx_lp = None
+        if ctx.needs_input_grad[0]:
+            if ctx.x_dtype == torch.float32:
+                dx = torch.empty_like(G["x"])
+                # (the block in front wants the row gradient as a 16-bit GEMM operand as well: same launch)
+                dx_lp = torch.empty(G["x"].shape, dtype=ctx.lp_dtype, device=dx.device) if ctx.lp_dtype is not None else None
+                entries.append((G["x"], dx, False, dx_lp))
+            else:
+                dx = torch.empty(G["x"].shape, dtype=ctx.x_dtype, device=G["x"].device)
+                entries.append((G["x"], None, False, dx))
+        for i, name in enumerate(("g1", "b1", "g2", "b2", "w", "c")):
+            if ctx.shapes[i] is None or not ctx.needs_input_grad[1 + i]:
+                outs.append(None)
+                continue
+            sk = ctx.sinks[i]
+            if sk is not None:
+                entries.append((G[name].reshape(-1), sk.buf.view(-1), not sk.fresh, None))
+                marks.append(sk)
+                outs.append(None)
+            else:
+                o = torch.empty(ctx.shapes[i], dtype=torch.float32, device=g.device)
+                entries.append((G[name].reshape(-1), o.view(-1), False, None))
+                outs.append(o)
+        ops.scaled_emit_group(g, entries)
+        for sk in marks:
+            sk.mark_written()
+        if dx_lp is not None:
+            _lp_put(dx, dx_lp)
+        return (dx, *outs, None, None, None, None)
+
+
+def head_bce_supported(x: Tensor, w: Tensor) -> bool:
+    return x.dim() == 2 and x.is_cuda and ops.head_bce_supported(x.shape[0], x.shape[1], w.shape[0])
+
+
+def head_bce(x, ln1, ln2, linear, target, *, lp_dtype=None):
+    """-> (loss, logits).  ln1: LayerNorm module or None; ln2: LayerNorm; linear: Linear; x [rows, d] fp32 or 16-bit."""
+    g1, b1, e1 = (ln1.weight, ln1.bias, ln1.eps) if ln1 is not None else (None, None, 0.0)
+    return _HeadBce.apply(x, g1, b1, ln2.weight, ln2.bias, linear.weight, linear.bias, target, e1, ln2.eps, lp_dtype)
 
 
 class _CeArgmax(torch.autograd.Function):

@@ -235,6 +235,29 @@ class ViViT(nn.Module):
         self.temporal_transformer.checkpoint = activation_checkpointing
 
     def forward(self, x):
+        pooled, pending = self._trunk(x)
+        if pending is not None:                                                     # the temporal stack's final norm (:43)
+            pooled = F.layernorm(pooled, pending.weight, pending.bias, pending.eps)
+        hn, hl = self.mlp_head[0], self.mlp_head[1]
+        h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)
+        return F.linear(h, hl.weight, hl.bias, out_f32=True)                        # :128
+
+    def loss(self, x, target):
+        """nn.BCEWithLogitsLoss()(self(x), target) (the training step of the reference's Lightning wrapper), with the head
+        -- final norm on the pooled row, mlp_head, the loss -- as one launch where the shape allows (8 rows at the metric
+        shape: the separate kernels are pure launch cost).  -> (loss, logits)."""
+        pooled, pending = self._trunk(x)
+        hn, hl = self.mlp_head[0], self.mlp_head[1]
+        if pooled.is_cuda and F.head_bce_supported(pooled, hl.weight):
+            mixed = pooled.dtype == torch.float32 and self.compute_dtype in (torch.bfloat16, torch.float16)
+            return F.head_bce(pooled, pending, hn, hl, target, lp_dtype=self.compute_dtype if mixed else None)
+        if pending is not None:
+            pooled = F.layernorm(pooled, pending.weight, pending.bias, pending.eps)
+        logits = F.linear(F.layernorm(pooled, hn.weight, hn.bias, hn.eps), hl.weight, hl.bias, out_f32=True)
+        return F.bce_with_logits(logits, target), logits
+
+    def _trunk(self, x):
+        """-> (pooled [b, dim], the LayerNorm still to be applied to it or None)."""
         if x.dim() != 5:
             raise ValueError("ViViT expects a clip tensor [b, t, c, H, W]")
         b, t = x.shape[0], x.shape[1]
@@ -261,10 +284,6 @@ class ViViT(nn.Module):
         seq = F.cls_norm_concat(s, sn.weight, sn.bias, self.temporal_token, b, t, sn.eps,
                                 out_dtype=torch.float32 if zone32 else None)       # :119-123
         if self.pool == 'cls' and tt.cls_prunable():                                # only x[:, 0] is read (:126)
-            pooled = F.layernorm(tt.forward_layers_cls(seq, cdt), tt.norm.weight, tt.norm.bias, tt.norm.eps)
-        else:
-            z = tt(seq, cdt)                                                        # :125
-            pooled = F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)  # :126
-        hn, hl = self.mlp_head[0], self.mlp_head[1]
-        h = F.layernorm(pooled, hn.weight, hn.bias, hn.eps)
-        return F.linear(h, hl.weight, hl.bias, out_f32=True)                        # :128
+            return tt.forward_layers_cls(seq, cdt), tt.norm
+        z = tt(seq, cdt)                                                            # :125
+        return (F.mean_rows(z) if self.pool == 'mean' else F.select_first_row(z)), None  # :126

@@ -841,6 +841,62 @@ def bce_logits_fwd(z: Tensor, target: Tensor) -> Tensor:
     return loss
 
 
+def head_bce_supported(rows: int, d: int, classes: int) -> bool:
+    return bool(L.load().dvt_head_bce_supported(int(rows), int(d), int(classes)))
+
+
+def head_bce_fwd(x: Tensor, g1, b1, eps1: float, g2: Tensor, b2: Tensor, eps2: float, w: Tensor, c, target: Tensor):
+    """LN -> LN -> Linear -> mean BCE in one launch (dvt_head_bce_fwd) -> (loss [1], logits [rows, C], grads): grads maps
+    "x", "g1", "b1", "g2", "b2", "w", "c" to fp32 views holding d(loss)/d(.) for an upstream gradient of 1."""
+    _need_cuda(x, g2, b2, w, target)
+    rows, d = x.shape
+    Cc = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == d and target.shape == (rows, Cc)
+    for t in (g1, b1, g2, b2, w, c, target):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    lib = L.load()
+    n = lib.dvt_head_bce_grads_elems(rows, d, Cc)
+    if n < 0:
+        raise ValueError(f"head_bce_fwd: unsupported shape rows={rows} d={d} classes={Cc}")
+    G = torch.empty((n,), dtype=torch.float32, device=x.device)
+    logits = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+    desc = L.HeadBceDesc()
+    desc.x, desc.x_dtype = x.data_ptr(), dt(x)
+    desc.g1, desc.b1 = (g1.data_ptr(), b1.data_ptr()) if g1 is not None else (None, None)
+    desc.g2, desc.b2, desc.w, desc.c = g2.data_ptr(), b2.data_ptr(), w.data_ptr(), (c.data_ptr() if c is not None else None)
+    desc.target, desc.logits, desc.loss, desc.grads = target.data_ptr(), logits.data_ptr(), loss.data_ptr(), G.data_ptr()
+    desc.rows, desc.d, desc.classes, desc.eps1, desc.eps2 = rows, d, Cc, float(eps1), float(eps2)
+    L.check(lib.dvt_head_bce_fwd(C.byref(desc), _stream()), "dvt_head_bce_fwd")
+    o, grads = 0, {}
+    for name, cnt in (("x", rows * d), ("g1", d), ("b1", d), ("g2", d), ("b2", d), ("w", Cc * d), ("c", (Cc + 63) // 64 * 64)):
+        grads[name] = G[o:o + (Cc if name == "c" else cnt)]
+        o += cnt
+    grads["x"] = grads["x"].view(rows, d)
+    grads["w"] = grads["w"].view(Cc, d)
+    return loss, logits, grads
+
+
+def scaled_emit_group(scale: Tensor, entries) -> None:
+    """dst = scale * src (+ dst), optional 16-bit copy of the result; entries: (src f32, dst f32 or None, accumulate,
+    dst_lp 16-bit or None).  One launch (dvt_scaled_emit_group)."""
+    if not entries:
+        return
+    _need_cuda(scale)
+    assert scale.dtype == torch.float32 and scale.numel() == 1
+    arr = (L.EmitEntry * len(entries))()
+    for i, (src, dst, acc, lp) in enumerate(entries):
+        _need_cuda(src)
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        assert dst is None or (dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == src.numel())
+        assert lp is None or (lp.is_contiguous() and lp.numel() == src.numel())
+        e = arr[i]
+        e.src, e.dst, e.dst_lp = src.data_ptr(), (dst.data_ptr() if dst is not None else None), (lp.data_ptr() if lp is not None else None)
+        e.n, e.accumulate, e.lp_dtype = src.numel(), int(bool(acc)), (dt(lp) if lp is not None else 0)
+    L.check(L.load().dvt_scaled_emit_group(scale.data_ptr(), C.cast(arr, C.c_void_p), len(entries), _stream()),
+            "dvt_scaled_emit_group")
+
+
 def bce_logits_bwd(z: Tensor, target: Tensor, gloss: Tensor) -> Tensor:
     _need_cuda(z, target, gloss)
     dz = torch.empty_like(z)

@@ -674,6 +674,43 @@ int dvt_bce_logits_fwd(const void* z, const float* target, float* loss, int64_t 
 /* dz = gscale * (sigmoid(z) - target) / n */
 int dvt_bce_logits_bwd(const void* z, const float* target, const float* gloss, void* dz,
                        int64_t n, int dtype, dvt_stream_t stream);
+/* The classification head and its loss in ONE launch (vit.py:97-100 mlp_head = LayerNorm + Linear on the pooled CLS row,
+ * :126-128; behind the temporal Transformer's final LayerNorm of :43, which commutes with the CLS pooling; the caller's
+ * nn.BCEWithLogitsLoss() mean):  h1 = LN(x; g1, b1) (skipped when g1 == NULL), h2 = LN(h1; g2, b2), z = h2 W^T + c,
+ * loss = mean BCE(z, target) -- eight rows at the metric shape, where the five launches this replaces (and the six of
+ * their backward) cost ~5 us each and compute nothing to speak of.  All arithmetic fp32 on the fp32 parameters.
+ * The same launch leaves d(loss)/d(everything) for an upstream gradient of 1 in `grads` (f32, dvt_head_bce_grads_elems
+ * elements: [dx rows*d][dg1 d][db1 d][dg2 d][db2 d][dW classes*d][dc classes], then scratch); the backward pass is then
+ * dvt_scaled_emit_group: scale by the incoming gradient of the loss and store / accumulate into the gradient buffers.
+ * Limits: rows <= 32, d / 64 in {1, 2, 3, 4, 6, 8, 12, 16}, classes <= 64, classes * d <= 12288 (dvt_head_bce_supported). */
+typedef struct dvt_head_bce_desc {
+  const void* x;          /* [rows, d] f32 or 16-bit (x_dtype) */
+  const float* g1;        /* first LayerNorm (NULL: none) */
+  const float* b1;
+  const float* g2;        /* second LayerNorm */
+  const float* b2;
+  const float* w;         /* [classes, d] */
+  const float* c;         /* [classes] or NULL */
+  const float* target;    /* [rows, classes] */
+  float* logits;          /* [rows, classes] out */
+  float* loss;            /* [1] out */
+  float* grads;           /* out, see above */
+  int32_t rows, d, classes, x_dtype;
+  float eps1, eps2;
+} dvt_head_bce_desc;
+int dvt_head_bce_supported(int rows, int d, int classes);
+int64_t dvt_head_bce_grads_elems(int rows, int d, int classes);
+int dvt_head_bce_fwd(const dvt_head_bce_desc* desc, dvt_stream_t stream);
+/* dst[i] = scale[0] * src[i] (+ dst[i] when accumulate), optionally also a 16-bit copy of the RESULT (dst_lp); dst may be
+ * NULL when only the copy is wanted.  Up to 16 entries per launch; scale is a device scalar. */
+typedef struct dvt_emit_entry {
+  const float* src;
+  float* dst;
+  void* dst_lp;
+  int64_t n;
+  int32_t accumulate, lp_dtype;
+} dvt_emit_entry;
+int dvt_scaled_emit_group(const float* scale, const dvt_emit_entry* entries, int count, dvt_stream_t stream);
 /* Hard-label distillation CE(student, argmax(teacher)), mean over rows:
  * src/models/frame_transformer.py:90,250.  student/teacher: [rows, C]. */
 int dvt_ce_argmax_fwd(const void* student, const void* teacher, float* loss, int64_t rows,

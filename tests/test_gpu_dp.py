@@ -31,7 +31,7 @@ def _data():
 def _step(net, flat, x, y):
     from dvt_amd import functional as F
     flat.zero_grad()
-    loss = F.bce_with_logits(net(x.cuda()), y.cuda())
+    loss = net.loss(x.cuda(), y.cuda())[0]
     loss.backward(torch.full((), flat.loss_scale, device="cuda"))
     flat.finish_backward()
     return loss
@@ -99,7 +99,7 @@ def test_parameter_without_gradient_is_left_alone_by_the_flat_optimizers(device,
     used_before = net.mlp_head[1].weight.detach().clone()
     for _ in range(3):
         flat.zero_grad()
-        F.bce_with_logits(net(x.cuda()), y.cuda()).backward(seed)
+        net.loss(x.cuda(), y.cuda())[0].backward(seed)
         flat.finish_backward()
         if opt in ("adamw", "adamw_scaled"):
             flat.adamw_step(lr=1e-2, weight_decay=0.09)
@@ -120,7 +120,7 @@ def test_parameter_without_gradient_is_left_alone_by_the_flat_optimizers(device,
     from dvt_amd import optim
     o = optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.09)
     flat.zero_grad()
-    F.bce_with_logits(net(x.cuda()), y.cuda()).backward(seed)
+    net.loss(x.cuda(), y.cuda())[0].backward(seed)
     flat.finish_backward()
     o.step()
     assert torch.equal(net.unused_probe.detach(), before) and net.unused_probe not in o.state
@@ -132,7 +132,7 @@ def _make_step(net, flat, x, y):
 
     def fwd_bwd():
         flat.zero_grad()
-        loss = F.bce_with_logits(net(x), y)
+        loss = net.loss(x, y)[0]
         loss.backward(seed)
         return loss
 

@@ -1111,3 +1111,41 @@ def test_abi_error_reporting_and_edge_sizes(dvt, device):
     # wrong device is refused before anything is launched
     with pytest.raises(RuntimeError, match="GPU"):
         ops.layernorm_fwd(one.cpu(), torch.ones(16), torch.zeros(16))
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d,C,ln1", [(8, 512, 19, True), (1, 64, 1, True), (32, 1024, 12, False), (5, 192, 7, True), (9, 768, 16, True)])
+def test_head_and_loss_in_one_launch(device, xdt, rows, d, C, ln1):
+    """dvt_head_bce_fwd + dvt_scaled_emit_group (vit.py:97-100,126-128 + BCEWithLogitsLoss): loss, logits and every
+    gradient against torch autograd in fp32 on the same (rounded) input, with a non-trivial upstream gradient, an
+    accumulating destination and the 16-bit copy of dx."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(rows * 1000 + d + C)
+    x = torch.randn(rows, d, generator=g).to(xdt)
+    P = [1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g), 1 + 0.1 * torch.randn(d, generator=g),
+         0.1 * torch.randn(d, generator=g), torch.randn(C, d, generator=g) / d ** 0.5, 0.1 * torch.randn(C, generator=g)]
+    t = (torch.rand(rows, C, generator=g) < 0.3).float()
+    xr = x.float().clone().requires_grad_(True)
+    Pr = [p.clone().requires_grad_(True) for p in P]
+    h = torch.nn.functional.layer_norm(xr, (d,), Pr[0], Pr[1], 1e-5) if ln1 else xr
+    z = torch.nn.functional.linear(torch.nn.functional.layer_norm(h, (d,), Pr[2], Pr[3], 1e-6), Pr[4], Pr[5])
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(z, t)
+    ref.backward(torch.tensor(3.0))
+    Pc = [p.cuda() for p in P]
+    loss, logits, G = ops.head_bce_fwd(x.cuda(), Pc[0] if ln1 else None, Pc[1] if ln1 else None, 1e-5, Pc[2], Pc[3], 1e-6,
+                                       Pc[4], Pc[5], t.cuda())
+    assert abs(float(loss) - float(ref)) < 1e-5 and rel_l2(logits, z.detach()) < 1e-5
+    scale = torch.tensor([3.0], device="cuda")
+    dx = torch.empty(rows, d, device="cuda")
+    dx_lp = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+    old = torch.randn(C, d, generator=g).cuda()
+    dw = old.clone()
+    names = (["g1", "b1"] if ln1 else []) + ["g2", "b2", "c"]
+    outs = {n: torch.empty_like(G[n]) for n in names}
+    ops.scaled_emit_group(scale, [(G["x"], dx, False, dx_lp), (G["w"].reshape(-1), dw.view(-1), True, None)]
+                          + [(G[n], outs[n], False, None) for n in names])
+    assert rel_l2(dx, xr.grad) < 2e-5 and torch.equal(dx_lp, dx.to(torch.bfloat16))
+    assert rel_l2(dw - old, Pr[4].grad) < 2e-5
+    want = dict(zip(["g1", "b1", "g2", "b2", "w", "c"], [p.grad for p in Pr]))
+    for n in names:
+        assert rel_l2(outs[n], want[n]) < 2e-5, n

@@ -39,8 +39,7 @@ def _run(net, npz, scale=1.0):
     from dvt_amd import functional as F
     x = torch.from_numpy(npz["x"]).cuda()
     y = torch.from_numpy(npz["target"]).cuda()
-    logits = net(x)
-    loss = F.bce_with_logits(logits, y)
+    loss, logits = net.loss(x, y)            # the training step's entry: head + loss as one launch where the shape allows
     loss.backward(torch.tensor(scale, device="cuda"))
     return logits, loss, {k: p.grad / scale for k, p in net.named_parameters()}
 
@@ -155,6 +154,35 @@ def test_longclip_config_composed_matches_reference_digest(device):
     assert int(flat.found_inf) == 0 and not torch.equal(before, flat.data)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fused_head_loss_equals_separate_kernels(device, mode):
+    """ViViT.loss (final norm on the pooled row + mlp_head + BCEWithLogitsLoss as ONE launch, gradients through one
+    scaled store) against BCE(forward(x)) through the separate LayerNorm / Linear / loss kernels: same logits, loss and
+    parameter gradients (fp32 arithmetic on both sides in fp32 mode; in bf16 mode the fused head is the more exact one --
+    the separate path rounds the head's input gradient to bf16 on its way into the temporal stack)."""
+    from dvt_amd import functional as F
+    g = golden("vivit_tiny.npz")
+    dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[mode]
+    res = []
+    for fused in (True, False):
+        net, _ = _build(g, dtype)
+        net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")})
+        net = net.cuda()
+        x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+        if fused:
+            loss, logits = net.loss(x, y)
+        else:
+            logits = net(x)
+            loss = F.bce_with_logits(logits, y)
+        loss.backward()
+        res.append((logits.detach().clone(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (la, a, ga), (lb, b, gb) = res
+    tol = 2e-5 if mode == "fp32" else 2e-2
+    assert rel_l2(la, lb) < tol and abs(a - b) < tol
+    for k in ga:
+        assert rel_l2(ga[k], gb[k]) < tol, (k, rel_l2(ga[k], gb[k]))
+
+
 def test_vivit_state_dict_roundtrip_and_eval_determinism(device):
     g = golden("vivit_tiny.npz")
     net, _ = _build(g, torch.bfloat16)
@@ -243,7 +271,7 @@ def test_training_trajectory_matches_cpu_reference(device):
     for step in range(20):
         x, y = xs[step % 4], ys[step % 4]
         flat.zero_grad()
-        loss = F.bce_with_logits(net(x.cuda()), y.cuda())
+        loss = net.loss(x.cuda(), y.cuda())[0]
         loss.backward(gloss)
         flat.finish_backward()
         flat.adamw_step(lr=1e-3, weight_decay=0.09)
@@ -284,7 +312,7 @@ def test_hipgraph_replay_equals_eager_steps_including_dropout(device):
 
         def step():
             flat.zero_grad()
-            loss = F.bce_with_logits(net(x), y)
+            loss = net.loss(x, y)[0]
             loss.backward(gloss)
             flat.finish_backward()
             flat.adamw_step(lr=1e-3, weight_decay=0.09)

@@ -51,3 +51,16 @@ for k, v in agg.items():
 print("\n# by kernel name")
 for k, v in sorted(byname.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{v[1] / n / 1e3:8.4f} ms {v[0] / n:7.2f} calls  {k}")
+
+# the last step in launch order (small-launch zone work: which launches, how long, how far apart)
+if len(sys.argv) > 4:
+    a, b = steps[-1]
+    t0 = int(rows[a]["Start_Timestamp"])
+    prev_end = t0
+    with open(sys.argv[4], "w") as fh:
+        for i, r in enumerate(rows[a:b]):
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            fh.write(f"{i:4d} t={(s - t0) / 1e3:9.1f} us  dur={(e - s) / 1e3:7.1f}  gap={(s - prev_end) / 1e3:6.1f}  "
+                     f"grid={g // int(r['Workgroup_Size_X']):6d}x{r['Workgroup_Size_X']:>4}  {short(r['Kernel_Name'])}\n")
+            prev_end = max(prev_end, e)
