@@ -100,8 +100,11 @@ template <typename T> __device__ __forceinline__ void store8_nt(T* p, const floa
   v8t v;
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
-  // from asm: beside an ordinary store of the same value under a runtime flag the compiler merges the two and drops `nt`
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(__builtin_bit_cast(i4t, v)) : "memory");
+  // from asm: beside an ordinary store of the same value under a runtime flag the compiler merges the two and drops `nt`.
+  // The s_nop is part of the instruction's contract: a store of more than 8 bytes reads its data registers over the wait
+  // states that follow, and the hazard recogniser cannot see into the asm -- a VALU write that recycles those registers in
+  // the very next slot corrupted the rows of the last lanes (tools/dev/gemm_astat.hip: rows 29..31 of a 32-row block).
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(i4t, v)) : "memory");
 }
 
 // ---------------------------------------------------------------- device: 16-bit MFMA element traits
