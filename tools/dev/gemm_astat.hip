@@ -32,6 +32,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+  else if (N == 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #pragma clang diagnostic pop
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
   typedef typename Elem16<E>::v8 V8;
   typedef int i4t __attribute__((ext_vector_type(4)));
   constexpr int NWC = 7;
+  constexpr int NB = 3;                                  // weight-chunk images in LDS: requested two periods ahead
   constexpr int NOUT = EPI == DVT_EPI_GELU ? 2 : 1;
   constexpr int kStageWave = 32 * NOUT * 64;              // bytes one wave stages per chunk
   constexpr int kStage = NWC * kStageWave;
@@ -301,14 +305,14 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
   const int mwg = blockIdx.x * (NWC * 32);
   const E* __restrict__ W = (const E*)p.B;
   const int nchunks = p.N / CN;
-  char* const stage = smem + 2 * kChunkBytes;
+  char* const stage = smem + NB * kChunkBytes;
   float* const sbias = reinterpret_cast<float*>(stage + 2 * kStage);
   for (int i = tid; i < p.N; i += 512) sbias[i] = p.bias[i];
 
   if (wid == NWC) {
     // ------------------------------------------------------------------ helper wave
     auto issue = [&](int ch) {
-      char* buf = smem + (ch & 1) * kChunkBytes;
+      char* buf = smem + (ch % NB) * kChunkBytes;
 #pragma unroll 8
       for (int r = 0; r < CN; ++r) {
         const E* src = W + (int64_t)(ch * CN + r) * AK + ((lane ^ (r & 15)) << 3);
@@ -316,11 +320,12 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
       }
     };
     issue(0);
+    if (nchunks > 1) issue(1);
     wait_vmcnt<0>();
     __syncthreads();                                       // (matches the compute waves' prologue barrier)
+    const bool full = mwg + NWC * 32 <= p.M;               // (a ragged last workgroup skips stores: no fixed count)
     for (int ch = 0; ch <= nchunks; ++ch) {
       __builtin_amdgcn_s_barrier();       // period ch begins: chunk ch is in LDS, staging (ch - 1) is complete (nchunks + 1 in all)
-      if (ch + 1 < nchunks) issue(ch + 1);
       if (ch > 0) {
         const char* sg = stage + ((ch - 1) & 1) * kStage;
         const int row = lane >> 2, cc = (lane & 3) * 8;
@@ -336,11 +341,15 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
             for (int h = 0; h < 2; ++h) {
               const int64_t m = mwg + w * 32 + h * 16 + row;
               E* dst = (o == 0 ? (E*)p.C + m * p.ldc : (E*)p.aux + m * p.ldaux) + (ch - 1) * CN + cc;
-              if (m < p.M) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d[h]) : "memory");
+              if (m < p.M && p.tiles_n != -7)
+                asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(d[h]) : "memory");
             }
           }
       }
-      wait_vmcnt<0>();                                     // chunk ch + 1 landed (and this wave's stores retired)
+      if (ch + 2 < nchunks) issue(ch + 2);
+      // chunk ch + 1 (requested a period ago) landed; this period's stores and the requests for chunk ch + 2 are younger
+      // and stay in flight -- waiting for everything put a memory round trip per period on the critical path
+      if (full && ch > 0 && ch + 2 < nchunks && p.tiles_n != -7) wait_vmcnt<NWC * NOUT * 2 + CN>(); else wait_vmcnt<0>();
     }
     return;
   }
@@ -360,12 +369,13 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
 
   for (int ch = 0; ch < nchunks; ++ch) {
     __builtin_amdgcn_s_barrier();
-    const char* buf = smem + (ch & 1) * kChunkBytes;
+    const char* buf = smem + (ch % NB) * kChunkBytes;
     f32x4 acc[2][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.tiles_n != -8)
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       V8 bf[2];
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512, 1) void gemm_astat4_kernel(const GemmParams p)
 template <typename E, int EPI>
 void launch_astat4(const GemmParams& p, hipStream_t st) {
   const int nout = EPI == DVT_EPI_GELU ? 2 : 1;
-  const int kSmem = 2 * kChunkBytes + 2 * 7 * 32 * nout * 64 + p.N * 4;
+  const int kSmem = 3 * kChunkBytes + 2 * 7 * 32 * nout * 64 + p.N * 4;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_astat4_kernel<E, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
@@ -755,9 +765,9 @@ int main(int argc, char** argv) {
       printf("%-36s 2 x 206 MB: %7.1f us  %6.0f GB/s\n", nm[variant], tt[2], 2.0 * n8 * 16 / (tt[2] * 1e-6) / 1e9);
     }
   }
-  constexpr int NV = 7;
+  constexpr int NV = 11;
   std::vector<double> t[NV];
-  const char* names[NV] = {"shipped cfg3 (256x256, 16 waves)", "shipped cfg5 (antiphase)", "A-stationary, 8 waves / WG", "A-stationary, 4 waves / WG", "A-stationary, two groups in antiphase", "A-stationary, stores under the next chunk", "A-stationary, 7 compute waves + 1 store wave"};
+  const char* names[NV] = {"shipped cfg3 (256x256, 16 waves)", "shipped cfg5 (antiphase)", "A-stationary, 8 waves / WG", "A-stationary, 4 waves / WG", "A-stationary, two groups in antiphase", "A-stationary, stores under the next chunk", "A-stationary, 7 compute waves + 1 store wave", "shipped cfg1 (256x128x32, 2 WG/CU)", "shipped cfg0 (256x256, 8 waves)", "store-wave form WITHOUT its stores", "store-wave form WITHOUT its MFMAs"};
   // every variant writes its own pair of output buffers (back-to-back launches into the SAME 412 MB ran up to 40 % slower
   // than into alternating ones: the previous launch's lines are still on their way out of the cache hierarchy)
   GemmParams pv[NV];
@@ -774,7 +784,10 @@ int main(int argc, char** argv) {
     else if (c == 3) launch_astat<bf16, 4, DVT_EPI_GELU>(pv[c], 0);
     else if (c == 4) launch_astat2<bf16, DVT_EPI_GELU>(pv[c], 0);
     else if (c == 5) launch_astat3<bf16, DVT_EPI_GELU>(pv[c], 0);
-    else launch_astat4<bf16, DVT_EPI_GELU>(pv[c], 0);
+    else if (c == 6) launch_astat4<bf16, DVT_EPI_GELU>(pv[c], 0);
+    else if (c == 7) dvt_gemm_dma_launch(pv[c], true, true, 1, 1, 0);
+    else if (c == 8) dvt_gemm_dma_launch(pv[c], true, true, 1, 0, 0);
+    else { GemmParams t = pv[c]; t.tiles_n = c == 9 ? -7 : -8; launch_astat4<bf16, DVT_EPI_GELU>(t, 0); }
   };
   for (int c = 0; c < NV; ++c) for (int it = 0; it < 3; ++it) run(c);
   hipDeviceSynchronize();

@@ -148,19 +148,21 @@ def main():
                 fh.write(f"| `{short(k[0])}` | {k[1]} | {k[2]} | {v[0]/9:.2f} | {v[1]/9e6:.4f} | {v[1]/v[0]/1e3:.1f} | "
                          f"{100*v[1]/tot:.1f} |\n")
             fh.write(f"\nTotal kernel time {tot/9e6:.3f} ms/step.\n")
-    for wl in ("pyramid", "frametransformer", "longclip"):      # secondary workloads: eager, 1 warm-up + 3 timed steps
-        st2 = find(os.path.join(prof, f"stats_{wl}"), "*kernel_stats.csv")
-        if not st2:
+    # Per-STEP tables (all workloads): a step = the launches between two optimizer launches, so that one-time set-up work
+    # (parameter copies into the flat buffers, warm-up allocations: the "copyBuffer per step" of the r03 tables was that,
+    # divided by the step count) does not appear as step work.  hipGraph replay, as the bench line is measured.
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev"))
+    import trace_steps
+    for wl, sub in (("bench", "stats"), ("pyramid", "stats_pyramid"), ("frametransformer", "stats_frametransformer"),
+                    ("longclip", "stats_longclip")):
+        tr2 = find(os.path.join(prof, sub), "*kernel_trace.csv")
+        if not tr2:
             continue
-        rows = list(csv.DictReader(open(st2)))
-        tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        with open(os.path.join(outd, f"{tag}_{wl}_kernel_stats.md"), "w") as fh:
-            fh.write(f"# rocprofv3 --kernel-trace --stats, bench.py --workload {wl} ({tag})\n\n4 steps in the trace (eager launches); "
-                     "per-step columns = totals / 4.\n\n| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")
-            for r in rows[:28]:
-                fh.write(f"| `{short(r['Name'])}` | {int(r['Calls'])//4} | {float(r['TotalDurationNs'])/4e6:.3f} | "
-                         f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
-            fh.write(f"\nTotal kernel time {tot/4e6:.2f} ms/step.\n")
+        name = f"{tag}_{wl}_kernel_stats.md" if wl != "bench" else f"{tag}_bench_kernel_per_step.md"
+        with open(os.path.join(outd, name), "w") as fh:
+            fh.write(f"# rocprofv3 --kernel-trace, bench.py" + (f" --workload {wl}" if wl != "bench" else "") + f" ({tag}): per-step table\n\n"
+                     "Steps = intervals between consecutive `adamw_fused_kernel` launches (hipGraph replay); the last 3 averaged.\n\n")
+            trace_steps.table(tr2, 3, 80, fh, os.path.join(outd, f"{tag}_{wl}_last_step_order.txt") if wl == "bench" else None)
     # ---- traffic
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {cmd}.  gfx950: FETCH_SIZE counts "
             "64 B per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact.  FETCH_SIZE is counted at the L2 fabric side "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Reproduces profiles/rNN_* on an MI355X box (run from the repo root through gpurun):
-#   bash tools/run_profiles.sh && python3 tools/profile_summarize.py gpurun_out/prof profiles r03
+#   bash tools/run_profiles.sh && python3 tools/profile_summarize.py gpurun_out/prof profiles r04
 # One rocprofv3 run per counter group (--pmc never together with other trace domains); the program itself follows `--`.
 set -e
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
@@ -18,6 +18,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_pyr
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write_pyramid" -- python3 "$BENCH" --workload pyramid --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/write_pyramid.log" 2>&1
 # secondary workloads: kernel-time breakdown
 for wl in pyramid frametransformer longclip; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- python3 "$BENCH" --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-graph > "$OUT/stats_$wl.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- python3 "$BENCH" --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > "$OUT/stats_$wl.log" 2>&1
 done
 echo "profiles collected under $OUT"
