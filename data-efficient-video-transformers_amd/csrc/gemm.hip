@@ -956,9 +956,18 @@ static int conv_tk(int cfg) { return cfg == 0 || cfg >= 6 ? 64 : 32; }
 
 // Forward / data-gradient launches with few output rows (layer 4 of a ResNet-18 on 224^2 frames: 49 pixels per frame)
 // leave most CUs without a 256x256 tile: the 256x128 configuration doubles the tile count (and runs two per CU).
+// Fewer still (R(2+1)D-18 layers 3 - 4 on 112^2 chunks: 16,464 and 2,744 output pixels): 128x128 tiles, two workgroups
+// per CU -- at under a workgroup per CU every halving of the tile halves the launch.  And a 256x128 grid of one to two
+// workgroups per CU runs as ONE round on the 72 KiB form (two per CU) instead of a full round plus a nearly empty one.
 static int conv_fwd_cfg(int64_t rows, int cout, int c) {
   const int cfg = conv_cfg(cout, c);
-  if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < (int64_t)dvt_num_cus() * 3) return c % 64 == 0 ? 7 : 1;
+  const int64_t cus = dvt_num_cus();
+  if (cout > 64 && c % 64 == 0) {
+    const int64_t t128 = dvt_cdiv(rows, 256) * dvt_cdiv(cout, 128);
+    if (t128 * 4 < cus * 3) return 9;
+    if (cfg == 0 && t128 > cus && t128 <= 2 * cus && c % 32 == 0) return 1;
+  }
+  if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < cus * 3) return c % 64 == 0 ? 7 : 1;
   return cfg;
 }
 
@@ -1033,6 +1042,7 @@ int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
   const int cfg = conv_fwd_cfg(d->N * Ho * Wo, d->Cout, d->C);
+  if (cfg == 9) return dvt_cdiv(d->N * Ho * Wo, 128) * 2;                             // 128-row tiles of two wave rows
   return dvt_cdiv(d->N * Ho * Wo, 256) * (cfg == 4 || cfg == 6 || cfg == 7 ? 4 : 2);   // wave rows per 256-row tile
 }
 

@@ -58,6 +58,7 @@ template <> struct Cfg<4> { enum { TM = 256, TN = 64, TK = 32, NW = 4, WN = 1, N
 template <> struct Cfg<6> { enum { TM = 256, TN = 64, TK = 64, NW = 4, WN = 1, NSTG = 2, PP = 0 }; };    // CFG 4 with 64-deep k-tiles, 2 x 40 KiB: 2 workgroups / CU
 template <> struct Cfg<7> { enum { TM = 256, TN = 128, TK = 64, NW = 8, WN = 2, NSTG = 2, PP = 0 }; };   // CFG 1's tile with 64-deep k-tiles: 8 waves of 64 x 64, 96 KiB
 template <> struct Cfg<8> { enum { TM = 224, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 5 with 7 sub-tiles per wave row
+template <> struct Cfg<9> { enum { TM = 128, TN = 128, TK = 64, NW = 4, WN = 2, NSTG = 2, PP = 0 }; };   // 4 waves of 64 x 64, 64 KiB: 2 workgroups / CU; convolutions with few output rows
 template <> struct Cfg<5> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 0 with the two wave rows in antiphase
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
@@ -738,6 +739,7 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
 #if DVT_GEMM256_UNIT == 1
 // configuration 6 (256x64x64 convolution tiles), kept out of the main module like configuration 5
 int dvt_conv_dma_launch_c6(const GemmParams& p, int cfg, hipStream_t st) {
+  if (cfg == 9) return p.elem == DVT_F16 ? launch_conv<f16, 9>(p, st) : launch_conv<bf16, 9>(p, st);
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv<f16, 7>(p, st) : launch_conv<bf16, 7>(p, st);
   return p.elem == DVT_F16 ? launch_conv<f16, 6>(p, st) : launch_conv<bf16, 6>(p, st);
 }
@@ -780,7 +782,7 @@ int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream
 // Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
 // fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32, cfg 4 = 256x64x32 (Cout <= 64).
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
-  if (cfg == 6 || cfg == 7) return dvt_conv_dma_launch_c6(p, cfg, st);
+  if (cfg == 6 || cfg == 7 || cfg == 9) return dvt_conv_dma_launch_c6(p, cfg, st);
   if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : cfg == 4 ? launch_conv<f16, 4>(p, st) : launch_conv<f16, 1>(p, st);
   return cfg == 0 ? launch_conv<bf16, 0>(p, st) : cfg == 4 ? launch_conv<bf16, 4>(p, st) : launch_conv<bf16, 1>(p, st);
 }
