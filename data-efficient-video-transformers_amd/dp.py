@@ -415,7 +415,15 @@ class FlatParameters:
         return self.loss_grad
 
     def adamw_step(self, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-        """torch.optim.AdamW semantics (frame_transformer.py:127-129) in one launch."""
+        """torch.optim.AdamW semantics (frame_transformer.py:127-129) in one launch.
+
+        One deviation, by construction of the flat buffers: the bias-correction step count is GLOBAL (one device counter for
+        all parameters), where torch keeps one per parameter and advances it only in steps in which that parameter has a
+        gradient.  The two agree whenever every parameter is written in every step -- the reference's training loops (all
+        modes of `FrameTransformer.training_step`, ViViT) -- and for parameters that never receive a gradient (skipped through
+        `skip64`, state untouched, as torch skips `.grad is None`).  A parameter that receives gradients only in SOME steps would
+        see the global count in its bias correction (1 - beta^t with t too large: a slightly larger effective step early on);
+        `tests/test_gpu_dp.py` covers the always-written and never-written cases, not the intermittent one."""
         if self.exp_avg is None:
             self.init_optimizer_state()
         self.step_count += 1
@@ -448,7 +456,8 @@ class FlatParameters:
         self._after_step()
 
     def adagrad_step(self, lr: float, weight_decay: float = 0.0, lr_decay: float = 0.0, eps: float = 1e-10) -> None:
-        """torch.optim.Adagrad semantics (frame_transformer.py:130-132) in one launch over the flat buffers."""
+        """torch.optim.Adagrad semantics (frame_transformer.py:130-132) in one launch over the flat buffers (the step count
+        that enters `lr / (1 + (t - 1) lr_decay)` is global, as in `adamw_step`; the reference uses lr_decay = 0)."""
         if getattr(self, "state_sum", None) is None:
             self.state_sum = torch.zeros_like(self.data)
         self.step_count += 1
