@@ -400,25 +400,28 @@ template <typename T, int MODE, bool POOL = false, int MSRC = 0>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int64_t rows, int C,
-                                                          int rows_per_block, int relu, int vc_log2,
+                                                          int rows_per_block, int relu, int vc,
                                                           float* __restrict__ partial,
                                                           const float* __restrict__ gamma = nullptr,
                                                           const float* __restrict__ beta = nullptr,
                                                           PoolGeom pg = PoolGeom{nullptr, 0, 0, 0, 0},
                                                           const unsigned char* __restrict__ mask = nullptr, int c_valid = 1 << 30) {
-  // 256 threads = vc column-vectors (8 channels each) x nrl row lanes; vc = min(32, C/8 rounded down to 2^k),
-  // so narrow maps (C = 64: vc = 8, 32 row lanes) keep every lane busy.  Four rows are requested before the first is
-  // consumed.  ReLU mask of MODE 1 (MSRC): 2 = the forward's mask bytes, 1 = the stored output y, 0 = recomputed from x.
+  // 256 threads = vc column-vectors (8 channels each) x nrl = 256 / vc row lanes (the 256 % vc last threads idle); vc is a
+  // divisor of C / 8 up to 32 (bn_vc), so narrow maps (C = 64: vc = 8, 32 row lanes) AND widths that are not powers of two
+  // (R(2+1)D's 144 / 240 / 464 / 928 planes) keep every lane busy -- with vc = 16 for C = 144 the second block column had 2
+  // of its 16 column lanes in use and those few threads walked the whole row range alone (198 us for 607 MB).  Four rows are
+  // requested before the first is consumed.  ReLU mask of MODE 1 (MSRC): 2 = the forward's mask bytes, 1 = the stored output
+  // y, 0 = recomputed from x.
   __shared__ float red[2][256][8];
   constexpr int U = POOL ? 1 : 4;
-  const int vc = 1 << vc_log2, nrl = 256 >> vc_log2;
-  const int cl = threadIdx.x & (vc - 1), rl = threadIdx.x >> vc_log2;
+  const int nrl = 256 / vc;
+  const int cl = threadIdx.x % vc, rl = threadIdx.x / vc;
   const int c = (blockIdx.x * vc + cl) * 8;
   const int cv = C >> 3;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c < C && r0 < r1) {
+  if (c < C && r0 < r1 && rl < nrl) {
     BnAffine<T> af;
     if (MODE == 1) af.init(mean, invstd, gamma, (relu && MSRC == 0) ? beta : nullptr, c, c_valid);
     constexpr int msrc = MSRC;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
     const int cc = (blockIdx.x * vc + cvi) * 8 + k;
     if (cc < C) {
       float acc = 0.f;
-      for (int r = 0; r < nrl; ++r) acc += red[st][(r << vc_log2) + cvi][k];
+      for (int r = 0; r < nrl; ++r) acc += red[st][r * vc + cvi][k];
       partial[((int64_t)blockIdx.y * 2 + st) * C + cc] = acc;
     }
   }
@@ -1485,11 +1488,22 @@ static int bn_vc_log2(int C) {
   return l;
 }
 
+// Column vectors per block of bn_colstats_kernel: C / 8 when that is at most 32, else its largest divisor up to 32 (every
+// lane busy); widths without a divisor of at least 8 keep the power-of-two form with a ragged last block column.
+static int bn_vc(int C) {
+  const int cv = C >> 3;
+  if (C % 8 || cv <= 0) return 1 << bn_vc_log2(C);
+  if (cv <= 32) return cv;
+  for (int v = 32; v >= 8; --v)
+    if (cv % v == 0) return v;
+  return 1 << bn_vc_log2(C);
+}
+
 // Row partition: about 2048 workgroups in total (8 per CU), at least 4 passes of the row lanes per workgroup.
 static int bn_parts(int64_t rows, int C, int* rpb) {
-  const int vcl = bn_vc_log2(C);
-  const int64_t gx = dvt_cdiv(C, 8 << vcl);
-  const int nrl = 256 >> vcl;
+  const int vc = bn_vc(C);
+  const int64_t gx = dvt_cdiv(C, 8 * vc);
+  const int nrl = 256 / vc;
   int64_t parts = 2048 / gx;
   const int64_t cap = rows / (4 * nrl);
   if (parts > cap) parts = cap;
@@ -1505,13 +1519,13 @@ int dvt_bn_stats(const void* x, float* mean, float* invstd, float* running_mean,
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
-  const int vcl = bn_vc_log2(C);
-  const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
+  const int vc = bn_vc(C);
+  const dim3 grid((unsigned)dvt_cdiv(C, 8 * vc), (unsigned)parts);
   const dim3 grid_s((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   if (C % 8 == 0 && dvt_aligned16(x) && dvt_aligned16(workspace)) {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)x,
                                                     (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                    (const float*)nullptr, rows, C, rpb, 0, vcl, (float*)workspace));
+                                                    (const float*)nullptr, rows, C, rpb, 0, vc, (float*)workspace));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_scalar_kernel<T, 0>), grid_s, dim3(256), 0, st, (const T*)x,
                                                     (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
@@ -1608,8 +1622,8 @@ int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_ma
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int parts = bn_parts(rows, C, &rpb);
-  const int vcl = bn_vc_log2(C);
-  const dim3 grid((unsigned)dvt_cdiv(C, 8 << vcl), (unsigned)parts);
+  const int vcl = bn_vc(C);                            // (column vectors per block, not a logarithm any more)
+  const dim3 grid((unsigned)dvt_cdiv(C, 8 * vcl), (unsigned)parts);
   const dim3 grid_s((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
   float* part = (float*)workspace;
@@ -1699,8 +1713,8 @@ int dvt_bn_bwd_pooled(const void* dy_pool, const void* idx, const void* x, const
                                                     vcl, part, pg));
   } else {
     DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, true>), grid, dim3(256), 0, st, (const T*)x,
-                                                    (const T*)dy_pool, (const T*)nullptr, mean, invstd, rows, C, rpb, relu, vcl,
-                                                    part, gamma, beta, pg));
+                                                    (const T*)dy_pool, (const T*)nullptr, mean, invstd, rows, C, rpb, relu,
+                                                    1 << vcl, part, gamma, beta, pg));
   }
   DVT_LAUNCH_CHECK("dvt_bn_bwd_pooled(stats)");
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);

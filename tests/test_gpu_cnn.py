@@ -126,7 +126,7 @@ def test_maxpool_fwd_bwd_matches_torch(dvt, device, H, W, k, stride, pad):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows,C", [(37, 8), (4099, 48), (70001, 64), (9000, 512)])
+@pytest.mark.parametrize("rows,C", [(37, 8), (4099, 48), (70001, 64), (9000, 512), (30011, 144), (4099, 240), (5000, 464), (2744, 928), (1000, 296)])
 def test_batchnorm_row_streaming_kernels_and_relu_mask(dvt, device, dtype, rows, C):
     """BatchNorm + residual + ReLU of a BasicBlock's second layer (custom_resnet.py:48-52) and its backward against plain
     fp64 arithmetic on the same rounded operands -- row counts that are not multiples of the kernels' row sweep, a channel
