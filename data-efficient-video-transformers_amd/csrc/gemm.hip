@@ -1026,6 +1026,19 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(!(d->residual && d->stats_partial), "dvt_conv2d_implicit: residual and stats_partial are exclusive");
   DVT_REQUIRE(dvt_aligned16(d->residual), "dvt_conv2d_implicit: residual must be 16-byte aligned");
   p.bn_partial = d->stats_partial;
+  if (d->bnb_z) {              // the BatchNorm in front of the layer: its backward column sums come out of this epilogue
+    DVT_REQUIRE(!d->stats_partial && d->bnb_partial && d->bnb_mean && d->bnb_invstd && d->bnb_gamma &&
+                    (!d->bnb_relu || d->bnb_mask || d->bnb_beta) && d->bnb_c_valid <= d->Cout && dvt_aligned16(d->bnb_z) &&
+                    dvt_aligned16(d->bnb_partial),
+                "dvt_conv2d_implicit: bnb_z needs bnb_partial, mean, invstd, gamma (and the mask bytes or beta under ReLU), "
+                "16-byte aligned, and excludes stats_partial");
+    if (d->residual && d->bnb_relu && !d->bnb_mask)
+      DVT_UNSUPPORTED("dvt_conv2d_implicit: bnb_z with a residual needs the ReLU mask bytes (bnb_mask)");
+    p.bn_partial = d->bnb_partial;
+    p.bnb_z = d->bnb_z; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma;
+    p.bnb_beta = d->bnb_beta; p.bnb_mask = (const unsigned char*)d->bnb_mask; p.bnb_relu = d->bnb_relu;
+    p.bnb_cv = d->bnb_c_valid > 0 ? d->bnb_c_valid : d->Cout;
+  }
   if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
     const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
     int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);
