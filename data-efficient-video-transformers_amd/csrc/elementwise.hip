@@ -401,6 +401,31 @@ __global__ void strided_rows_sum_kernel(const T* __restrict__ src, int64_t row_s
   strided_rows_sum_block<T>(src, row_stride, R, out, accumulate, blockIdx.x);
 }
 
+// The same sum for FEW rows of MANY columns (the learnable pixel-space CLS chunk of FrameTransformer: B = 2 rows of 451 k
+// values, frame_transformer.py:105,195): a thread per 8-column chunk walks the rows -- the block-per-chunk form above spent a
+// 256-thread workgroup and two barriers on each 32 bytes (56,448 workgroups, 119 us).
+template <typename T>
+__global__ void few_rows_sum_kernel(const T* __restrict__ src, int64_t row_stride, int64_t R, int64_t chunks,
+                                    float* __restrict__ out, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < chunks; ch += stride) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t r = 0; r < R; ++r) {
+      float v[8];
+      load8<T>(src + r * row_stride + (ch << 3), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    if (accumulate) {
+      float o[8];
+      load8<float>(out + (ch << 3), o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += o[k];
+    }
+    store8<float>(out + (ch << 3), acc);
+  }
+}
+
 // ------------------------------------------------------------------ CLS row gather
 template <typename T>
 __global__ void rows_gather_fwd_kernel(const T* __restrict__ src, int64_t src_row_stride,
@@ -664,9 +689,15 @@ int dvt_rows_sum(const void* src, int64_t row_stride, int64_t rows, int64_t cols
   DVT_REQUIRE(cols % 8 == 0 && row_stride % 8 == 0 && dvt_aligned16(src) && dvt_aligned16(out),
               "dvt_rows_sum: cols / row stride must be multiples of 8 and buffers 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  DVT_DISPATCH_DTYPE(dtype, T,
-                     hipLaunchKernelGGL((strided_rows_sum_kernel<T>), dim3((unsigned)(cols >> 3)), dim3(kBlock), 0,
-                                        st, (const T*)src, row_stride, rows, out, accumulate));
+  if (rows <= 16 && cols >= 8192) {
+    DVT_DISPATCH_DTYPE(dtype, T,
+                       hipLaunchKernelGGL((few_rows_sum_kernel<T>), dim3(grid_for(cols >> 3)), dim3(kBlock), 0, st,
+                                          (const T*)src, row_stride, rows, cols >> 3, out, accumulate));
+  } else {
+    DVT_DISPATCH_DTYPE(dtype, T,
+                       hipLaunchKernelGGL((strided_rows_sum_kernel<T>), dim3((unsigned)(cols >> 3)), dim3(kBlock), 0,
+                                          st, (const T*)src, row_stride, rows, out, accumulate));
+  }
   DVT_LAUNCH_CHECK("dvt_rows_sum");
   return DVT_OK;
 }

@@ -552,6 +552,7 @@ def test_default_frame_transformer_vid_step_matches_oracle(dvt, device):
     (2, 256, 9, 11, 512, (3, 1), 1, (1, 0)),   # rectangular (temporal) kernel
     (4, 64, 16, 16, 128, 1, 2, 0),         # 1x1 stride-2 downsample
     (1, 512, 7, 7, 512, 3, 1, 1),
+    (16, 64, 56, 56, 144, 3, 1, 1),        # 144 output columns over many rows (R(2+1)D-18 layer 1)
 ])
 def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geom):
     """dvt_conv2d_implicit (gather fused into the GEMM operand DMA) == dvt_im2col + dvt_gemm, forward and the
@@ -572,11 +573,11 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
     xr = x.float().cpu().view(N, H, W, Cin).permute(0, 3, 1, 2)
     cpu = torch.nn.functional.conv2d(xr, w.cpu(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
     assert rel_l2(y, cpu) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
-    if ops._pair(stride) == (1, 1):
-        Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
-        dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
-        wd = ops.conv_weight_pack_dgrad(w, dtype)
-        (ph, pw) = ops._pair(pad)
+    Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+    (ph, pw) = ops._pair(pad)
+    wd = ops.conv_weight_pack_dgrad(w, dtype)
+    dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
+    if ops._pair(stride) == (1, 1) and ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw)):
         dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, (kh - 1 - ph, kw - 1 - pw))
         dref = ops.col2im(ops.linear_dgrad(dz, wp), N, Cin, H, W, k, stride, pad)
         assert dx.shape == dref.shape and rel_l2(dx, dref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
@@ -821,7 +822,8 @@ def test_channel_padding_is_exact_zero_extension(dvt, device, dtype, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,H,W,Cout,k,stride,pad", [(6, 64, 28, 28, 64, 3, 1, 1), (3, 64, 30, 26, 128, 3, 2, 1),
-                                                        (40, 128, 14, 14, 256, 3, 1, 1), (5, 64, 56, 56, 64, (1, 3), 1, (0, 1))])
+                                                        (40, 128, 14, 14, 256, 3, 1, 1), (5, 64, 56, 56, 64, (1, 3), 1, (0, 1)),
+                                                        (8, 64, 56, 56, 144, 3, 1, 1)])
 def test_conv_epilogue_batchnorm_statistics(dvt, device, N, C, H, W, Cout, k, stride, pad):
     """Column sums / sums of squares left by the implicit-convolution epilogue (incl. the > 256-part fold) against the
     stand-alone statistics pass over the stored output: mean, invstd and the running-statistics update."""

@@ -1149,3 +1149,20 @@ def test_head_and_loss_in_one_launch(device, xdt, rows, d, C, ln1):
     want = dict(zip(["g1", "b1", "g2", "b2", "w", "c"], [p.grad for p in Pr]))
     for n in names:
         assert rel_l2(outs[n], want[n]) < 2e-5, n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols,stride", [(2, 451584, 451584 * 14), (16, 8192, 8192), (5, 40, 48), (300, 512, 512), (1, 16384, 16384)])
+def test_rows_sum_few_and_many_rows(device, dtype, rows, cols, stride):
+    """dvt_rows_sum: out[c] (+)= sum_r src[r * stride + c] -- the block-per-chunk form and the thread-per-chunk form for few
+    rows of many columns (the pixel-space CLS chunk's gradient over the batch, frame_transformer.py:105,195)."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    buf = torch.randn((rows - 1) * stride + cols, generator=g).to(dtype).cuda()
+    view = torch.as_strided(buf, (rows, cols), (stride, 1)).float()
+    out = ops.rows_sum(buf, stride, rows, cols)
+    assert rel_l2(out, view.sum(0)) < 2e-6
+    prev = torch.randn(cols, generator=g).cuda()
+    acc = prev.clone()
+    ops.rows_sum(buf, stride, rows, cols, out=acc, accumulate=True)
+    assert rel_l2(acc, prev + view.sum(0)) < 2e-6
