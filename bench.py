@@ -270,6 +270,13 @@ def build_workload(args, workload, rank, comm):
     flat = FlatParameters(net, bucket_mb=args.bucket_mb, compute_dtype=cdt, comm=comm, grad_reduce_dtype=rdt)
     flat.broadcast_parameters(0)
     flat.sync_compute_copy()
+    # A/B switch (measured SLOWER, so off: vivit 5.72 -> 5.94 ms, pyramid 13.5 -> 14.07, frametransformer 20.9 -> 21.87 on one
+    # box): the optimizer step of every gradient bucket behind that bucket (and its all-reduce) while backward continues
+    # (dp.enable_overlapped_adamw: bit-identical to the one-launch step) -- an HBM-saturating kernel beside the backward GEMMs
+    # costs them more than the 0.15-0.27 ms it hides
+    if (args.overlap_optimizer and cdt != torch.float16 and torch.cuda.is_available()
+            and (comm is not None or flat.world == 1)):
+        flat.enable_overlapped_adamw(lr=5e-6, weight_decay=0.09)
 
     gen = torch.Generator().manual_seed(1130 + rank)
     if workload == "frametransformer":
@@ -581,11 +588,14 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
     # optimizer share of the step (SURVEY 8d asks for it separately): fused AdamW + bf16 weight mirror on the flat buffers
     o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     o0.record()
+    ovl = flat._ovl
+    flat.disable_overlapped_adamw()                           # (the one-launch form: what the optimizer costs on its own)
     for _ in range(5):
         flat.adamw_step(lr=0.0, weight_decay=0.0)            # lr = 0: timing only, the weights stay put
     o1.record()
     torch.cuda.synchronize()
     optimizer_ms = o0.elapsed_time(o1) / 5
+    flat._ovl = ovl
 
     # ---- roofline of the dominant kernel family, live HIP events (separate short pass so the
     #      event records do not perturb the headline timing)
@@ -808,6 +818,8 @@ def main():
                     "single-GPU box -- the gradient exchange then goes through torch.distributed as well)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and the RCCL communicator even "
                     "with one rank (rehearses the multi-GPU code path on a single GPU)")
+    ap.add_argument("--overlap-optimizer", action="store_true", help="A/B switch (measured slower): the AdamW step per "
+                    "gradient bucket beside the backward instead of as one launch behind it")
     ap.add_argument("--no-cls-fold", action="store_true", help="A/B switch: run the last space layer's single-query attention "
                     "without folding the K / V projections into the query (functional.CLS_FOLD_MIN_ROWS)")
     ap.add_argument("--no-pair-launch", action="store_true", help="A/B switch: weight and data gradient of the launch-bound "

@@ -245,6 +245,8 @@ SIGNATURES = {
     "dvt_comm_destroy": (c_int, [c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     "dvt_adamw_step_fused": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_int, c_p]),
+    "dvt_adamw_step_range": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_int, c_p]),
+    "dvt_step_increment": (c_int, [c_p, c_p]),
 }
 
 _lib: Optional[C.CDLL] = None

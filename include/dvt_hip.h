@@ -765,6 +765,13 @@ int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
 int dvt_adamw_step_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
                          const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream);
+/* dvt_adamw_step_fused on one RANGE of the flat buffers (pointers already offset; skip64 offset by range start / 64) WITHOUT
+ * advancing the step counter: the optimizer step of one gradient bucket, enqueued behind that bucket's all-reduce on the
+ * exchange stream while backward is still running; dvt_step_increment(step_dev2) closes the step. */
+int dvt_adamw_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
+                         const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream);
+int dvt_step_increment(int64_t* step_dev2, dvt_stream_t stream);
 /* AdamW under dynamic loss scaling (BASELINE configs[4]: fp16 + loss scaling; torch.cuda.amp.GradScaler rule).
  * grad holds the gradient of (scale * loss).  On the device, in stream order: found_inf |= any non-finite grad;
  * unless found_inf: the dvt_adamw_step_dev update with grad / scale and step_dev += 1; then
