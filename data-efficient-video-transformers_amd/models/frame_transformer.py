@@ -96,12 +96,16 @@ class EncoderLayer(nn.Module):
         (``MultiheadAttention(dropout=p)``, inside the attention kernel)."""
         a = self.self_attn
         if self.training and self.p > 0.0:
+            # (F.fork: a tensor with two consumers -- the sublayer and its residual add -- gets its two gradients summed by
+            # dvt_add instead of by autograd's own accumulate kernel: no ATen kernel inside the step)
+            x, xr = F.fork(x)
             sa = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
                               prenorm=False, residual=False, b_qkv=a.in_proj_bias, seq_first=True, attn_dropout=self.p)
-            x = F.layernorm(F.add(x, F.dropout(sa, self.p, True)), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = F.layernorm(F.add(xr, F.dropout(sa, self.p, True)), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x, xr = F.fork(x)
             h = F.dropout(F.relu(F.linear(x, self.linear1.weight, self.linear1.bias)), self.p, True)
             y = F.dropout(F.linear(h, self.linear2.weight, self.linear2.bias), self.p, True)
-            return F.layernorm(F.add(x, y), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return F.layernorm(F.add(xr, y), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
                          prenorm=False, residual=True, b_qkv=a.in_proj_bias, seq_first=True)
         x = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
