@@ -274,17 +274,45 @@ __device__ __forceinline__ void pack_rows(const dvt_pack_entry& q, int blk, int 
   const int taps = q.kh * q.kw, rowlen = q.cin_l * taps;
   const int co0 = blk * R;
   const int64_t src0 = (int64_t)co0 * rowlen, src_end = (int64_t)q.cout_l * rowlen;
-  for (int i = threadIdx.x; i < R * rowlen; i += 256) lds[i] = src0 + i < src_end ? q.src[src0 + i] : 0.f;
+  const int total = R * rowlen;
+  if ((rowlen & 3) == 0 && (((uintptr_t)q.src) & 15) == 0) {   // 16-byte loads (the rows are contiguous in the parameter)
+    for (int i = threadIdx.x * 4; i < total; i += 1024) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (src0 + i < src_end) v = *reinterpret_cast<const f32x4*>(q.src + src0 + i);
+      *reinterpret_cast<f32x4*>(lds + i) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += 256) lds[i] = src0 + i < src_end ? q.src[src0 + i] : 0.f;
+  }
   __syncthreads();
   D* __restrict__ dst = (D*)q.dst;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int body = taps * q.cin_p;
-  for (int p = ty; p < R * taps; p += 4) {                     // (row, tap) pairs, one per wave at a time
-    const int r = p / taps, tap = p - r * taps;
-    if (co0 + r >= q.cout_p) break;
-    D* __restrict__ d = dst + (int64_t)(co0 + r) * q.ld + tap * q.cin_p;
-    const float* l = lds + r * rowlen + tap;
-    for (int ci = tx; ci < q.cin_p; ci += 64) d[ci] = from_f32<D>(ci < q.cin_l ? l[ci * taps] : 0.f);
+  if (sizeof(D) == 2 && (q.cin_p & 7) == 0 && (q.ld & 7) == 0 && (((uintptr_t)q.dst) & 15) == 0) {
+    // a thread writes 8 consecutive input channels of one (row, tap) pair: one 16-byte store from eight LDS reads of stride
+    // `taps` (2-byte stores were 128 bytes per wave instruction)
+    const int c8n = q.cin_p >> 3, chunks = R * taps * c8n;
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+      const int pr = ch / c8n, c8 = ch - pr * c8n;
+      const int r = pr / taps, tap = pr - r * taps;
+      if (co0 + r >= q.cout_p) break;
+      const float* l = lds + r * rowlen + tap;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ci = c8 * 8 + k;
+        v[k] = ci < q.cin_l ? l[ci * taps] : 0.f;
+      }
+      store8<D>(dst + (int64_t)(co0 + r) * q.ld + tap * q.cin_p + c8 * 8, v);
+    }
+  } else {
+    for (int p = ty; p < R * taps; p += 4) {                     // (row, tap) pairs, one per wave at a time
+      const int r = p / taps, tap = p - r * taps;
+      if (co0 + r >= q.cout_p) break;
+      D* __restrict__ d = dst + (int64_t)(co0 + r) * q.ld + tap * q.cin_p;
+      const float* l = lds + r * rowlen + tap;
+      for (int ci = tx; ci < q.cin_p; ci += 64) d[ci] = from_f32<D>(ci < q.cin_l ? l[ci * taps] : 0.f);
+    }
   }
   if (q.ld > body)                                             // K padding of the row
     for (int r = 0; r < R && co0 + r < q.cout_p; ++r)
@@ -297,12 +325,39 @@ __device__ __forceinline__ void pack_tile_t(const dvt_pack_entry& q, int blk, fl
   const int tiles_co = (q.cout_p + 63) / 64;
   const int co0 = (blk % tiles_co) * 64, c0 = (blk / tiles_co) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int co = co0 + r, c = c0 + tx;
-    lds[r * 65 + tx] = (co < q.cout_l && c < rowlen) ? q.src[(int64_t)co * rowlen + c] : 0.f;
+  if ((rowlen & 3) == 0 && (((uintptr_t)q.src) & 15) == 0) {   // 16-byte loads: thread = (row, four columns), four rounds
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 256 + threadIdx.x, r = idx >> 4, c4 = (idx & 15) << 2;
+      const int co = co0 + r, c = c0 + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (co < q.cout_l && c < rowlen) v = *reinterpret_cast<const f32x4*>(q.src + (int64_t)co * rowlen + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lds[r * 65 + c4 + k] = v[k];
+    }
+  } else {
+    for (int r = ty; r < 64; r += 4) {
+      const int co = co0 + r, c = c0 + tx;
+      lds[r * 65 + tx] = (co < q.cout_l && c < rowlen) ? q.src[(int64_t)co * rowlen + c] : 0.f;
+    }
   }
   __syncthreads();
   D* __restrict__ dst = (D*)q.dst;
+  if (sizeof(D) == 2 && (q.cout_p & 7) == 0 && (((uintptr_t)q.dst) & 15) == 0) {
+    // a thread writes 8 consecutive output channels of one (channel, tap) row: 16-byte stores, 128 bytes per row from 8 lanes
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ch = it * 256 + threadIdx.x, cc = ch >> 3, o8 = (ch & 7) << 3;
+      const int c = c0 + cc, co = co0 + o8;
+      if (c >= cols || co >= q.cout_p) continue;
+      const int ci = c / taps, tap = c - ci * taps;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = lds[(o8 + k) * 65 + cc];
+      store8<D>(dst + ((int64_t)ci * taps + (taps - 1 - tap)) * q.cout_p + co, v);
+    }
+    return;
+  }
   const int co = co0 + tx;
   if (co >= q.cout_p) return;
   for (int cc = ty; cc < 64; cc += 4) {
