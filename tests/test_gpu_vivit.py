@@ -183,6 +183,31 @@ def test_fused_head_loss_equals_separate_kernels(device, mode):
         assert rel_l2(ga[k], gb[k]) < tol, (k, rel_l2(ga[k], gb[k]))
 
 
+def test_fused_head_loss_with_mean_pooling(device):
+    """pool == 'mean' (vit.py:126): the temporal stack's final norm has already been applied to every row, so the fused head
+    runs without its first LayerNorm (g1 == NULL form of dvt_head_bce_fwd) == the separate kernels."""
+    from dvt_amd import functional as F
+    from dvt_amd.models.vit import ViViT
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        net = ViViT(32, 16, 6, 4, dim=64, depth=2, heads=2, dim_head=32, pool='mean', compute_dtype=torch.float32).cuda()
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(3, 4, 3, 32, 32, generator=g).cuda()
+        y = (torch.rand(3, 6, generator=g) < 0.5).float().cuda()
+        if fused:
+            loss, logits = net.loss(x, y)
+        else:
+            logits = net(x)
+            loss = F.bce_with_logits(logits, y)
+        loss.backward()
+        res.append((logits.detach().clone(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (la, a, ga), (lb, b, gb) = res
+    assert rel_l2(la, lb) < 2e-5 and abs(a - b) < 2e-5
+    for k in ga:
+        assert rel_l2(ga[k], gb[k]) < 5e-5, (k, rel_l2(ga[k], gb[k]))
+
+
 def test_vivit_state_dict_roundtrip_and_eval_determinism(device):
     g = golden("vivit_tiny.npz")
     net, _ = _build(g, torch.bfloat16)
