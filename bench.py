@@ -379,6 +379,8 @@ def cnn_roofline(summ, nprof, workload):
             name = f"implicit weight gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'} (split-K; the reduce rides in the layer's data-gradient launch)"
         elif kind == "halo3x3_c64":
             name = "conv3x3_c64 (LDS halo patch; forward and data gradient of layer 1)"
+        elif kind == "halo3x3_c64_wgrad":
+            name = "conv3x3_c64 weight gradient (LDS halo patches; one partial per workgroup, summed by the split-K reduce)"
         else:
             name = f"implicit forward / data gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'}"
         f = fams.setdefault(name, [0.0, 0.0, 0, 0.0, kind])
@@ -395,7 +397,8 @@ def cnn_roofline(summ, nprof, workload):
                 pmc, pfile = json.load(fh)["families"], os.path.relpath(files[-1], ROOT)
         except Exception:
             pmc = {}
-    pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64"}
+    pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
+               "halo3x3_c64_wgrad": "conv3x3_c64_wgrad"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):

@@ -1,0 +1,274 @@
+// conv3x3_wgrad.hip -- weight gradient of the 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels
+// (layer 1 of ResNet-18, custom_resnet.py:19-22,109: four such layers per frame) from LDS-resident halo patches.
+//
+//   dW[co][ci][ki][kj] = sum over frames and pixels (h, w) of dz[h, w, co] * x[h + ki - 1, w + kj - 1, ci]
+//
+// The implicit form (gemm256.hip, mn-major operands) gathers the input map once per filter tap -- nine shifted copies of
+// every pixel through the CU's vector-memory path per k-tile (150 us per layer at 256 frames of 56^2, 0.17 of the MFMA
+// peak).  Here a workgroup owns R whole output rows of one frame at a time, stages the (R + 2) x (W + 2) x 64 input patch
+// and the R x W x 64 gradient tile ONCE each, and all nine taps read their shifted windows of the patch from LDS.
+//
+//   * Both images are [position][64 channels] with 128-byte rows (the mn-major layout of the GEMM family: operands are
+//     read with ds_read_b64_tr_b16, 32-byte units XOR-swizzled by f(position)).  The gradient tile is laid out in the
+//     PATCH's coordinate system -- PW = W + 2 positions per row, the two halo columns zero -- so that tap (ki, kj) of
+//     output position p is patch position p + ki * PW + kj for every p: the reduction runs over positions, and a tap is a
+//     constant address offset.  KP = R * PW rounded up to 32 positions per tile (zero gradient rows behind the last).
+//   * Output [co 64][tap * 64 + ci 576] = 4 x 36 MFMA blocks; 8 waves: waves 0..3 own five (tap, ci-block) column blocks
+//     each, waves 4..7 four (wave w and w + 4 share a SIMD: nine blocks, 36 MFMAs per 32 positions, on every SIMD), for
+//     all four co blocks; the next step's fragments (4 dz + 5 x transposing reads) are requested under the MFMAs of the
+//     current one (a 12-wave form without that prefetch -- 168 VGPRs -- ran at 13 k cycles per tile, 78-88 us per layer).
+//   * Persistent grid (one workgroup per CU); the accumulators live in registers over the workgroup's whole tile sequence;
+//     the next tile's two images stream into second buffers under the MFMAs of the current one.  At the end every
+//     workgroup leaves ONE fp32 partial [576][64] in a slab, and the family's split-K reduce (dvt_splitk_pending with
+//     conv_taps: scatter into the parameter's own [co][ci][3][3] layout) sums the slabs -- stand-alone or carried.
+#include "common.h"
+
+namespace {
+
+constexpr int kC = 64;
+constexpr int kNW = 8;                       // waves per workgroup
+constexpr int kM = 9 * kC;                   // 576 slab rows: tap * 64 + ci
+constexpr int kMaxXP = 8;                    // patch pieces (1 KiB) per wave: patch <= 64 KiB
+constexpr int kMaxZP = 6;                    // gradient-tile pieces per wave: tile <= 48 KiB
+
+struct CwParams {
+  const void* x;        // [N, H, W, 64]
+  const void* dz;       // [N, H, W, 64]
+  float* slab;          // [grid][576][64]
+  int N, H, W, R, PW, KP, tiles_per_img, ntiles;
+  int patch_pos;        // (R + 2) * PW: positions the patch DMA covers
+  int patch_bytes, dz_bytes;
+};
+
+__device__ __attribute__((aligned(16))) unsigned int cw_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int cw_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+
+template <typename E>
+__global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int PW = p.PW;
+  char* xb[2] = {smem, smem + p.patch_bytes};
+  char* zb[2] = {smem + 2 * p.patch_bytes, smem + 2 * p.patch_bytes + p.dz_bytes};
+  const E* xg = (const E*)p.x;
+  const E* zg = (const E*)p.dz;
+  const int xp = (p.patch_pos * 128 + 1023) >> 10;       // pieces the patch DMA writes
+  const int zp = p.dz_bytes >> 10;
+
+  // positions of a patch buffer behind the DMA's range are read (times zero gradient rows) but never written: zero once
+  for (int b = 0; b < 2; ++b)
+    for (int i = xp * 1024 + threadIdx.x * 16; i < p.patch_bytes; i += kNW * 64 * 16)
+      *reinterpret_cast<f32x4*>(xb[b] + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-lane coordinates of this wave's DMA pieces (fixed for the whole launch): slot = 16-byte chunk of a position
+  // one register per piece: row << 16 | column << 4 | source chunk << 1 | valid
+  int xq[kMaxXP], zq[kMaxZP];
+  const int c16 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < kMaxXP; ++i) {
+    const int piece = wid + kNW * i;
+    const int pos = (piece * 64 + lane) >> 3;
+    const int r = pos / PW, c = pos - r * PW;
+    const int ok = (piece < xp && pos < p.patch_pos) ? 1 : 0;
+    xq[i] = (r << 16) | (c << 4) | (((((c16 >> 1) ^ cw_swz(pos)) << 1) | (c16 & 1)) << 1) | ok;
+  }
+#pragma unroll
+  for (int i = 0; i < kMaxZP; ++i) {
+    const int piece = wid + kNW * i;
+    const int pos = (piece * 64 + lane) >> 3;
+    const int r = pos / PW, c = pos - r * PW;
+    const int ok = (piece < zp && r < p.R && c < p.W) ? 1 : 0;
+    zq[i] = (r << 16) | (c << 4) | (((((c16 >> 1) ^ cw_swz(pos)) << 1) | (c16 & 1)) << 1) | ok;
+  }
+  auto load_tile = [&](int tile, int b) {
+    const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
+#pragma unroll
+    for (int i = 0; i < kMaxXP; ++i) {
+      const int piece = wid + kNW * i;
+      if (piece < xp) {                          // wave-uniform
+        const int h = h0 - 1 + (xq[i] >> 16), w = ((xq[i] >> 4) & 0xFFF) - 1;
+        const bool ok = (xq[i] & 1) && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        const E* src = ok ? xg + ((int64_t)(n * p.H + h) * p.W + w) * kC + ((xq[i] >> 1) & 7) * 8
+                          : reinterpret_cast<const E*>(cw_zero16);
+        dvt_dma16(src, xb[b] + piece * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxZP; ++i) {
+      const int piece = wid + kNW * i;
+      if (piece < zp) {
+        const int h = h0 + (zq[i] >> 16);
+        const bool ok = (zq[i] & 1) && h < p.H;
+        const E* src = ok ? zg + ((int64_t)(n * p.H + h) * p.W + ((zq[i] >> 4) & 0xFFF)) * kC + ((zq[i] >> 1) & 7) * 8
+                          : reinterpret_cast<const E*>(cw_zero16);
+        dvt_dma16(src, zb[b] + piece * 1024);
+      }
+    }
+  };
+
+  // this wave's column blocks nb0 .. nb0 + cnt - 1: nb -> tap = nb / 4 (offset ki * PW + kj), ci block = nb % 4.
+  // Byte offsets of this lane's two transposing reads per fragment inside an image, for k-step 0; a k-step adds 32 positions
+  // = 4 KiB, which changes neither bit 1 nor bit 3 of the position: the swizzle term is fixed for the whole launch.
+  const int cnt = wid < 4 ? 5 : 4;                        // wave-uniform
+  const int nb0 = wid < 4 ? 5 * wid : 20 + 4 * (wid - 4);
+  int zo[4][2], xo[5][2];
+  {
+    const int q = li >> 2, pp = li & 3;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = 8 * g + 4 * hf + q;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) zo[m][hf] = k * 128 + ((m ^ cw_swz(k)) << 5) + 8 * pp;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int nb = min(nb0 + j, 35), tap = nb >> 2, ki = tap / 3, kj = tap - 3 * ki;
+        const int kx = k + ki * PW + kj;
+        xo[j][hf] = kx * 128 + (((nb & 3) ^ cw_swz(kx)) << 5) + 8 * pp;
+      }
+    }
+  }
+  f32x4 acc[4][5];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nks = p.KP >> 5;
+  for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
+    const char* cx = xb[it & 1];
+    const char* cz = zb[it & 1];
+    if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x, (it + 1) & 1);
+    V8 zf[2][4], xf[2][5];
+    auto rd = [&](int ks, V8* zv, V8* xv) {
+      const char* bz = cz + ks * 4096;
+      const char* bx = cx + ks * 4096;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        zv[m] = __builtin_shufflevector(Elem16<E>::tr_read(bz + zo[m][0]), Elem16<E>::tr_read(bz + zo[m][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < 4 || cnt == 5)
+          xv[j] = __builtin_shufflevector(Elem16<E>::tr_read(bx + xo[j][0]), Elem16<E>::tr_read(bx + xo[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    rd(0, zf[0], xf[0]);
+    for (int ks = 0; ks < nks; ks += 2) {        // two steps per trip: the fragment buffers alternate without indexing
+      if (ks + 1 < nks) rd(ks + 1, zf[1], xf[1]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (j < 4 || cnt == 5) acc[m][j] = Elem16<E>::mma(zf[0][m], xf[0][j], acc[m][j]);
+      if (ks + 1 < nks) {
+        if (ks + 2 < nks) rd(ks + 2, zf[0], xf[0]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (j < 4 || cnt == 5) acc[m][j] = Elem16<E>::mma(zf[1][m], xf[1][j], acc[m][j]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
+    __builtin_amdgcn_s_barrier();                                  // and everybody is done with this tile's
+  }
+
+  // ---- this workgroup's partial: slab[blockIdx][m = tap * 64 + 16 cb + li][n = 16 mb + 4 g .. + 3]
+  // (mma(dz fragment, x fragment): lane (g, li) holds C[co = 16 mb + 4 g + r][ci = 16 cb + li])
+  float* out = p.slab + (int64_t)blockIdx.x * kM * kC;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j >= cnt) break;
+    const int nb = nb0 + j, tap = nb >> 2, cb = nb & 3;
+    float* row = out + (int64_t)(tap * kC + cb * 16 + li) * kC + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[m][j];
+  }
+}
+
+// rows per tile and the two image sizes for a W-wide map
+int plan(int H, int W, CwParams* q) {
+  if (H < 1 || W < 1) return 0;
+  const int PW = W + 2;
+  for (int R = H < 16 ? H : 16; R >= 1; --R) {
+    const int KP = (R * PW + 31) & ~31;
+    const int patch_pos = (R + 2) * PW;
+    const int need = KP + 2 * PW + 2 > patch_pos ? KP + 2 * PW + 2 : patch_pos;
+    const int pbytes = ((need * 128) + 1023) & ~1023, zbytes = KP * 128;
+    const int xp = (patch_pos * 128 + 1023) >> 10, zp = zbytes >> 10;
+    if (2 * (pbytes + zbytes) > 160 * 1024) continue;
+    if (xp > kNW * kMaxXP || zp > kNW * kMaxZP) continue;
+    if (KP > 512) continue;                               // (long reductions per tile gain nothing: keep tiles plentiful)
+    q->R = R; q->PW = PW; q->KP = KP; q->patch_pos = patch_pos; q->patch_bytes = pbytes; q->dz_bytes = zbytes;
+    return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_conv3x3_c64_wgrad_supported(int64_t N, int H, int W, int dtype) {
+  CwParams q;
+  return N > 0 && dvt_is_16bit(dtype) && plan(H, W, &q) && N * H * W < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+static int cw_grid(int64_t N, int H, const CwParams& q) {
+  const int64_t ntiles = N * dvt_cdiv(H, q.R);
+  return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
+}
+
+size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W) {
+  CwParams q;
+  if (N <= 0 || !plan(H, W, &q)) return 0;
+  return (size_t)cw_grid(N, H, q) * kM * kC * sizeof(float);
+}
+
+int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int accumulate,
+                          int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && dz && dw && workspace && N > 0 && H > 0 && W > 0, "dvt_conv3x3_c64_wgrad: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(dz) && dvt_aligned16(dw) && dvt_aligned16(workspace),
+              "dvt_conv3x3_c64_wgrad: buffers must be 16-byte aligned");
+  DVT_REQUIRE(!defer_reduce || pending, "dvt_conv3x3_c64_wgrad: defer_reduce needs a pending descriptor to fill");
+  CwParams p;
+  if (!dvt_conv3x3_c64_wgrad_supported(N, H, W, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x3_c64_wgrad: needs a 16-bit dtype and two (patch + gradient tile) pairs in 160 KiB of LDS");
+  plan(H, W, &p);
+  p.x = x; p.dz = dz; p.slab = (float*)workspace;
+  p.N = (int)N; p.H = H; p.W = W;
+  p.tiles_per_img = (int)dvt_cdiv(H, p.R);
+  p.ntiles = (int)(N * p.tiles_per_img);
+  const int grid = cw_grid(N, H, p);
+  const int lds = 2 * (p.patch_bytes + p.dz_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DVT_BF16) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  } else {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<f16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  }
+  DVT_LAUNCH_CHECK("dvt_conv3x3_c64_wgrad");
+  // the slabs are summed by the family's split-K reduce, which scatters [tap * 64 + ci][co] into the parameter's [co][ci][3][3]
+  dvt_splitk_pending q{};
+  q.slab = p.slab; q.splits = grid; q.valid = 1; q.M = kM; q.N = kC; q.C = dw; q.ldc = kC;
+  q.accumulate = accumulate; q.cs_accumulate = 0; q.cs_slab = nullptr; q.cs_out = nullptr;
+  q.conv_cin = kC; q.conv_taps = 9; q.conv_cin_l = 0; q.conv_cout_l = 0;
+  if (defer_reduce) {
+    *pending = q;
+    return DVT_OK;
+  }
+  return dvt_splitk_reduce_pending(&q, stream);
+}
+
+}  // extern "C"

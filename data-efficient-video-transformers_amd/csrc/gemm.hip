@@ -690,8 +690,78 @@ __global__ void splitk_reduce_pending_kernel(const dvt_splitk_pending q) {
   splitk_reduce_f32_part(q, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
+// Many slabs of a small product (the per-workgroup partials of dvt_conv3x3_c64_wgrad: 256 x [576][64]): one thread per
+// 8-element vector summing all of them is 4,608 threads on 18 CUs and 32 dependent batches of loads (41 us).  Here a block
+// = 32 vectors x 8 slab groups: every thread sums splits / 8 slabs, the eight group sums of a vector meet in LDS and are
+// added in group order (fixed order: reproducible); 144 blocks, 4 batches per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const dvt_splitk_pending q) {
+  __shared__ float red[8][32][9];
+  const int vl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t nvec = q.M * q.N / 8, MN = q.M * q.N;
+  const int64_t i = (int64_t)blockIdx.x * 32 + vl;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < nvec) {
+    const int per = (q.splits + 7) / 8;
+    const int z1 = min(q.splits, (grp + 1) * per);
+    int z = grp * per;
+    constexpr int ZB = 8;
+    for (; z + ZB <= z1; z += ZB) {
+      float v[ZB][8];
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) load8<float>(q.slab + (int64_t)(z + u) * MN + i * 8, v[u]);
+#pragma unroll
+      for (int u = 0; u < ZB; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[u][k];
+    }
+    for (; z < z1; ++z) {
+      float v[8];
+      load8<float>(q.slab + (int64_t)z * MN + i * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[grp][vl][k] = acc[k];
+  __syncthreads();
+  if (grp != 0 || i >= nvec) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float t = red[0][vl][k];
+#pragma unroll
+    for (int gidx = 1; gidx < 8; ++gidx) t += red[gidx][vl][k];
+    acc[k] = t;
+  }
+  const int64_t e = i * 8, m = e / q.N, n = e % q.N;
+  if (q.conv_taps > 0) {                                   // (m = tap * Cin + ci, n = co) -> the parameter's C[co][ci][tap]
+    const int64_t tap = m / q.conv_cin, ci = m - tap * q.conv_cin;
+    const int64_t cin_l = q.conv_cin_l > 0 ? q.conv_cin_l : q.conv_cin, cout_l = q.conv_cout_l > 0 ? q.conv_cout_l : q.N;
+    if (ci >= cin_l) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (n + k < cout_l) {
+        float* o = q.C + ((n + k) * cin_l + ci) * q.conv_taps + tap;
+        *o = q.accumulate ? *o + acc[k] : acc[k];
+      }
+    return;
+  }
+  float* o = q.C + m * q.ldc + n;
+  if (q.accumulate) {
+    float old[8];
+    load8<float>(o, old);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += old[k];
+  }
+  store8<float>(o, acc);
+}
+
 static int launch_pending_reduce(const dvt_splitk_pending* q, hipStream_t st) {
   if (!q || !q->valid) return DVT_OK;
+  if (q->splits >= 64 && !q->cs_slab && q->M * q->N <= ((int64_t)1 << 20)) {
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)dvt_cdiv(q->M * q->N / 8, 32)), dim3(256), 0, st, *q);
+    DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce, many slabs)");
+    return DVT_OK;
+  }
   const int64_t nvec = q->M * q->N / 8;
   int64_t blocks = dvt_cdiv(nvec, 256);
   const int64_t cap = (int64_t)dvt_num_cus() * 8;

@@ -1312,6 +1312,8 @@ def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: i
 # 21.24 ms).  A fused launch's epilogue grows by what the statistics pass cost -- +40-53 us per 256 x 128 launch against
 # 30-45 us of bn_colstats saved: the z rows arrive in the un-overlapped epilogue at half the speed of a streaming kernel.
 BN_BWD_FUSE = os.environ.get("DVT_BN_BWD_FUSE", "0") != "0"
+# weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
+HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
 _bn_front = {}
 _bn_hand = {}
 
@@ -1543,9 +1545,15 @@ class _ConvBnAct(torch.autograd.Function):
         direct_dw = ctx.wg_implicit and ctx.pair is None
         if direct_dw:
             dw_master = sw.buf.view(wshape) if sw is not None else torch.empty(wshape, dtype=torch.float32, device=dz.device)
-            _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
-                                                master=dw_master, accumulate=(not sw.fresh) if sw is not None else False,
-                                                logical=(Cout_l, Cin_l))
+            acc_w = (not sw.fresh) if sw is not None else False
+            if (HALO_WGRAD and HALO_CONV and Cin == 64 and Cout == 64 and not padded and (kh, kw) == (3, 3)
+                    and ops._pair(stride) == (1, 1) and ops._pair(pad) == (1, 1)
+                    and ops.conv3x3_c64_wgrad_supported(xc, dz, N, H, W)):
+                # layer 1 of ResNet-18: input patch and gradient tile staged once per R rows, the nine taps read from LDS
+                pend = ops.conv3x3_c64_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True)
+            else:
+                _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
+                                                    master=dw_master, accumulate=acc_w, logical=(Cout_l, Cin_l))
             unpack = dwp = None
         elif ctx.wg_implicit:
             dwt, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim,

@@ -1289,6 +1289,36 @@ def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool 
     return (y, partial, parts) if want_stats else y
 
 
+def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
+        return False
+    if not (x.is_contiguous() and dz.is_contiguous() and x.shape == (N * H * W, 64) and dz.shape == (N * H * W, 64)):
+        return False
+    return bool(L.load().dvt_conv3x3_c64_wgrad_supported(N, H, W, dt(x)))
+
+
+def conv3x3_c64_wgrad(x: Tensor, dz: Tensor, N: int, H: int, W: int, master: Tensor, *, accumulate: bool = False,
+                      defer_reduce: bool = False):
+    """Weight gradient of the 64 -> 64 3x3 / 1 / 1 convolution from LDS halo patches (dvt_conv3x3_c64_wgrad), summed into
+    ``master`` (the parameter's own gradient f32 [64, 64, 3, 3]; += when accumulate).  defer_reduce: -> pending, for
+    ``splitk_reduce_pending`` / a carrying launch (the workgroups' partials live in the deferred-reduce scratch slot)."""
+    _need_cuda(x, dz, master)
+    assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == 64 * 64 * 9
+    lib = L.load()
+    pend = L.SplitKPending()
+    nbytes = int(lib.dvt_conv3x3_c64_wgrad_workspace_bytes(N, H, W))
+    ws = _deferred_workspace(nbytes, x.device, pend) if defer_reduce else workspace(nbytes, x.device, slot="conv3_wgrad")
+    nb = (x.numel() + dz.numel()) * x.element_size() + master.numel() * 4
+    with _timed(("conv", "halo3x3_c64_wgrad", 576, 64, N * H * W, nb), 2.0 * N * H * W * 64 * 576):
+        L.check(lib.dvt_conv3x3_c64_wgrad(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, H, W,
+                                          int(accumulate), int(defer_reduce), C.byref(pend), dt(x), _stream()),
+                "dvt_conv3x3_c64_wgrad")
+    if defer_reduce:
+        pend._keep = (ws, master)
+        return pend
+    return None
+
+
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
                     want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None, bnb=None):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.

@@ -606,6 +606,16 @@ typedef struct dvt_conv_desc {
  * [2][64] f32 partial column sums for dvt_bn_stats_from_partials.  _supported: 16-bit dtype and W <= 56-ish (two patches
  * must fit beside the weights in 160 KiB); callers fall back to dvt_conv2d_implicit otherwise. */
 int dvt_conv3x3_c64_supported(int64_t N, int H, int W, int dtype);
+/* Weight gradient of the same layer from LDS-resident halo patches: a workgroup of the persistent grid stages the input
+ * patch and the gradient tile of R output rows once each (the implicit form gathers the input nine times), accumulates
+ * [co 64][tap * 64 + ci] over its tile sequence in registers and leaves ONE fp32 partial per workgroup in `workspace`
+ * (dvt_conv3x3_c64_wgrad_workspace_bytes); the split-K reduce of the family sums the partials into the parameter's own
+ * layout dw f32 [64][64][3][3] (+= when accumulate) -- right away, or (defer_reduce) described in *pending for a later
+ * dvt_splitk_reduce_pending / a carrying launch.  x, dz NHWC [N*H*W, 64]. */
+int dvt_conv3x3_c64_wgrad_supported(int64_t N, int H, int W, int dtype);
+size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W);
+int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int accumulate,
+                          int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */

@@ -731,6 +731,36 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dvt, device, dt
         assert torch.equal(b[1], a[1])                 # (the shortcut gradient: dy under the mask, no statistics involved)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (2, 13, 20), (1, 5, 56), (300, 8, 8), (70, 56, 56)])
+def test_conv3x3_c64_weight_gradient_from_lds_halo_patches(dvt, device, dtype, N, H, W):
+    """dvt_conv3x3_c64_wgrad (layer 1 of ResNet-18: 64 -> 64, 3 x 3 / 1 / 1): input patch and gradient tile staged once per
+    tile, taps read as shifted windows of the patch, one fp32 partial per workgroup of the persistent grid, summed into the
+    parameter layout by the split-K reduce -- against the implicit weight gradient (same products, other summation order)
+    and against torch's conv2d weight gradient in fp32 on the same rounded operands; ragged last tiles, maps narrower and
+    wider than a tile, more tiles than workgroups, accumulate, deferred reduce."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N * H * W, 64, generator=g).to(dtype).cuda()
+    dz = (torch.randn(N * H * W, 64, generator=g) / 8).to(dtype).cuda()
+    assert ops.conv3x3_c64_wgrad_supported(x, dz, N, H, W)
+    dw = torch.full((64, 64, 3, 3), float("nan"), device="cuda")
+    ops.conv3x3_c64_wgrad(x, dz, N, H, W, dw)
+    xr = x.float().view(N, H, W, 64).permute(0, 3, 1, 2)
+    zr = dz.float().view(N, H, W, 64).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xr, (64, 64, 3, 3), zr, stride=1, padding=1)
+    assert torch.isfinite(dw).all() and rel_l2(dw, ref) < 2e-5
+    imp = torch.empty(64, 64, 3, 3, device="cuda")
+    ops.conv2d_implicit_wgrad(x, dz, N, 64, H, W, 64, 3, 1, 1, master=imp)
+    assert rel_l2(dw, imp) < 2e-5
+    # accumulate into an existing gradient, through a deferred reduce resolved explicitly
+    old = torch.randn(64, 64, 3, 3, generator=g).cuda()
+    acc = old.clone()
+    pend = ops.conv3x3_c64_wgrad(x, dz, N, H, W, acc, accumulate=True, defer_reduce=True)
+    ops.splitk_reduce_pending(pend)
+    assert rel_l2(acc - old, ref) < 2e-5
+
+
 def test_resnet_gradients_equal_with_and_without_fused_batchnorm_backward_sums(dvt, device, monkeypatch):
     """functional.BN_BWD_FUSE (off by default: measured neutral): the hand-off of the BatchNorm-backward sums between the
     backward passes of neighbouring layers -- recomputed masks, mask bytes of block outputs, shortcut gradients joining in
