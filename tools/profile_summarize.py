@@ -60,7 +60,7 @@ def conv_family(name):
     if m:
         ak, conv = m.group(1) == "1", m.group(3) == "1"
     else:
-        m = re.search(r"E, (true|false), \d+, \d+, \d+, (true|false)>", name)
+        m = re.search(r"E, (true|false), \d+, \d+, \d+, (true|false)(?:, (?:true|false))?>", name)   # (+ the BNB flag of round 4)
         if not m:
             return None
         ak, conv = True, m.group(2) == "true"
