@@ -17,6 +17,10 @@
 //     each, waves 4..7 four (wave w and w + 4 share a SIMD: nine blocks, 36 MFMAs per 32 positions, on every SIMD), for
 //     all four co blocks; the next step's fragments (4 dz + 5 x transposing reads) are requested under the MFMAs of the
 //     current one (a 12-wave form without that prefetch -- 168 VGPRs -- ran at 13 k cycles per tile, 78-88 us per layer).
+//     Measured at 256 frames of 56^2 (tools/dev/cw_probe.py, kernel with parts switched off): 96 us in all; the DMA stream
+//     and barriers alone 46 us; the LDS reads + MFMAs alone 79 us, i.e. ~13.5 k cycles per tile for 288 MFMAs per SIMD
+//     (4.6 k): 136 transposing reads per 32 positions and CU cost ~12.5 cycles each.  ds_read_b64_tr_b16 moves 8 bytes
+//     per lane; one such read per MFMA is the floor of any kernel whose two operands are both channel-contiguous.
 //   * Persistent grid (one workgroup per CU); the accumulators live in registers over the workgroup's whole tile sequence;
 //     the next tile's two images stream into second buffers under the MFMAs of the current one.  At the end every
 //     workgroup leaves ONE fp32 partial [576][64] in a slab, and the family's split-K reduce (dvt_splitk_pending with

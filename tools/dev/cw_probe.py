@@ -1,0 +1,21 @@
+"""Dev: dvt_conv3x3_c64_wgrad at the pyramid shape (256 frames of 56^2), timed."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from dvt_amd import ops
+N, H, W = 256, 56, 56
+x = torch.randn(N * H * W, 64, device="cuda").to(torch.bfloat16)
+dz = torch.randn(N * H * W, 64, device="cuda").to(torch.bfloat16)
+dw = torch.empty(64, 64, 3, 3, device="cuda")
+for _ in range(3):
+    pend = ops.conv3x3_c64_wgrad(x, dz, N, H, W, dw, defer_reduce=True); pend.valid = 0
+ts = []
+for rep in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        pend = ops.conv3x3_c64_wgrad(x, dz, N, H, W, dw, defer_reduce=True); pend.valid = 0
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+ts.sort()
+print(f"DVT_CW_DBG={os.environ.get('DVT_CW_DBG', '0')}: {ts[2]:.1f} us per launch")
