@@ -1,4 +1,6 @@
-"""Dev: dvt_conv3x3_c64_wgrad at the pyramid shape (256 frames of 56^2), timed."""
+"""Dev: dvt_conv3x3_c64_wgrad at the pyramid shape (256 frames of 56^2), timed.  The split quoted in conv3x3_wgrad.hip
+(DMA stream alone / LDS reads + MFMAs alone) came from a build with two debug switches in the kernel (DVT_CW_DBG = 1: no
+fragment reads / MFMAs, 2: no tile DMA after the first), not kept in the product source."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
