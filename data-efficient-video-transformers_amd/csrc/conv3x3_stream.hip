@@ -1,0 +1,484 @@
+// conv3x3_stream.hip -- 3x3 / stride 1 / pad 1 convolutions of the R(2+1)D-18 layer-1 spatial pair (video_resnet.py:
+// Conv2Plus1D, 64 -> 144 mid planes forward, 144 -> 64 as the data gradient) from LDS halo patches with STREAMED weights.
+//
+// conv3x3.hip keeps the 64 x 576 weights resident; at 144 channels on either side they are 162 KiB and cannot be.  The
+// implicit GEMM (gemm256.hip) then pays 9 gathers of the input per output pixel plus, at 144 output channels, a 256-wide
+// tile column that is 44 % padding (358 us forward, 535 us data gradient at 336 frames of 56^2: both bound by the L2 -> LDS
+// operand supply).  Here a workgroup owns R whole output rows of one frame (R * W <= 224 pixels = 7 compute waves of 32),
+// the input patch is staged once per tile (per 48-channel chunk at 144 input channels), and the weights stream through a
+// ring of three 18 KiB stages (one tap x 144 x 64, or one tap row x 64 x 48) that every tile re-reads from L2:
+// 0.94 KiB (forward) / 1.2 KiB (data gradient) of L2 -> LDS traffic per output pixel instead of 2.3 / 3.2.
+//
+//   * wave 7 is the PRODUCER: it issues every LDS-DMA of the workgroup (weight stage g + 3 and a group of pieces of the next
+//     patch chunk after barrier g + 1) and is the only wave that counts vmcnt, with compile-time batch sizes; the compute
+//     waves never wait on memory, only on the one s_barrier per stage the producer joins once the stage's bytes have landed;
+//   * a compute wave owns 32 pixels x all output channels: acc[u][t] = W-fragment(u) x X-fragment(t) (C^T convention of
+//     gemm256.hip); the barrier that opens stage g + 1 sits before the LAST step's MFMAs of stage g, after that wave's
+//     last LDS read of stage g has returned, so the first fragments of g + 1 are fetched under those MFMAs;
+//   * LDS images are lane-linear for the DMA; the bank swizzle lives on the global source address and on the fragment read:
+//     128-byte pixels / weight rows XOR the 16-byte slot with (column or row & 7) as conv3x3.hip does; 96-byte ones
+//     (48-channel chunks: 6 slots, consecutive rows 6 slots apart repeat mod 16 after 8 rows) flip slot bit 0 by slot bit 4,
+//     which separates rows r and r + 8; patch rows are padded to a multiple of 32 slots so that a tap row keeps that bit;
+//   * the 48-channel chunk is one 16x16x32 and one 16x16x16 MFMA step;
+//   * epilogue: 16 pixels at a time through LDS, whole pixel rows stored; 144-wide outputs carry the column sums / sums of
+//     squares of the stored values for the BatchNorm that follows (one partial row per compute wave and workgroup), 64-wide
+//     outputs the optional second gradient path (residual) of the data gradient.
+#include "common.h"
+
+namespace {
+
+template <int CI_, int CO_> struct SC;
+// PPG pieces (1 KiB) per patch group, NG groups per chunk; the groups of the NEXT chunk ride the batches at chunk-relative
+// stage positions GPOS .. SPC - 1 and the last group the batch of the chunk's own first stage.
+template <> struct SC<64, 144> { enum { CK = 64, NCH = 1, TPS = 1, PPG = 7, GPOS = 3, NG = 7, STG_DEDICATED = 0 }; };
+template <> struct SC<144, 64> { enum { CK = 48, NCH = 3, TPS = 3, PPG = 17, GPOS = 2, NG = 2, STG_DEDICATED = 1 }; };
+
+constexpr int kWStage = 18 * 1024;           // one weight stage: TPS taps x CO rows x CK channels
+constexpr int kNC = 7;                       // compute waves
+
+struct StreamParams {
+  const void* x;         // [N, H, W, CI]
+  const void* w;         // [CO][9 * CI] k-major, k = tap * CI + c
+  void* y;               // [N, H, W, CO]
+  float* bn_partial;     // [grid * 7][2][CO] or nullptr
+  const void* residual;  // [N, H, W, CO] added to the output rows, or nullptr
+  int N, H, W, R, tiles_per_img, ntiles;
+  int PW, SPR;           // patch columns, 16-byte slots per patch row
+  unsigned magic;        // ceil(2^32 / PW) (128-byte pixels) or ceil(2^32 / SPR) (96-byte pixels)
+};
+
+__device__ __attribute__((aligned(16))) unsigned int conv3s_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <typename E> struct Mma16;
+template <> struct Mma16<bf16> {
+  static __device__ __forceinline__ f32x4 mma(bf16x4 a, bf16x4 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<f16> {
+  static __device__ __forceinline__ f32x4 mma(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <typename E, int CI, int CO>
+__global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams p) {
+  typedef SC<CI, CO> C;
+  using V8 = typename Elem16<E>::v8;
+  using V4 = typename Elem16<E>::v4;
+  constexpr int CK = C::CK, NCH = C::NCH, TPS = C::TPS, SPC = 9 / TPS, PPG = C::PPG, GPOS = C::GPOS, NG = C::NG;
+  constexpr int SPP = CK / 8;                  // 16-byte slots per pixel / weight row
+  constexpr int NB = CO / 16;                  // output-channel blocks
+  constexpr int kPatch = NG * PPG * 1024;      // one patch (chunk) buffer
+  constexpr int NSTEP = CK == 64 ? 2 : 6;      // fragment steps per stage
+  constexpr int kStgWave = 16 * CO * 2;        // epilogue staging per wave: 16 pixels
+  static_assert(NCH * SPC == 9 && TPS * CO * CK * 2 == kWStage && (NSTEP & 1) == 0, "stage geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wring = smem;
+  char* const pbuf = smem + 3 * kWStage;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int grid = gridDim.x;
+
+  if (wid == kNC) {
+    // ================================================================ producer
+    // Per-lane constants of every DMA slot this wave ever fills (the LDS images do not depend on the tile):
+    //   woff[i]  element offset of weight piece i's 16 bytes inside (row-major w, tap 0 / chunk 0)
+    //   poff[q]  patch piece q: bits 0..19 element offset from the tile's first pixel, biased by (W + 1) * CI;
+    //            bits 20..27 patch row; bit 31 = never loaded (padding slot, or a column outside the frame)
+    const E* xg = (const E*)p.x;
+    const E* wg = (const E*)p.w;
+    int woff[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const int sl = i * 64 + lane;
+      if constexpr (CK == 64) {
+        const int row = sl >> 3, cs = (sl & 7) ^ (row & 7);
+        woff[i] = row * (9 * CI) + cs * 8;
+      } else {
+        const int s = sl ^ ((sl >> 4) & 1);
+        const int ra = s / 6, cs = s - ra * 6, kj = ra >> 6, co = ra & 63;
+        woff[i] = co * (9 * CI) + kj * CI + cs * 8;
+      }
+    }
+    unsigned poff[NG * PPG];
+#pragma unroll
+    for (int q = 0; q < NG * PPG; ++q) {
+      const int sl = q * 64 + lane;
+      int pr, pc, cs;
+      bool v;
+      if constexpr (CK == 64) {
+        const int pixel = sl >> 3;
+        pr = (int)__umulhi((unsigned)pixel, p.magic);
+        pc = pixel - pr * p.PW;
+        cs = (sl & 7) ^ (pc & 7);
+        v = pr < p.R + 2;
+      } else {
+        const int s = sl ^ ((sl >> 4) & 1);
+        pr = (int)__umulhi((unsigned)s, p.magic);
+        const int within = s - pr * p.SPR;
+        pc = within / 6;
+        cs = within - pc * 6;
+        v = pr < p.R + 2 && pc < p.PW;
+      }
+      v = v && (unsigned)(pc - 1) < (unsigned)p.W;
+      poff[q] = v ? (unsigned)((pr * p.W + pc) * CI + cs * 8) | ((unsigned)pr << 20) : 0x80000000u;
+    }
+    auto issue_weights = [&](int sg) {             // stage position sg of a tile
+      char* dst = wring + (sg % 3) * kWStage;
+      const E* base = CK == 64 ? wg + sg * CI : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        int o = woff[i];
+        asm volatile("" : "+v"(o));                 // (keeps the 64-bit sums out of loop-invariant registers: 18 x 9 pairs)
+        dvt_dma16(base + o, dst + i * 1024);
+      }
+    };
+    auto issue_group = [&](int tile, int cc, int grp, char* dst) {   // grp: compile-time at every call site
+      const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
+      // element (h0 - 1, -1, chunk cc) of the frame: poff's bias
+      const E* base = xg + ((int64_t)(n * p.H + h0 - 1) * p.W - 1) * CI + cc * CK;
+#pragma unroll
+      for (int i = 0; i < PPG; ++i) {
+        unsigned pk = poff[grp * PPG + i];
+        asm volatile("" : "+v"(pk));                // (same: the unpacked fields stay temporaries)
+        const int h = h0 - 1 + (int)((pk >> 20) & 0xFF);
+        const bool ok = (int)pk >= 0 && (unsigned)h < (unsigned)p.H;
+        const E* src = ok ? base + (pk & 0xFFFFF) : reinterpret_cast<const E*>(conv3s_zero16);
+        dvt_dma16(src, dst + (grp * PPG + i) * 1024);
+      }
+    };
+    // the batch of the stage at chunk cc (runtime), chunk-relative position pos (compile-time) of tile ta (tb: the tile after)
+    auto issue_batch = [&](int ita, int ta, int tb, int cc, int pos) {
+      issue_weights(cc * SPC + pos);
+      if (pos == 0) {
+        issue_group(ta, cc, NG - 1, pbuf + ((ita * NCH + cc) & 1) * kPatch);
+      } else if (pos >= GPOS) {
+        const bool same = cc + 1 < NCH;
+        issue_group(same ? ta : tb, same ? cc + 1 : 0, pos - GPOS, pbuf + ((ita * NCH + cc + 1) & 1) * kPatch);
+      }
+    };
+    auto batch_size = [](int pos) { return 18 + ((pos == 0 || pos >= GPOS) ? PPG : 0); };
+
+    int tile = blockIdx.x;
+    int t1 = tile + grid < p.ntiles ? tile + grid : tile;
+#pragma unroll
+    for (int gr = 0; gr < NG - 1; ++gr) issue_group(tile, 0, gr, pbuf);
+    issue_batch(0, tile, t1, 0, 0);
+    issue_batch(0, tile, t1, 1 / SPC, 1 % SPC);
+    issue_batch(0, tile, t1, 2 / SPC, 2 % SPC);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // B_0
+    for (int it = 0; tile < p.ntiles; ++it, tile += grid) {
+      t1 = tile + grid < p.ntiles ? tile + grid : tile;
+      const int t2 = t1 + grid < p.ntiles ? t1 + grid : t1;
+#pragma unroll 1
+      for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+        for (int pos = 0; pos < SPC; ++pos) {
+          wait_vm(batch_size((pos + 2) % SPC));                     // batch g + 1 has landed, g + 2 may be in flight
+          __builtin_amdgcn_s_barrier();                             // B_{g+1}: stage g + 1 open, stage g's buffers free
+          // batch g + 3: chunk cc + (pos + 3) / SPC, position (pos + 3) % SPC -- of the next tile past this one's chunks
+          int c3 = cc + (pos + 3) / SPC;
+          if (c3 < NCH) issue_batch(it, tile, t1, c3, (pos + 3) % SPC);
+          else issue_batch(it + 1, t1, t2, c3 - NCH, (pos + 3) % SPC);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ================================================================== compute waves
+  const int PW = p.PW, npix = p.R * p.W;
+  const int prow = p.SPR * 16;
+  int xo[2][3][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int m = wid * 32 + t * 16 + li;
+    m = m < npix ? m : 0;                          // padding rows of the MFMA tile: computed on pixel 0, never stored
+    const int r = m / p.W, c = m - r * p.W;
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj) {
+      if constexpr (CK == 64) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xo[t][kj][kk] = (r * PW + c + kj) * 128 + (((kk * 4 + g) ^ ((c + kj) & 7)) << 4);
+      } else {
+        int s = r * p.SPR + (c + kj) * 6 + g;
+        xo[t][kj][0] = (s ^ ((s >> 4) & 1)) << 4;
+        s = r * p.SPR + (c + kj) * 6 + 4 + (g >> 1);
+        xo[t][kj][1] = ((s ^ ((s >> 4) & 1)) << 4) + (g & 1) * 8;
+      }
+    }
+  }
+  int wo[2];
+  if constexpr (CK == 64) {
+    wo[0] = li * 128 + (((0 + g) ^ (li & 7)) << 4);
+    wo[1] = li * 128 + (((4 + g) ^ (li & 7)) << 4);
+  } else {
+    int s = li * 6 + g;
+    wo[0] = (s ^ ((s >> 4) & 1)) << 4;
+    s = li * 6 + 4 + (g >> 1);
+    wo[1] = ((s ^ ((s >> 4) & 1)) << 4) + (g & 1) * 8;
+  }
+
+  V8 wf8[CK == 64 ? 2 : 1][NB], xf8[CK == 64 ? 2 : 1][2];
+  V4 wf4[NB], xf4[2];
+  (void)wf4; (void)xf4;
+  // fragments of step j of stage (patch buffer pb, position sg)
+  auto rd = [&](const char* pb, int sg, int j) {
+    const char* wb = wring + (sg % 3) * kWStage;
+    if constexpr (CK == 64) {
+      const int ki = sg / 3, kj = sg % 3;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) wf8[j][u] = *reinterpret_cast<const V8*>(wb + wo[j] + u * 2048);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) xf8[j][t] = *reinterpret_cast<const V8*>(pb + ki * prow + xo[t][kj][j]);
+    } else {
+      const int ki = sg % 3, kj = j >> 1;
+      if ((j & 1) == 0) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) wf8[0][u] = *reinterpret_cast<const V8*>(wb + wo[0] + (kj * 64 + 16 * u) * 96);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xf8[0][t] = *reinterpret_cast<const V8*>(pb + ki * prow + xo[t][kj][0]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) wf4[u] = *reinterpret_cast<const V4*>(wb + wo[1] + (kj * 64 + 16 * u) * 96);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xf4[t] = *reinterpret_cast<const V4*>(pb + ki * prow + xo[t][kj][1]);
+      }
+    }
+  };
+  auto patch_of = [&](int it, int sg) -> const char* { return pbuf + ((it * NCH + sg / SPC) & 1) * kPatch; };
+
+  float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)bs; (void)bq;
+  int tile = blockIdx.x;
+  __builtin_amdgcn_s_barrier();                                     // B_0
+  rd(patch_of(0, 0), 0, 0);
+  for (int it = 0; tile < p.ntiles; ++it, tile += grid) {
+    f32x4 acc[NB][2];
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sg = 0; sg < 9; ++sg) {
+      const char* pb = patch_of(it, sg);
+#pragma unroll
+      for (int j = 0; j < NSTEP; ++j) {
+        if (j + 1 < NSTEP) {
+          rd(pb, sg, j + 1);
+        } else {
+          // this wave's last read of stage g has returned: open stage g + 1 and fetch its first fragments under the MFMAs
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                             // B_{g+1}
+          if (sg + 1 < 9) rd(patch_of(it, sg + 1), sg + 1, 0);
+          else rd(patch_of(it + 1, 0), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CK == 64) {
+#pragma unroll
+          for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[u][t] = Elem16<E>::mma(wf8[j][u], xf8[j][t], acc[u][t]);
+        } else if ((j & 1) == 0) {
+#pragma unroll
+          for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[u][t] = Elem16<E>::mma(wf8[0][u], xf8[0][t], acc[u][t]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[u][t] = Mma16<E>::mma(wf4[u], xf4[t], acc[u][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue.  Staging: the dedicated region, or the patch buffer this tile consumed (every wave is past B of the next
+    // tile's first stage, i.e. past its last read of it; the producer refills it only after the barrier inside that stage).
+    const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
+    const int rows_ok = min(p.R, p.H - h0);
+    const int valid = rows_ok * p.W;
+    E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * CO;
+    char* stg = (C::STG_DEDICATED ? pbuf + 2 * kPatch : pbuf + ((it * NCH + NCH - 1) & 1) * kPatch) + wid * kStgWave;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int m0 = wid * 32 + t * 16;
+      if constexpr (CO == 64) {
+        const E* rt = p.residual ? (const E*)p.residual + ((int64_t)(n * p.H + h0) * p.W) * CO : nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          V4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (E)acc[u][t][r];
+          *reinterpret_cast<V4*>(stg + li * 128 + (((u * 2 + (g >> 1)) ^ ((li >> 1) & 7)) << 4) + (g & 1) * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int r = ps * 8 + (lane >> 3), c = lane & 7;
+          V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+          if (m0 + r < valid) {
+            if (rt) {
+              const V8 rv = *reinterpret_cast<const V8*>(rt + (int64_t)(m0 + r) * CO + c * 8);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] = (E)((float)v[k] + (float)rv[k]);
+            }
+            *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * CO + c * 8) = v;
+          }
+        }
+      } else {
+        constexpr int CH = CO / 8;                 // 16-byte chunks per pixel row (18)
+        constexpr int PPP = 64 / CH;               // pixels per pass (3)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          V4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (E)acc[u][t][r];
+          *reinterpret_cast<V4*>(stg + li * (CO * 2) + u * 32 + g * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int r3 = lane / CH, c18 = lane - r3 * CH;
+#pragma unroll
+        for (int ps = 0; ps < (16 + PPP - 1) / PPP; ++ps) {
+          const int px = ps * PPP + r3;
+          if (r3 < PPP && px < 16 && m0 + px < valid) {
+            const V8 v = *reinterpret_cast<const V8*>(stg + px * (CO * 2) + c18 * 16);
+            *reinterpret_cast<V8*>(yt + (int64_t)(m0 + px) * CO + c18 * 8) = v;
+            if (p.bn_partial) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float f = (float)v[k];
+                bs[k] += f;
+                bq[k] = fmaf(f, f, bq[k]);
+              }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if constexpr (CO != 64) {
+    if (p.bn_partial) {
+      constexpr int CH = CO / 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bs[k] += __shfl(bs[k], lane + CH, 64) + __shfl(bs[k], lane + 2 * CH, 64);
+        bq[k] += __shfl(bq[k], lane + CH, 64) + __shfl(bq[k], lane + 2 * CH, 64);
+      }
+      if (lane < CH) {
+        float* pr = p.bn_partial + ((int64_t)blockIdx.x * kNC + wid) * 2 * CO + lane * 8;
+        *reinterpret_cast<f32x4*>(pr) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+        *reinterpret_cast<f32x4*>(pr + 4) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+        *reinterpret_cast<f32x4*>(pr + CO) = f32x4{bq[0], bq[1], bq[2], bq[3]};
+        *reinterpret_cast<f32x4*>(pr + CO + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
+      }
+    }
+  }
+}
+
+struct Plan { int R, PW, SPR, lds; unsigned magic; };
+
+template <int CI, int CO>
+int plan_for(int H, int W, Plan* o) {
+  typedef SC<CI, CO> C;
+  if (W <= 0 || H <= 0 || W > 224) return 0;
+  int r = 224 / W;
+  if (r > H) r = H;
+  if (r < 1) return 0;
+  const int PW = W + 2;
+  const int spp = C::CK / 8;
+  const int spr = spp == 8 ? PW * 8 : ((PW * spp + 31) & ~31);
+  const int slots = (r + 2) * spr;
+  if ((slots + 63) / 64 > C::NG * C::PPG) return 0;
+  const int kPatch = C::NG * C::PPG * 1024;
+  const int stg = kNC * 16 * CO * 2;
+  if (!C::STG_DEDICATED && stg > kPatch) return 0;
+  o->R = r; o->PW = PW; o->SPR = spr;
+  o->lds = 3 * kWStage + 2 * kPatch + (C::STG_DEDICATED ? stg : 0);
+  const unsigned d = spp == 8 ? (unsigned)PW : (unsigned)spr;
+  o->magic = (unsigned)(((1ull << 32) + d - 1) / d);
+  return o->lds <= 160 * 1024;
+}
+
+int plan_any(int Cin, int Cout, int H, int W, Plan* o) {
+  if (Cin == 64 && Cout == 144) return plan_for<64, 144>(H, W, o);
+  if (Cin == 144 && Cout == 64) return plan_for<144, 64>(H, W, o);
+  return 0;
+}
+
+template <typename E, int CI, int CO>
+void launch(const StreamParams& p, int lds, int grid, hipStream_t st) {
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<E, CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO>), dim3(grid), dim3(512), lds, st, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_conv3x3_stream_supported(int64_t N, int H, int W, int Cin, int Cout, int dtype) {
+  Plan pl;
+  return N > 0 && dvt_is_16bit(dtype) && plan_any(Cin, Cout, H, W, &pl) && N * H * W < ((int64_t)1 << 30) ? 1 : 0;
+}
+
+int64_t dvt_conv3x3_stream_stats_parts(int64_t N, int H, int W, int Cin, int Cout) {
+  Plan pl;
+  if (!plan_any(Cin, Cout, H, W, &pl)) return 0;
+  const int64_t ntiles = N * dvt_cdiv(H, pl.R);
+  return (ntiles < dvt_num_cus() ? ntiles : dvt_num_cus()) * kNC;    // one partial row per compute wave of the persistent grid
+}
+
+int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
+                       int Cin, int Cout, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && w && y && N >= 0 && H > 0 && W > 0, "dvt_conv3x3_stream: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y) && dvt_aligned16(stats_partial) && dvt_aligned16(residual),
+              "dvt_conv3x3_stream: buffers must be 16-byte aligned");
+  if (N == 0) return DVT_OK;
+  if (!dvt_conv3x3_stream_supported(N, H, W, Cin, Cout, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x3_stream: needs a 16-bit dtype, (Cin, Cout) = (64, 144) or (144, 64) and a patch of 224 / W rows within its LDS buffer");
+  DVT_REQUIRE(!(stats_partial && Cout == 64) && !(residual && Cout != 64),
+              "dvt_conv3x3_stream: statistics come with the 144-wide output, the residual with the 64-wide one");
+  Plan pl;
+  plan_any(Cin, Cout, H, W, &pl);
+  StreamParams p;
+  p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.residual = residual;
+  p.N = (int)N; p.H = H; p.W = W; p.R = pl.R; p.PW = pl.PW; p.SPR = pl.SPR; p.magic = pl.magic;
+  p.tiles_per_img = (int)dvt_cdiv(H, pl.R);
+  p.ntiles = (int)(N * p.tiles_per_img);
+  const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) {
+    if (dtype == DVT_BF16) launch<bf16, 64, 144>(p, pl.lds, grid, st);
+    else launch<f16, 64, 144>(p, pl.lds, grid, st);
+  } else {
+    if (dtype == DVT_BF16) launch<bf16, 144, 64>(p, pl.lds, grid, st);
+    else launch<f16, 144, 64>(p, pl.lds, grid, st);
+  }
+  DVT_LAUNCH_CHECK("dvt_conv3x3_stream");
+  return DVT_OK;
+}
+
+}  // extern "C"

@@ -1034,7 +1034,12 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c) {
   const int64_t cus = dvt_num_cus();
   if (cout > 64 && c % 64 == 0) {
     const int64_t t128 = dvt_cdiv(rows, 256) * dvt_cdiv(cout, 128);
-    if (t128 * 4 < cus * 3) return 9;
+    if (t128 * 4 < cus * 3) {
+      // at most one 128x128 workgroup per CU: nothing shares the CU, so the deeper ring (three k-tiles in flight instead of
+      // one) costs no occupancy and covers the operand latency a single in-flight k-tile leaves exposed (R(2+1)D layer 4:
+      // 72 k-tiles of 0.2 us MFMA work each took 3 us)
+      return dvt_cdiv(rows, 128) * dvt_cdiv(cout, 128) <= cus ? 10 : 9;
+    }
     if (cfg == 0 && t128 > cus && t128 <= 2 * cus && c % 32 == 0) return 1;
   }
   if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < cus * 3) return c % 64 == 0 ? 7 : 1;
@@ -1055,7 +1060,9 @@ static bool conv_implicit_ok(const dvt_conv_desc* d) {
   const int tk = d->Cout <= 128 ? 32 : 64;
   // C % k-tile == 0 (a k-tile inside one filter tap), or C == 8: the stem, its 3 channels zero-extended to one 16-byte
   // chunk per (pixel, tap) by dvt_nchw_to_nhwc_pad
-  if ((d->C % tk && d->C != 8) || d->Cout % 8) return false;
+  // (or any C % 8 == 0: the k-tile then straddles taps and every lane derives its own, ConvRows::dma)
+  if (d->C % 8 || d->Cout % 8) return false;
+  (void)tk;
   // the C == 8 gather derives a lane's tap by a 16-bit multiply-shift division (ConvRows::dma): exact for these bounds only
   if (d->C == 8 && !((int64_t)d->kh * d->kw < 1024 && d->kw < 64)) return false;
   int64_t Ho, Wo;
@@ -1079,7 +1086,7 @@ int64_t dvt_conv2d_implicit_k(const dvt_conv_desc* d) {
 int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(d, "dvt_conv2d_implicit: null descriptor");
   if (!conv_implicit_ok(d))
-    DVT_UNSUPPORTED("dvt_conv2d_implicit: needs a 16-bit dtype, C %% 64 == 0 (C %% 32 for Cout <= 128), Cout %% 8 == 0 and "
+    DVT_UNSUPPORTED("dvt_conv2d_implicit: needs a 16-bit dtype, C %% 8 == 0, Cout %% 8 == 0 and "
                     "16-byte aligned buffers");
   int64_t Ho64, Wo64;
   conv_out_hw(d, &Ho64, &Wo64);
@@ -1093,6 +1100,8 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   p.alpha = 1.0f; p.elem = d->dtype; p.k_per_split = p.K; p.slab = nullptr; p.tiles_n = 0; p.colsum_slab = nullptr;
   p.cH = d->H; p.cW = d->W; p.cC = d->C; p.cHo = Ho; p.cWo = Wo; p.ckh = d->kh; p.ckw = d->kw;
   p.csh = d->sh; p.csw = d->sw; p.cph = d->ph; p.cpw = d->pw;
+  p.cmc = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(d->C / 8) - 1) / (uint64_t)(d->C / 8));   // (C == 8: unused)
+  p.cmk = d->kw == 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + (uint64_t)d->kw - 1) / (uint64_t)d->kw);
   DVT_REQUIRE(!(d->residual && d->stats_partial), "dvt_conv2d_implicit: residual and stats_partial are exclusive");
   DVT_REQUIRE(dvt_aligned16(d->residual), "dvt_conv2d_implicit: residual must be 16-byte aligned");
   p.bn_partial = d->stats_partial;
@@ -1125,7 +1134,7 @@ int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
   const int cfg = conv_fwd_cfg(d->N * Ho * Wo, d->Cout, d->C);
-  if (cfg == 9) return dvt_cdiv(d->N * Ho * Wo, 128) * 2;                             // 128-row tiles of two wave rows
+  if (cfg == 9 || cfg == 10) return dvt_cdiv(d->N * Ho * Wo, 128) * 2;                             // 128-row tiles of two wave rows
   return dvt_cdiv(d->N * Ho * Wo, 256) * (cfg == 4 || cfg == 6 || cfg == 7 ? 4 : 2);   // wave rows per 256-row tile
 }
 

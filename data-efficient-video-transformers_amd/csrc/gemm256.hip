@@ -59,6 +59,7 @@ template <> struct Cfg<6> { enum { TM = 256, TN = 64, TK = 64, NW = 4, WN = 1, N
 template <> struct Cfg<7> { enum { TM = 256, TN = 128, TK = 64, NW = 8, WN = 2, NSTG = 2, PP = 0 }; };   // CFG 1's tile with 64-deep k-tiles: 8 waves of 64 x 64, 96 KiB
 template <> struct Cfg<8> { enum { TM = 224, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 5 with 7 sub-tiles per wave row
 template <> struct Cfg<9> { enum { TM = 128, TN = 128, TK = 64, NW = 4, WN = 2, NSTG = 2, PP = 0 }; };   // 4 waves of 64 x 64, 64 KiB: 2 workgroups / CU; convolutions with few output rows
+template <> struct Cfg<10> { enum { TM = 128, TN = 128, TK = 64, NW = 4, WN = 2, NSTG = 4, PP = 0 }; };  // CFG 9 with three k-tiles in flight, 128 KiB: grids of at most one workgroup per CU (deep K, operand latency exposed)
 template <> struct Cfg<5> { enum { TM = 256, TN = 256, TK = 64, NW = 8, WN = 4, NSTG = 2, PP = 1 }; };   // CFG 0 with the two wave rows in antiphase
 
 constexpr int kEpiStride = 64 + 4;               // floats per staged row
@@ -147,6 +148,24 @@ struct ConvRows {
         const int hi = h0[i] + ki, wi = w0[i] + kj;
         const bool ok = tap < ntap && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
         const bf16* src = ok ? p.A + (int64_t)(pix[i] + hi * p.cW + wi) * 8 : reinterpret_cast<const bf16*>(dvt_zero16);
+        dvt_dma16(src, tile + (wid * PPW + i) * 1024);
+      }
+      return;
+    }
+    if (p.cC % TK) {
+      // C % 8 == 0 only (R(2+1)D-18's 144 mid planes, video_resnet.py:69): a k-tile may straddle filter taps, so every lane
+      // derives the tap of its own 16-byte chunk (chunk index / chunks per tap, by multiplication); k >= kh*kw*C (K is
+      // rounded up to the k-tile) reads the zero page
+      const unsigned cpc = (unsigned)p.cC >> 3, ntap = (unsigned)(p.ckh * p.ckw);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const unsigned kq = (unsigned)(k0 + coff[i]) >> 3;
+        const unsigned tap = __umulhi(kq, p.cmc);
+        const int c = (int)(kq - tap * cpc) * 8;
+        const unsigned ki = p.ckw == 1 ? tap : __umulhi(tap, p.cmk);
+        const int hi = h0[i] + (int)ki, wi = w0[i] + (int)(tap - ki * p.ckw);
+        const bool ok = tap < ntap && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+        const bf16* src = ok ? p.A + ((int64_t)(pix[i] + hi * p.cW + wi) * p.cC + c) : reinterpret_cast<const bf16*>(dvt_zero16);
         dvt_dma16(src, tile + (wid * PPW + i) * 1024);
       }
       return;
@@ -257,6 +276,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -438,7 +459,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
     {
       const int issued = min(nko - 1, kt + NSTG - 2);                 // youngest k-tile in flight
       const int young = issued - kt;                                 // k-tiles that may stay in flight
-      if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
+      if (NSTG >= 4 && young >= 2) wait_vm<2 * kPPT>();
+      else if (NSTG >= 3 && young >= 1) wait_vm<kPPT>();
       else wait_vm<0>();
     }
     // (2) one barrier: everybody's pieces of kt landed AND everybody finished reading the
@@ -821,6 +843,7 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
 // configuration 6 (256x64x64 convolution tiles), kept out of the main module like configuration 5
 int dvt_conv_dma_launch_c6(const GemmParams& p, int cfg, hipStream_t st) {
   if (cfg == 9) return p.elem == DVT_F16 ? launch_conv<f16, 9>(p, st) : launch_conv<bf16, 9>(p, st);
+  if (cfg == 10) return p.elem == DVT_F16 ? launch_conv<f16, 10>(p, st) : launch_conv<bf16, 10>(p, st);
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv<f16, 7>(p, st) : launch_conv<bf16, 7>(p, st);
   return p.elem == DVT_F16 ? launch_conv<f16, 6>(p, st) : launch_conv<bf16, 6>(p, st);
 }
@@ -863,7 +886,7 @@ int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream
 // Implicit-GEMM convolution forward / data gradient: C[M = N*Ho*Wo, Cout] = gather(x) * Wp^T with the gather
 // fused into the A-operand DMA.  cfg 0 = 256x256x64 (Cout > 128), cfg 1 = 256x128x32, cfg 4 = 256x64x32 (Cout <= 64).
 int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st) {
-  if (cfg == 6 || cfg == 7 || cfg == 9) return dvt_conv_dma_launch_c6(p, cfg, st);
+  if (cfg == 6 || cfg == 7 || cfg == 9 || cfg == 10) return dvt_conv_dma_launch_c6(p, cfg, st);
   if (p.elem == DVT_F16) return cfg == 0 ? launch_conv<f16, 0>(p, st) : cfg == 4 ? launch_conv<f16, 4>(p, st) : launch_conv<f16, 1>(p, st);
   return cfg == 0 ? launch_conv<bf16, 0>(p, st) : cfg == 4 ? launch_conv<bf16, 4>(p, st) : launch_conv<bf16, 1>(p, st);
 }

@@ -38,6 +38,7 @@ struct GemmParams {
   int pig_blocks;
   dvt_splitk_pending pig;
   // implicit-GEMM convolution (A operand gathered from an NHWC map instead of read from a column matrix)
+  unsigned cmc, cmk;   // ceil(2^32 / (cC / 8)), ceil(2^32 / ckw) (0 for ckw == 1): the per-lane tap of ConvRows' general form
   int cH, cW, cC, cHo, cWo, ckh, ckw, csh, csw, cph, cpw;   // != nullptr (mn-major A, slab output): partial sum_k A(m,k) per K slice, [splits][M]
 };
 

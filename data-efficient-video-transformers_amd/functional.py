@@ -1278,6 +1278,7 @@ IMPLICIT_CONV = True
 # BatchNorm batch statistics from the implicit convolution's GEMM epilogue (fp32 accumulators) instead of a separate pass
 # over the stored output
 FUSE_BN_STATS = True
+GENERAL_TAPS = os.environ.get("DVT_GENERAL_TAPS", "1") != "0"   # implicit kernels for any C % 8 == 0 (per-lane taps), K not padded to 64
 HALO_CONV = True          # 64 -> 64 channel 3x3 / 1 / 1 convolutions from an LDS-resident halo patch (dvt_conv3x3_c64)
 
 
@@ -1399,7 +1400,12 @@ class _ConvBnAct(torch.autograd.Function):
         if direct and IMPLICIT_CONV and dtype in (torch.bfloat16, torch.float16) and Cout % 8 == 0 and \
                 Cin % (32 if Cout <= 128 else 64) == 0 and (N * H * W) % 64 == 0:
             direct = False
-        ld = K if direct else (ops.conv2d_implicit_k(Cin, Cout, k) if stem8 else _kpad(K, dtype))
+        # C % 8 == 0 but not a whole number of k-tiles per filter tap (144 mid planes of R(2+1)D-18): the implicit kernels
+        # derive every lane's tap themselves and take K rounded up to THEIR k-tile (zero weight columns behind kh*kw*C)
+        # (and K itself, not K rounded up to 64, where the taps are whole k-tiles: 288 mid planes x 3 temporal taps = 864)
+        gen = (IMPLICIT_CONV and GENERAL_TAPS and not direct and not nchw and not stem8 and dtype in (torch.bfloat16, torch.float16)
+               and xc.dtype == dtype and xc.is_cuda and Cin % 8 == 0 and Cout % 8 == 0)
+        ld = K if direct else (ops.conv2d_implicit_k(Cin, Cout, k) if (stem8 or gen) else _kpad(K, dtype))
         if pair is not None:
             kh_o, kw_o, pw_o, _ = pair
             w4 = w.reshape(Cout_l, Cin_l, kh_o * kw_o)
@@ -1409,14 +1415,25 @@ class _ConvBnAct(torch.autograd.Function):
             wp = ops.conv_weight_pack(w4, ld, dtype)
         else:                                      # packed once per optimizer step for all layers (zero extension included)
             wp = _packed_weight(w, 0, Cout_l, Cin_l, kh, kw, Cout, Cin, ld, dtype)
-        implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8) and xc.dtype == dtype and
+        implicit = (IMPLICIT_CONV and not direct and not nchw and (ld == K or stem8 or gen) and xc.dtype == dtype and
                     ops.conv2d_implicit_supported(xc, wp, N, Cin, H, W, Cout, k, stride, pad, ctx.trim))
+        if gen and not implicit:                   # (misaligned operands: the explicit path and its 64-padded columns)
+            ld = _kpad(K, dtype)
+            wp = _packed_weight(w, 0, Cout_l, Cin_l, kh, kw, Cout, Cin, ld, dtype)
         if ctx.trim and not implicit:
             raise RuntimeError("the pixel-pair stem needs the implicit convolution kernels")
         stats_partial = None
         halo = (HALO_CONV and implicit and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and (sh, sw) == (1, 1)
                 and ops._pair(pad) == (1, 1) and ops.conv3x3_c64_supported(xc, wp, N, H, W))
-        if halo:                                  # layer 1 of ResNet-18: LDS-resident halo patch instead of nine gathers
+        stream = (HALO_CONV and implicit and not halo and ld == K and (kh, kw) == (3, 3) and (sh, sw) == (1, 1)
+                  and ops._pair(pad) == (1, 1) and ops.conv3x3_stream_supported(xc, wp, N, H, W, Cin, Cout))
+        if stream:                                # layer 1 of R(2+1)D-18, 64 -> 144: halo patch, weights streamed through LDS
+            col = None
+            if training and FUSE_BN_STATS:
+                z, stats_partial, stats_parts = ops.conv3x3_stream(xc, wp, N, H, W, Cin, Cout, want_stats=True)
+            else:
+                z = ops.conv3x3_stream(xc, wp, N, H, W, Cin, Cout)
+        elif halo:                                # layer 1 of ResNet-18: LDS-resident halo patch instead of nine gathers
             col = None
             if training and FUSE_BN_STATS:
                 z, stats_partial, stats_parts = ops.conv3x3_c64(xc, wp, N, H, W, want_stats=True)
@@ -1629,6 +1646,9 @@ class _ConvBnAct(torch.autograd.Function):
             if (HALO_CONV and Cin == 64 and Cout == 64 and (kh, kw) == (3, 3) and pd == (1, 1)
                     and ops.conv3x3_c64_supported(dz, wd, N, Ho, Wo)):
                 dx = ops.conv3x3_c64(dz, wd, N, Ho, Wo, residual=join_alias())
+            elif (HALO_CONV and (kh, kw) == (3, 3) and pd == (1, 1)
+                    and ops.conv3x3_stream_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
+                dx = ops.conv3x3_stream(dz, wd, N, Ho, Wo, Cout, Cin, residual=join_alias())
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 # this launch writes the COMPLETE gradient of the layer's input when the shortcut (if any) joins in its
                 # epilogue: then it can also leave the backward column sums of the BatchNorm that produced that input

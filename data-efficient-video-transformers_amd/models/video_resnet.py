@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F
+from .. import ops
 
 
 class Conv2Plus1D(nn.Sequential):
@@ -38,6 +39,24 @@ class Conv2Plus1D(nn.Sequential):
 CPAD = 64     # mid-plane counts 45 / 230 / 460 / 921 are zero-padded to multiples of 64 (MFMA / LDS-DMA tile widths)
 
 
+def _mid_cpad(conv, frames, H, W, dtype):
+    """Channel padding of a spatial convolution's mid planes.  Multiples of 32 (288, 576, 1152) are whole k-tiles per filter
+    tap for every consumer as they are; layer 1's 144 stay 144 where the streamed-weight halo kernels take the layer and its
+    data gradient (ops.conv3x3_stream: the temporal convolution behind reads 144-channel pixels through the implicit
+    kernels' per-lane taps) -- 192 would be a third more bytes and MFMA work on every mid-plane map; the rest is padded to
+    the 64-wide tiles."""
+    c = conv.out_channels
+    if dtype not in (torch.bfloat16, torch.float16):
+        return CPAD
+    if c % 32 == 0:
+        return 32
+    if (c == 144 and conv.in_channels == 64 and tuple(conv.kernel_size[1:]) == (3, 3) and tuple(conv.stride[1:]) == (1, 1)
+            and tuple(conv.padding[1:]) == (1, 1) and ops.conv3x3_stream_geometry(frames, H, W, 144, 64, dtype)
+            and ops.conv3x3_stream_geometry(frames, H, W, 64, 144, dtype)):
+        return 16
+    return CPAD
+
+
 def _spatial(fm, conv, bn, relu, dtype, fork=None):
     """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames.  fork="alias": the map has a second consumer
     (the block's shortcut); the layer hands it out as a second result so that the shortcut's gradient joins this layer's
@@ -45,7 +64,7 @@ def _spatial(fm, conv, bn, relu, dtype, fork=None):
     y, N, T, H, W = fm
     k, s, p = conv.kernel_size[1:], conv.stride[1:], conv.padding[1:]
     out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
-                            cpad=CPAD, fork=fork)
+                            cpad=_mid_cpad(conv, N * T, H, W, dtype), fork=fork)
     Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
     if fork is not None:
         return (out[0], N, T, Ho, Wo), out[1]

@@ -1289,6 +1289,44 @@ def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool 
     return (y, partial, parts) if want_stats else y
 
 
+def conv3x3_stream_supported(x: Tensor, wp: Tensor, N: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
+        return False
+    if (Cin, Cout) not in ((64, 144), (144, 64)):
+        return False
+    if not (x.is_contiguous() and wp.is_contiguous() and tuple(wp.shape) == (Cout, 9 * Cin) and x.shape == (N * H * W, Cin)):
+        return False
+    return bool(L.load().dvt_conv3x3_stream_supported(N, H, W, Cin, Cout, dt(x)))
+
+
+def conv3x3_stream_geometry(N: int, H: int, W: int, Cin: int, Cout: int, dtype: torch.dtype) -> bool:
+    """Whether dvt_conv3x3_stream takes this (frames, map, channel pair): what a model needs to know before it decides the
+    channel padding of the layer (no tensors yet)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(L.load().dvt_conv3x3_stream_supported(N, H, W, Cin, Cout, _DT[dtype]))
+
+
+def conv3x3_stream(x: Tensor, wp: Tensor, N: int, H: int, W: int, Cin: int, Cout: int, want_stats: bool = False,
+                   residual: Optional[Tensor] = None):
+    """3x3 / 1 / 1 convolution 64 -> 144 or 144 -> 64 from LDS halo patches with streamed weights (dvt_conv3x3_stream); same
+    contract as conv3x3_c64 (statistics with the 144-wide output, residual with the 64-wide one)."""
+    _need_cuda(x, wp, residual)
+    y = torch.empty((N * H * W, Cout), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == y.shape
+    lib = L.load()
+    partial, parts = None, 0
+    if want_stats:
+        parts = int(lib.dvt_conv3x3_stream_stats_parts(N, H, W, Cin, Cout))
+        partial = workspace((parts + 64) * 2 * Cout * 4, x.device, slot="bn_partial")
+    nb = (x.numel() + y.numel() + wp.numel()) * x.element_size()
+    with _timed(("conv", "halo3x3_stream", N * H * W, Cout, 9 * Cin, nb), 2.0 * N * H * W * Cout * 9 * Cin):
+        L.check(lib.dvt_conv3x3_stream(x.data_ptr(), wp.data_ptr(), y.data_ptr(), _p(partial), _p(residual), N, H, W, Cin, Cout,
+                                       dt(x), _stream()), "dvt_conv3x3_stream")
+    return (y, partial, parts) if want_stats else y
+
+
 def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
         return False

@@ -619,6 +619,16 @@ int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* worksp
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */
+/* The same convolution where one side has 144 channels -- the spatial half of R(2+1)D-18's layer-1 Conv2Plus1D
+ * (video_resnet.py: 64 -> 144 mid planes forward, 144 -> 64 as the data gradient with the rotated weights): the weights
+ * (162 KiB) cannot stay in LDS, so they stream through a ring of 18 KiB stages issued by a producer wave while seven
+ * compute waves run the taps of the staged patch (per 48-channel chunk at 144 input channels).  (Cin, Cout) = (64, 144)
+ * or (144, 64); x [N*H*W, Cin], w [Cout][9 * Cin] (k = tap * Cin + c), y [N*H*W, Cout].  stats_partial: only with
+ * Cout = 144, [dvt_conv3x3_stream_stats_parts + 64][2][144]; residual: only with Cout = 64. */
+int dvt_conv3x3_stream_supported(int64_t N, int H, int W, int Cin, int Cout, int dtype);
+int64_t dvt_conv3x3_stream_stats_parts(int64_t N, int H, int W, int Cin, int Cout);
+int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
+                       int Cin, int Cout, int dtype, dvt_stream_t stream);
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */

@@ -56,11 +56,15 @@ def test_conv_bn_relu_block(dvt, device, dtype, tol, k, stride, pad, Cin, Cout, 
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy.to(dtype).float())
     y.backward(gy.to(dtype).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda())
-    assert rel_l2(convd.weight.grad, wr.grad) < 2 * tol
-    assert rel_l2(bnd.weight.grad, gr.grad) < 2 * tol and rel_l2(bnd.bias.grad, br.grad) < 2 * tol
-    assert rel_l2(rd.grad, rr.grad.permute(0, 2, 3, 1).reshape(-1, Cout)) < 2 * tol
+    # (gradients: a ReLU decision that flips against the fp32 oracle -- y within the 16-bit rounding of z of zero -- moves one
+    # of ~5,000 live elements of the layer's gradient, 1.4 % of its L2 norm; the implicit path's statistics (fp32 accumulators
+    # in the GEMM epilogue) and the explicit path's (the rounded z) flip different ones: tools/dev/taps_check.py)
+    gtol = (2.5 if dtype == torch.bfloat16 else 2) * tol
+    assert rel_l2(convd.weight.grad, wr.grad) < gtol
+    assert rel_l2(bnd.weight.grad, gr.grad) < gtol and rel_l2(bnd.bias.grad, br.grad) < gtol
+    assert rel_l2(rd.grad, rr.grad.permute(0, 2, 3, 1).reshape(-1, Cout)) < gtol
     if not nchw_in:
-        assert rel_l2(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)) < 2 * tol
+        assert rel_l2(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)) < gtol
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -224,6 +228,41 @@ def test_conv3x3_c64_from_an_lds_halo_patch(dvt, device, dtype, N, H, W):
     res = torch.randn(N * H * W, 64, generator=g).to(dtype).cuda()     # the shortcut's gradient joining a data gradient
     z3 = ops.conv3x3_c64(xd, wp, N, H, W, residual=res)
     assert torch.equal(z3, (z.float() + res.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cin,Cout", [(64, 144), (144, 64)])
+@pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (2, 13, 20), (1, 5, 56), (300, 8, 8), (150, 9, 40)])
+def test_conv3x3_stream_halo_patch_with_streamed_weights(dvt, device, dtype, Cin, Cout, N, H, W):
+    """dvt_conv3x3_stream (the spatial half of R(2+1)D-18's layer-1 Conv2Plus1D, video_resnet.py: 64 -> 144 forward and
+    144 -> 64 as the data gradient) against F.conv2d on the same 16-bit operands; BatchNorm partial sums of the 144-wide
+    output against the statistics of that output, the residual of the 64-wide one; tile heights that do and do not divide
+    H, fewer and (many) more tiles than CUs (producer ring over several tiles, both patch buffers, clamped last tile)."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05)
+    ref = TF.conv2d(x.float(), w.to(dtype).float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+    wp = ops.conv_weight_pack(w.cuda(), 9 * Cin, dtype)
+    assert ops.conv3x3_stream_supported(xd, wp, N, H, W, Cin, Cout)
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
+    if Cout == 144:
+        z, partial, parts = ops.conv3x3_stream(xd, wp, N, H, W, Cin, Cout, want_stats=True)
+        assert rel_l2(z.float().cpu(), ref) < tol
+        mean, invstd = ops.bn_stats_from_partials(partial, parts, z.shape[0], Cout, None, None, 1e-5, 0.1)
+        zf = ref.double()
+        assert torch.allclose(mean.cpu().double(), zf.mean(0), atol=2e-3)
+        assert rel_l2(invstd.cpu().double(), 1.0 / torch.sqrt(zf.var(0, unbiased=False) + 1e-5)) < 2e-3
+        assert torch.equal(z, ops.conv3x3_stream(xd, wp, N, H, W, Cin, Cout))     # no statistics: same values
+    else:
+        z = ops.conv3x3_stream(xd, wp, N, H, W, Cin, Cout)
+        assert rel_l2(z.float().cpu(), ref) < tol
+        res = torch.randn(N * H * W, Cout, generator=g).to(dtype).cuda()          # the shortcut's gradient joining in
+        z3 = ops.conv3x3_stream(xd, wp, N, H, W, Cin, Cout, residual=res)
+        assert torch.equal(z3, (z.float() + res.float()).to(dtype))
+    worst = (z.float().cpu() - ref).abs().max().item()
+    assert worst < (0.25 if dtype == torch.bfloat16 else 0.03), worst           # no stray pixel hidden inside the L2 norm
 
 
 def test_maxpool_first_max_and_eval_bn(dvt, device):
@@ -593,6 +632,36 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
     x45 = torch.zeros(4 * 8 * 8, 40, dtype=dtype, device="cuda")
     assert not ops.conv2d_implicit_supported(x45, ops.conv_weight_pack(torch.zeros(64, 40, 3, 3, device="cuda"), 360, dtype),
                                              4, 40, 8, 8, 64, 3, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(2, 144, 12, 49, 64, (3, 1), 1, (1, 0)),      # R(2+1)D-18 layer-1 temporal conv (un-padded mid planes)
+                                  (2, 144, 12, 49, 128, (3, 1), (2, 1), (1, 0)),
+                                  (3, 144, 14, 14, 256, 3, 1, 1),                # 64-deep k-tiles: 1296 -> 1344
+                                  (2, 40, 17, 13, 64, 3, 2, 1), (1, 72, 9, 9, 200, (1, 3), 1, (0, 1)),
+                                  (2, 8 * 29, 6, 6, 64, 3, 1, 1)])
+def test_implicit_gemm_with_taps_that_split_a_k_tile(dvt, device, dtype, geom):
+    """dvt_conv2d_implicit with C % 8 == 0 but no whole number of k-tiles per filter tap (the 144 mid planes of
+    video_resnet.py:69 left un-padded): every lane of the operand DMA derives the tap of its own chunk, K is rounded up to the
+    k-tile with zero weight columns.  Against conv2d on the same rounded operands; operands in front of NaN-filled memory."""
+    ops = dvt.ops
+    N, Cin, H, W, Cout, k, stride, pad = geom
+    g = torch.Generator().manual_seed(77)
+    (kh, kw) = ops._pair(k)
+    xb = torch.full((N * H * W + 64, Cin), float("nan"), dtype=dtype, device="cuda")
+    x = xb[: N * H * W]
+    x.copy_(torch.randn(N * H * W, Cin, generator=g).to(dtype))
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).cuda()
+    ld = ops.conv2d_implicit_k(Cin, Cout, k)
+    assert ld >= kh * kw * Cin and ld % 32 == 0
+    wp = ops.conv_weight_pack(w, ld, dtype)
+    assert ops.conv2d_implicit_supported(x, wp, N, Cin, H, W, Cout, k, stride, pad)
+    y, partial, parts = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True)
+    xr = x.float().cpu().view(N, H, W, Cin).permute(0, 3, 1, 2)
+    cpu = torch.nn.functional.conv2d(xr, w.to(dtype).float().cpu(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert y.shape == cpu.shape and rel_l2(y, cpu) < (5e-3 if dtype == torch.bfloat16 else 8e-4)
+    mean, _ = ops.bn_stats_from_partials(partial, parts, y.shape[0], Cout, None, None, 1e-5, 0.1)
+    assert torch.allclose(mean.cpu(), cpu.mean(0), atol=3e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

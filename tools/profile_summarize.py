@@ -50,6 +50,8 @@ def gemm_family(name):
 def conv_family(name):
     """Kernels of the per-frame CNN encoder: the implicit-GEMM convolution (gemm_dma_kernel with A_CONV = true: forward /
     data gradient when A is k-major, weight gradient when both operands are mn-major) and the LDS-halo 3x3 kernel."""
+    if "conv3x3_stream_kernel" in name:
+        return "conv3x3_stream"
     if "conv3x3_c64_wgrad_kernel" in name:
         return "conv3x3_c64_wgrad"
     if "conv3x3_c64_kernel" in name:
