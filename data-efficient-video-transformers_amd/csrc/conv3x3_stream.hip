@@ -27,11 +27,15 @@
 
 namespace {
 
-template <int CI_, int CO_> struct SC;
+template <int CI_, int CO_, int NTAP_> struct SC;
 // PPG pieces (1 KiB) per patch group, NG groups per chunk; the groups of the NEXT chunk ride the batches at chunk-relative
 // stage positions GPOS .. SPC - 1 and the last group the batch of the chunk's own first stage.
-template <> struct SC<64, 144> { enum { CK = 64, NCH = 1, TPS = 1, PPG = 7, GPOS = 3, NG = 7, STG_DEDICATED = 0 }; };
-template <> struct SC<144, 64> { enum { CK = 48, NCH = 3, TPS = 3, PPG = 17, GPOS = 2, NG = 2, STG_DEDICATED = 1 }; };
+template <> struct SC<64, 144, 9> { enum { CK = 64, NCH = 1, TPS = 1, PPG = 7, GPOS = 3, NG = 7, STG_DEDICATED = 0 }; };
+template <> struct SC<144, 64, 9> { enum { CK = 48, NCH = 3, TPS = 3, PPG = 17, GPOS = 2, NG = 2, STG_DEDICATED = 1 }; };
+// NTAP = 3: a (3, 1) filter over rows `row_pitch` pixels apart (the temporal half of Conv2Plus1D over the [T, H*W] view of a clip,
+// as the data gradient 64 -> 144): three stages per tile, no column halo; the whole patch rides the batch of the tile's first
+// stage (62 DMA instructions, one below the vmcnt range).
+template <> struct SC<64, 144, 3> { enum { CK = 64, NCH = 1, TPS = 1, PPG = 45, GPOS = 3, NG = 1, STG_DEDICATED = 0 }; };
 
 constexpr int kWStage = 18 * 1024;           // one weight stage: TPS taps x CO rows x CK channels
 constexpr int kNC = 7;                       // compute waves
@@ -42,9 +46,13 @@ struct StreamParams {
   void* y;               // [N, H, W, CO]
   float* bn_partial;     // [grid * 7][2][CO] or nullptr
   const void* residual;  // [N, H, W, CO] added to the output rows, or nullptr
-  int N, H, W, R, tiles_per_img, ntiles;
+  int N, H, W, R, tiles_per_img, ntiles;   // N images of H rows x W columns (the (3, 1) form: image = one column segment of a clip)
   int PW, SPR;           // patch columns, 16-byte slots per patch row
   unsigned magic;        // ceil(2^32 / PW) (128-byte pixels) or ceil(2^32 / SPR) (96-byte pixels)
+  unsigned magic_w;      // ceil(2^32 / W)
+  int hb;                // images per outer block: pixel 0 of image n = (n / hb) * pitch_n + (n % hb) * pitch_h
+  int64_t pitch_n;
+  int pitch_h, row_pitch;   // pixels between the image's rows (W for a dense NHWC frame)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int conv3s_zero16[4] = {0u, 0u, 0u, 0u};
@@ -67,22 +75,26 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
     case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
     case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 63: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-template <typename E, int CI, int CO>
+template <typename E, int CI, int CO, int NTAP>
 __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams p) {
-  typedef SC<CI, CO> C;
+  typedef SC<CI, CO, NTAP> C;
   using V8 = typename Elem16<E>::v8;
   using V4 = typename Elem16<E>::v4;
-  constexpr int CK = C::CK, NCH = C::NCH, TPS = C::TPS, SPC = 9 / TPS, PPG = C::PPG, GPOS = C::GPOS, NG = C::NG;
+  constexpr int CK = C::CK, NCH = C::NCH, TPS = C::TPS, SPC = NTAP / TPS, PPG = C::PPG, GPOS = C::GPOS, NG = C::NG;
   constexpr int SPP = CK / 8;                  // 16-byte slots per pixel / weight row
   constexpr int NB = CO / 16;                  // output-channel blocks
   constexpr int kPatch = NG * PPG * 1024;      // one patch (chunk) buffer
   constexpr int NSTEP = CK == 64 ? 2 : 6;      // fragment steps per stage
   constexpr int kStgWave = 16 * CO * 2;        // epilogue staging per wave: 16 pixels
-  static_assert(NCH * SPC == 9 && TPS * CO * CK * 2 == kWStage && (NSTEP & 1) == 0, "stage geometry");
+  constexpr int NST = NCH * SPC;               // stages per tile
+  constexpr int HALO = NTAP == 9 ? 1 : 0;      // zero columns either side of the patch rows
+  static_assert(NST % 3 == 0 && NST >= 3 && TPS * CO * CK * 2 == kWStage && (NSTEP & 1) == 0, "stage geometry");
+  static_assert(NTAP == 9 || CK == 64, "the (3, 1) form exists for 128-byte pixels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;
   char* const pbuf = smem + 3 * kWStage;
@@ -95,8 +107,10 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     // ================================================================ producer
     // Per-lane constants of every DMA slot this wave ever fills (the LDS images do not depend on the tile):
     //   woff[i]  element offset of weight piece i's 16 bytes inside (row-major w, tap 0 / chunk 0)
-    //   poff[q]  patch piece q: bits 0..19 element offset from the tile's first pixel, biased by (W + 1) * CI;
-    //            bits 20..27 patch row; bit 31 = never loaded (padding slot, or a column outside the frame)
+    //   poff[q]  patch piece q: bits 0..23 element offset from (patch row 0, column -HALO) of the image; bits 24..30 the patch
+    //            row; bit 31 = never loaded (padding slot, or a column outside the frame)
+    // (one wave issues every DMA of the workgroup and a wave64 VALU instruction costs four cycles: at 35 pieces per stage
+    // each instruction of the per-piece address arithmetic is ~5 % of a stage)
     const E* xg = (const E*)p.x;
     const E* wg = (const E*)p.w;
     int woff[18];
@@ -105,11 +119,11 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
       const int sl = i * 64 + lane;
       if constexpr (CK == 64) {
         const int row = sl >> 3, cs = (sl & 7) ^ (row & 7);
-        woff[i] = row * (9 * CI) + cs * 8;
+        woff[i] = row * (NTAP * CI) + cs * 8;
       } else {
         const int s = sl ^ ((sl >> 4) & 1);
         const int ra = s / 6, cs = s - ra * 6, kj = ra >> 6, co = ra & 63;
-        woff[i] = co * (9 * CI) + kj * CI + cs * 8;
+        woff[i] = co * (NTAP * CI) + kj * CI + cs * 8;
       }
     }
     unsigned poff[NG * PPG];
@@ -132,12 +146,12 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
         cs = within - pc * 6;
         v = pr < p.R + 2 && pc < p.PW;
       }
-      v = v && (unsigned)(pc - 1) < (unsigned)p.W;
-      poff[q] = v ? (unsigned)((pr * p.W + pc) * CI + cs * 8) | ((unsigned)pr << 20) : 0x80000000u;
+      v = v && (unsigned)(pc - HALO) < (unsigned)p.W;
+      poff[q] = v ? (unsigned)(pr * p.row_pitch * CI + pc * CI + cs * 8) | ((unsigned)pr << 24) : 0x80000000u;
     }
     auto issue_weights = [&](int sg) {             // stage position sg of a tile
       char* dst = wring + (sg % 3) * kWStage;
-      const E* base = CK == 64 ? wg + sg * CI : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;
+      const E* base = CK == 64 ? wg + sg * CI : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;   // (CK == 64: stage = tap)
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
         int o = woff[i];
@@ -147,16 +161,28 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     };
     auto issue_group = [&](int tile, int cc, int grp, char* dst) {   // grp: compile-time at every call site
       const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
-      // element (h0 - 1, -1, chunk cc) of the frame: poff's bias
-      const E* base = xg + ((int64_t)(n * p.H + h0 - 1) * p.W - 1) * CI + cc * CK;
+      const int nq = n / p.hb;
+      // element (row h0 - 1, column -HALO, chunk cc) of the image
+      const E* base = xg + (nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)(h0 - 1) * p.row_pitch - HALO) * CI + cc * CK;
+      const bool interior = h0 >= 1 && h0 + p.R + 1 <= p.H;     // every patch row lies inside the image
+      if (interior) {
 #pragma unroll
-      for (int i = 0; i < PPG; ++i) {
-        unsigned pk = poff[grp * PPG + i];
-        asm volatile("" : "+v"(pk));                // (same: the unpacked fields stay temporaries)
-        const int h = h0 - 1 + (int)((pk >> 20) & 0xFF);
-        const bool ok = (int)pk >= 0 && (unsigned)h < (unsigned)p.H;
-        const E* src = ok ? base + (pk & 0xFFFFF) : reinterpret_cast<const E*>(conv3s_zero16);
-        dvt_dma16(src, dst + (grp * PPG + i) * 1024);
+        for (int i = 0; i < PPG; ++i) {
+          unsigned pk = poff[grp * PPG + i];
+          asm volatile("" : "+v"(pk));              // (same: the unpacked fields stay temporaries)
+          const E* src = (int)pk >= 0 ? base + (pk & 0xFFFFFF) : reinterpret_cast<const E*>(conv3s_zero16);
+          dvt_dma16(src, dst + (grp * PPG + i) * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PPG; ++i) {
+          unsigned pk = poff[grp * PPG + i];
+          asm volatile("" : "+v"(pk));
+          const int h = h0 - 1 + (int)((pk >> 24) & 0x7F);
+          const bool ok = (int)pk >= 0 && (unsigned)h < (unsigned)p.H;
+          const E* src = ok ? base + (pk & 0xFFFFFF) : reinterpret_cast<const E*>(conv3s_zero16);
+          dvt_dma16(src, dst + (grp * PPG + i) * 1024);
+        }
       }
     };
     // the batch of the stage at chunk cc (runtime), chunk-relative position pos (compile-time) of tile ta (tb: the tile after)
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
   auto rd = [&](const char* pb, int sg, int j) {
     const char* wb = wring + (sg % 3) * kWStage;
     if constexpr (CK == 64) {
-      const int ki = sg / 3, kj = sg % 3;
+      const int ki = NTAP == 9 ? sg / 3 : sg, kj = NTAP == 9 ? sg % 3 : 0;
 #pragma unroll
       for (int u = 0; u < NB; ++u) wf8[j][u] = *reinterpret_cast<const V8*>(wb + wo[j] + u * 2048);
 #pragma unroll
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int sg = 0; sg < 9; ++sg) {
+    for (int sg = 0; sg < NST; ++sg) {
       const char* pb = patch_of(it, sg);
 #pragma unroll
       for (int j = 0; j < NSTEP; ++j) {
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
           // this wave's last read of stage g has returned: open stage g + 1 and fetch its first fragments under the MFMAs
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();                             // B_{g+1}
-          if (sg + 1 < 9) rd(patch_of(it, sg + 1), sg + 1, 0);
+          if (sg + 1 < NST) rd(patch_of(it, sg + 1), sg + 1, 0);
           else rd(patch_of(it + 1, 0), 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -313,13 +339,15 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
     const int rows_ok = min(p.R, p.H - h0);
     const int valid = rows_ok * p.W;
-    E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * CO;
+    const int nq = n / p.hb;
+    const int64_t pix0 = nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)h0 * p.row_pitch;   // the tile's first pixel
+    E* yt = (E*)p.y + pix0 * CO;
     char* stg = (C::STG_DEDICATED ? pbuf + 2 * kPatch : pbuf + ((it * NCH + NCH - 1) & 1) * kPatch) + wid * kStgWave;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;
       if constexpr (CO == 64) {
-        const E* rt = p.residual ? (const E*)p.residual + ((int64_t)(n * p.H + h0) * p.W) * CO : nullptr;
+        const E* rt = p.residual ? (const E*)p.residual + pix0 * CO : nullptr;      // (dense frames: row_pitch == W)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           V4 o;
@@ -360,7 +388,12 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
           const int px = ps * PPP + r3;
           if (r3 < PPP && px < 16 && m0 + px < valid) {
             const V8 v = *reinterpret_cast<const V8*>(stg + px * (CO * 2) + c18 * 16);
-            *reinterpret_cast<V8*>(yt + (int64_t)(m0 + px) * CO + c18 * 8) = v;
+            int64_t po = m0 + px;                  // pixel offset from the tile's first: rows of the tile are row_pitch apart
+            if (NTAP != 9) {
+              const int r = (int)__umulhi((unsigned)(m0 + px), p.magic_w);
+              po = (int64_t)r * p.row_pitch + (m0 + px - r * p.W);
+            }
+            *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
             if (p.bn_partial) {
 #pragma unroll
               for (int k = 0; k < 8; ++k) {
@@ -397,18 +430,18 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
 
 struct Plan { int R, PW, SPR, lds; unsigned magic; };
 
-template <int CI, int CO>
+template <int CI, int CO, int NTAP>
 int plan_for(int H, int W, Plan* o) {
-  typedef SC<CI, CO> C;
+  typedef SC<CI, CO, NTAP> C;
   if (W <= 0 || H <= 0 || W > 224) return 0;
   int r = 224 / W;
   if (r > H) r = H;
   if (r < 1) return 0;
-  const int PW = W + 2;
+  const int PW = W + (NTAP == 9 ? 2 : 0);
   const int spp = C::CK / 8;
   const int spr = spp == 8 ? PW * 8 : ((PW * spp + 31) & ~31);
   const int slots = (r + 2) * spr;
-  if ((slots + 63) / 64 > C::NG * C::PPG) return 0;
+  if ((slots + 63) / 64 > C::NG * C::PPG || r + 2 > 127) return 0;
   const int kPatch = C::NG * C::PPG * 1024;
   const int stg = kNC * 16 * CO * 2;
   if (!C::STG_DEDICATED && stg > kPatch) return 0;
@@ -420,19 +453,36 @@ int plan_for(int H, int W, Plan* o) {
 }
 
 int plan_any(int Cin, int Cout, int H, int W, Plan* o) {
-  if (Cin == 64 && Cout == 144) return plan_for<64, 144>(H, W, o);
-  if (Cin == 144 && Cout == 64) return plan_for<144, 64>(H, W, o);
+  if (Cin == 64 && Cout == 144) return plan_for<64, 144, 9>(H, W, o);
+  if (Cin == 144 && Cout == 64) return plan_for<144, 64, 9>(H, W, o);
   return 0;
 }
 
-template <typename E, int CI, int CO>
+// (3, 1) form over the [T, L] view of a clip (L = H * W pixels per frame): images = column segments of S pixels, S the divisor of
+// L with the fullest 224-pixel tile (ties: the longer segment -- fewer patch rows per output row)
+int plan_t(int T, int L, Plan* o, int* S) {
+  int best = 0, bs = 0;
+  for (int s = 1; s <= 224 && s <= L; ++s) {
+    if (L % s) continue;
+    Plan pl;
+    if (!plan_for<64, 144, 3>(T, s, &pl)) continue;
+    const int use = pl.R * s;
+    if (use >= best) { best = use; bs = s; }
+  }
+  if (!bs || best < 112) return 0;
+  *S = bs;
+  if (!plan_for<64, 144, 3>(T, bs, o)) return 0;
+  return (int64_t)(o->R + 2) * L * 64 + (int64_t)bs * 64 < ((int64_t)1 << 24);   // the producer's 24-bit patch offsets
+}
+
+template <typename E, int CI, int CO, int NTAP>
 void launch(const StreamParams& p, int lds, int grid, hipStream_t st) {
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<E, CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<E, CI, CO, NTAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     set = true;
   }
-  hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO>), dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO, NTAP>), dim3(grid), dim3(512), lds, st, p);
 }
 
 }  // namespace
@@ -466,18 +516,53 @@ int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_parti
   StreamParams p;
   p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.residual = residual;
   p.N = (int)N; p.H = H; p.W = W; p.R = pl.R; p.PW = pl.PW; p.SPR = pl.SPR; p.magic = pl.magic;
+  p.magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)W - 1) / (uint64_t)W);
+  p.hb = 1; p.pitch_n = (int64_t)H * W; p.pitch_h = 0; p.row_pitch = W;
   p.tiles_per_img = (int)dvt_cdiv(H, pl.R);
   p.ntiles = (int)(N * p.tiles_per_img);
   const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 64) {
-    if (dtype == DVT_BF16) launch<bf16, 64, 144>(p, pl.lds, grid, st);
-    else launch<f16, 64, 144>(p, pl.lds, grid, st);
+    if (dtype == DVT_BF16) launch<bf16, 64, 144, 9>(p, pl.lds, grid, st);
+    else launch<f16, 64, 144, 9>(p, pl.lds, grid, st);
   } else {
-    if (dtype == DVT_BF16) launch<bf16, 144, 64>(p, pl.lds, grid, st);
-    else launch<f16, 144, 64>(p, pl.lds, grid, st);
+    if (dtype == DVT_BF16) launch<bf16, 144, 64, 9>(p, pl.lds, grid, st);
+    else launch<f16, 144, 64, 9>(p, pl.lds, grid, st);
   }
   DVT_LAUNCH_CHECK("dvt_conv3x3_stream");
+  return DVT_OK;
+}
+
+int dvt_conv3x1_stream_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype) {
+  Plan pl;
+  int S;
+  return N > 0 && T > 0 && L > 0 && Cin == 64 && Cout == 144 && dvt_is_16bit(dtype) && plan_t(T, L, &pl, &S) &&
+                 N * T * L < ((int64_t)1 << 30) ? 1 : 0;
+}
+
+int dvt_conv3x1_stream(const void* x, const void* w, void* y, int64_t N, int T, int L, int Cin, int Cout, int dtype,
+                       dvt_stream_t stream) {
+  DVT_REQUIRE(x && w && y && N >= 0 && T > 0 && L > 0, "dvt_conv3x1_stream: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y), "dvt_conv3x1_stream: buffers must be 16-byte aligned");
+  if (N == 0) return DVT_OK;
+  if (!dvt_conv3x1_stream_supported(N, T, L, Cin, Cout, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x1_stream: needs a 16-bit dtype, (Cin, Cout) = (64, 144) and a divisor of L that fills half a 224-pixel tile");
+  Plan pl;
+  int S = 0;
+  plan_t(T, L, &pl, &S);
+  StreamParams p;
+  p.x = x; p.w = w; p.y = y; p.bn_partial = nullptr; p.residual = nullptr;
+  p.hb = L / S;                                    // images: (clip, column segment)
+  p.N = (int)(N * p.hb); p.H = T; p.W = S; p.R = pl.R; p.PW = pl.PW; p.SPR = pl.SPR; p.magic = pl.magic;
+  p.magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)S - 1) / (uint64_t)S);
+  p.pitch_n = (int64_t)T * L; p.pitch_h = S; p.row_pitch = L;
+  p.tiles_per_img = (int)dvt_cdiv(T, pl.R);
+  p.ntiles = (int)(N * p.hb * p.tiles_per_img);
+  const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DVT_BF16) launch<bf16, 64, 144, 3>(p, pl.lds, grid, st);
+  else launch<f16, 64, 144, 3>(p, pl.lds, grid, st);
+  DVT_LAUNCH_CHECK("dvt_conv3x1_stream");
   return DVT_OK;
 }
 

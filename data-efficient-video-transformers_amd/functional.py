@@ -1649,6 +1649,9 @@ class _ConvBnAct(torch.autograd.Function):
             elif (HALO_CONV and (kh, kw) == (3, 3) and pd == (1, 1)
                     and ops.conv3x3_stream_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
                 dx = ops.conv3x3_stream(dz, wd, N, Ho, Wo, Cout, Cin, residual=join_alias())
+            elif (HALO_CONV and (kh, kw) == (3, 1) and pd == (1, 0) and (joined[0] or ctx.fork != "alias")
+                    and ops.conv3x1_stream_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
+                dx = ops.conv3x1_stream(dz, wd, N, Ho, Wo, Cout, Cin)      # temporal half of layer 1's Conv2Plus1D: 64 -> 144
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 # this launch writes the COMPLETE gradient of the layer's input when the shortcut (if any) joins in its
                 # epilogue: then it can also leave the backward column sums of the BatchNorm that produced that input

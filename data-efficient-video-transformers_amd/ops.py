@@ -1327,6 +1327,26 @@ def conv3x3_stream(x: Tensor, wp: Tensor, N: int, H: int, W: int, Cin: int, Cout
     return (y, partial, parts) if want_stats else y
 
 
+def conv3x1_stream_supported(x: Tensor, wp: Tensor, N: int, T: int, HW: int, Cin: int, Cout: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype or (Cin, Cout) != (64, 144):
+        return False
+    if not (x.is_contiguous() and wp.is_contiguous() and tuple(wp.shape) == (Cout, 3 * Cin) and x.shape == (N * T * HW, Cin)):
+        return False
+    return bool(L.load().dvt_conv3x1_stream_supported(N, T, HW, Cin, Cout, dt(x)))
+
+
+def conv3x1_stream(x: Tensor, wp: Tensor, N: int, T: int, HW: int, Cin: int, Cout: int) -> Tensor:
+    """(3, 1) / 1 / (1, 0) convolution 64 -> 144 over the [T, HW] view of N clips (dvt_conv3x1_stream): the temporal half of
+    R(2+1)D's layer-1 Conv2Plus1D as its data gradient."""
+    _need_cuda(x, wp)
+    y = torch.empty((N * T * HW, Cout), dtype=x.dtype, device=x.device)
+    nb = (x.numel() + y.numel() + wp.numel()) * x.element_size()
+    with _timed(("conv", "halo3x3_stream", N * T * HW, Cout, 3 * Cin, nb), 2.0 * N * T * HW * Cout * 3 * Cin):
+        L.check(L.load().dvt_conv3x1_stream(x.data_ptr(), wp.data_ptr(), y.data_ptr(), N, T, HW, Cin, Cout, dt(x), _stream()),
+                 "dvt_conv3x1_stream")
+    return y
+
+
 def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
         return False

@@ -629,6 +629,12 @@ int dvt_conv3x3_stream_supported(int64_t N, int H, int W, int Cin, int Cout, int
 int64_t dvt_conv3x3_stream_stats_parts(int64_t N, int H, int W, int Cin, int Cout);
 int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                        int Cin, int Cout, int dtype, dvt_stream_t stream);
+/* The (3, 1) sibling over the [T, L] view of N clips (L = H * W pixels per frame; rows of the "image" are L pixels apart): the
+ * temporal half of the same Conv2Plus1D as its data gradient, 64 -> 144 channels, stride 1, pad (1, 0).  x [N*T*L, 64],
+ * w [144][3 * 64], y [N*T*L, 144].  A tile is R frames of one column segment (a divisor of L); three weight stages per tile. */
+int dvt_conv3x1_stream_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
+int dvt_conv3x1_stream(const void* x, const void* w, void* y, int64_t N, int T, int L, int Cin, int Cout, int dtype,
+                       dvt_stream_t stream);
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */

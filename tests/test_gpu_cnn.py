@@ -265,6 +265,26 @@ def test_conv3x3_stream_halo_patch_with_streamed_weights(dvt, device, dtype, Cin
     assert worst < (0.25 if dtype == torch.bfloat16 else 0.03), worst           # no stray pixel hidden inside the L2 norm
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,T,H,W", [(3, 12, 56, 56), (2, 5, 14, 8), (30, 7, 8, 8), (1, 16, 28, 28)])
+def test_conv3x1_stream_temporal_data_gradient(dvt, device, dtype, N, T, H, W):
+    """dvt_conv3x1_stream (the temporal half of R(2+1)D-18's layer-1 Conv2Plus1D as its data gradient: 64 -> 144 channels over
+    the [T, H*W] view of a clip, rows H*W pixels apart) against F.conv2d with a (3, 1) filter on the same 16-bit operands;
+    frame counts that the tile height does and does not divide, more tiles than CUs."""
+    from dvt_amd import ops
+    g = torch.Generator().manual_seed(47)
+    HW = H * W
+    x = torch.randn(N, 64, T, HW, generator=g).to(dtype)
+    w = (torch.randn(144, 64, 3, 1, generator=g) * 0.07)
+    ref = TF.conv2d(x.float(), w.to(dtype).float(), padding=(1, 0)).permute(0, 2, 3, 1).reshape(-1, 144)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous().cuda()
+    wp = ops.conv_weight_pack(w.cuda(), 3 * 64, dtype)
+    assert ops.conv3x1_stream_supported(xd, wp, N, T, HW, 64, 144)
+    z = ops.conv3x1_stream(xd, wp, N, T, HW, 64, 144)
+    assert rel_l2(z.float().cpu(), ref) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    assert (z.float().cpu() - ref).abs().max().item() < (0.25 if dtype == torch.bfloat16 else 0.03)
+
+
 def test_maxpool_first_max_and_eval_bn(dvt, device):
     g = torch.Generator().manual_seed(32)
     N, C, H, W = 2, 8, 9, 11
