@@ -9,6 +9,11 @@
 // ring of three 18 KiB stages (one tap x 144 x 64, or one tap row x 64 x 48) that every tile re-reads from L2:
 // 0.94 KiB (forward) / 1.2 KiB (data gradient) of L2 -> LDS traffic per output pixel instead of 2.3 / 3.2.
 //
+//   * measured and dropped (336 frames of 56^2, in-step; run-to-run spread +-4 %): the seven compute waves carrying the weight
+//     stream (3 or 2 pieces of every stage each, counted vmcnt with the epilogue's stores on the same counter) and the
+//     producer only the patches: 174 -> 182 us forward, 218 -> 228 us data gradient; fragments two steps ahead in the
+//     96-byte form (three register sets): 218 -> 220 us; a ring of four weight stages there: 220 -> 241 us.  Neither the
+//     loader wave's in-flight window, nor the LDS round trip, nor the ring depth is what bounds these kernels.
 //   * wave 7 is the PRODUCER: it issues every LDS-DMA of the workgroup (weight stage g + 3 and a group of pieces of the next
 //     patch chunk after barrier g + 1) and is the only wave that counts vmcnt, with compile-time batch sizes; the compute
 //     waves never wait on memory, only on the one s_barrier per stage the producer joins once the stage's bytes have landed;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
       v = v && (unsigned)(pc - HALO) < (unsigned)p.W;
       poff[q] = v ? (unsigned)(pr * p.row_pitch * CI + pc * CI + cs * 8) | ((unsigned)pr << 24) : 0x80000000u;
     }
-    auto issue_weights = [&](int sg) {             // stage position sg of a tile
+    auto issue_weights = [&](int sg) __attribute__((always_inline)) {             // stage position sg of a tile
       char* dst = wring + (sg % 3) * kWStage;
       const E* base = CK == 64 ? wg + sg * CI : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;   // (CK == 64: stage = tap)
 #pragma unroll
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
         dvt_dma16(base + o, dst + i * 1024);
       }
     };
-    auto issue_group = [&](int tile, int cc, int grp, char* dst) {   // grp: compile-time at every call site
+    auto issue_group = [&](int tile, int cc, int grp, char* dst) __attribute__((always_inline)) {   // grp: compile-time at every call site
       const int n = tile / p.tiles_per_img, h0 = (tile - n * p.tiles_per_img) * p.R;
       const int nq = n / p.hb;
       // element (row h0 - 1, column -HALO, chunk cc) of the image
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
       }
     };
     // the batch of the stage at chunk cc (runtime), chunk-relative position pos (compile-time) of tile ta (tb: the tile after)
-    auto issue_batch = [&](int ita, int ta, int tb, int cc, int pos) {
+    auto issue_batch = [&](int ita, int ta, int tb, int cc, int pos) __attribute__((always_inline)) {
       issue_weights(cc * SPC + pos);
       if (pos == 0) {
         issue_group(ta, cc, NG - 1, pbuf + ((ita * NCH + cc) & 1) * kPatch);
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
         issue_group(same ? ta : tb, same ? cc + 1 : 0, pos - GPOS, pbuf + ((ita * NCH + cc + 1) & 1) * kPatch);
       }
     };
-    auto batch_size = [](int pos) { return 18 + ((pos == 0 || pos >= GPOS) ? PPG : 0); };
+    auto batch_size = [](int pos) __attribute__((always_inline)) { return 18 + ((pos == 0 || pos >= GPOS) ? PPG : 0); };
 
     int tile = blockIdx.x;
     int t1 = tile + grid < p.ntiles ? tile + grid : tile;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
   V4 wf4[NB], xf4[2];
   (void)wf4; (void)xf4;
   // fragments of step j of stage (patch buffer pb, position sg)
-  auto rd = [&](const char* pb, int sg, int j) {
+  auto rd = [&](const char* pb, int sg, int j) __attribute__((always_inline)) {
     const char* wb = wring + (sg % 3) * kWStage;
     if constexpr (CK == 64) {
       const int ki = NTAP == 9 ? sg / 3 : sg, kj = NTAP == 9 ? sg % 3 : 0;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
       }
     }
   };
-  auto patch_of = [&](int it, int sg) -> const char* { return pbuf + ((it * NCH + sg / SPC) & 1) * kPatch; };
+  auto patch_of = [&](int it, int sg) __attribute__((always_inline)) -> const char* { return pbuf + ((it * NCH + sg / SPC) & 1) * kPatch; };
 
   float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   (void)bs; (void)bq;
@@ -388,10 +393,12 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
           const int px = ps * PPP + r3;
           if (r3 < PPP && px < 16 && m0 + px < valid) {
             const V8 v = *reinterpret_cast<const V8*>(stg + px * (CO * 2) + c18 * 16);
-            int64_t po = m0 + px;                  // pixel offset from the tile's first: rows of the tile are row_pitch apart
+            int mpx = m0 + px;
+            asm volatile("" : "+v"(mpx));          // (the 12 tile-invariant 64-bit store offsets stay out of loop-carried registers)
+            int64_t po = mpx;                      // pixel offset from the tile's first: rows of the tile are row_pitch apart
             if (NTAP != 9) {
-              const int r = (int)__umulhi((unsigned)(m0 + px), p.magic_w);
-              po = (int64_t)r * p.row_pitch + (m0 + px - r * p.W);
+              const int r = (int)__umulhi((unsigned)mpx, p.magic_w);
+              po = (int64_t)r * p.row_pitch + (mpx - r * p.W);
             }
             *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
             if (p.bn_partial) {
