@@ -42,13 +42,15 @@ struct CwParams {
   int N, H, W, R, PW, KP, tiles_per_img, ntiles;
   int patch_pos;        // (R + 2) * PW: positions the patch DMA covers
   int patch_bytes, dz_bytes;
+  int ldz, zc0, zcv;    // dz rows are ldz channels long; this launch takes channels [zc0, zc0 + zcv) of them (zcv <= 64)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int cw_zero16[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ int cw_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
 
-template <typename E>
+// MB: output-channel blocks of 16 this launch computes (4: a whole 64-channel group; 1: the 16-channel tail of a 144-wide dz)
+template <typename E, int MB>
 __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using V8 = typename Elem16<E>::v8;
@@ -106,8 +108,9 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
       const int piece = wid + kNW * i;
       if (piece < zp) {
         const int h = h0 + (zq[i] >> 16);
-        const bool ok = (zq[i] & 1) && h < p.H;
-        const E* src = ok ? zg + ((int64_t)(n * p.H + h) * p.W + ((zq[i] >> 4) & 0xFFF)) * kC + ((zq[i] >> 1) & 7) * 8
+        const int sc = ((zq[i] >> 1) & 7) * 8;                   // channel of this chunk inside the group
+        const bool ok = (zq[i] & 1) && h < p.H && sc < p.zcv;
+        const E* src = ok ? zg + ((int64_t)(n * p.H + h) * p.W + ((zq[i] >> 4) & 0xFFF)) * p.ldz + p.zc0 + sc
                           : reinterpret_cast<const E*>(cw_zero16);
         dvt_dma16(src, zb[b] + piece * 1024);
       }
@@ -135,9 +138,9 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
       }
     }
   }
-  f32x4 acc[4][5];
+  f32x4 acc[MB][5];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MB; ++m)
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -151,12 +154,12 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
     const char* cx = xb[it & 1];
     const char* cz = zb[it & 1];
     if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x, (it + 1) & 1);
-    V8 zf[2][4], xf[2][5];
+    V8 zf[2][MB], xf[2][5];
     auto rd = [&](int ks, V8* zv, V8* xv) {
       const char* bz = cz + ks * 4096;
       const char* bx = cx + ks * 4096;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MB; ++m)
         zv[m] = __builtin_shufflevector(Elem16<E>::tr_read(bz + zo[m][0]), Elem16<E>::tr_read(bz + zo[m][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int j = 0; j < 5; ++j)
@@ -167,14 +170,14 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
     for (int ks = 0; ks < nks; ks += 2) {        // two steps per trip: the fragment buffers alternate without indexing
       if (ks + 1 < nks) rd(ks + 1, zf[1], xf[1]);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int j = 0; j < 5; ++j)
           if (j < 4 || cnt == 5) acc[m][j] = Elem16<E>::mma(zf[0][m], xf[0][j], acc[m][j]);
       if (ks + 1 < nks) {
         if (ks + 2 < nks) rd(ks + 2, zf[0], xf[0]);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
           for (int j = 0; j < 5; ++j)
             if (j < 4 || cnt == 5) acc[m][j] = Elem16<E>::mma(zf[1][m], xf[1][j], acc[m][j]);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
     const int nb = nb0 + j, tap = nb >> 2, cb = nb & 3;
     float* row = out + (int64_t)(tap * kC + cb * 16 + li) * kC + 4 * g;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[m][j];
+    for (int m = 0; m < MB; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[m][j];   // (MB == 1: columns 16.. stay unwritten, unread)
   }
 }
 
@@ -218,16 +221,77 @@ int plan(int H, int W, CwParams* q) {
 
 }  // namespace
 
+extern "C" int dvt_conv3x3_c64_wgrad_supported(int64_t N, int H, int W, int dtype);
+
+namespace {
+
+int cw_grid(int64_t N, int H, const CwParams& q) {
+  const int64_t ntiles = N * dvt_cdiv(H, q.R);
+  return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
+}
+
+// one launch: channels [c0, c0 + cv) of a dz whose rows are ldz channels long, partials into p.slab
+template <typename E>
+void cw_launch(const CwParams& p, int grid, int lds, hipStream_t st) {
+  if (p.zcv > 16) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<E, 4>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  } else {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<E, 1>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  }
+}
+
+// Cz output channels (64, or 80..  in steps of 16: the 144 mid planes of R(2+1)D-18's layer 1) as groups of 64: one launch
+// and one reduce per group over the SAME slab region (stream order), the last group's reduce deferred on request.
+int cw_run(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cz, int accumulate,
+                  int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream, const char* who) {
+  DVT_REQUIRE(x && dz && dw && workspace && N > 0 && H > 0 && W > 0, "%s: bad arguments", who);
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(dz) && dvt_aligned16(dw) && dvt_aligned16(workspace),
+              "%s: buffers must be 16-byte aligned", who);
+  DVT_REQUIRE(!defer_reduce || pending, "%s: defer_reduce needs a pending descriptor to fill", who);
+  CwParams p;
+  if (!dvt_conv3x3_c64_wgrad_supported(N, H, W, dtype) || Cz < 64 || Cz % 16)
+    DVT_UNSUPPORTED("%s: needs a 16-bit dtype, Cout >= 64 in steps of 16 and two (patch + gradient tile) pairs in 160 KiB of LDS", who);
+  plan(H, W, &p);
+  p.x = x; p.dz = dz; p.slab = (float*)workspace;
+  p.N = (int)N; p.H = H; p.W = W; p.ldz = Cz;
+  p.tiles_per_img = (int)dvt_cdiv(H, p.R);
+  p.ntiles = (int)(N * p.tiles_per_img);
+  const int grid = cw_grid(N, H, p);
+  const int lds = 2 * (p.patch_bytes + p.dz_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int ngroups = (Cz + kC - 1) / kC;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    p.zc0 = gi * kC;
+    p.zcv = Cz - p.zc0 < kC ? Cz - p.zc0 : kC;
+    if (dtype == DVT_BF16) cw_launch<bf16>(p, grid, lds, st);
+    else cw_launch<f16>(p, grid, lds, st);
+    DVT_LAUNCH_CHECK(who);
+    // the slabs are summed by the family's split-K reduce, which scatters [tap * 64 + ci][co] into the parameter's [co][ci][3][3]
+    dvt_splitk_pending q{};
+    q.slab = p.slab; q.splits = grid; q.valid = 1; q.M = kM; q.N = kC; q.C = dw + (int64_t)p.zc0 * kM; q.ldc = kC;
+    q.accumulate = accumulate; q.cs_accumulate = 0; q.cs_slab = nullptr; q.cs_out = nullptr;
+    q.conv_cin = kC; q.conv_taps = 9; q.conv_cin_l = 0; q.conv_cout_l = p.zcv < kC ? p.zcv : 0;
+    if (defer_reduce && gi == ngroups - 1) {
+      *pending = q;
+      return DVT_OK;
+    }
+    const int rc = dvt_splitk_reduce_pending(&q, stream);
+    if (rc != DVT_OK) return rc;
+  }
+  return DVT_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int dvt_conv3x3_c64_wgrad_supported(int64_t N, int H, int W, int dtype) {
   CwParams q;
   return N > 0 && dvt_is_16bit(dtype) && plan(H, W, &q) && N * H * W < ((int64_t)1 << 31) ? 1 : 0;
-}
-
-static int cw_grid(int64_t N, int H, const CwParams& q) {
-  const int64_t ntiles = N * dvt_cdiv(H, q.R);
-  return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
 }
 
 size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W) {
@@ -238,41 +302,12 @@ size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W) {
 
 int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int accumulate,
                           int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && dz && dw && workspace && N > 0 && H > 0 && W > 0, "dvt_conv3x3_c64_wgrad: bad arguments");
-  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(dz) && dvt_aligned16(dw) && dvt_aligned16(workspace),
-              "dvt_conv3x3_c64_wgrad: buffers must be 16-byte aligned");
-  DVT_REQUIRE(!defer_reduce || pending, "dvt_conv3x3_c64_wgrad: defer_reduce needs a pending descriptor to fill");
-  CwParams p;
-  if (!dvt_conv3x3_c64_wgrad_supported(N, H, W, dtype))
-    DVT_UNSUPPORTED("dvt_conv3x3_c64_wgrad: needs a 16-bit dtype and two (patch + gradient tile) pairs in 160 KiB of LDS");
-  plan(H, W, &p);
-  p.x = x; p.dz = dz; p.slab = (float*)workspace;
-  p.N = (int)N; p.H = H; p.W = W;
-  p.tiles_per_img = (int)dvt_cdiv(H, p.R);
-  p.ntiles = (int)(N * p.tiles_per_img);
-  const int grid = cw_grid(N, H, p);
-  const int lds = 2 * (p.patch_bytes + p.dz_bytes);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == DVT_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16>), dim3(grid), dim3(kNW * 64), lds, st, p);
-  } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<f16>), dim3(grid), dim3(kNW * 64), lds, st, p);
-  }
-  DVT_LAUNCH_CHECK("dvt_conv3x3_c64_wgrad");
-  // the slabs are summed by the family's split-K reduce, which scatters [tap * 64 + ci][co] into the parameter's [co][ci][3][3]
-  dvt_splitk_pending q{};
-  q.slab = p.slab; q.splits = grid; q.valid = 1; q.M = kM; q.N = kC; q.C = dw; q.ldc = kC;
-  q.accumulate = accumulate; q.cs_accumulate = 0; q.cs_slab = nullptr; q.cs_out = nullptr;
-  q.conv_cin = kC; q.conv_taps = 9; q.conv_cin_l = 0; q.conv_cout_l = 0;
-  if (defer_reduce) {
-    *pending = q;
-    return DVT_OK;
-  }
-  return dvt_splitk_reduce_pending(&q, stream);
+  return cw_run(x, dz, dw, workspace, N, H, W, kC, accumulate, defer_reduce, pending, dtype, stream, "dvt_conv3x3_c64_wgrad");
+}
+
+int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cout,
+                               int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
+  return cw_run(x, dz, dw, workspace, N, H, W, Cout, accumulate, defer_reduce, pending, dtype, stream, "dvt_conv3x3_c64_wgrad_wide");
 }
 
 }  // extern "C"

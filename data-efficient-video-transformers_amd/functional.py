@@ -1315,6 +1315,7 @@ def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: i
 BN_BWD_FUSE = os.environ.get("DVT_BN_BWD_FUSE", "0") != "0"
 # weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
 HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
+HALO_WGRAD_COUT = (64, 144) if os.environ.get("DVT_HALO_WGRAD_WIDE", "1") != "0" else (64,)
 _bn_front = {}
 _bn_hand = {}
 
@@ -1563,11 +1564,12 @@ class _ConvBnAct(torch.autograd.Function):
         if direct_dw:
             dw_master = sw.buf.view(wshape) if sw is not None else torch.empty(wshape, dtype=torch.float32, device=dz.device)
             acc_w = (not sw.fresh) if sw is not None else False
-            if (HALO_WGRAD and HALO_CONV and Cin == 64 and Cout == 64 and not padded and (kh, kw) == (3, 3)
+            if (HALO_WGRAD and HALO_CONV and Cin == 64 and Cout in HALO_WGRAD_COUT and not padded and (kh, kw) == (3, 3)
                     and ops._pair(stride) == (1, 1) and ops._pair(pad) == (1, 1)
-                    and ops.conv3x3_c64_wgrad_supported(xc, dz, N, H, W)):
-                # layer 1 of ResNet-18: input patch and gradient tile staged once per R rows, the nine taps read from LDS
-                pend = ops.conv3x3_c64_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True)
+                    and ops.conv3x3_c64_wgrad_supported(xc, dz, N, H, W, Cout)):
+                # layer 1 of ResNet-18 (and, in 64-channel groups of dz, of R(2+1)D-18: 64 -> 144): input patch and gradient
+                # tile staged once per R rows, the nine taps read from LDS
+                pend = ops.conv3x3_c64_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True, Cout=Cout)
             else:
                 _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
                                                     master=dw_master, accumulate=acc_w, logical=(Cout_l, Cin_l))

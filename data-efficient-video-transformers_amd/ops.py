@@ -1347,30 +1347,37 @@ def conv3x1_stream(x: Tensor, wp: Tensor, N: int, T: int, HW: int, Cin: int, Cou
     return y
 
 
-def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int) -> bool:
+def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int, Cout: int = 64) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
         return False
-    if not (x.is_contiguous() and dz.is_contiguous() and x.shape == (N * H * W, 64) and dz.shape == (N * H * W, 64)):
+    if Cout < 64 or Cout % 16:
+        return False
+    if not (x.is_contiguous() and dz.is_contiguous() and x.shape == (N * H * W, 64) and dz.shape == (N * H * W, Cout)):
         return False
     return bool(L.load().dvt_conv3x3_c64_wgrad_supported(N, H, W, dt(x)))
 
 
 def conv3x3_c64_wgrad(x: Tensor, dz: Tensor, N: int, H: int, W: int, master: Tensor, *, accumulate: bool = False,
-                      defer_reduce: bool = False):
+                      defer_reduce: bool = False, Cout: int = 64):
     """Weight gradient of the 64 -> 64 3x3 / 1 / 1 convolution from LDS halo patches (dvt_conv3x3_c64_wgrad), summed into
     ``master`` (the parameter's own gradient f32 [64, 64, 3, 3]; += when accumulate).  defer_reduce: -> pending, for
     ``splitk_reduce_pending`` / a carrying launch (the workgroups' partials live in the deferred-reduce scratch slot)."""
     _need_cuda(x, dz, master)
-    assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == 64 * 64 * 9
+    assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == Cout * 64 * 9
     lib = L.load()
     pend = L.SplitKPending()
     nbytes = int(lib.dvt_conv3x3_c64_wgrad_workspace_bytes(N, H, W))
     ws = _deferred_workspace(nbytes, x.device, pend) if defer_reduce else workspace(nbytes, x.device, slot="conv3_wgrad")
     nb = (x.numel() + dz.numel()) * x.element_size() + master.numel() * 4
-    with _timed(("conv", "halo3x3_c64_wgrad", 576, 64, N * H * W, nb), 2.0 * N * H * W * 64 * 576):
-        L.check(lib.dvt_conv3x3_c64_wgrad(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, H, W,
-                                          int(accumulate), int(defer_reduce), C.byref(pend), dt(x), _stream()),
-                "dvt_conv3x3_c64_wgrad")
+    with _timed(("conv", "halo3x3_c64_wgrad", 576, Cout, N * H * W, nb), 2.0 * N * H * W * Cout * 576):
+        if Cout == 64:
+            L.check(lib.dvt_conv3x3_c64_wgrad(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, H, W,
+                                              int(accumulate), int(defer_reduce), C.byref(pend), dt(x), _stream()),
+                    "dvt_conv3x3_c64_wgrad")
+        else:       # (one launch + reduce per 64-channel group of dz over the same workspace; the last reduce deferred)
+            L.check(lib.dvt_conv3x3_c64_wgrad_wide(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, H, W, Cout,
+                                                   int(accumulate), int(defer_reduce), C.byref(pend), dt(x), _stream()),
+                    "dvt_conv3x3_c64_wgrad_wide")
     if defer_reduce:
         pend._keep = (ws, master)
         return pend

@@ -616,6 +616,12 @@ int dvt_conv3x3_c64_wgrad_supported(int64_t N, int H, int W, int dtype);
 size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W);
 int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int accumulate,
                           int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
+/* The same with Cout output channels (>= 64 in steps of 16: the 64 -> 144 spatial half of R(2+1)D-18's layer-1 Conv2Plus1D,
+ * video_resnet.py:25): the kernel runs once per 64-channel group of dz (the last group's blocks of 16 only), each group's
+ * partials summed into its rows of dw f32 [Cout][64][3][3] before the next launch reuses the workspace (same size as for
+ * 64 channels); defer_reduce defers the LAST group's reduce. */
+int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cout,
+                               int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */

@@ -850,6 +850,31 @@ def test_conv3x3_c64_weight_gradient_from_lds_halo_patches(dvt, device, dtype, N
     assert rel_l2(acc - old, ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(3, 56, 56, 144), (2, 13, 20, 144), (300, 8, 8, 144), (2, 28, 28, 80), (2, 28, 28, 128)])
+def test_conv3x3_c64_weight_gradient_with_more_output_channels(dvt, device, dtype, N, H, W, Cout):
+    """dvt_conv3x3_c64_wgrad_wide (the 64 -> 144 spatial half of R(2+1)D-18's layer-1 Conv2Plus1D): the halo-patch kernel once
+    per 64-channel group of a dz whose rows are Cout channels long (the 16-channel tail on one block of 16), every group summed
+    into its rows of the parameter layout over the same workspace; against torch's fp32 conv2d weight gradient on the same
+    operands; accumulate through a deferred reduce of the last group."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(N * 100 + H + Cout)
+    x = torch.randn(N * H * W, 64, generator=g).to(dtype).cuda()
+    dz = (torch.randn(N * H * W, Cout, generator=g) / 8).to(dtype).cuda()
+    assert ops.conv3x3_c64_wgrad_supported(x, dz, N, H, W, Cout)
+    dw = torch.full((Cout, 64, 3, 3), float("nan"), device="cuda")
+    ops.conv3x3_c64_wgrad(x, dz, N, H, W, dw, Cout=Cout)
+    xr = x.float().view(N, H, W, 64).permute(0, 3, 1, 2)
+    zr = dz.float().view(N, H, W, Cout).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xr, (Cout, 64, 3, 3), zr, stride=1, padding=1)
+    assert torch.isfinite(dw).all() and rel_l2(dw, ref) < 2e-5
+    old = torch.randn(Cout, 64, 3, 3, generator=g).cuda()
+    acc = old.clone()
+    pend = ops.conv3x3_c64_wgrad(x, dz, N, H, W, acc, accumulate=True, defer_reduce=True, Cout=Cout)
+    ops.splitk_reduce_pending(pend)
+    assert rel_l2(acc - old, ref) < 2e-5
+
+
 def test_resnet_gradients_equal_with_and_without_fused_batchnorm_backward_sums(dvt, device, monkeypatch):
     """functional.BN_BWD_FUSE (off by default: measured neutral): the hand-off of the BatchNorm-backward sums between the
     backward passes of neighbouring layers -- recomputed masks, mask bytes of block outputs, shortcut gradients joining in
