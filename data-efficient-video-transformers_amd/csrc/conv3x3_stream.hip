@@ -9,11 +9,22 @@
 // ring of three 18 KiB stages (one tap x 144 x 64, or one tap row x 64 x 48) that every tile re-reads from L2:
 // 0.94 KiB (forward) / 1.2 KiB (data gradient) of L2 -> LDS traffic per output pixel instead of 2.3 / 3.2.
 //
-//   * measured and dropped (336 frames of 56^2, in-step; run-to-run spread +-4 %): the seven compute waves carrying the weight
-//     stream (3 or 2 pieces of every stage each, counted vmcnt with the epilogue's stores on the same counter) and the
-//     producer only the patches: 174 -> 182 us forward, 218 -> 228 us data gradient; fragments two steps ahead in the
-//     96-byte form (three register sets): 218 -> 220 us; a ring of four weight stages there: 220 -> 241 us.  Neither the
-//     loader wave's in-flight window, nor the LDS round trip, nor the ring depth is what bounds these kernels.
+//   * Where the time goes (tools/dev/stream_probe.py, isolated launches at 336 frames of 56^2, parts switched off): the whole
+//     kernel 236-248 us forward / 227 us data gradient; without the MFMAs 156 / 167 us; without MFMAs and fragment reads
+//     147 / 149 us; that skeleton with half the weight pieces 132 / 136 us; without any steady-state DMA (barriers and the
+//     epilogue's stores alone) 57 / 25 us = the output at 5.3 TB/s.  The DMA stream costs 90-125 us whatever its size, and
+//     the MFMAs add their own 60-85 us on top instead of hiding under it.
+//   * Measured and dropped (in-step times; run-to-run spread +-4 %): (a) the seven compute waves carrying the weight stream
+//     (3 or 2 pieces of every stage each, counted vmcnt with the epilogue's stores on the same counter), producer only the
+//     patches: 174 -> 182 us forward, 218 -> 228 us data gradient; (b) additionally the patch requested by the compute waves
+//     once per tile, no producer at all (a wave's memory operations return in order, so on the producer's counter every
+//     stage's wait for its L2-resident weights also waited for the HBM patch pieces in front of them): 187 us forward,
+//     99 us the (3, 1) form (102-105); (c) the data gradient's weights through the compute waves' REGISTERS
+//     (global_load_dwordx4 behind one barrier, ds_write_b128 before the next; the producer only the patch chunks): 230 us;
+//     (d) fragments two steps ahead in the 96-byte form (three register sets): 220 us; (e) a ring of four weight stages
+//     there: 241 us.  Neither the loader wave's in-flight window, nor the ordering of its counter, nor the LDS-DMA path as
+//     such, nor the LDS round trip, nor the ring depth is what bounds these kernels; the variants are equivalent within the
+//     spread and the simplest one stays.
 //   * wave 7 is the PRODUCER: it issues every LDS-DMA of the workgroup (weight stage g + 3 and a group of pieces of the next
 //     patch chunk after barrier g + 1) and is the only wave that counts vmcnt, with compile-time batch sizes; the compute
 //     waves never wait on memory, only on the one s_barrier per stage the producer joins once the stage's bytes have landed;
