@@ -176,6 +176,9 @@ def main():
     traffic_tables(prof, "fetch_pyramid", "write_pyramid", outd, f"{tag}_pyramid_pmc_traffic",
                    f"# HBM traffic per launch from PMC counters, bench.py --workload pyramid ({tag})\n\n"
                    + note.format(cmd="bench.py --workload pyramid --steps 1 --warmup 1 --no-graph"), conv_family)
+    traffic_tables(prof, "fetch_frametransformer", "write_frametransformer", outd, f"{tag}_frametransformer_pmc_traffic",
+                   f"# HBM traffic per launch from PMC counters, bench.py --workload frametransformer ({tag})\n\n"
+                   + note.format(cmd="bench.py --workload frametransformer --steps 1 --warmup 1 --no-graph"), conv_family)
     # ---- MFMA busy
     mf = load_counters(os.path.join(prof, "mfma"))
     if mf:
