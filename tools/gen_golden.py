@@ -589,6 +589,11 @@ def main():
         vivit_lowprec_case(vit, "c2", c2, 1, SEED + 20, modes)
         vivit_lowprec_case(vit, "metric", cm, 1, SEED + 30, modes)
         vivit_lowprec_case(vit, "longclip", c5, 1, SEED + 70, modes)
+    if want("metric_b8"):
+        # the batch bench.py TIMES (B = 8 per GPU at the metric shape): same digest form, so the GPU tests hold the HIP
+        # path to the executed reference at the exact grid sizes of the headline
+        vivit_digest_case(vit, "metric_b8_digest", cm, batch=8, seed=SEED + 80)
+        vivit_lowprec_case(vit, "metric_b8", cm, 8, SEED + 80, modes=["amp_bf16", "pure_bf16", "amp_fp16", "pure_fp16"])
     if want("pyramid_full"):      # existing modes of an existing fixture are kept unless --force is given
         pyramid_digest_case("pyramid")
         pyramid_digest_case("crossmodal")
