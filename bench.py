@@ -270,14 +270,6 @@ def build_workload(args, workload, rank, comm):
     flat = FlatParameters(net, bucket_mb=args.bucket_mb, compute_dtype=cdt, comm=comm, grad_reduce_dtype=rdt)
     flat.broadcast_parameters(0)
     flat.sync_compute_copy()
-    # A/B switch (measured SLOWER, so off: vivit 5.72 -> 5.94 ms, pyramid 13.5 -> 14.07, frametransformer 20.9 -> 21.87 on one
-    # box): the optimizer step of every gradient bucket behind that bucket (and its all-reduce) while backward continues
-    # (dp.enable_overlapped_adamw: bit-identical to the one-launch step) -- an HBM-saturating kernel beside the backward GEMMs
-    # costs them more than the 0.15-0.27 ms it hides
-    if (args.overlap_optimizer and cdt != torch.float16 and torch.cuda.is_available()
-            and (comm is not None or flat.world == 1)):
-        flat.enable_overlapped_adamw(lr=5e-6, weight_decay=0.09)
-
     gen = torch.Generator().manual_seed(1130 + rank)
     if workload == "frametransformer":
         x = torch.randn(B, 13, 12, 3, 112, 112, generator=gen).cuda()     # MMX_Light_dl.py:286 batch contract
@@ -823,8 +815,6 @@ def main():
                     "single-GPU box -- the gradient exchange then goes through torch.distributed as well)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and the RCCL communicator even "
                     "with one rank (rehearses the multi-GPU code path on a single GPU)")
-    ap.add_argument("--overlap-optimizer", action="store_true", help="A/B switch (measured slower): the AdamW step per "
-                    "gradient bucket beside the backward instead of as one launch behind it")
     ap.add_argument("--no-cls-fold", action="store_true", help="A/B switch: run the last space layer's single-query attention "
                     "without folding the K / V projections into the query (functional.CLS_FOLD_MIN_ROWS)")
     ap.add_argument("--no-pair-launch", action="store_true", help="A/B switch: weight and data gradient of the launch-bound "

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvt_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 3            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)
+ABI_VERSION = 4            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_DGELU, EPI_DRELU = range(6)
 
 c_i64 = C.c_int64
@@ -72,9 +72,7 @@ class ConvDesc(C.Structure):
                [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32),
                 ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p),
                 ("residual", C.c_void_p), ("wgrad_master_layout", C.c_int32), ("wgrad_accumulate", C.c_int32),
-                ("wgrad_cout_l", C.c_int32), ("wgrad_cin_l", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("bnb_z", "bnb_mean", "bnb_invstd", "bnb_gamma", "bnb_beta", "bnb_mask", "bnb_partial")] + \
-               [("bnb_relu", C.c_int32), ("bnb_c_valid", C.c_int32)]
+                ("wgrad_cout_l", C.c_int32), ("wgrad_cin_l", C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -183,7 +181,6 @@ SIGNATURES = {
     "dvt_bn_eval_invstd": (c_int, [c_p, c_p, c_int, c_f, c_p]),
     "dvt_bn_apply_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_p]),
     "dvt_bn_bwd": (c_int, [c_p] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
-    "dvt_bn_bwd_partials": (c_int, [c_p] * 13 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p]),
     "dvt_maxpool_fwd": (c_int, [c_p, c_p, c_p, c_i64] + [c_int] * 7 + [c_p]),
     "dvt_bn_relu_maxpool_fwd": (c_int, [c_p] * 7 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_bn_bwd_pooled": (c_int, [c_p] * 11 + [c_i64] + [c_int] * 7 + [c_p]),
@@ -254,8 +251,6 @@ SIGNATURES = {
     "dvt_comm_destroy": (c_int, [c_p]),
     "dvt_adamw_step_dev": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     "dvt_adamw_step_fused": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_int, c_p]),
-    "dvt_adamw_step_range": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_int, c_p]),
-    "dvt_step_increment": (c_int, [c_p, c_p]),
 }
 
 _lib: Optional[C.CDLL] = None

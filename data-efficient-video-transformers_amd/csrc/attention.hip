@@ -1310,8 +1310,10 @@ size_t with_patches(size_t lds, int waves, AttnParams& p) {
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > 64 * 1024) {                  // (unconditional: the attribute is per device, the call is cheap)
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return dvt_fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }
   return 0;
 }
 

@@ -799,8 +799,8 @@ int dvt_attn_cls_fwd(const dvt_attn_cls_desc* q, dvt_stream_t stream) {
   const ClsParams p = cls_params(q);
   const size_t lds = cls_fwd_lds(p.N, p.H, p.d);
   DVT_DISPATCH_16BIT(q->dtype, E, {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)attn_cls_fwd_kernel<E, kRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)attn_cls_fwd_kernel<E, kRPW>, 160 * 1024);
     hipLaunchKernelGGL((attn_cls_fwd_kernel<E, kRPW>), dim3((unsigned)p.S), dim3(kThreads), lds, (hipStream_t)stream, p);
   });
   DVT_LAUNCH_CHECK("dvt_attn_cls_fwd");
@@ -813,8 +813,8 @@ int dvt_attn_cls_bwd(const dvt_attn_cls_desc* q, dvt_stream_t stream) {
   const ClsParams p = cls_params(q);
   const size_t lds = cls_bwd_lds(p.N, p.H, p.d);
   DVT_DISPATCH_16BIT(q->dtype, E, {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)attn_cls_bwd_kernel<E, kRPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)attn_cls_bwd_kernel<E, kRPW>, 160 * 1024);
     hipLaunchKernelGGL((attn_cls_bwd_kernel<E, kRPW>), dim3((unsigned)p.S), dim3(kThreads), lds, (hipStream_t)stream, p);
   });
   DVT_LAUNCH_CHECK("dvt_attn_cls_bwd");

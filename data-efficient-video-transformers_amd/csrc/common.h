@@ -43,6 +43,19 @@ static inline bool dvt_is_16bit(int dt) { return dt == DVT_BF16 || dt == DVT_F16
 static inline int64_t dvt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int dvt_num_cus();
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel PER DEVICE: one flag per (call site, device),
+// atomic (two host threads racing on a first call both set it: idempotent), the return code recorded -- the launch behind a
+// failed call fails as well and DVT_LAUNCH_CHECK reports it.
+struct DvtLdsAttr { unsigned long long done = 0ull; };
+static inline void dvt_lds_attr(DvtLdsAttr& f, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev >= 0 && ((__atomic_load_n(&f.done, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { (void)dvt_fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"); return; }
+  if (dev >= 0) __atomic_fetch_or(&f.done, 1ull << dev, __ATOMIC_RELEASE);
+}
+
 // ---------------------------------------------------------------- device: scalar conversions
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -1661,31 +1661,9 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
   return DVT_OK;
 }
 
-static int bn_bwd_impl(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean,
-                       const float* invstd, const float* gamma, const float* beta, void* dx, void* dres, float* dgamma,
-                       float* dbeta, void* workspace, int64_t rows, int C, int c_valid, int relu, int training, int accumulate,
-                       int dtype, const float* ext_part, int ext_parts, dvt_stream_t stream);
-
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
                int64_t rows, int C, int c_valid, int relu, int training, int accumulate, int dtype, dvt_stream_t stream) {
-  return bn_bwd_impl(dy, x, y, relu_mask, mean, invstd, gamma, beta, dx, dres, dgamma, dbeta, workspace, rows, C, c_valid, relu,
-                     training, accumulate, dtype, nullptr, 0, stream);
-}
-
-int dvt_bn_bwd_partials(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean,
-                        const float* invstd, const float* gamma, const float* beta, void* dx, void* dres, float* dgamma,
-                        float* dbeta, void* workspace, int64_t rows, int C, int c_valid, int relu, int training, int accumulate,
-                        int dtype, const float* partials, int nparts, dvt_stream_t stream) {
-  DVT_REQUIRE(partials && nparts > 0 && dvt_aligned16(partials), "dvt_bn_bwd_partials: partials [nparts][2][C] required");
-  return bn_bwd_impl(dy, x, y, relu_mask, mean, invstd, gamma, beta, dx, dres, dgamma, dbeta, workspace, rows, C, c_valid, relu,
-                     training, accumulate, dtype, partials, nparts, stream);
-}
-
-static int bn_bwd_impl(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean,
-                       const float* invstd, const float* gamma, const float* beta, void* dx, void* dres, float* dgamma,
-                       float* dbeta, void* workspace, int64_t rows, int C, int c_valid, int relu, int training, int accumulate,
-                       int dtype, const float* ext_part, int ext_parts, dvt_stream_t stream) {
   DVT_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && c_valid <= C,
               "dvt_bn_bwd: bad arguments");
   if (c_valid <= 0) c_valid = C;
@@ -1704,18 +1682,7 @@ static int bn_bwd_impl(const void* dy, const void* x, const void* y, const void*
   const dim3 grid_s((unsigned)dvt_cdiv(C, 256), (unsigned)parts);
   // scratch: [parts][2][C] partials, then [2][C] for this launch's (not accumulated) dgamma/dbeta
   float* part = (float*)workspace;
-  const float* fin_src = part;
-  if (ext_part) {                                      // the sums came out of the producing convolution's epilogue
-    fin_src = ext_part;
-    parts = 0;
-    if (ext_parts > 256) {                             // thousands of wave-row partials: folded to 64 rows first, as in
-      const int folds = 64;                            // dvt_bn_stats_from_partials (a finalize block is bound by what one CU pulls)
-      hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)dvt_cdiv(C, 32), (unsigned)folds), dim3(1024), 0, st, ext_part,
-                         ext_parts, C, (int)dvt_cdiv(ext_parts, folds), part);
-      fin_src = part;
-      parts = ext_parts = folds;
-    }
-  } else if (cvec) {
+  if (cvec) {
 #define DVT_BN_CS(MSRC)                                                                                                      \
   DVT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_colstats_kernel<T, 1, false, MSRC>), grid, dim3(256), 0, st, (const T*)x, \
                                                   (const T*)dy, (const T*)y, mean, invstd, rows, C, rpb, relu, vcl, part, gamma, \
@@ -1733,7 +1700,7 @@ static int bn_bwd_impl(const void* dy, const void* x, const void* y, const void*
   // keep the local dgamma/dbeta 16-byte aligned behind the partials
   float* loc = part + (((size_t)parts * 2 * C + 3) & ~(size_t)3);
   // dgamma / dbeta are published (overwritten or accumulated) by the same launch that leaves this launch's own sums in `loc`
-  bn_finalize_launch<1>(st, fin_src, ext_part ? ext_parts : parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta,
+  bn_finalize_launch<1>(st, part, parts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate, dgamma, dbeta,
                      c_valid);
   DVT_LAUNCH_CHECK("dvt_bn_bwd(finalize)");
   if (cvec) {

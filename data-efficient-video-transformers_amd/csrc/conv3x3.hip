@@ -266,12 +266,12 @@ int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial,
   const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVT_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x3_c64_kernel<bf16>, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_c64_kernel<bf16>), dim3(grid), dim3(512), lds, st, p);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x3_c64_kernel<f16>, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_c64_kernel<f16>), dim3(grid), dim3(512), lds, st, p);
   }
   DVT_LAUNCH_CHECK("dvt_conv3x3_c64");

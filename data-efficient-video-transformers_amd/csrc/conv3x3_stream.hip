@@ -451,7 +451,7 @@ struct Plan { int R, PW, SPR, lds; unsigned magic; };
 template <int CI, int CO, int NTAP>
 int plan_for(int H, int W, Plan* o) {
   typedef SC<CI, CO, NTAP> C;
-  if (W <= 0 || H <= 0 || W > 224) return 0;
+  if (W < 2 || H <= 0 || W > 224) return 0;     // (W == 1: the magic reciprocals ceil(2^32 / d) do not exist for d == 1)
   int r = 224 / W;
   if (r > H) r = H;
   if (r < 1) return 0;
@@ -495,11 +495,8 @@ int plan_t(int T, int L, Plan* o, int* S) {
 
 template <typename E, int CI, int CO, int NTAP>
 void launch(const StreamParams& p, int lds, int grid, hipStream_t st) {
-  static bool set = false;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<E, CI, CO, NTAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    set = true;
-  }
+  static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x3_stream_kernel<E, CI, CO, NTAP>, 160 * 1024);
   hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO, NTAP>), dim3(grid), dim3(512), lds, st, p);
 }
 

@@ -234,12 +234,12 @@ int cw_grid(int64_t N, int H, const CwParams& q) {
 template <typename E>
 void cw_launch(const CwParams& p, int grid, int lds, hipStream_t st) {
   if (p.zcv > 16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x3_c64_wgrad_kernel<E, 4>, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<E, 4>), dim3(grid), dim3(kNW * 64), lds, st, p);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x3_c64_wgrad_kernel<E, 1>, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<E, 1>), dim3(grid), dim3(kNW * 64), lds, st, p);
   }
 }

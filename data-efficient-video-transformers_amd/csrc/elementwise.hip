@@ -759,8 +759,7 @@ template <typename M>
 __global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                           float b1, float b2, float eps, float wd, int64_t* step_dev,
-                                                          const uint8_t* __restrict__ skip, M* __restrict__ mirror,
-                                                          int increment = 1) {
+                                                          const uint8_t* __restrict__ skip, M* __restrict__ mirror) {
   const int64_t steps = step_dev[0];
   const float t = (float)(steps + 1);
   const float bc1 = 1.0f - powf(b1, t);
@@ -812,13 +811,11 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p,
     const unsigned long long ticket = __hip_atomic_fetch_add((unsigned long long*)(step_dev + 1), 1ull, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == (unsigned long long)gridDim.x - 1) {
-      if (increment) step_dev[0] = steps + 1;          // (a launch over one RANGE of the flat buffer leaves the count alone)
+      step_dev[0] = steps + 1;
       step_dev[1] = 0;
     }
   }
 }
-
-__global__ void step_increment_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
 // ---- dropout (nn.Dropout in training mode: frame_transformer.py:22,41-44; TPN.py:92,95; vit.py:23,25,43,104)
 // Counter-based Philox4x32-10: element i draws word (i & 3) of block (offset + i / 4) under the key (seed).  No mask
@@ -1258,37 +1255,6 @@ int dvt_adamw_step_fused(float* param, const float* grad, float* exp_avg, float*
     hipLaunchKernelGGL((adamw_fused_kernel<f16>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, weight_decay, step_dev2, skip64, (f16*)mirror);
   DVT_LAUNCH_CHECK("dvt_adamw_step_fused");
-  return DVT_OK;
-}
-
-int dvt_adamw_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
-                         const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream) {
-  if (n == 0) return DVT_OK;
-  DVT_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev2 && n > 0, "dvt_adamw_step_range: bad arguments");
-  DVT_REQUIRE(dvt_aligned16(param) && dvt_aligned16(grad) && dvt_aligned16(exp_avg) && dvt_aligned16(exp_avg_sq),
-              "dvt_adamw_step_range: buffers must be 16-byte aligned");
-  DVT_REQUIRE(!mirror || (dvt_is_16bit(mirror_dtype) && ((uintptr_t)mirror & 7) == 0),
-              "dvt_adamw_step_range: mirror must be bf16 / f16 and 8-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(grid_for((n >> 2) + 1)), block(256);
-  if (!mirror)
-    hipLaunchKernelGGL((adamw_fused_kernel<float>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, step_dev2, skip64, (float*)nullptr, 0);
-  else if (mirror_dtype == DVT_BF16)
-    hipLaunchKernelGGL((adamw_fused_kernel<bf16>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, step_dev2, skip64, (bf16*)mirror, 0);
-  else
-    hipLaunchKernelGGL((adamw_fused_kernel<f16>), grid, block, 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, step_dev2, skip64, (f16*)mirror, 0);
-  DVT_LAUNCH_CHECK("dvt_adamw_step_range");
-  return DVT_OK;
-}
-
-int dvt_step_increment(int64_t* step_dev2, dvt_stream_t stream) {
-  DVT_REQUIRE(step_dev2, "dvt_step_increment: null counter");
-  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev2);
-  DVT_LAUNCH_CHECK("dvt_step_increment");
   return DVT_OK;
 }
 

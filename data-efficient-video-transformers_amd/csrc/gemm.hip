@@ -936,14 +936,11 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(NTHREADS);
     const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
     DVT_DISPATCH_16BIT(d->in_dtype, E, {
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        attr_set = true;
-      }
+      static DvtLdsAttr a_tt, a_tf, a_ft, a_ff;
+      dvt_lds_attr(a_tt, (const void*)gemm_mfma_kernel<E, true, true>, kSmemBytes);
+      dvt_lds_attr(a_tf, (const void*)gemm_mfma_kernel<E, true, false>, kSmemBytes);
+      dvt_lds_attr(a_ft, (const void*)gemm_mfma_kernel<E, false, true>, kSmemBytes);
+      dvt_lds_attr(a_ff, (const void*)gemm_mfma_kernel<E, false, false>, kSmemBytes);
       if (ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, true, true>), grid, block, kSmemBytes, st, p);
       else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, true, false>), grid, block, kSmemBytes, st, p);
       else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<E, false, true>), grid, block, kSmemBytes, st, p);
@@ -1108,19 +1105,6 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(!(d->residual && d->stats_partial), "dvt_conv2d_implicit: residual and stats_partial are exclusive");
   DVT_REQUIRE(dvt_aligned16(d->residual), "dvt_conv2d_implicit: residual must be 16-byte aligned");
   p.bn_partial = d->stats_partial;
-  if (d->bnb_z) {              // the BatchNorm in front of the layer: its backward column sums come out of this epilogue
-    DVT_REQUIRE(!d->stats_partial && d->bnb_partial && d->bnb_mean && d->bnb_invstd && d->bnb_gamma &&
-                    (!d->bnb_relu || d->bnb_mask || d->bnb_beta) && d->bnb_c_valid <= d->Cout && dvt_aligned16(d->bnb_z) &&
-                    dvt_aligned16(d->bnb_partial),
-                "dvt_conv2d_implicit: bnb_z needs bnb_partial, mean, invstd, gamma (and the mask bytes or beta under ReLU), "
-                "16-byte aligned, and excludes stats_partial");
-    if (d->residual && d->bnb_relu && !d->bnb_mask)
-      DVT_UNSUPPORTED("dvt_conv2d_implicit: bnb_z with a residual needs the ReLU mask bytes (bnb_mask)");
-    p.bn_partial = d->bnb_partial;
-    p.bnb_z = d->bnb_z; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma;
-    p.bnb_beta = d->bnb_beta; p.bnb_mask = (const unsigned char*)d->bnb_mask; p.bnb_relu = d->bnb_relu;
-    p.bnb_cv = d->bnb_c_valid > 0 ? d->bnb_c_valid : d->Cout;
-  }
   if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
     const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
     int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);

@@ -296,7 +296,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 //      4 x 4 unrolled passes was ~19k ISA lines per kernel and thrashed the I-cache).
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_SLAB = 2 };
 
-template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false, bool BNB = false>
+template <typename E, bool A_KMAJOR, bool B_KMAJOR, int CFG, int EPI, int OUT, bool A_CONV = false>
 __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void gemm_dma_kernel(const GemmParams p) {
   // A_CONV: the A operand is gathered from an NHWC map (k-major: forward / data gradient; mn-major: weight gradient)
   typedef Cfg<CFG> C;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
   constexpr int NPS = (WROWS + 31) / 32;               // passes of 32 rows (the last one half empty when WROWS = 112)
   V8 rs[kNeedLd ? NPS : 1][4];
-  if (kNeedLd && !BNB) {
+  if (kNeedLd) {
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
@@ -571,41 +571,10 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       }
   }
   // fused BatchNorm statistics (convolution outputs): per-lane sums of its 8 columns over its rows of the tile.
-  // Forward launches: {sum y, sum y^2} of the output (the BatchNorm behind the convolution).  Data-gradient launches
-  // (p.bnb_z): the output IS the gradient dy arriving at the BatchNorm (+ ReLU) in FRONT of the layer, and the sums are that
-  // BatchNorm's backward column sums {sum dz, sum dz * xhat} -- its separate statistics pass over dy and z is not launched.
-  // dy enters as stored (rounded to the element type), the mask as the BatchNorm's own kernels decide it.
-  // (BNB is a template parameter: its registers -- the z rows, the per-column statistics -- must not cost the ordinary
-  // instantiations anything; the residual + BNB form reads the mask bytes only, its block outputs always have them)
-  constexpr bool kCanBn = OUT == OUT_BF16 && (EPI == DVT_EPI_NONE || (EPI == DVT_EPI_RESIDUAL && BNB));
-  constexpr bool kRecompute = EPI == DVT_EPI_NONE;        // ReLU mask recomputed from z when there are no mask bytes
+  // {sum y, sum y^2} of the output as the BatchNorm behind the convolution needs them.
+  constexpr bool kCanBn = OUT == OUT_BF16 && EPI == DVT_EPI_NONE;
   const bool do_bn = kCanBn && p.bn_partial != nullptr;
-  constexpr bool bnb = BNB && kCanBn;
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bsq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float bmu[8], bis[8], bsc[kRecompute ? 8 : 1], bsh[kRecompute ? 8 : 1];
-  V8 znext[4];
-  auto z_request = [&](int ps) {                     // the four z rows of pass ps (clamped rows: loaded, never used)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
-      m = m < p.M ? m : p.M - 1;
-      znext[j] = *reinterpret_cast<const V8*>((const E*)p.bnb_z + (int64_t)m * p.N + (n_ok ? n : 0));
-    }
-  };
-  if (kCanBn && bnb) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int nn = n_ok ? n + k : 0;
-      const float g = nn < p.bnb_cv ? p.bnb_gamma[nn] : 0.f, b = (nn < p.bnb_cv && p.bnb_beta) ? p.bnb_beta[nn] : 0.f;
-      bmu[k] = p.bnb_mean[nn];
-      bis[k] = p.bnb_invstd[nn];
-      if (kRecompute) {
-        bsc[k] = bis[k] * g;                          // the folded affine of the BatchNorm kernels (BnAffine): y = z * s + t
-        bsh[k] = fmaf(-bmu[k], bsc[k], b);
-      }
-    }
-    z_request(0);
-  }
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
 #pragma unroll
@@ -616,20 +585,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
           *reinterpret_cast<f32x4*>(es + (tt * 16 + li) * kEpiStride + u * 16 + 4 * g) = acc[u][ps * 2 + tt] * p.alpha;
     wave_lds_fence();
     float v[4][8];
-    V8 cur[4], zcur[4];
-    if (kCanBn && bnb) {                                 // this pass's z rows have been requested a pass ago; the next
-#pragma unroll                                           // pass's are requested before this pass's stores
-      for (int j = 0; j < 4; ++j) zcur[j] = znext[j];
-      if (ps + 1 < NPS) z_request(ps + 1);
-      if (kNeedLd) {                                     // (residual rows of this pass: requested here, not all up front)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
-          m = m < p.M ? m : p.M - 1;
-          rs[kNeedLd ? ps : 0][j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + (n_ok ? n : 0));
-        }
-      }
-    }
+    V8 cur[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = (lane >> 3) + 8 * j;
@@ -664,25 +620,11 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             const float ld = (float)cur[j][k];
             v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
-          if (kCanBn && do_bn && !bnb) {
+          if (kCanBn && do_bn) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               bsum[k] += v[j][k];
               bsq[k] = fmaf(v[j][k], v[j][k], bsq[k]);
-            }
-          }
-          if (kCanBn && bnb) {
-            unsigned mb = 0xFFu;
-            if (p.bnb_relu && p.bnb_mask) mb = p.bnb_mask[(int64_t)m * (p.N >> 3) + (n >> 3)];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float zf = (float)zcur[j][k];
-              const float dyv = (float)(E)v[j][k];
-              bool on = true;
-              if (p.bnb_relu) on = (p.bnb_mask || !kRecompute) ? ((mb >> k) & 1u) != 0u : fmaf(zf, bsc[kRecompute ? k : 0], bsh[kRecompute ? k : 0]) > 0.f;
-              const float dzv = on ? dyv : 0.f;
-              bsum[k] += dzv;
-              bsq[k] = fmaf(dzv, (zf - bmu[k]) * bis[k], bsq[k]);
             }
           }
           if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
@@ -722,12 +664,8 @@ template <int CFG> constexpr int smem_bytes() {
 
 template <typename E, bool AK, bool BK, int CFG, int EPI, int OUT>
 int launch_one(const GemmParams& p, dim3 grid, dim3 block, int smem_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, AK, BK, CFG, EPI, OUT>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_set = true;
-  }
+  static DvtLdsAttr attr_set;
+    dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, AK, BK, CFG, EPI, OUT>, smem_bytes);
   hipLaunchKernelGGL((gemm_dma_kernel<E, AK, BK, CFG, EPI, OUT>), grid, block, smem_bytes, st, p);
   DVT_LAUNCH_CHECK("dvt_gemm(dma)");
   return DVT_OK;
@@ -773,45 +711,15 @@ int launch_conv(const GemmParams& pin, hipStream_t st) {
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n + p.pig_blocks), 1, 1), block(C::NW * 64);   // + a carried split-K reduce
-  if (p.bnb_z) {                                    // data gradient that also leaves the BatchNorm-backward sums of its output
-    if (p.epilogue == DVT_EPI_RESIDUAL) {
-      if (!p.bnb_mask && p.bnb_relu) return DVT_ERR_UNSUPPORTED;    // (the residual form reads mask bytes only)
-      static bool attr_set_rb = false;
-      if (!attr_set_rb) {
-        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        attr_set_rb = true;
-      }
-      hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true, true>), grid, block, kSmem, st, p);
-    } else {
-      static bool attr_set_b = false;
-      if (!attr_set_b) {
-        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-        attr_set_b = true;
-      }
-      hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true, true>), grid, block, kSmem, st, p);
-    }
-    DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma, bn backward sums)");
-    return DVT_OK;
-  }
   if (p.epilogue == DVT_EPI_RESIDUAL) {             // data gradient joined by the shortcut's gradient (dvt_conv_desc.residual)
-    static bool attr_set_r = false;
-    if (!attr_set_r) {
-      (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-      attr_set_r = true;
-    }
+    static DvtLdsAttr attr_set_r;
+    dvt_lds_attr(attr_set_r, (const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true>, kSmem);
     hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_RESIDUAL, OUT_BF16, true>), grid, block, kSmem, st, p);
     DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma, residual)");
     return DVT_OK;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_set = true;
-  }
+  static DvtLdsAttr attr_set;
+    dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>, kSmem);
   hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_BF16, true>), grid, block, kSmem, st, p);
   DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma)");
   return DVT_OK;
@@ -826,12 +734,8 @@ int launch_conv_wgrad(const GemmParams& pin, int split, hipStream_t st) {
   const int tiles_m = (int)dvt_cdiv(p.M, C::TM);
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_set = true;
-  }
+  static DvtLdsAttr attr_set;
+    dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB, true>, kSmem);
   hipLaunchKernelGGL((gemm_dma_kernel<E, false, false, CFG, DVT_EPI_NONE, OUT_SLAB, true>), grid, block, kSmem, st, p);
   DVT_LAUNCH_CHECK("dvt_conv2d_implicit_wgrad(dma)");
   return DVT_OK;

@@ -24,16 +24,6 @@ struct GemmParams {
   float* colsum_slab;
   int accumulate_colsum;   // gemm_small.hip only: colsum_slab is the final bias-gradient vector; += when set
   float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
-  // bnb_z != nullptr (with bn_partial; epilogue none / residual): C is the gradient dy that arrives at a BatchNorm (+ ReLU)
-  // whose pre-normalisation input is bnb_z [M, N]; the partial sums are then those of that BatchNorm's BACKWARD --
-  // {sum dz, sum dz * xhat} with dz = dy under the ReLU mask (mask bytes, or recomputed from z) -- instead of {sum, sum^2}
-  const void* bnb_z;
-  const float* bnb_mean;
-  const float* bnb_invstd;
-  const float* bnb_gamma;
-  const float* bnb_beta;
-  const unsigned char* bnb_mask;
-  int bnb_relu, bnb_cv;
   // a split-K reduce of an EARLIER launch carried in `pig_blocks` extra workgroups at the end of this grid (gemm256.hip)
   int pig_blocks;
   dvt_splitk_pending pig;

@@ -287,11 +287,8 @@ int launch_small_pair(const GemmParams& pw_in, const GemmParams& pd_in, hipStrea
   GemmParams pw = pw_in, pd = pd_in;
   pw.tiles_n = (int)dvt_cdiv(pw.N, STN);
   pd.tiles_n = (int)dvt_cdiv(pd.N, STN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_small_pair_kernel<E, TM2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_set = true;
-  }
+  static DvtLdsAttr attr_set;
+    dvt_lds_attr(attr_set, (const void*)gemm_small_pair_kernel<E, TM2>, kSmem);
   const int nw = (int)(dvt_cdiv(pw.M, 64) * pw.tiles_n), nd = (int)(dvt_cdiv(pd.M, TM2) * pd.tiles_n);
   hipLaunchKernelGGL((gemm_small_pair_kernel<E, TM2>), dim3((unsigned)(nw + nd)), dim3(256), kSmem, st, pw, pd, nw);
   DVT_LAUNCH_CHECK("dvt_gemm_pair(small)");
@@ -304,11 +301,8 @@ int launch_small(const GemmParams& pin, hipStream_t st) {
   static_assert(kSmem <= 160 * 1024, "LDS budget");
   GemmParams p = pin;
   p.tiles_n = (int)dvt_cdiv(p.N, STN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_small_kernel<E, AK, BK, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_set = true;
-  }
+  static DvtLdsAttr attr_set;
+    dvt_lds_attr(attr_set, (const void*)gemm_small_kernel<E, AK, BK, TM>, kSmem);
   const dim3 grid((unsigned)(dvt_cdiv(p.M, TM) * p.tiles_n)), block(256);
   hipLaunchKernelGGL((gemm_small_kernel<E, AK, BK, TM>), grid, block, kSmem, st, p);
   DVT_LAUNCH_CHECK("dvt_gemm(small)");

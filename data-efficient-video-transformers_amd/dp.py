@@ -268,10 +268,8 @@ class FlatParameters:
         self.skip_mask = None
         self._skip_sig = ()
         self._packed = {}              # (parameter index, form, padded shape, dtype) -> (packed tensor, pack entry)
+        self._packed_version = {}      # same key -> the parameter's _version when its packed form was last refreshed
         self._packed_valid = False
-        self._ovl = None               # hyper-parameters of the overlapped optimizer step (enable_overlapped_adamw)
-        self._ovl_stream = None
-        self._ovl_updated = []
 
     # ------------------------------------------------------------------ compute copy
     def _after_step(self) -> None:
@@ -291,16 +289,29 @@ class FlatParameters:
         self.compute_valid = False
         self._packed_valid = False
 
-    def packed_weight(self, key, make):
+    def invalidate_packed(self) -> None:
+        """The packed convolution weights are stale (the next use repacks all of them in one launch)."""
+        self._packed_valid = False
+
+    def packed_weight(self, key, make, version: int = 0):
         """GEMM-operand forms of convolution weights (functional._packed_weight): kept here per (parameter, form) and ALL
         refreshed by ONE launch at their first use after the weights changed (an optimizer step, a broadcast, a loaded
-        checkpoint) -- a training step then packs its convolution weights once instead of twice per layer."""
+        checkpoint) -- a training step then packs its convolution weights once instead of twice per layer.
+        ``version``: the parameter's autograd version counter; an in-place edit the store did not make itself
+        (``nn.Module.load_state_dict``, ``p.copy_`` / ``p.mul_`` under no_grad, a foreign torch optimizer) bumps it and
+        invalidates every packed form.  Not seen: writes through ``p.data`` (a separate counter) and raw-pointer kernels
+        -- call ``invalidate_compute_copy()`` after those.  A hipGraph that captures forward + backward only must begin
+        with the cache invalid (``graph.capture_step`` does that) so that the repack launch is part of the graph."""
         e = self._packed.get(key)
         if e is None:
             dst, entry = make()
             self._packed[key] = (dst, entry)
+            self._packed_version[key] = version
             ops.conv_weight_pack_group([entry])
             return dst
+        if self._packed_version.get(key) != version:
+            self._packed_version[key] = version
+            self._packed_valid = False
         if not self._packed_valid:
             ops.conv_weight_pack_group([en for _, en in self._packed.values()])
             self._packed_valid = True
@@ -316,7 +327,6 @@ class FlatParameters:
         self._pending = list(self.bucket_size)
         self._launched = [False] * len(self.bucket_ranges)
         self._handles = []
-        self._ovl_updated = [False] * len(self.bucket_ranges)
 
     def _launch_bucket(self, b: int) -> None:
         if self._launched[b] or self.defer_exchange:
@@ -325,66 +335,6 @@ class FlatParameters:
         if self._exchanging():
             lo, hi = self.bucket_ranges[b]
             self._handles.append(self._all_reduce(self.grad[lo:hi], None if self.grad16 is None else self.grad16[lo:hi]))
-        if self._ovl is not None:
-            self._overlapped_update(b)
-
-    # ------------------------------------------------------------------ optimizer step overlapped with backward
-    def enable_overlapped_adamw(self, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-        """From now on a gradient bucket's AdamW update (and the 16-bit mirror of its new weights) is enqueued the moment the
-        bucket is final -- behind its all-reduce, on the exchange stream -- instead of in one launch behind the whole
-        backward: the early layers' backward GEMMs leave HBM bandwidth and wave slots unused, and the update of the layers
-        that are already done runs beside them.  ``adamw_step`` (same hyper-parameters) then only closes the step.
-        Same arithmetic per element as the one-launch step (same kernel on sub-ranges: bit-identical results).  Needs every
-        parameter to be written at most once per step (a late write into a bucket that has already been updated raises) and
-        is not available under dynamic loss scaling (the step must know found_inf over ALL gradients before any update)."""
-        if getattr(self, "scaler", None) is not None:
-            raise RuntimeError("overlapped AdamW is not available under dynamic loss scaling")
-        if self.data.device.type != "cuda":
-            raise RuntimeError("overlapped AdamW needs the flat buffers on the GPU")
-        if self.comm is None and self.world > 1:
-            raise RuntimeError("overlapped AdamW at world > 1 needs the RCCL communicator (comm=)")
-        if self.defer_exchange:
-            raise RuntimeError("overlapped AdamW and defer_exchange exclude each other")
-        if self.exp_avg is None:
-            self.init_optimizer_state()
-        self._ovl = dict(lr=float(lr), wd=float(weight_decay), b1=float(betas[0]), b2=float(betas[1]), eps=float(eps))
-        if self.comm is None and self._ovl_stream is None:
-            self._ovl_stream = torch.cuda.Stream()
-        self._ovl_updated = [False] * len(self.bucket_ranges)
-
-    def disable_overlapped_adamw(self) -> None:
-        self._ovl = None
-
-    def _side_stream(self):
-        return self.comm.stream if self.comm is not None else self._ovl_stream
-
-    def _overlapped_update(self, b: int) -> None:
-        """AdamW on bucket b's range, on the side stream, behind the bucket's all-reduce (same stream) or -- without an
-        exchange -- behind everything enqueued so far on the compute stream."""
-        if self._ovl_updated[b]:
-            return
-        self._ovl_updated[b] = True
-        lo, hi = self.bucket_ranges[b]
-        side = self._side_stream()
-        if not self._exchanging():                       # (the all-reduce already forked the side stream otherwise)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            side.wait_event(ev)
-        o = self._ovl
-        # a bucket that completed DURING backward had every parameter written: nothing to skip whatever last step's mask says
-        skip = None if (self._pending[b] == 0 or self.skip_mask is None) else self.skip_mask[lo // _ALIGN:]
-        mirror = None if self.compute is None else self.compute[lo:hi]
-        lib = L.load()
-        L.check(lib.dvt_adamw_step_range(self.data[lo:hi].data_ptr(), self.grad[lo:hi].data_ptr(),
-                                         self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, o["lr"],
-                                         o["b1"], o["b2"], o["eps"], o["wd"], self.step_dev.data_ptr(),
-                                         None if skip is None else skip.data_ptr(),
-                                         None if mirror is None else mirror.data_ptr(),
-                                         0 if mirror is None else ops._DT[mirror.dtype], side.cuda_stream),
-                "dvt_adamw_step_range")
-        done = torch.cuda.Event()
-        done.record(side)
-        self._handles.append(_Enqueued(done))
 
     def _exchanging(self) -> bool:
         """With a communicator the collective also runs at world 1 (RCCL then copies in place): the single-rank rehearsal
@@ -430,19 +380,8 @@ class FlatParameters:
                 self.exchange_all()
             return
         late = [s for s in self.sinks if s.late_written]
-        if late and self._ovl is not None:
-            raise RuntimeError("a parameter was written again after its bucket had been exchanged and UPDATED: the overlapped "
-                               "optimizer step needs every parameter to be written at most once per step "
-                               "(disable_overlapped_adamw)")
         for b in range(len(self.bucket_ranges)):
             self._launch_bucket(b)
-        if self._ovl is not None:                        # all ranges are enqueued: the step counter advances behind them
-            side = self._side_stream()
-            L.check(L.load().dvt_step_increment(self.step_dev.data_ptr(), side.cuda_stream), "dvt_step_increment")
-            done = torch.cuda.Event()
-            done.record(side)
-            self._handles.append(_Enqueued(done))
-            self._ovl_closed = True
         late_handles = [self._all_reduce(s._late) for s in late]
         for h in self._handles + late_handles:
             h.wait()
@@ -502,19 +441,6 @@ class FlatParameters:
         if self.exp_avg is None:
             self.init_optimizer_state()
         self.step_count += 1
-        if self._ovl is not None:
-            o = self._ovl
-            if (o["lr"], o["wd"], o["b1"], o["b2"], o["eps"]) != (float(lr), float(weight_decay), float(betas[0]),
-                                                                  float(betas[1]), float(eps)):
-                raise ValueError("adamw_step: hyper-parameters differ from enable_overlapped_adamw's")
-            if not getattr(self, "_ovl_closed", False) or not all(self._ovl_updated):
-                raise RuntimeError("overlapped AdamW: finish_backward() must run before adamw_step()")
-            self._ovl_closed = False                     # (the updates ran behind their buckets; nothing left to launch)
-            if self.compute is not None:
-                self.compute_valid = True
-            self._packed_valid = False
-            self._after_step()
-            return
         if getattr(self, "scaler", None) is not None:
             ops.adamw_step_scaled_(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.scale_dev,
                                    self.found_inf, self.good_steps, self.loss_grad, lr=lr, beta1=betas[0],

@@ -128,7 +128,6 @@ def ln_flush(end_of_step: bool = False):
     _ln_pending_sinks.clear()
     if end_of_step:
         _lp_hand.clear()
-        bn_fuse_clear()
 
 
 def _ln_bwd(dy, x, g, mean, rstd, sg, sb, **kw):
@@ -169,17 +168,26 @@ def _emit_into(sink, t: Tensor):
 # residual add in the GEMM epilogue), and their gradients likewise.  A block's backward needs the incoming fp32 gradient as a
 # 16-bit GEMM operand as well: the LayerNorm backward that produced it wrote that copy in the same pass and leaves it here,
 # keyed by the gradient's address (a miss -- autograd handed a different tensor on -- costs one cast launch, not correctness).
+# An entry HOLDS the fp32 tensor (so the caching allocator cannot hand its address to another gradient while the entry lives)
+# and its version counter (an in-place change of the fp32 values after the copy was made is a miss); entries nobody took
+# (the first temporal block's, whose consumer is not a block) are dropped at the start of the next forward (`lp_clear`) and in
+# `ln_flush(end_of_step=True)`.
 _lp_hand = {}
 
 
+def lp_clear() -> None:
+    _lp_hand.clear()
+
+
 def _lp_put(t32: Tensor, lp: Tensor) -> None:
-    _lp_hand[t32.data_ptr()] = (tuple(t32.shape), lp)
+    _lp_hand[t32.data_ptr()] = (t32, t32._version, lp)
 
 
 def _lp_take(t32: Tensor, T: torch.dtype) -> Tensor:
     e = _lp_hand.pop(t32.data_ptr(), None)
-    if e is not None and e[0] == tuple(t32.shape) and e[1].dtype == T:
-        return e[1]
+    if (e is not None and e[0].shape == t32.shape and e[0].stride() == t32.stride() and e[0].dtype == t32.dtype
+            and t32._version == e[1] and e[2].dtype == T):
+        return e[2]
     return ops.cast(t32, T)
 
 
@@ -1299,31 +1307,12 @@ def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: i
         dst, entry = make()
         ops.conv_weight_pack_group([entry])
         return dst
-    return sink.owner.packed_weight((sink.index, kind, cout_p, cin_p, ld, dtype), make)
+    return sink.owner.packed_weight((sink.index, kind, cout_p, cin_p, ld, dtype), make, w._version)
 
 
-# ---- BatchNorm-backward column sums out of the data-gradient convolution that produces dy (dvt_conv_desc.bnb_*).
-# Two hand-offs between the backward passes of neighbouring layers, both keyed by a tensor's address and both holding the
-# tensor itself (so the address cannot be recycled while the entry lives, and autograd cannot accumulate a second gradient
-# path into the buffer in place -- a gradient with another contributor arrives as a NEW tensor and simply misses):
-#   _bn_front[y.data_ptr()]  layer L's forward: what the producer of dy needs to know about L's BatchNorm;
-#   _bn_hand[dx.data_ptr()]  layer L + 1's backward: the sums it left for L's BatchNorm backward.
-# Entries are consumed (popped) by the backward passes; `bn_fuse_clear` (end of a step) drops what a pass left behind.
-# OFF by default: measured neutral (same-box A/B, 12 steps x 2: pyramid 14.168 -> 14.172-14.202 ms, frametransformer 21.35 ->
-# 21.24 ms).  A fused launch's epilogue grows by what the statistics pass cost -- +40-53 us per 256 x 128 launch against
-# 30-45 us of bn_colstats saved: the z rows arrive in the un-overlapped epilogue at half the speed of a streaming kernel.
-BN_BWD_FUSE = os.environ.get("DVT_BN_BWD_FUSE", "0") != "0"
 # weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
 HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
 HALO_WGRAD_COUT = (64, 144) if os.environ.get("DVT_HALO_WGRAD_WIDE", "1") != "0" else (64,)
-_bn_front = {}
-_bn_hand = {}
-
-
-def bn_fuse_clear() -> None:
-    _bn_front.clear()
-    _bn_hand.clear()
-
 
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
@@ -1503,12 +1492,6 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.w4 = w4.detach() if (implicit and pair is not None) else None
         ctx.wg_implicit = wg_implicit
         ctx.logical = (Cout_l, Cin_l, padded)
-        ctx.y_ptr = 0
-        if (BN_BWD_FUSE and any(ctx.needs_input_grad) and not pooled and dtype in (torch.bfloat16, torch.float16)
-                and Cout % 8 == 0 and z.dtype == dtype and (not relu or rmask is not None or residual is None)):
-            ctx.y_ptr = y.data_ptr()
-            _bn_front[ctx.y_ptr] = dict(y=y, z=z, mean=mean, invstd=invstd, gamma=g32, beta=b32, mask=rmask, relu=relu,
-                                        c_valid=cval, rows=z.shape[0], C=Cout)
         if fork is None:
             return y
         if nchw or stem8:
@@ -1524,14 +1507,6 @@ class _ConvBnAct(torch.autograd.Function):
         N, Cin, H, W, k, stride, pad, nchw = geom
         Cout_l, Cin_l, padded = ctx.logical
         sw, sg, sb = ctx.sinks
-        # the column sums of this BatchNorm's backward, if the data-gradient convolution that wrote dy left them
-        hand = _bn_hand.pop(dy.data_ptr(), None)
-        if ctx.y_ptr:
-            _bn_front.pop(ctx.y_ptr, None)
-        partials = None
-        if (hand is not None and pidx is None and hand[0].data_ptr() == dy.data_ptr() and hand[0].shape == dy.shape
-                and dy.dtype == z.dtype and dy.is_contiguous() and tuple(dy.shape) == tuple(z.shape)):
-            partials = (hand[1], hand[2])
         dy = _as(dy.contiguous(), z.dtype)
         Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
         Wo -= ctx.trim
@@ -1542,8 +1517,7 @@ class _ConvBnAct(torch.autograd.Function):
             if pidx is not None:       # dy is the pooled gradient
                 dz_, dg_, db_ = ops.bn_bwd_pooled(dy, pidx, z, mean, invstd, g32, b32, N, Ho, Wo, relu, training, **kw)
                 return dz_, None, dg_, db_
-            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, c_valid=cval,
-                              partials=partials, **kw)
+            return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, c_valid=cval, **kw)
 
         if sg is not None and sb is not None and sg.fresh != sb.fresh:
             dz, dres, dgam, dbet = bn_backward()
@@ -1655,21 +1629,8 @@ class _ConvBnAct(torch.autograd.Function):
                     and ops.conv3x1_stream_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
                 dx = ops.conv3x1_stream(dz, wd, N, Ho, Wo, Cout, Cin)      # temporal half of layer 1's Conv2Plus1D: 64 -> 144
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
-                # this launch writes the COMPLETE gradient of the layer's input when the shortcut (if any) joins in its
-                # epilogue: then it can also leave the backward column sums of the BatchNorm that produced that input
-                will_join = (not joined[0]) and ctx.fork == "alias"
-                front = _bn_front.get(xc.data_ptr()) if (BN_BWD_FUSE and xc is not None and (joined[0] or will_join)) else None
-                if front is not None and not (front["rows"] == N * H * W and front["C"] == Cin and front["z"].dtype == dz.dtype
-                                              and front["y"].data_ptr() == xc.data_ptr()
-                                              and not (will_join and front["relu"] and front["mask"] is None)):
-                    front = None
-                r = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
-                                        residual=join_alias(), bnb=front)   # [N*H*W, Cin], no dcol / col2im
-                if front is not None:
-                    dx, part, parts = r
-                    _bn_hand[dx.data_ptr()] = (dx, part, parts)
-                else:
-                    dx = r
+                dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
+                                         residual=join_alias())   # [N*H*W, Cin], no dcol / col2im
         if ctx.x_needs and dx is None and (nchw or ctx.geom0 is not None) and ctx.dx_frames:
             if ctx.geom0 is not None:            # implicit stem: the frames' own geometry and the plain [Cout, taps * Cin] pack
                 N0, C0, H0, W0, k0, s0, p0 = ctx.geom0

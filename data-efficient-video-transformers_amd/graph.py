@@ -23,10 +23,12 @@ from typing import Callable, Tuple
 import torch
 
 
-def capture_step(step_fn: Callable[[], torch.Tensor], warmup: int = 3) -> Tuple[Callable[[], None], torch.Tensor]:
+def capture_step(step_fn: Callable[[], torch.Tensor], warmup: int = 3, flat=None) -> Tuple[Callable[[], None], torch.Tensor]:
     """Returns (replay, static_output).  ``replay()`` re-runs the captured step;
     ``static_output`` is the tensor returned by ``step_fn`` during capture (its
-    storage is overwritten by every replay)."""
+    storage is overwritten by every replay).  ``flat`` (a ``dp.FlatParameters``): its cached packed convolution
+    weights are marked stale before the capture, so the one repack launch per step is recorded in the graph even when
+    ``step_fn`` does not contain the optimizer step that normally invalidates them."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -34,6 +36,8 @@ def capture_step(step_fn: Callable[[], torch.Tensor], warmup: int = 3) -> Tuple[
             step_fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    if flat is not None:
+        flat.invalidate_packed()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = step_fn()
@@ -41,7 +45,7 @@ def capture_step(step_fn: Callable[[], torch.Tensor], warmup: int = 3) -> Tuple[
 
 
 def capture_step_segments(fwd_bwd_fn: Callable[[], torch.Tensor], exchange_fn: Callable[[], None],
-                          update_fn: Callable[[], None], warmup: int = 3) -> Tuple[Callable[[], None], torch.Tensor]:
+                          update_fn: Callable[[], None], warmup: int = 3, flat=None) -> Tuple[Callable[[], None], torch.Tensor]:
     """Two graphs around an eagerly launched exchange:  replay() = graph(fwd_bwd) ; exchange_fn() ; graph(update).
     ``fwd_bwd_fn`` must leave the gradient exchange to ``exchange_fn`` (``FlatParameters.finish_backward(exchange=False)``
     then ``FlatParameters.exchange_all()``)."""
@@ -54,6 +58,8 @@ def capture_step_segments(fwd_bwd_fn: Callable[[], torch.Tensor], exchange_fn: C
             update_fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    if flat is not None:
+        flat.invalidate_packed()
     g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(g1):
         out = fwd_bwd_fn()

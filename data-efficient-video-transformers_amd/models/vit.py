@@ -265,6 +265,7 @@ class ViViT(nn.Module):
             raise ValueError(f"clip has {t} frames but pos_embedding was built for {self.num_frames} "
                              "(vit.py:94,115 broadcast)")
         T = self.compute_dtype
+        F.lp_clear()            # 16-bit gradient copies a previous step's backward left untaken (functional._lp_hand)
         n = (x.shape[3] // self.patch_size) * (x.shape[4] // self.patch_size)
         pe = self.to_patch_embedding[1]
         emb = F.patch_embed(x, pe.weight, pe.bias, self.patch_size, T)              # vit.py:110

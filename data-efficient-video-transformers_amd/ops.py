@@ -1385,13 +1385,10 @@ def conv3x3_c64_wgrad(x: Tensor, dz: Tensor, N: int, H: int, W: int, master: Ten
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                    want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None, bnb=None):
+                    want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
     want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
-    epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials).
-    bnb (data-gradient launches): dict(z, mean, invstd, gamma, beta, mask, relu, c_valid) of the BatchNorm in FRONT of the
-    layer -- the output is the gradient arriving at it; also returns (partial, parts) with that BatchNorm's backward column
-    sums for ``bn_bwd(..., partials=)`` (dvt_conv_desc.bnb_*)."""
+    epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
     _need_cuda(x, wp)
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     Wo -= trim_w                                  # columns dropped at the right edge (dvt_conv_desc.trim_w)
@@ -1408,24 +1405,13 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
     nb = (x.numel() + wp.numel() + y.numel() * (2 if residual is not None else 1)) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
-    if bnb is not None:
-        assert not want_stats
-        z = bnb["z"]
-        assert z.is_contiguous() and z.shape == y.shape and z.dtype == x.dtype
-        parts = int(lib.dvt_conv2d_implicit_stats_parts(C.byref(d)))
-        # (a tensor of its own, not a workspace slot: its reader is a later autograd node)
-        partial = torch.empty((int(lib.dvt_conv2d_implicit_stats_bytes(C.byref(d))) // 4,), dtype=torch.float32, device=x.device)
-        d.bnb_z, d.bnb_mean, d.bnb_invstd = z.data_ptr(), bnb["mean"].data_ptr(), bnb["invstd"].data_ptr()
-        d.bnb_gamma, d.bnb_beta, d.bnb_mask = bnb["gamma"].data_ptr(), _p(bnb.get("beta")), _p(bnb.get("mask"))
-        d.bnb_relu, d.bnb_c_valid, d.bnb_partial = int(bool(bnb["relu"])), int(bnb.get("c_valid") or 0), partial.data_ptr()
-        nb += z.numel() * z.element_size()
     if carry is not None and carry.valid:             # the layer's weight-gradient reduce rides in this launch's grid tail
         d.carry = C.addressof(carry)
     with _timed(("conv", "implicit", N * Ho * Wo, Cout, kh * kw * Cc, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
     if carry is not None:
         carry.valid = 0
-    return (y, partial, parts) if (want_stats or bnb is not None) else y
+    return (y, partial, parts) if want_stats else y
 
 
 def bn_stats_from_partials(partial: Tensor, parts: int, rows: int, Cc: int, running_mean: Optional[Tensor],
@@ -1603,11 +1589,9 @@ def bn_apply_fwd(z: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: T
 
 def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
            training: bool, want_dres: bool, *, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-           accumulate: bool = False, beta: Optional[Tensor] = None, mask: Optional[Tensor] = None, c_valid: int = 0,
-           partials=None):
+           accumulate: bool = False, beta: Optional[Tensor] = None, mask: Optional[Tensor] = None, c_valid: int = 0):
     """ReLU mask: ``mask`` (bn_apply_fwd(want_mask=True)) if given, else ``y``, else recomputed from z (``beta`` given, no
-    residual branch).  partials = (tensor, parts): the column sums {sum dz, sum dz * xhat} as the data-gradient convolution
-    that produced dy left them (``conv2d_implicit(bnb=)``): no statistics pass over dy and z."""
+    residual branch)."""
     rows, Cc = z.shape
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
@@ -1625,19 +1609,12 @@ def bn_bwd(dy: Tensor, z: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Ten
     # shortcut's gradient)
     esz = z.element_size()
     per_pass = z.numel() * esz * (2 + (y is not None)) + (mask.numel() if mask is not None else 0)
-    nb = (1 if partials is not None else 2) * per_pass + z.numel() * esz * (1 + int(want_dres))
+    nb = 2 * per_pass + z.numel() * esz * (1 + int(want_dres))
     with _timed(("hbm", "bn_bwd", rows * Cc), nb):
-        if partials is not None:
-            L.check(lib.dvt_bn_bwd_partials(dy.data_ptr(), z.data_ptr(), _p(y), _p(mask), mean.data_ptr(), invstd.data_ptr(),
-                                            gamma.data_ptr(), _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(),
-                                            dbeta.data_ptr(), ws.data_ptr(), rows, Cc, c_valid, int(relu), int(training),
-                                            int(accumulate), dt(z), partials[0].data_ptr(), int(partials[1]), _stream()),
-                    "dvt_bn_bwd_partials")
-        else:
-            L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), _p(mask), mean.data_ptr(), invstd.data_ptr(),
-                                   gamma.data_ptr(), _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(),
-                                   ws.data_ptr(), rows, Cc, c_valid, int(relu), int(training), int(accumulate), dt(z), _stream()),
-                    "dvt_bn_bwd")
+        L.check(lib.dvt_bn_bwd(dy.data_ptr(), z.data_ptr(), _p(y), _p(mask), mean.data_ptr(), invstd.data_ptr(),
+                               gamma.data_ptr(), _p(beta), dz.data_ptr(), _p(dres), dgamma.data_ptr(), dbeta.data_ptr(),
+                               ws.data_ptr(), rows, Cc, c_valid, int(relu), int(training), int(accumulate), dt(z), _stream()),
+                "dvt_bn_bwd")
     return dz, dres, dgamma, dbeta
 
 

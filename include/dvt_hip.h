@@ -35,7 +35,7 @@ extern "C" {
  * signature.  v2: dvt_gemm_desc / dvt_conv_desc gained defer_reduce / pending / carry, dvt_splitk_pending and the
  * head-wise / folded-attention descriptors were added.  Callers MUST zero-initialise every descriptor (memset / = {0})
  * before filling it: a zero in a field this header adds later means "feature off". */
-#define DVT_ABI_VERSION 3
+#define DVT_ABI_VERSION 4
 
 typedef void* dvt_stream_t; /* hipStream_t */
 
@@ -582,21 +582,6 @@ typedef struct dvt_conv_desc {
    * of the packed dWt -- the split-K reduce scatters into it (dvt_splitk_pending.conv_taps). */
   int32_t wgrad_master_layout, wgrad_accumulate;
   int32_t wgrad_cout_l, wgrad_cin_l;   /* channel-padded layers: the parameter's own channel counts (0: Cout / C) */
-  /* data gradient, optional (bnb_z != NULL): this launch's output y [N*Ho*Wo, Cout] is the gradient arriving at the
-   * BatchNorm (+ ReLU) in FRONT of the layer (custom_resnet.py:30-33 / 36-52 in backward order); bnb_z is that BatchNorm's
-   * input (same shape and dtype), bnb_mean / bnb_invstd its statistics [Cout], bnb_gamma / bnb_beta its parameters
-   * (bnb_c_valid entries, 0: Cout), bnb_relu whether a ReLU follows it, bnb_mask its mask bytes (NULL: recomputed from z).
-   * The epilogue then leaves that BatchNorm's backward column sums {sum dz, sum dz * xhat} per wave row in bnb_partial
-   * (size and row count as for stats_partial: dvt_conv2d_implicit_stats_bytes / _parts), and dvt_bn_bwd_partials uses them
-   * instead of a statistics pass of its own over dy and z.  Exclusive with stats_partial. */
-  const void* bnb_z;
-  const float* bnb_mean;
-  const float* bnb_invstd;
-  const float* bnb_gamma;
-  const float* bnb_beta;
-  const void* bnb_mask;
-  float* bnb_partial;
-  int32_t bnb_relu, bnb_c_valid;
 } dvt_conv_desc;
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
  * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a
@@ -695,11 +680,6 @@ int dvt_bn_apply_fwd(const void* x, const float* mean, const float* invstd, cons
 int dvt_bn_bwd(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
                const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
                int64_t rows, int C, int c_valid, int relu, int training, int accumulate, int dtype, dvt_stream_t stream);
-/* dvt_bn_bwd with the column sums taken from `partials` ([nparts][2][C] f32: {sum dz, sum dz * xhat} per part, as a
- * data-gradient dvt_conv2d_implicit leaves them in bnb_partial) instead of from a pass over dy and x. */
-int dvt_bn_bwd_partials(const void* dy, const void* x, const void* y, const void* relu_mask, const float* mean, const float* invstd,
-               const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
-               int64_t rows, int C, int c_valid, int relu, int training, int accumulate, int dtype, const float* partials, int nparts, dvt_stream_t stream);
 /* The ResNet stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) without the normalised map in HBM:
  * _fwd reads the convolution output z once and writes the pooled map y[N*Ho*Wo, C] and the argmax taps idx (same values
  * and taps as dvt_bn_apply_fwd followed by dvt_maxpool_fwd); dvt_bn_bwd_pooled is dvt_bn_bwd whose incoming gradient
@@ -797,13 +777,6 @@ int dvt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
 int dvt_adamw_step_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
                          const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream);
-/* dvt_adamw_step_fused on one RANGE of the flat buffers (pointers already offset; skip64 offset by range start / 64) WITHOUT
- * advancing the step counter: the optimizer step of one gradient bucket, enqueued behind that bucket's all-reduce on the
- * exchange stream while backward is still running; dvt_step_increment(step_dev2) closes the step. */
-int dvt_adamw_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev2,
-                         const uint8_t* skip64, void* mirror, int mirror_dtype, dvt_stream_t stream);
-int dvt_step_increment(int64_t* step_dev2, dvt_stream_t stream);
 /* AdamW under dynamic loss scaling (BASELINE configs[4]: fp16 + loss scaling; torch.cuda.amp.GradScaler rule).
  * grad holds the gradient of (scale * loss).  On the device, in stream order: found_inf |= any non-finite grad;
  * unless found_inf: the dvt_adamw_step_dev update with grad / scale and step_dev += 1; then

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_channel_without_gpu():
     import dvt_amd
     lib = dvt_amd._lib.load()
-    assert lib.dvt_version() == 3
+    assert lib.dvt_version() == 4
     # argument validation happens before any HIP call: safe on a CPU-only box
     rc = lib.dvt_cast(None, 0, None, 1, 8, None)
     assert rc == -1

@@ -777,50 +777,6 @@ def test_grouped_weight_pack_is_the_two_transposes(dvt, device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("geom", [(3, 64, 20, 20, 128, 3, False, 0), (2, 128, 14, 14, 256, 3, True, 0), (5, 64, 9, 13, 160, 3, False, 0),
-                                  (2, 240, 7, 7, 64, 1, False, 230), (40, 64, 28, 28, 64, (3, 1), True, 0), (1, 512, 7, 7, 512, 3, True, 0)])
-def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dvt, device, dtype, geom):
-    """dvt_conv_desc.bnb_*: the data-gradient convolution of layer L + 1 (dz [rows, Cout] with the rotated weights -> the
-    gradient dy [rows, Cin] arriving at layer L's BatchNorm + ReLU, optionally joined by a shortcut gradient in the residual
-    epilogue) leaves that BatchNorm's backward column sums; dvt_bn_bwd_partials on them == dvt_bn_bwd with its own
-    statistics pass over the same dy (dx to a rounding of the element type, dgamma / dbeta to fp32 summation order).  Mask
-    from bytes (residual layers) or recomputed from z; a channel-padded BatchNorm (c_valid); thousands of partial rows."""
-    ops = dvt.ops
-    N, Cin, H, W, Cout, k, with_res, cvalid = geom          # Cin = channels of layer L's output (the launch's output columns)
-    g = torch.Generator().manual_seed(N * 7 + Cin)
-    (kh, kw) = ops._pair(k)
-    pad = (kh // 2, kw // 2)
-    rows = N * H * W
-    dz1 = torch.randn(rows, Cout, generator=g).to(dtype).cuda()                       # gradient of layer L + 1's conv output
-    w = (torch.randn(Cout, Cin, kh, kw, generator=g) / (Cin * kh * kw) ** 0.5).cuda()
-    wd = ops.conv_weight_pack_dgrad(w, dtype)
-    z = torch.randn(rows, Cin, generator=g).to(dtype).cuda()                          # layer L's conv output
-    cv = cvalid or Cin
-    gamma, beta = (1 + 0.2 * torch.randn(cv, generator=g)).cuda(), (0.2 * torch.randn(cv, generator=g)).cuda()
-    mean, invstd = (0.1 * torch.randn(Cin, generator=g)).cuda(), (1 + 0.1 * torch.rand(Cin, generator=g)).cuda()
-    short = torch.randn(rows, Cin, generator=g).to(dtype).cuda() if with_res else None
-    mask = None
-    if with_res:            # a block output: BN + residual + ReLU left mask bytes in forward
-        ident = torch.randn(rows, Cin, generator=g).to(dtype).cuda()
-        _, mask = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, ident, True, want_mask=True, c_valid=cvalid)
-    pd = (kh - 1 - pad[0], kw - 1 - pad[1])
-    assert ops.conv2d_implicit_supported(dz1, wd, N, Cout, H, W, Cin, k, 1, pd)
-    front = dict(z=z, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mask=mask, relu=True, c_valid=cvalid)
-    dy, part, parts = ops.conv2d_implicit(dz1, wd, N, Cout, H, W, Cin, k, 1, pd, residual=short, bnb=front)
-    dy_ref = ops.conv2d_implicit(dz1, wd, N, Cout, H, W, Cin, k, 1, pd, residual=short)
-    assert torch.equal(dy, dy_ref)
-    a = ops.bn_bwd(dy, z, None, mean, invstd, gamma, True, True, with_res, beta=beta, mask=mask, c_valid=cvalid)
-    b = ops.bn_bwd(dy, z, None, mean, invstd, gamma, True, True, with_res, beta=beta, mask=mask, c_valid=cvalid,
-                   partials=(part, parts))
-    assert rel_l2(b[2], a[2]) < 1e-5 and rel_l2(b[3], a[3]) < 1e-5                   # dgamma, dbeta
-    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
-    assert float((b[0].float() - a[0].float()).abs().max()) <= tol * float(a[0].float().abs().max())
-    assert rel_l2(b[0], a[0]) < 1e-3
-    if with_res:
-        assert torch.equal(b[1], a[1])                 # (the shortcut gradient: dy under the mask, no statistics involved)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (2, 13, 20), (1, 5, 56), (300, 8, 8), (70, 56, 56)])
 def test_conv3x3_c64_weight_gradient_from_lds_halo_patches(dvt, device, dtype, N, H, W):
     """dvt_conv3x3_c64_wgrad (layer 1 of ResNet-18: 64 -> 64, 3 x 3 / 1 / 1): input patch and gradient tile staged once per
@@ -873,35 +829,6 @@ def test_conv3x3_c64_weight_gradient_with_more_output_channels(dvt, device, dtyp
     pend = ops.conv3x3_c64_wgrad(x, dz, N, H, W, acc, accumulate=True, defer_reduce=True, Cout=Cout)
     ops.splitk_reduce_pending(pend)
     assert rel_l2(acc - old, ref) < 2e-5
-
-
-def test_resnet_gradients_equal_with_and_without_fused_batchnorm_backward_sums(dvt, device, monkeypatch):
-    """functional.BN_BWD_FUSE (off by default: measured neutral): the hand-off of the BatchNorm-backward sums between the
-    backward passes of neighbouring layers -- recomputed masks, mask bytes of block outputs, shortcut gradients joining in
-    the producing launch, gradients with a second contributor (the pyramid taps) missing the hand-off -- gives the same
-    (x2, x3, x4) and parameter gradients as the separate statistics passes."""
-    from dvt_amd import functional as F
-    from dvt_amd.models.custom_resnet import resnet18
-    g = torch.Generator().manual_seed(23)
-    x = torch.randn(8, 3, 96, 96, generator=g).cuda()
-    seeds = [torch.randn(8, c, s_, s_, generator=g).cuda() for c, s_ in ((128, 12), (256, 6), (512, 3))]
-    res = []
-    for fuse in (False, True):
-        monkeypatch.setattr(F, "BN_BWD_FUSE", fuse)
-        F.bn_fuse_clear()
-        torch.manual_seed(5)
-        net = resnet18(compute_dtype=torch.bfloat16).cuda().train()
-        outs = net(x)
-        loss = sum((o.float() * s_).sum() for o, s_ in zip(outs, seeds))
-        loss.backward()
-        assert not F._bn_hand and not (fuse and F._bn_front)          # every entry was consumed
-        res.append(([o.detach().float().clone() for o in outs], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
-    (oa, ga), (ob, gb) = res
-    for a, b in zip(oa, ob):
-        assert torch.equal(a, b)
-    worst = max(rel_l2(gb[k], ga[k]) for k in ga)
-    assert worst < 2e-2, worst                                         # (bf16: the sums differ in fp32 summation order only,
-                                                                       #  dz is rounded to bf16 after them)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -310,42 +310,3 @@ def test_twice_used_layernorm_with_gamma_and_beta_in_different_buckets(device):
                 assert e < 1e-4, (step, n, e)
     finally:
         comm.destroy()
-
-
-@pytest.mark.parametrize("with_comm", [False, True])
-def test_overlapped_adamw_equals_the_one_launch_step(device, with_comm):
-    """FlatParameters.enable_overlapped_adamw: every gradient bucket's AdamW update (+ 16-bit mirror) runs behind that bucket
-    (and its all-reduce) on the side stream while backward continues; three steps of a small ViViT == the one-launch
-    optimizer step, bit for bit (master weights, moments, mirror, step counter), with tiny buckets (many ranges), without
-    a communicator and with the RCCL one at world 1; a parameter nobody writes stays untouched."""
-    from dvt_amd.dp import Communicator, FlatParameters
-    from dvt_amd.models.vit import ViViT
-    comm = Communicator(1, 0, Communicator.unique_id()) if with_comm else None
-    try:
-        res = []
-        for overlapped in (False, True):
-            torch.manual_seed(3)
-            net = ViViT(32, 16, 5, 4, dim=64, depth=2, heads=2, dim_head=32, compute_dtype=torch.bfloat16).cuda().train()
-            net.unused = torch.nn.Parameter(torch.ones(70, device="cuda"))            # never receives a gradient
-            flat = FlatParameters(net, bucket_mb=0.05, compute_dtype=torch.bfloat16, comm=comm)
-            assert len(flat.bucket_ranges) > 4
-            if overlapped:
-                flat.enable_overlapped_adamw(lr=1e-2, weight_decay=0.05)
-            g = torch.Generator().manual_seed(11)
-            for step in range(3):
-                x = torch.randn(2, 4, 3, 32, 32, generator=g).to(torch.bfloat16).cuda()
-                y = (torch.rand(2, 5, generator=g) < 0.4).float().cuda()
-                flat.zero_grad()
-                net.loss(x, y)[0].backward()
-                flat.finish_backward()
-                flat.adamw_step(lr=1e-2, weight_decay=0.05)
-            torch.cuda.synchronize()
-            res.append((flat.data.clone(), flat.exp_avg.clone(), flat.exp_avg_sq.clone(), flat.compute.clone(),
-                        flat.step_dev.clone(), net.unused.detach().clone()))
-        a, b = res
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
-        assert int(a[4][0]) == 3 and int(a[4][1]) == 0 and torch.equal(a[5], torch.ones(70, device="cuda"))
-    finally:
-        if comm is not None:
-            comm.destroy()
