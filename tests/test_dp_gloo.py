@@ -120,6 +120,110 @@ def test_two_rank_allreduce_equals_full_batch(tmp_path, bucket_mb, twice):
         assert torch.equal(res["data"][off:off + n].view(params[k].shape), params[k].detach())
 
 
+BENCH_BUCKET_MB = 13.0        # bench.py --bucket-mb default: the plan the first 8-GPU run will use
+
+
+def _metric_model():
+    from dvt_amd.models.vit import ViViT
+    torch.manual_seed(1130)
+    return ViViT(224, 16, 19, 32, dim=512, depth=4, heads=8, dim_head=64, compute_dtype=torch.float32)
+
+
+def _expected_plan(sizes, bucket_mb):
+    """Independent restatement of the bucket rule: walk the parameters in REVERSE registration order
+    (= backward completion order), close a bucket once it holds >= bucket_mb of fp32 gradients; 64-element aligned slices."""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    limit, ranges, hi = int(bucket_mb * (1 << 20) / 4), [], total
+    for i in range(len(sizes) - 1, -1, -1):
+        if hi - offs[i] >= limit or i == 0:
+            ranges.append([offs[i], hi])
+            hi = offs[i]
+    return ranges, total
+
+
+def _plan_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvt_amd.dp import FlatParameters
+    net = _metric_model()
+    flat = FlatParameters(net, bucket_mb=BENCH_BUCKET_MB, compute_dtype=None)
+    named = list(net.named_parameters())
+    twice = "space_transformer.norm.weight"          # written again after its bucket has been launched (late buffer)
+    never = "temporal_token"                         # nobody writes it in step 0 (zero fill + skip mask)
+    launched_at = {}
+    for step in range(2):
+        flat.zero_grad()
+        for i in range(len(named) - 1, -1, -1):      # backward completion order
+            k, p = named[i]
+            if k == never and step == 0:
+                continue
+            s = p._dvt_sink
+            val = (rank + 1) * (i + 1) * 1e-3 * flat.loss_scale * (0.25 if k == twice else 1.0)
+            assert s.fresh
+            s.buf.fill_(val)
+            s.mark_written()
+            if step == 0:
+                launched_at[i] = sum(flat._launched)
+        s = dict(named)[twice]._dvt_sink               # the second write: its bucket's all-reduce is in flight
+        i2 = [k for k, _ in named].index(twice)
+        assert flat._launched[s.bucket] and s.fresh    # (fresh now names the late buffer)
+        s.buf.fill_((rank + 1) * (i2 + 1) * 1e-3 * flat.loss_scale * 0.75)
+        s.mark_written()
+        assert s.late_written
+        flat.finish_backward()
+        if step == 0:
+            i = [k for k, _ in named].index(never)
+            assert flat.sinks[i].unwritten and flat.skip_mask is not None and int(flat.skip_mask.sum()) == (named[i][1].numel() + 63) // 64
+        else:
+            assert flat.skip_mask is None
+    if rank == 0:
+        torch.save({"ranges": flat.bucket_ranges, "offsets": flat.offsets, "total": flat.total,
+                    "launched_at": launched_at, "bucket_size": flat.bucket_size,
+                    "grad_means": [float(p.grad.double().mean()) for _, p in named],
+                    "grad_spread": [float((p.grad.max() - p.grad.min()).abs()) for _, p in named]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_bucket_plan_at_the_metric_parameter_set(tmp_path):
+    """The exact gradient-exchange plan of the headline run -- bench.py's 13 MiB buckets over the d = 512 ViViT's 28.8 M
+    parameters -- at world 2 over gloo: bucket boundaries against an independent restatement of the rule, buckets fire in
+    backward completion order as their last parameter is written, a twice-written parameter goes through the late buffer,
+    a never-written one through the zero fill and the skip mask, and the reduced flat gradient is the rank mean."""
+    import dvt_amd  # noqa: F401
+    port = _free_port()
+    out = str(tmp_path / "plan.pt")
+    mp.spawn(_plan_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    net = _metric_model()
+    sizes = [p.numel() for p in net.parameters()]
+    want, total = _expected_plan(sizes, BENCH_BUCKET_MB)
+    assert res["total"] == total and [list(r) for r in res["ranges"]] == want
+    mb = [(hi - lo) * 4 / (1 << 20) for lo, hi in want]
+    print(f"[bucket plan] {len(want)} buckets (MiB, in launch order): " + ", ".join(f"{m:.1f}" for m in mb))
+    assert len(want) == 7 and all(m >= BENCH_BUCKET_MB for m in mb[:-1]) and sum(res["bucket_size"]) == len(sizes)
+    # a bucket is launched exactly when its lowest-offset parameter (the last one written in backward order) is written;
+    # the bucket holding the never-written parameter waits for finish_backward
+    names = [k for k, _ in net.named_parameters()]
+    i_never = names.index("temporal_token")
+    starts = {lo for lo, hi in want if not (lo <= res["offsets"][i_never] < hi)}
+    fired = 0
+    for i in range(len(sizes) - 1, -1, -1):
+        if i == i_never:
+            continue
+        if res["offsets"][i] in starts:
+            fired += 1
+        assert res["launched_at"][i] == fired, i
+    assert fired == len(want) - 1
+    for i, (m, sp) in enumerate(zip(res["grad_means"], res["grad_spread"])):
+        assert sp == 0.0 and abs(m - 1.5 * (i + 1) * 1e-3) < 1e-6 * (i + 1), i      # mean over ranks of (rank + 1) * (i + 1) * 1e-3
+
+
 def test_bucket_layout_covers_every_parameter_once():
     from dvt_amd.dp import FlatParameters
     net = _model()
