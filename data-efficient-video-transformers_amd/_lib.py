@@ -72,12 +72,14 @@ class ConvDesc(C.Structure):
                [("workspace", C.c_void_p), ("stats_partial", C.c_void_p), ("trim_w", C.c_int32),
                 ("defer_reduce", C.c_int32), ("pending", C.c_void_p), ("carry", C.c_void_p),
                 ("residual", C.c_void_p), ("wgrad_master_layout", C.c_int32), ("wgrad_accumulate", C.c_int32),
-                ("wgrad_cout_l", C.c_int32), ("wgrad_cin_l", C.c_int32)]
+                ("wgrad_cout_l", C.c_int32), ("wgrad_cin_l", C.c_int32),
+                ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_rows", C.c_void_p), ("residual_compact", C.c_int32)]
 
 
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + \
-               [(n, C.c_int32) for n in ("cout_l", "cin_l", "kh", "kw", "cout_p", "cin_p", "ld", "kind", "dtype")]
+               [(n, C.c_int32) for n in ("cout_l", "cin_l", "kh", "kw", "cout_p", "cin_p", "ld", "kind", "dtype",
+                                         "cls_sh", "cls_sw", "cls_rh", "cls_rw")]
 
 
 class HeadBceDesc(C.Structure):

@@ -319,6 +319,19 @@ __device__ __forceinline__ void pack_rows(const dvt_pack_entry& q, int blk, int 
       for (int j = body + threadIdx.x; j < q.ld; j += 256) dst[(int64_t)(co0 + r) * q.ld + j] = from_f32<D>(0.f);
 }
 
+// destination tap block of source tap (ki, kj) in the data-gradient forms: kind 1 = all taps, rotated; kind 2 = the taps of one
+// parity class of a strided convolution (ki = rh + j * sh, j < nth; kj likewise), in decreasing ki / kj order; -1: not in it
+__host__ __device__ inline int pack_cls_nt(int k, int r, int s) { return r < k ? (k - r + s - 1) / s : 0; }
+__device__ __forceinline__ int pack_dst_tap(const dvt_pack_entry& q, int tap, int* ntaps_dst) {
+  if (q.kind != 2) { *ntaps_dst = q.kh * q.kw; return q.kh * q.kw - 1 - tap; }
+  const int nth = pack_cls_nt(q.kh, q.cls_rh, q.cls_sh), ntw = pack_cls_nt(q.kw, q.cls_rw, q.cls_sw);
+  *ntaps_dst = nth * ntw;
+  const int ki = tap / q.kw, kj = tap - ki * q.kw;
+  const int dh = ki - q.cls_rh, dw = kj - q.cls_rw;
+  if (dh < 0 || dw < 0 || dh % q.cls_sh || dw % q.cls_sw) return -1;
+  return (nth - 1 - dh / q.cls_sh) * ntw + (ntw - 1 - dw / q.cls_sw);
+}
+
 template <typename D>
 __device__ __forceinline__ void pack_tile_t(const dvt_pack_entry& q, int blk, float* lds) {
   const int taps = q.kh * q.kw, rowlen = q.cin_l * taps, cols = q.cin_p * taps;
@@ -351,10 +364,13 @@ __device__ __forceinline__ void pack_tile_t(const dvt_pack_entry& q, int blk, fl
       const int c = c0 + cc, co = co0 + o8;
       if (c >= cols || co >= q.cout_p) continue;
       const int ci = c / taps, tap = c - ci * taps;
+      int ntd;
+      const int td = pack_dst_tap(q, tap, &ntd);
+      if (td < 0) continue;
       float v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = lds[(o8 + k) * 65 + cc];
-      store8<D>(dst + ((int64_t)ci * taps + (taps - 1 - tap)) * q.cout_p + co, v);
+      store8<D>(dst + ((int64_t)ci * ntd + td) * q.cout_p + co, v);
     }
     return;
   }
@@ -364,7 +380,9 @@ __device__ __forceinline__ void pack_tile_t(const dvt_pack_entry& q, int blk, fl
     const int c = c0 + cc;
     if (c >= cols) break;
     const int ci = c / taps, tap = c - ci * taps;
-    dst[((int64_t)ci * taps + (taps - 1 - tap)) * q.cout_p + co] = from_f32<D>(lds[tx * 65 + cc]);
+    int ntd;
+    const int td = pack_dst_tap(q, tap, &ntd);
+    if (td >= 0) dst[((int64_t)ci * ntd + td) * q.cout_p + co] = from_f32<D>(lds[tx * 65 + cc]);
   }
 }
 
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(256) void weight_pack_group_kernel(const PackGroup 
   const int blk = (int)blockIdx.x - g.begin[e];
   int R;
   pack_plan(q, &R);
-  if (q.kind == 1) {
+  if (q.kind >= 1) {
     if (q.dtype == DVT_BF16) pack_tile_t<bf16>(q, blk, lds);
     else if (q.dtype == DVT_F16) pack_tile_t<f16>(q, blk, lds);
     else pack_tile_t<float>(q, blk, lds);
@@ -1474,7 +1492,10 @@ int dvt_conv_weight_pack_group(const dvt_pack_entry* entries, int count, dvt_str
     for (int i = 0; i < g.n; ++i) {
       const dvt_pack_entry& q = entries[base + i];
       DVT_REQUIRE(q.src && q.dst && q.cout_l > 0 && q.cin_l > 0 && q.kh > 0 && q.kw > 0 && q.cout_p >= q.cout_l &&
-                      q.cin_p >= q.cin_l && (q.kind == 0 || q.kind == 1) && (q.kind == 1 || q.ld >= q.kh * q.kw * q.cin_p) &&
+                      q.cin_p >= q.cin_l && q.kind >= 0 && q.kind <= 2 && (q.kind != 0 || q.ld >= q.kh * q.kw * q.cin_p) &&
+                      (q.kind != 2 || (q.cls_sh > 0 && q.cls_sw > 0 && q.cls_rh >= 0 && q.cls_rh < q.cls_sh && q.cls_rw >= 0 &&
+                                       q.cls_rw < q.cls_sw && pack_cls_nt(q.kh, q.cls_rh, q.cls_sh) > 0 &&
+                                       pack_cls_nt(q.kw, q.cls_rw, q.cls_sw) > 0)) &&
                       (q.dtype == DVT_F32 || dvt_is_16bit(q.dtype)),
                   "dvt_conv_weight_pack_group: bad entry %d", base + i);
       g.e[i] = q;

@@ -1050,6 +1050,7 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c, int taps) {
 static inline void conv_out_hw(const dvt_conv_desc* d, int64_t* Ho, int64_t* Wo) {
   *Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1;
   *Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1 - (d->trim_w > 0 ? d->trim_w : 0);
+  if (d->out_h > 0 && d->out_w > 0) { *Ho = d->out_h; *Wo = d->out_w; }   // (a parity class of a strided data gradient)
 }
 
 static bool conv_implicit_ok(const dvt_conv_desc* d) {
@@ -1105,6 +1106,11 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
   DVT_REQUIRE(!(d->residual && d->stats_partial), "dvt_conv2d_implicit: residual and stats_partial are exclusive");
   DVT_REQUIRE(dvt_aligned16(d->residual), "dvt_conv2d_implicit: residual must be 16-byte aligned");
   p.bn_partial = d->stats_partial;
+  DVT_REQUIRE((d->out_h > 0) == (d->out_w > 0) && (!d->out_rows || (((uintptr_t)d->out_rows & 3) == 0 && !d->stats_partial)) &&
+                  (!d->residual_compact || (d->out_rows && d->residual)),
+              "dvt_conv2d_implicit: out_h / out_w come together; out_rows is 4-byte aligned and excludes stats_partial; "
+              "residual_compact needs out_rows and a residual");
+  p.orow = d->out_rows; p.res_compact = d->residual_compact;
   if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
     const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
     int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);

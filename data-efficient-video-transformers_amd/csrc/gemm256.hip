@@ -559,6 +559,20 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   // all sixteen residual / aux rows of the wave's four passes are requested up front (the fragment registers are dead
   // here): one memory round trip for the whole epilogue instead of one per pass, and every load precedes every store
   constexpr int NPS = (WROWS + 31) / 32;               // passes of 32 rows (the last one half empty when WROWS = 112)
+  // scattered output rows (implicit convolution only: the parity classes of a strided data gradient, p.orow)
+  constexpr bool kCanMap = A_CONV && A_KMAJOR && OUT == OUT_BF16;
+  const bool mapped = kCanMap && p.orow != nullptr;
+  int orow[kCanMap ? NPS : 1][4];
+  if (kCanMap && mapped) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
+        m = m < p.M ? m : p.M - 1;
+        orow[kCanMap ? ps : 0][j] = p.orow[m];
+      }
+  }
   V8 rs[kNeedLd ? NPS : 1][4];
   if (kNeedLd) {
 #pragma unroll
@@ -567,6 +581,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       for (int j = 0; j < 4; ++j) {
         int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
         m = m < p.M ? m : p.M - 1;                    // clamped row: loaded unconditionally, never stored
+        if (kCanMap && mapped && !p.res_compact) m = orow[kCanMap ? ps : 0][j];
         rs[ps][j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + (n_ok ? n : 0));
       }
   }
@@ -628,7 +643,8 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             }
           }
           if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
-          DVT_C_STORE((E*)p.C + (int64_t)m * p.ldc + n, v[j]);
+          const int mo = (kCanMap && mapped) ? orow[kCanMap ? ps : 0][j] : m;
+          DVT_C_STORE((E*)p.C + (int64_t)mo * p.ldc + n, v[j]);
         }
       }
     }

@@ -24,6 +24,10 @@ struct GemmParams {
   float* colsum_slab;
   int accumulate_colsum;   // gemm_small.hip only: colsum_slab is the final bias-gradient vector; += when set
   float* bn_partial;    // != nullptr (bf16 output, no epilogue): partial[(tile_m * 2 + wave_m)][{sum, sum of squares}][N] of C's columns
+  // implicit convolution, bf16 output: row m of the product is row orow[m] of C (and of the residual unless res_compact):
+  // the parity classes of a strided convolution's data gradient scatter into the full-size gradient (dvt_conv_desc.out_rows)
+  const int* orow;
+  int res_compact;
   // a split-K reduce of an EARLIER launch carried in `pig_blocks` extra workgroups at the end of this grid (gemm256.hip)
   int pig_blocks;
   dvt_splitk_pending pig;

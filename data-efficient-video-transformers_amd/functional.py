@@ -1288,6 +1288,9 @@ IMPLICIT_CONV = True
 FUSE_BN_STATS = True
 GENERAL_TAPS = os.environ.get("DVT_GENERAL_TAPS", "1") != "0"   # implicit kernels for any C % 8 == 0 (per-lane taps), K not padded to 64
 HALO_CONV = True          # 64 -> 64 channel 3x3 / 1 / 1 convolutions from an LDS-resident halo patch (dvt_conv3x3_c64)
+# data gradient of STRIDED convolutions as one implicit launch per parity class of input pixels (1 / 2 / 2 / 4 taps of a
+# 3 x 3 / 2 filter) scattering into the full-size gradient, instead of a dcol GEMM + col2im pass
+STRIDED_IMPLICIT = os.environ.get("DVT_STRIDED_IMPLICIT", "1") != "0"
 
 
 def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: int, cout_p: int, cin_p: int, ld: int,
@@ -1308,6 +1311,24 @@ def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: i
         ops.conv_weight_pack_group([entry])
         return dst
     return sink.owner.packed_weight((sink.index, kind, cout_p, cin_p, ld, dtype), make, w._version)
+
+
+def _packed_class_weight(w: Tensor, cout_l: int, cin_l: int, kh: int, kw: int, cout_p: int, cin_p: int, cls, dtype) -> Tensor:
+    """The data-gradient operand of one parity class of a strided convolution (dvt_pack_entry kind 2): [cin_p, nth*ntw*cout_p]
+    with the class's taps only; cached and refreshed like the other packed forms (`_packed_weight`)."""
+    sh, sw, rh, rw = cls
+    ntaps = ((kh - rh + sh - 1) // sh) * ((kw - rw + sw - 1) // sw)
+
+    def make():
+        src = w.detach().contiguous()
+        dst = torch.empty((cin_p, ntaps * cout_p), dtype=dtype, device=w.device)
+        return dst, (src, dst, cout_l, cin_l, kh, kw, cout_p, cin_p, 0, 2, (sh, sw, rh, rw))
+    sink = _sink(w)
+    if sink is None or w.dtype != torch.float32:
+        dst, entry = make()
+        ops.conv_weight_pack_group([entry])
+        return dst
+    return sink.owner.packed_weight((sink.index, 2, cout_p, cin_p, (sh, sw, rh, rw), dtype), make, w._version)
 
 
 # weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
@@ -1631,6 +1652,29 @@ class _ConvBnAct(torch.autograd.Function):
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
                                          residual=join_alias())   # [N*H*W, Cin], no dcol / col2im
+        if (ctx.x_needs and dx is None and STRIDED_IMPLICIT and ctx.implicit and ctx.geom0 is None and not nchw
+                and (sh_, sw_) != (1, 1) and ctx.w_ref is not None and N * H * W < (1 << 31)):
+            # strided layer (custom_resnet.py:19-22 with stride 2; R(2+1)D's strided halves): the input pixels fall into
+            # sh x sw parity classes, each the stride-1 convolution of dz with its own taps, scattered into dx by a row table
+            classes = ops.strided_dgrad_classes(k, stride, pad, H, W)
+            if classes is not None and all(ops.conv2d_implicit_k(Cout, Cin, nt) == nt[0] * nt[1] * Cout
+                                           for (_, _, nt, _, _, _) in classes):
+                full = compact = None
+                if not joined[0]:                # the shortcut's gradient joins in the residual epilogue of the class launches
+                    if ctx.fork == "alias":
+                        full = dshort.view(N * H * W, Cin)
+                    elif (int(ctx.fork), int(ctx.fork)) == (sh_, sw_):
+                        compact = dshort.view(-1, Cin)      # a strided 1 x 1 shortcut touches class (0, 0) only
+                    joined[0] = full is not None or compact is not None
+                dx = torch.empty((N * H * W, Cin), dtype=dz.dtype, device=dz.device)
+                order = sorted(classes, key=lambda c: c[2][0] * c[2][1])       # the class with the most taps carries the reduce
+                for i, (a, b, nt, pq, (rh, rw), hq) in enumerate(order):
+                    wc = _packed_class_weight(ctx.w_ref, Cout_l, Cin_l, kh, kw, Cout, Cin, (sh_, sw_, rh, rw), dtype)
+                    res, rc = (full, False) if full is not None else ((compact, True) if (compact is not None and a == 0 and b == 0)
+                                                                      else (None, False))
+                    ops.conv2d_implicit(dz, wc, N, Cout, Ho, Wo, Cin, nt, 1, pq, out=dx, out_hw=hq,
+                                        out_rows=ops.strided_class_rows(N, H, W, sh_, sw_, a, b, dz.device), residual=res,
+                                        residual_compact=rc, carry=pend if i == len(order) - 1 else None)
         if ctx.x_needs and dx is None and (nchw or ctx.geom0 is not None) and ctx.dx_frames:
             if ctx.geom0 is not None:            # implicit stem: the frames' own geometry and the plain [Cout, taps * Cin] pack
                 N0, C0, H0, W0, k0, s0, p0 = ctx.geom0

@@ -1385,17 +1385,34 @@ def conv3x3_c64_wgrad(x: Tensor, dz: Tensor, N: int, H: int, W: int, master: Ten
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
-                    want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None):
+                    want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None,
+                    out: Optional[Tensor] = None, out_hw=None, out_rows: Optional[Tensor] = None, residual_compact: bool = False):
     """NHWC matrix x [N*H*W, C], packed weights wp [Cout, kh*kw*C] -> [N*Ho*Wo, Cout]; gather fused into the GEMM.
     want_stats: also returns (partial, parts), the per-block column sums / sums of squares of the output that the GEMM
-    epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials)."""
+    epilogue leaves for the BatchNorm behind the convolution (bn_stats_from_partials).
+    out / out_hw / out_rows / residual_compact: one parity class of a strided convolution's data gradient
+    (dvt_conv_desc.out_h / out_w / out_rows): the launch computes out_hw pixels per image and writes row m of its product
+    to row out_rows[m] of ``out`` (a full-size map the classes fill between them)."""
     _need_cuda(x, wp)
     Ho, Wo = conv_out_hw(H, W, k, stride, pad)
     Wo -= trim_w                                  # columns dropped at the right edge (dvt_conv_desc.trim_w)
-    y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
+    if out_hw is not None:
+        Ho, Wo = out_hw
+    if out_rows is not None:
+        assert out is not None and out.is_contiguous() and out.dtype == x.dtype and out.shape[1] == Cout and not want_stats
+        assert out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() == N * Ho * Wo
+        y = out
+    else:
+        assert out is None and not residual_compact
+        y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
     d = _conv_desc(x, wp, y, N, Cc, H, W, Cout, k, stride, pad, trim_w)
+    if out_hw is not None:
+        d.out_h, d.out_w = Ho, Wo
+    if out_rows is not None:
+        d.out_rows, d.residual_compact = out_rows.data_ptr(), int(residual_compact)
     if residual is not None:                          # a second gradient path joining this one: added on the accumulators
-        assert residual.is_contiguous() and residual.dtype == x.dtype and residual.shape == y.shape and not want_stats
+        assert residual.is_contiguous() and residual.dtype == x.dtype and not want_stats
+        assert residual.shape == ((N * Ho * Wo, Cout) if (residual_compact or out_rows is None) else y.shape)
         d.residual = residual.data_ptr()
     lib = L.load()
     partial, parts = None, 0
@@ -1404,14 +1421,61 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
         partial = workspace(lib.dvt_conv2d_implicit_stats_bytes(C.byref(d)), x.device, slot="bn_partial")
         d.stats_partial = _p(partial)
     (kh, kw) = _pair(k)
-    nb = (x.numel() + wp.numel() + y.numel() * (2 if residual is not None else 1)) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
+    rows = N * Ho * Wo
+    nb = (x.numel() + wp.numel() + rows * Cout * (2 if residual is not None else 1)) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
     if carry is not None and carry.valid:             # the layer's weight-gradient reduce rides in this launch's grid tail
         d.carry = C.addressof(carry)
-    with _timed(("conv", "implicit", N * Ho * Wo, Cout, kh * kw * Cc, nb), 2.0 * N * Ho * Wo * Cout * kh * kw * Cc):
+    with _timed(("conv", "implicit", rows, Cout, kh * kw * Cc, nb), 2.0 * rows * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
     if carry is not None:
         carry.valid = 0
     return (y, partial, parts) if want_stats else y
+
+
+_CLASS_ROWS = {}
+
+
+def strided_class_rows(N: int, H: int, W: int, sh: int, sw: int, a: int, b: int, device) -> Tensor:
+    """int32 [N * Hq * Wq]: the row of the full-size NHWC map [N*H*W, C] that pixel (n, hq, wq) of parity class (a, b) --
+    input pixel (sh * hq + a, sw * wq + b) -- names.  Static per geometry: built once on the host, cached on the device."""
+    key = (N, H, W, sh, sw, a, b, str(device))
+    t = _CLASS_ROWS.get(key)
+    if t is None:
+        import numpy as np
+        hq = np.arange(a, H, sh, dtype=np.int64)
+        wq = np.arange(b, W, sw, dtype=np.int64)
+        rows = (np.arange(N, dtype=np.int64)[:, None, None] * (H * W) + hq[None, :, None] * W + wq[None, None, :]).reshape(-1)
+        assert rows.size == 0 or rows.max() < (1 << 31)
+        t = torch.from_numpy(rows.astype(np.int32)).to(device)
+        _CLASS_ROWS[key] = t
+    return t
+
+
+def strided_dgrad_classes(k, stride, pad, H: int, W: int):
+    """The parity classes of the data gradient of a (k, stride, pad) convolution over an H x W input, or None when the
+    decomposition does not apply (a class without a tap -- e.g. a strided 1 x 1 -- or with taps above / left of the map).
+    -> [(a, b, (nth, ntw), (ph', pw'), (rh, rw), (Hq, Wq))]: class (a, b) = input pixels (hi % sh, wi % sw); its gradient is the
+    stride-1 convolution of dz with the nth x ntw taps ki = rh + j * sh (decreasing), padded by (ph', pw') in front."""
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
+    if sh == 1 and sw == 1:
+        return None
+    out = []
+    for a in range(sh):
+        for b in range(sw):
+            dims = []
+            for (kk, s, p, r0, ext) in ((kh, sh, ph, a, H), (kw, sw, pw, b, W)):
+                r = (r0 + p) % s
+                nt = (kk - r + s - 1) // s if r < kk else 0
+                padq = (nt - 1) - (r0 + p) // s
+                q = (ext - r0 + s - 1) // s if ext > r0 else 0
+                dims.append((nt, padq, r, q))
+            (nth, pph, rh, Hq), (ntw, ppw, rw, Wq) = dims
+            if Hq == 0 or Wq == 0:
+                continue
+            if nth == 0 or ntw == 0 or pph < 0 or ppw < 0:
+                return None
+            out.append((a, b, (nth, ntw), (pph, ppw), (rh, rw), (Hq, Wq)))
+    return out
 
 
 def bn_stats_from_partials(partial: Tensor, parts: int, rows: int, Cc: int, running_mean: Optional[Tensor],
@@ -1504,16 +1568,22 @@ def unpad3_f32(src: Tensor, A: int, B: int, K: int, Bp: int, *, out: Optional[Te
 
 def conv_weight_pack_group(entries) -> None:
     """Both packed forms of many convolution weights in one launch.  entries: (src f32 [cout_l, cin_l, kh*kw] contiguous,
-    dst tensor, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind) with kind 0 = forward operand [cout_p, ld], 1 = data-gradient
-    operand [cin_p, kh*kw*cout_p]."""
+    dst tensor, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind[, (sh, sw, rh, rw)]) with kind 0 = forward operand [cout_p, ld],
+    1 = data-gradient operand [cin_p, kh*kw*cout_p], 2 = the data-gradient operand of one parity class of a strided
+    convolution [cin_p, nth*ntw*cout_p] (dvt_pack_entry.cls_*)."""
     if not entries:
         return
     arr = (L.PackEntry * len(entries))()
-    for i, (src, dst, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind) in enumerate(entries):
+    for i, ent in enumerate(entries):
+        (src, dst, cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind), cls = ent[:10], (ent[10] if len(ent) > 10 else None)
         _need_cuda(src, dst)
         assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == cout_l * cin_l * kh * kw
-        assert dst.is_contiguous() and dst.numel() == (cout_p * ld if kind == 0 else cin_p * kh * kw * cout_p)
         e = arr[i]
+        ntaps = kh * kw
+        if kind == 2:                                  # one parity class of a strided convolution's data gradient
+            e.cls_sh, e.cls_sw, e.cls_rh, e.cls_rw = cls
+            ntaps = ((kh - cls[2] + cls[0] - 1) // cls[0]) * ((kw - cls[3] + cls[1] - 1) // cls[1])
+        assert dst.is_contiguous() and dst.numel() == (cout_p * ld if kind == 0 else cin_p * ntaps * cout_p)
         e.src, e.dst = src.data_ptr(), dst.data_ptr()
         e.cout_l, e.cin_l, e.kh, e.kw, e.cout_p, e.cin_p, e.ld, e.kind, e.dtype = cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind, dt(dst)
     L.check(L.load().dvt_conv_weight_pack_group(C.cast(arr, C.c_void_p), len(entries), _stream()), "dvt_conv_weight_pack_group")

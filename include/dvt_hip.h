@@ -549,6 +549,11 @@ typedef struct dvt_pack_entry {
   const float* src;      /* f32 [cout_l][cin_l][kh*kw] */
   void* dst;
   int32_t cout_l, cin_l, kh, kw, cout_p, cin_p, ld, kind, dtype;
+  /* kind 2 (ABI v4): the data-gradient operand of ONE parity class of a strided convolution -- dst[cin_p][nth*ntw*cout_p]
+   * holding only the taps ki = cls_rh + j * cls_sh (j < nth = ceil((kh - cls_rh) / cls_sh)), kj likewise, in DECREASING
+   * ki / kj order (so that tap t of the class reads dz row hq + t - pad'), channels transposed as in kind 1.  The class of
+   * input pixels hi % sh == a uses cls_rh = (a + ph) % sh. */
+  int32_t cls_sh, cls_sw, cls_rh, cls_rw;
 } dvt_pack_entry;
 int dvt_conv_weight_pack_group(const dvt_pack_entry* entries, int count, dvt_stream_t stream);
 typedef struct dvt_conv_desc {
@@ -582,6 +587,18 @@ typedef struct dvt_conv_desc {
    * of the packed dWt -- the split-K reduce scatters into it (dvt_splitk_pending.conv_taps). */
   int32_t wgrad_master_layout, wgrad_accumulate;
   int32_t wgrad_cout_l, wgrad_cin_l;   /* channel-padded layers: the parameter's own channel counts (0: Cout / C) */
+  /* forward / data gradient, optional (ABI v4).  The data gradient of a STRIDED convolution (custom_resnet.py:19-22 with
+   * stride 2, the 1 x 1 / 2 downsample of :124-130; R(2+1)D's strided halves) as implicit launches: the input pixels
+   * (hi, wi) fall into sh x sw parity classes (hi % sh, wi % sw), and the gradient of one class is a stride-1 convolution of
+   * dz with the class's taps (1 / 2 / 2 / 4 of a 3 x 3 / 2 filter: dvt_pack_entry kind 2), whose output rows are SCATTERED
+   * into the full-size gradient.  out_h / out_w (> 0): the launch computes out_h x out_w output pixels per image instead of
+   * the usual (H + 2 ph - kh) / sh + 1 (taps that fall outside the map read zeros, as padding does).  out_rows (int32
+   * [N * out_h * out_w]): row m of the launch is row out_rows[m] of y (and of `residual`, unless residual_compact: then
+   * residual row m joins -- the compact gradient of a strided 1 x 1 shortcut, which touches one class only).  No column
+   * matrix, no col2im pass. */
+  int32_t out_h, out_w;
+  const int32_t* out_rows;
+  int32_t residual_compact;
 } dvt_conv_desc;
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (layer 1 of ResNet-18, custom_resnet.py:19-22,
  * 109; also its data gradient, with the rotated weights of dvt_conv_weight_pack_dgrad) from an LDS-resident halo patch: a

@@ -854,6 +854,70 @@ def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
     assert float((got2.float() - want2).abs().max()) <= (1e-6 if dtype == torch.float32 else 8e-3) * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [
+    # N, Cin, H, W, Cout, k, stride, pad, shortcut ("alias": full-size second gradient; 2: compact gradient of a 1x1 / 2 shortcut)
+    (3, 64, 16, 16, 128, 3, 2, 1, None), (2, 64, 9, 11, 128, 3, 2, 1, "alias"), (2, 128, 14, 14, 256, 3, 2, 1, 2),
+    (5, 256, 7, 7, 512, 3, 2, 1, 2), (2, 64, 12, 49, 64, (3, 1), (2, 1), (1, 0), None), (3, 288, 7, 16, 128, (3, 1), (2, 1), (1, 0), "alias"),
+    (40, 64, 28, 28, 128, 3, 2, 1, 2)])
+def test_strided_data_gradient_by_parity_classes(dvt, device, dtype, geom):
+    """dvt_conv_desc.out_h / out_w / out_rows + dvt_pack_entry kind 2: the data gradient of a STRIDED convolution
+    (custom_resnet.py:19-22 with stride 2 and the 1x1 / 2 shortcut of :124-130; R(2+1)D's (3, 1) / (2, 1) temporal halves) as
+    one implicit launch per parity class of input pixels, scattered into the full-size gradient with the shortcut's gradient
+    (full-size, or the compact one of a strided 1x1) joining in the residual epilogue == conv_transpose in fp64 on the same
+    16-bit operands, and == the dcol GEMM + col2im path it replaces (same operands, fp32 accumulation on both sides)."""
+    ops = dvt.ops
+    N, Cin, H, W, Cout, k, stride, pad, short = geom
+    (kh, kw), (sh, sw), (ph, pw) = ops._pair(k), ops._pair(stride), ops._pair(pad)
+    g = torch.Generator().manual_seed(N * 13 + Cin + H)
+    Ho, Wo = ops.conv_out_hw(H, W, k, stride, pad)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) / (Cout * kh * kw / (sh * sw)) ** 0.5).cuda()
+    dz = torch.randn(N * Ho * Wo, Cout, generator=g).to(dtype).cuda()
+    full = compact = None
+    if short == "alias":
+        full = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
+    elif short:
+        Hs, Ws = (H - 1) // short + 1, (W - 1) // short + 1
+        compact = torch.randn(N * Hs * Ws, Cin, generator=g).to(dtype).cuda()
+    classes = ops.strided_dgrad_classes(k, stride, pad, H, W)
+    assert classes is not None and len(classes) == sh * sw
+    dx = torch.full((N * H * W, Cin), float("nan"), dtype=dtype, device="cuda")      # every row must be written by some class
+    entries, wcs = [], []
+    for (a, b, nt, pq, (rh, rw), hq) in classes:
+        wc = torch.empty((Cin, nt[0] * nt[1] * Cout), dtype=dtype, device="cuda")
+        entries.append((w.contiguous(), wc, Cout, Cin, kh, kw, Cout, Cin, 0, 2, (sh, sw, rh, rw)))
+        wcs.append(wc)
+    ops.conv_weight_pack_group(entries)
+    for (a, b, nt, pq, _, hq), wc in zip(classes, wcs):
+        res, rc = (full, False) if full is not None else ((compact, True) if (compact is not None and (a, b) == (0, 0)) else (None, False))
+        ops.conv2d_implicit(dz, wc, N, Cout, Ho, Wo, Cin, nt, 1, pq, out=dx, out_hw=hq,
+                            out_rows=ops.strided_class_rows(N, H, W, sh, sw, a, b, dz.device), residual=res, residual_compact=rc)
+    assert torch.isfinite(dx.float()).all()
+    # fp64 adjoint on the same rounded operands
+    w64 = w.to(dtype).double().cpu()
+    dz64 = dz.double().cpu().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    x0 = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    TF.conv2d(x0, w64, None, (sh, sw), (ph, pw)).backward(dz64)
+    want = x0.grad.permute(0, 2, 3, 1).reshape(-1, Cin).clone()
+    if full is not None:
+        want += full.double().cpu()
+    if compact is not None:
+        wv = want.view(N, H, W, Cin)
+        wv[:, ::short, ::short] += compact.double().cpu().view(N, Hs, Ws, Cin)
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4          # the output's own rounding
+    assert rel_l2(dx, want) < tol
+    # the path it replaces: dcol GEMM + col2im (+ the joined shortcut gradient)
+    wp = ops.conv_weight_pack(w, kh * kw * Cin, dtype)
+    dcol = ops.linear_dgrad(dz, wp)
+    if full is not None:
+        old = ops.col2im(dcol, N, Cin, H, W, k, stride, pad, add=full)
+    elif compact is not None:
+        old = ops.col2im(dcol, N, Cin, H, W, k, stride, pad, add=compact, add_stride=int(short))
+    else:
+        old = ops.col2im(dcol, N, Cin, H, W, k, stride, pad)
+    assert rel_l2(dx, old) < 2 * tol                          # (the old path rounds dcol to 16 bits before it sums the taps)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_channel_padding_is_exact_zero_extension(dvt, device, dtype, tol):
     """cpad: a 24 -> 45 convolution followed by a 45 -> 32 one, run at padded widths 64 (R(2+1)D mid planes): the
