@@ -284,10 +284,12 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 #ifndef DVT_GEMM_NT
 #define DVT_GEMM_NT 1
 #endif
+#ifndef DVT_C_STORE          // (a dev harness that includes this file may define its own: tools/dev/gemm_storewave_price.hip)
 #if DVT_GEMM_NT
 #define DVT_C_STORE(ptr, vals) do { if (p.stream_out) store8_nt<E>(ptr, vals); else store8<E>(ptr, vals); } while (0)
 #else
 #define DVT_C_STORE(ptr, vals) store8<E>(ptr, vals)
+#endif
 #endif
 
 // OUT: 0 = C in bf16 with the fused epilogue EPI, 1 = C in fp32 (optionally accumulated),
