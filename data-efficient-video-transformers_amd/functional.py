@@ -1291,6 +1291,9 @@ HALO_CONV = True          # 64 -> 64 channel 3x3 / 1 / 1 convolutions from an LD
 # data gradient of STRIDED convolutions as one implicit launch per parity class of input pixels (1 / 2 / 2 / 4 taps of a
 # 3 x 3 / 2 filter) scattering into the full-size gradient, instead of a dcol GEMM + col2im pass
 STRIDED_IMPLICIT = os.environ.get("DVT_STRIDED_IMPLICIT", "1") != "0"
+# ... for maps of at least this many input pixels: below it the four class launches are latency-bound (17 - 21 us each at
+# 12 k rows per class, `gpurun_out/r5_pyr_strided_order.txt`) and the dcol GEMM + col2im pair is as fast
+STRIDED_IMPLICIT_MIN_PIXELS = int(os.environ.get("DVT_STRIDED_IMPLICIT_MIN_PIXELS", "150000"))
 
 
 def _packed_weight(w: Tensor, kind: int, cout_l: int, cin_l: int, kh: int, kw: int, cout_p: int, cin_p: int, ld: int,
@@ -1653,7 +1656,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
                                          residual=join_alias())   # [N*H*W, Cin], no dcol / col2im
         if (ctx.x_needs and dx is None and STRIDED_IMPLICIT and ctx.implicit and ctx.geom0 is None and not nchw
-                and (sh_, sw_) != (1, 1) and ctx.w_ref is not None and N * H * W < (1 << 31)):
+                and (sh_, sw_) != (1, 1) and ctx.w_ref is not None and STRIDED_IMPLICIT_MIN_PIXELS <= N * H * W < (1 << 31)):
             # strided layer (custom_resnet.py:19-22 with stride 2; R(2+1)D's strided halves): the input pixels fall into
             # sh x sw parity classes, each the stride-1 convolution of dz with its own taps, scattered into dx by a row table
             classes = ops.strided_dgrad_classes(k, stride, pad, H, W)

@@ -918,6 +918,41 @@ def test_strided_data_gradient_by_parity_classes(dvt, device, dtype, geom):
     assert rel_l2(dx, old) < 2 * tol                          # (the old path rounds dcol to 16 bits before it sums the taps)
 
 
+@pytest.mark.parametrize("short", ["none", "alias", "compact"])
+def test_conv_block_backward_with_and_without_strided_class_launches(dvt, device, monkeypatch, short):
+    """functional._ConvBnAct.backward routes the data gradient of a strided layer through the parity-class launches
+    (STRIDED_IMPLICIT, maps of at least STRIDED_IMPLICIT_MIN_PIXELS) or through dcol GEMM + col2im: same input gradient (the
+    shortcut's gradient joined: none / the full-size one of fork="alias" / the compact one of a strided 1x1 shortcut), same
+    parameter gradients -- the weight gradient's split-K reduce is carried by the last class launch."""
+    F = dvt.functional
+    N, Cin, H, W, Cout = 4, 64, 18, 14, 128
+    g = torch.Generator().manual_seed(41)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 2, 1, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(Cout).cuda().train()
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) * (2.0 / (Cin * 9)) ** 0.5).cuda())
+    x0 = torch.randn(N * H * W, Cin, generator=g).to(torch.bfloat16).cuda()
+    Ho, Wo = dvt.ops.conv_out_hw(H, W, 3, 2, 1)
+    gy = torch.randn(N * Ho * Wo, Cout, generator=g).to(torch.bfloat16).cuda()
+    gs = torch.randn(N * (H * W if short == "alias" else Ho * Wo), Cin, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for floor in (1 << 40, 0):                       # class launches off (nothing is large enough) / on for every size
+        monkeypatch.setattr(F, "STRIDED_IMPLICIT_MIN_PIXELS", floor)
+        x = x0.clone().requires_grad_(True)
+        conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+        fork = {"none": None, "alias": "alias", "compact": 2}[short]
+        out = F.conv_bn_act(x, conv, bn, (N, Cin, H, W, False), relu=True, dtype=torch.bfloat16, fork=fork)
+        if fork is None:
+            out.backward(gy)
+        else:
+            y, second = out
+            torch.autograd.backward([y, second], [gy, gs])
+        res.append((x.grad.float().clone(), conv.weight.grad.clone(), bn.weight.grad.clone()))
+    (dx0, dw0, dg0), (dx1, dw1, dg1) = res
+    assert rel_l2(dx1, dx0) < 8e-3                   # (the explicit path rounds dcol to bf16 before it sums the taps)
+    assert torch.equal(dw1, dw0) and torch.equal(dg1, dg0)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_channel_padding_is_exact_zero_extension(dvt, device, dtype, tol):
     """cpad: a 24 -> 45 convolution followed by a 45 -> 32 one, run at padded widths 64 (R(2+1)D mid planes): the
