@@ -239,6 +239,7 @@ SIGNATURES = {
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),
     "dvt_conv2d_implicit_stats_parts": (c_i64, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_stats_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "dvt_conv2d_implicit_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dvt_bn_stats_from_partials": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_f, c_f, c_p]),
     "dvt_conv2d_implicit_wgrad_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),

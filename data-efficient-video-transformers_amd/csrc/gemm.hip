@@ -218,6 +218,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
   }
 }
 
+constexpr int kConvSplitRows = 64;   // output rows per workgroup of conv_split_reduce_kernel = per BatchNorm partial row
+// out[m][n] = sum_z slab[z][m][n] (+ residual[m][n]) rounded to E; optional BatchNorm partial sums of the fp32 sums, one row
+// {sum, sum of squares} per kConvSplitRows output rows.  block = 32 column groups of 8 x 8 row lanes.
+template <typename E>
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                                                E* __restrict__ out, const E* __restrict__ residual,
+                                                                float* __restrict__ bn_partial) {
+  __shared__ float red[2][8][32][8];
+  const int cgl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = (blockIdx.x * 32 + cgl) * 8;
+  const int r0 = blockIdx.y * kConvSplitRows;
+  const int64_t MN = (int64_t)M * N;
+  float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    for (int r = r0 + rl; r < min(M, r0 + kConvSplitRows); r += 8) {
+      const int64_t e = (int64_t)r * N + n;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int z = 0; z < splits; z += 4) {              // four slices per round trip, summed in slice order
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (z + u < splits) load8<float>(slab + (int64_t)(z + u) * MN + e, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (z + u < splits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[u][k];
+          }
+      }
+      if (residual) {
+        float rv[8];
+        load8<E>(residual + e, rv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += rv[k];
+      }
+      if (bn_partial) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { bs[k] += acc[k]; bq[k] = fmaf(acc[k], acc[k], bq[k]); }
+      }
+      store8<E>(out + e, acc);
+    }
+  }
+  if (!bn_partial) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][rl][cgl][k] = bs[k]; red[1][rl][cgl][k] = bq[k]; }
+  __syncthreads();
+  if (rl < 2 && n < N) {                                 // row lane 0: sums, row lane 1: sums of squares; fixed order
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      t[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[k] += red[rl][q][cgl][k];
+    }
+    store8<float>(bn_partial + ((int64_t)blockIdx.y * 2 + rl) * N + n, t);
+  }
+}
+
 // C (+)= sum_z slab[z]   (fixed order => reproducible)
 template <typename OutT>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
@@ -1046,6 +1104,24 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c, int taps) {
   return cfg;
 }
 
+// Split-K for forward / data-gradient launches that leave CUs empty AND run a deep reduction (R(2+1)D-18 layers 3 - 4 on
+// 112^2 chunks: 2,744 - 4,116 output pixels x K up to 10,368 = 88 - 198 workgroups of 128 x 128, each a chain of up to 162
+// k-tiles at ~1 us per k-tile -- the latency of one workgroup's DMA ring, not MFMA time).  The reduction is cut into S
+// slices (blockIdx.z) so that about two 64 KiB workgroups sit on every CU; fp32 slabs, summed in slice order by
+// conv_split_reduce_kernel, which also rounds to the map's type, adds the shortcut's gradient and leaves the BatchNorm
+// partial sums (from the fp32 sums, like the one-slice epilogue).  1 = no split.
+static int conv_fwd_split(int64_t rows, int cout, int c, int taps, int64_t K) {
+  const int cfg = conv_fwd_cfg(rows, cout, c, taps);
+  if ((cfg != 9 && cfg != 10) || K % 64) return 1;
+  const int64_t tiles = dvt_cdiv(rows, 128) * dvt_cdiv(cout, 128), cus = dvt_num_cus();
+  const int64_t nk = K / 64;
+  if (tiles * 5 > cus * 4 || nk < 24) return 1;    // four fifths of the CUs busy already, or too shallow to be worth a reduce
+  int64_t s = (2 * cus + tiles - 1) / tiles;       // two workgroups per CU
+  if (s > nk / 6) s = nk / 6;                      // at least six k-tiles per slice
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : (int)s;
+}
+
 // output size of the convolution a descriptor names (trim_w: columns dropped at the right edge)
 static inline void conv_out_hw(const dvt_conv_desc* d, int64_t* Ho, int64_t* Wo) {
   *Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1;
@@ -1075,6 +1151,25 @@ static bool conv_implicit_ok(const dvt_conv_desc* d) {
 }
 
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* d) { return conv_implicit_ok(d) ? 1 : 0; }
+
+// slices of the reduction this descriptor's launch uses (1: the one-launch form); scattered class launches stay unsplit
+static int conv_desc_split(const dvt_conv_desc* d) {
+  if (!d || d->out_rows || d->C <= 0 || d->sh <= 0 || d->sw <= 0) return 1;
+  int64_t Ho, Wo;
+  conv_out_hw(d, &Ho, &Wo);
+  if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 1;
+  return conv_fwd_split(d->N * Ho * Wo, d->Cout, d->C, d->kh * d->kw, dvt_conv2d_implicit_k(d));
+}
+
+// S fp32 slabs [rows][N] for a split launch (0: none needed)
+size_t dvt_conv2d_implicit_workspace_bytes(const dvt_conv_desc* d) {
+  const int s = conv_desc_split(d);
+  if (s <= 1) return 0;
+  int64_t Ho, Wo;
+  conv_out_hw(d, &Ho, &Wo);
+  return (size_t)s * (size_t)(d->N * Ho * Wo) * (size_t)d->Cout * sizeof(float);
+}
+
 
 // Row length of the packed weights [Cout][K]: kh*kw*C, rounded up to the k-tile in the C == 8 (stem) form.
 int64_t dvt_conv2d_implicit_k(const dvt_conv_desc* d) {
@@ -1111,6 +1206,27 @@ int dvt_conv2d_implicit(const dvt_conv_desc* d, dvt_stream_t stream) {
               "dvt_conv2d_implicit: out_h / out_w come together; out_rows is 4-byte aligned and excludes stats_partial; "
               "residual_compact needs out_rows and a residual");
   p.orow = d->out_rows; p.res_compact = d->residual_compact;
+  const int split = conv_desc_split(d);
+  if (split > 1) {
+    DVT_REQUIRE(d->workspace && dvt_aligned16(d->workspace),
+                "dvt_conv2d_implicit: this shape runs split-K and needs dvt_conv2d_implicit_workspace_bytes of 16-byte aligned workspace");
+    hipStream_t st = (hipStream_t)stream;
+    if (d->carry && d->carry->valid) {             // (the grid tail of a split launch carries nothing: the reduce runs by itself)
+      const int rc = dvt_splitk_reduce_pending(d->carry, stream);
+      if (rc != DVT_OK) return rc;
+    }
+    const int64_t nk = p.K / 64;
+    p.k_per_split = (int)(dvt_cdiv(nk, split) * 64);
+    p.slab = (float*)d->workspace;
+    p.epilogue = DVT_EPI_NONE; p.residual = nullptr; p.bn_partial = nullptr;
+    const int rc = dvt_conv_dma_launch_split(p, split, st);
+    if (rc != DVT_OK) return rc;
+    const dim3 grid((unsigned)dvt_cdiv(p.N, 256), (unsigned)dvt_cdiv(p.M, kConvSplitRows));
+    DVT_DISPATCH_16BIT(d->dtype, E, hipLaunchKernelGGL((conv_split_reduce_kernel<E>), grid, dim3(256), 0, st, (const float*)p.slab,
+                                                       split, p.M, p.N, (E*)d->y, (const E*)d->residual, d->stats_partial));
+    DVT_LAUNCH_CHECK("dvt_conv2d_implicit(split-K reduce)");
+    return DVT_OK;
+  }
   if (d->carry && d->carry->valid) {               // a pending split-K reduce rides in this launch's grid tail
     const int64_t slab_bytes_c = d->carry->M * d->carry->N * 4 * d->carry->splits;
     int64_t nb = dvt_cdiv(slab_bytes_c, (int64_t)1 << 19);
@@ -1126,6 +1242,7 @@ int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* d) {
   int64_t Ho, Wo;
   conv_out_hw(d, &Ho, &Wo);
   if (Ho <= 0 || Wo <= 0 || d->N <= 0) return 0;
+  if (conv_desc_split(d) > 1) return dvt_cdiv(d->N * Ho * Wo, kConvSplitRows);                      // split launch: the reduce's row blocks
   const int cfg = conv_fwd_cfg(d->N * Ho * Wo, d->Cout, d->C, d->kh * d->kw);
   if (cfg == 9 || cfg == 10) return dvt_cdiv(d->N * Ho * Wo, 128) * 2;                             // 128-row tiles of two wave rows
   return dvt_cdiv(d->N * Ho * Wo, 256) * (cfg == 4 || cfg == 6 || cfg == 7 ? 4 : 2);   // wave rows per 256-row tile

@@ -769,6 +769,25 @@ int dvt_conv_dma_launch_c6(const GemmParams& p, int cfg, hipStream_t st) {
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv<f16, 7>(p, st) : launch_conv<bf16, 7>(p, st);
   return p.elem == DVT_F16 ? launch_conv<f16, 6>(p, st) : launch_conv<bf16, 6>(p, st);
 }
+// forward / data gradient with the reduction split over blockIdx.z into fp32 slabs (few output rows x deep K: R(2+1)D layers
+// 3 - 4): 128 x 128 tiles, two workgroups per CU; the caller's reduce sums the slabs (gemm.hip: conv_split_reduce_kernel)
+template <typename E>
+static int launch_conv_split(const GemmParams& pin, int split, hipStream_t st) {
+  typedef Cfg<9> C;
+  constexpr int kSmem = smem_bytes<9>();
+  GemmParams p = pin;
+  p.pig_blocks = 0;
+  p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
+  const dim3 grid((unsigned)(dvt_cdiv(p.M, C::TM) * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
+  static DvtLdsAttr attr_set;
+  dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, true, true, 9, DVT_EPI_NONE, OUT_SLAB, true>, kSmem);
+  hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, 9, DVT_EPI_NONE, OUT_SLAB, true>), grid, block, kSmem, st, p);
+  DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma, split K)");
+  return DVT_OK;
+}
+int dvt_conv_dma_launch_split(const GemmParams& p, int split, hipStream_t st) {
+  return p.elem == DVT_F16 ? launch_conv_split<f16>(p, split, st) : launch_conv_split<bf16>(p, split, st);
+}
 int dvt_conv_wgrad_dma_launch_c6(const GemmParams& p, int split, int cfg, hipStream_t st) {
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 7>(p, split, st) : launch_conv_wgrad<bf16, 7>(p, split, st);
   return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 6>(p, split, st) : launch_conv_wgrad<bf16, 6>(p, split, st);

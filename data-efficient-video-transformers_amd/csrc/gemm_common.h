@@ -155,6 +155,7 @@ int dvt_conv_dma_launch(const GemmParams& p, int cfg, hipStream_t st);
 int dvt_conv_wgrad_dma_launch(const GemmParams& p, int split, int cfg, hipStream_t st);
 int dvt_gemm_dma_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, int cfg, hipStream_t st);
 int dvt_conv_dma_launch_c6(const GemmParams& p, int cfg, hipStream_t st);                                             // gemm256_pp.hip
+int dvt_conv_dma_launch_split(const GemmParams& p, int split, hipStream_t st);                                         // gemm256_pp.hip
 int dvt_conv_wgrad_dma_launch_c6(const GemmParams& p, int split, int cfg, hipStream_t st);                             // gemm256_pp.hip
 int dvt_gemm_dma_launch_224(const GemmParams& p, bool b_kmajor, hipStream_t st);                                          // gemm256_pp.hip
 int dvt_gemm_dma_launch_pp(const GemmParams& p, bool a_kmajor, bool b_kmajor, int split, hipStream_t st);   // gemm256_pp.hip

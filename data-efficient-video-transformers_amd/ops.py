@@ -1425,6 +1425,9 @@ def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout
     nb = (x.numel() + wp.numel() + rows * Cout * (2 if residual is not None else 1)) * x.element_size()    # implicit GEMM: the image is read once, not kh*kw times
     if carry is not None and carry.valid:             # the layer's weight-gradient reduce rides in this launch's grid tail
         d.carry = C.addressof(carry)
+    wsb = int(lib.dvt_conv2d_implicit_workspace_bytes(C.byref(d)))
+    if wsb:                                           # few output rows x deep K: split-K slabs (dvt_conv2d_implicit_workspace_bytes)
+        d.workspace = workspace(wsb, x.device, slot="conv_split").data_ptr()
     with _timed(("conv", "implicit", rows, Cout, kh * kw * Cc, nb), 2.0 * rows * Cout * kh * kw * Cc):
         L.check(lib.dvt_conv2d_implicit(C.byref(d), _stream()), "dvt_conv2d_implicit")
     if carry is not None:

@@ -563,7 +563,7 @@ typedef struct dvt_conv_desc {
   int64_t N;
   int32_t H, W, C, Cout, kh, kw, sh, sw, ph, pw;
   int32_t dtype;
-  void* workspace;   /* weight gradient only */
+  void* workspace;   /* weight gradient; forward / data gradient when dvt_conv2d_implicit_workspace_bytes(desc) > 0 */
   /* forward only, optional: the BatchNorm that follows the convolution (custom_resnet.py:30,33,104: conv -> bn) needs the
    * column sums and sums of squares of y; when stats_partial != NULL (>= dvt_conv2d_implicit_stats_bytes(desc)) the GEMM
    * epilogue leaves them here from its fp32 accumulators, per 128-row block: [parts][2][Cout] f32 with
@@ -647,6 +647,10 @@ int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */
 int64_t dvt_conv2d_implicit_k(const dvt_conv_desc* desc);
+/* Scratch a forward / data-gradient launch of this descriptor needs (0 for most shapes): launches with few output rows and a
+ * deep reduction (R(2+1)D layers 3 - 4) split K over workgroups into fp32 slabs in desc->workspace and sum them in a second
+ * launch that also rounds, adds `residual` and leaves the BatchNorm partial sums (same contract as the one-launch form). */
+size_t dvt_conv2d_implicit_workspace_bytes(const dvt_conv_desc* desc);
 int dvt_conv2d_implicit(const dvt_conv_desc* desc, dvt_stream_t stream);
 int64_t dvt_conv2d_implicit_stats_parts(const dvt_conv_desc* desc);
 size_t dvt_conv2d_implicit_stats_bytes(const dvt_conv_desc* desc);

@@ -655,6 +655,51 @@ def test_implicit_gemm_convolution_matches_explicit_path(dvt, device, dtype, geo
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(8, 256, 14, 14, 512, 3, 1, 1),               # 1,568 rows x K = 2,304: 52 tiles of 128 x 128
+                                  (56, 512, 7, 7, 1152, 3, 1, 1),               # R(2+1)D layer 4: 2,744 rows, 1,152 mid planes, K = 4,608
+                                  (56, 1152, 2, 49, 512, (3, 1), 1, (1, 0)),    # ... its temporal half over the [T, H*W] view, K = 3,456
+                                  (3, 1152, 7, 7, 512, 3, 1, 1)])               # 147 rows (a ragged row tile), K = 10,368: eight slices
+def test_implicit_gemm_splits_a_deep_reduction_over_workgroups(dvt, device, dtype, geom):
+    """dvt_conv2d_implicit_workspace_bytes > 0: launches that leave CUs empty and run a deep reduction (the forward / data
+    gradient convolutions of R(2+1)D-18's layers 3 - 4, video_resnet.py:147-157) split K over blockIdx.z into fp32 slabs and sum
+    them in a second launch that rounds to the map's type, adds the shortcut's gradient and leaves the BatchNorm partial sums:
+    against conv2d in fp32 on the same rounded operands; statistics against the fp32 result; residual; a carried weight-gradient
+    reduce handed to such a launch is performed (as a launch of its own) before it."""
+    ops = dvt.ops
+    import ctypes as C
+    N, Cin, H, W, Cout, k, stride, pad = geom
+    g = torch.Generator().manual_seed(N + Cin)
+    (kh, kw) = ops._pair(k)
+    x = torch.randn(N * H * W, Cin, generator=g).to(dtype).cuda()
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).cuda()
+    wp = ops.conv_weight_pack(w, kh * kw * Cin, dtype)
+    d = ops._conv_desc(x, wp, None, N, Cin, H, W, Cout, k, stride, pad)
+    lib = dvt._lib.load()
+    assert lib.dvt_conv2d_implicit_workspace_bytes(C.byref(d)) > 0               # the split path is the one under test
+    y, partial, parts = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad, want_stats=True)
+    xr = x.float().view(N, H, W, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xr, w.to(dtype).float(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)   # (torch on the GPU: fp32 oracle of the same operands)
+    tol = 5e-3 if dtype == torch.bfloat16 else 8e-4
+    assert y.shape == ref.shape and rel_l2(y, ref) < tol
+    assert parts == (y.shape[0] + 63) // 64
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, y.shape[0], Cout, None, None, 1e-5, 0.1)
+    assert torch.allclose(mean, ref.mean(0), atol=2e-3) and rel_l2(invstd, (ref.var(0, unbiased=False) + 1e-5).rsqrt()) < 2e-3
+    y2 = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad)         # without statistics: the same values
+    assert torch.equal(y2, y)
+    res = torch.randn(y.shape, generator=g).to(dtype).cuda()
+    yr = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad, residual=res)
+    assert rel_l2(yr, ref + res.float()) < tol
+    # a pending split-K reduce (a weight gradient's) handed over as `carry`: done when the launch returns
+    a = torch.randn(4096, 64, generator=g).to(dtype).cuda()
+    b = torch.randn(4096, 128, generator=g).to(dtype).cuda()
+    dw, pend = ops.linear_wgrad(a, b, defer_reduce=True)
+    if pend is not None and pend.valid:
+        y3 = ops.conv2d_implicit(x, wp, N, Cin, H, W, Cout, k, stride, pad, carry=pend)
+        assert torch.equal(y3, y) and not pend.valid
+        assert rel_l2(dw, a.float().t() @ b.float()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("geom", [(2, 144, 12, 49, 64, (3, 1), 1, (1, 0)),      # R(2+1)D-18 layer-1 temporal conv (un-padded mid planes)
                                   (2, 144, 12, 49, 128, (3, 1), (2, 1), (1, 0)),
                                   (3, 144, 14, 14, 256, 3, 1, 1),                # 64-deep k-tiles: 1296 -> 1344
