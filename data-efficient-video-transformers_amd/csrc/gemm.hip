@@ -1107,7 +1107,7 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c, int taps) {
 // Split-K for forward / data-gradient launches that leave CUs empty AND run a deep reduction (R(2+1)D-18 layers 3 - 4 on
 // 112^2 chunks: 2,744 - 4,116 output pixels x K up to 10,368 = 88 - 198 workgroups of 128 x 128, each a chain of up to 162
 // k-tiles at ~1 us per k-tile -- the latency of one workgroup's DMA ring, not MFMA time).  The reduction is cut into S
-// slices (blockIdx.z) so that about two 64 KiB workgroups sit on every CU; fp32 slabs, summed in slice order by
+// slices (blockIdx.z) so that about one and a half workgroups sit on every CU; fp32 slabs, summed in slice order by
 // conv_split_reduce_kernel, which also rounds to the map's type, adds the shortcut's gradient and leaves the BatchNorm
 // partial sums (from the fp32 sums, like the one-slice epilogue).  1 = no split.
 static int conv_fwd_split(int64_t rows, int cout, int c, int taps, int64_t K) {
@@ -1116,7 +1116,9 @@ static int conv_fwd_split(int64_t rows, int cout, int c, int taps, int64_t K) {
   const int64_t tiles = dvt_cdiv(rows, 128) * dvt_cdiv(cout, 128), cus = dvt_num_cus();
   const int64_t nk = K / 64;
   if (tiles * 5 > cus * 4 || nk < 24) return 1;    // four fifths of the CUs busy already, or too shallow to be worth a reduce
-  int64_t s = (2 * cus + tiles - 1) / tiles;       // two workgroups per CU
+  // about one and a half workgroups per CU (same-box sweep on the frametransformer step, gpurun_out/r5_sweep_split2.log:
+  // 17.57 ms unsplit; 17.38 - 17.43 at one per CU, 17.34 - 17.39 at 1.5, 17.44 - 17.45 at two)
+  int64_t s = (3 * cus / 2 + tiles - 1) / tiles;
   if (s > nk / 6) s = nk / 6;                      // at least six k-tiles per slice
   if (s > 8) s = 8;
   return s < 2 ? 1 : (int)s;

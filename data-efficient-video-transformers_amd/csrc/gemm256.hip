@@ -771,22 +771,25 @@ int dvt_conv_dma_launch_c6(const GemmParams& p, int cfg, hipStream_t st) {
 }
 // forward / data gradient with the reduction split over blockIdx.z into fp32 slabs (few output rows x deep K: R(2+1)D layers
 // 3 - 4): 128 x 128 tiles, two workgroups per CU; the caller's reduce sums the slabs (gemm.hip: conv_split_reduce_kernel)
-template <typename E>
+template <typename E, int CFG>
 static int launch_conv_split(const GemmParams& pin, int split, hipStream_t st) {
-  typedef Cfg<9> C;
-  constexpr int kSmem = smem_bytes<9>();
+  typedef Cfg<CFG> C;
+  constexpr int kSmem = smem_bytes<CFG>();
   GemmParams p = pin;
   p.pig_blocks = 0;
   p.tiles_n = (int)dvt_cdiv(p.N, C::TN);
   const dim3 grid((unsigned)(dvt_cdiv(p.M, C::TM) * p.tiles_n), 1, (unsigned)split), block(C::NW * 64);
   static DvtLdsAttr attr_set;
-  dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, true, true, 9, DVT_EPI_NONE, OUT_SLAB, true>, kSmem);
-  hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, 9, DVT_EPI_NONE, OUT_SLAB, true>), grid, block, kSmem, st, p);
+  dvt_lds_attr(attr_set, (const void*)gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_SLAB, true>, kSmem);
+  hipLaunchKernelGGL((gemm_dma_kernel<E, true, true, CFG, DVT_EPI_NONE, OUT_SLAB, true>), grid, block, kSmem, st, p);
   DVT_LAUNCH_CHECK("dvt_conv2d_implicit(dma, split K)");
   return DVT_OK;
 }
+// (at most one workgroup per CU in all: the four-deep ring of configuration 10; else two 64 KiB workgroups per CU)
 int dvt_conv_dma_launch_split(const GemmParams& p, int split, hipStream_t st) {
-  return p.elem == DVT_F16 ? launch_conv_split<f16>(p, split, st) : launch_conv_split<bf16>(p, split, st);
+  const bool one = dvt_cdiv(p.M, 128) * dvt_cdiv(p.N, 128) * split <= dvt_num_cus();
+  if (p.elem == DVT_F16) return one ? launch_conv_split<f16, 10>(p, split, st) : launch_conv_split<f16, 9>(p, split, st);
+  return one ? launch_conv_split<bf16, 10>(p, split, st) : launch_conv_split<bf16, 9>(p, split, st);
 }
 int dvt_conv_wgrad_dma_launch_c6(const GemmParams& p, int split, int cfg, hipStream_t st) {
   if (cfg == 7) return p.elem == DVT_F16 ? launch_conv_wgrad<f16, 7>(p, split, st) : launch_conv_wgrad<bf16, 7>(p, split, st);
