@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
       const double us = time_it([&](int it) { dvt_gemm_dma_launch(with_bufs(p, it), true, s.bk, 1, s.shipped, 0); });
       printf("  shipped (cfg %d)                         %7.1f us  %6.1f TF/s\n", s.shipped, us, flops / us * 1e-6);
     }
-    for (int cfg : {0, 3, 1, 7}) {
+    for (int cfg : {0, 3, 1, 7, 9}) {
       double t[6];
       for (int mode : {0, 1, 2, 4, 5}) {
         t[mode] = time_it([&](int it) {
@@ -121,11 +121,11 @@ int main(int argc, char** argv) {
     else if (s.epi == DVT_EPI_RESIDUAL) run_cfg<bf16, true, true, CFG, DVT_EPI_RESIDUAL>(q, mode, 0);                      \
     else run_cfg<bf16, true, true, CFG, DVT_EPI_NONE>(q, mode, 0);                                                         \
   } while (0)
-          if (cfg == 0) RUN(0); else if (cfg == 3) RUN(3); else if (cfg == 1) RUN(1); else RUN(7);
+          if (cfg == 0) RUN(0); else if (cfg == 3) RUN(3); else if (cfg == 1) RUN(1); else if (cfg == 7) RUN(7); else RUN(9);
 #undef RUN
         });
       }
-      const char* nm = cfg == 0 ? "256x256x64, 8 waves " : cfg == 3 ? "256x256x64, 16 waves" : cfg == 1 ? "256x128x32, 2 WG/CU" : "256x128x64, 8 waves ";
+      const char* nm = cfg == 0 ? "256x256x64, 8 waves " : cfg == 3 ? "256x256x64, 16 waves" : cfg == 1 ? "256x128x32, 2 WG/CU" : cfg == 7 ? "256x128x64, 8 waves " : "128x128x64, 2 WG/CU";
       printf("  cfg %d %s  full %7.1f  no stores %7.1f  no main loop %7.1f us | register-transpose epilogue: full %7.1f  no stores %7.1f us\n",
              cfg, nm, t[0], t[1], t[2], t[4], t[5]);
     }
