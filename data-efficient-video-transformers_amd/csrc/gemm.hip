@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mfma_kernel(const GemmParams
 }
 
 constexpr int kConvSplitRows = 64;   // output rows per workgroup of conv_split_reduce_kernel = per BatchNorm partial row
-// out[m][n] = sum_z slab[z][m][n] (+ residual[m][n]) rounded to E; optional BatchNorm partial sums of the fp32 sums, one row
+// out[m][n] = sum_z slab[z][m][n] (+ residual[m][n]) rounded to E; optional BatchNorm partial sums of the stored values, one row
 // {sum, sum of squares} per kConvSplitRows output rows.  block = 32 column groups of 8 x 8 row lanes.
 template <typename E>
 __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
@@ -253,9 +253,13 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += rv[k];
       }
-      if (bn_partial) {
+      if (bn_partial) {                            // of the values as stored (one statistics convention on every route)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { bs[k] += acc[k]; bq[k] = fmaf(acc[k], acc[k], bq[k]); }
+        for (int k = 0; k < 8; ++k) {
+          const float f = (float)(E)acc[k];
+          bs[k] += f;
+          bq[k] = fmaf(f, f, bq[k]);
+        }
       }
       store8<E>(out + e, acc);
     }
@@ -1109,7 +1113,7 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c, int taps) {
 // k-tiles at ~1 us per k-tile -- the latency of one workgroup's DMA ring, not MFMA time).  The reduction is cut into S
 // slices (blockIdx.z) so that about one and a half workgroups sit on every CU; fp32 slabs, summed in slice order by
 // conv_split_reduce_kernel, which also rounds to the map's type, adds the shortcut's gradient and leaves the BatchNorm
-// partial sums (from the fp32 sums, like the one-slice epilogue).  1 = no split.
+// partial sums (of the stored values, like the one-slice epilogue).  1 = no split.
 static int conv_fwd_split(int64_t rows, int cout, int c, int taps, int64_t K) {
   const int cfg = conv_fwd_cfg(rows, cout, c, taps);
   if ((cfg != 9 && cfg != 10) || K % 64) return 1;

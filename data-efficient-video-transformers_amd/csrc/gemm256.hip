@@ -588,7 +588,7 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       }
   }
   // fused BatchNorm statistics (convolution outputs): per-lane sums of its 8 columns over its rows of the tile.
-  // {sum y, sum y^2} of the output as the BatchNorm behind the convolution needs them.
+  // {sum y, sum y^2} of the STORED output as the BatchNorm behind the convolution needs them.
   constexpr bool kCanBn = OUT == OUT_BF16 && EPI == DVT_EPI_NONE;
   const bool do_bn = kCanBn && p.bn_partial != nullptr;
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bsq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -637,11 +637,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
             const float ld = (float)cur[j][k];
             v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
-          if (kCanBn && do_bn) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              bsum[k] += v[j][k];
-              bsq[k] = fmaf(v[j][k], v[j][k], bsq[k]);
+          if (kCanBn && do_bn) {                     // of the values as STORED (rounded to E): what the BatchNorm behind the
+#pragma unroll                                        // layer normalises, and what every other route sums (halo / streamed-weight
+            for (int k = 0; k < 8; ++k) {            // kernels, the split-K reduce, dvt_bn_stats on z): one convention
+              const float f = (float)(E)v[j][k];
+              bsum[k] += f;
+              bsq[k] = fmaf(f, f, bsq[k]);
             }
           }
           if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);

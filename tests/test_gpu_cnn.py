@@ -57,9 +57,10 @@ def test_conv_bn_relu_block(dvt, device, dtype, tol, k, stride, pad, Cin, Cout, 
     ref.backward(gy.to(dtype).float())
     y.backward(gy.to(dtype).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda())
     # (gradients: a ReLU decision that flips against the fp32 oracle -- y within the 16-bit rounding of z of zero -- moves one
-    # of ~5,000 live elements of the layer's gradient, 1.4 % of its L2 norm; the implicit path's statistics (fp32 accumulators
-    # in the GEMM epilogue) and the explicit path's (the rounded z) flip different ones: tools/dev/taps_check.py)
-    gtol = (2.5 if dtype == torch.bfloat16 else 2) * tol
+    # of ~5,000 live elements of the layer's gradient, 1.4 % of its L2 norm.  Round 5: every route -- implicit epilogue, halo /
+    # streamed-weight kernels, split-K reduce, the explicit statistics pass -- sums the STORED 16-bit z, so the bound is the
+    # round-3 one again: 2 x tol)
+    gtol = 2 * tol
     assert rel_l2(convd.weight.grad, wr.grad) < gtol
     assert rel_l2(bnd.weight.grad, gr.grad) < gtol and rel_l2(bnd.bias.grad, br.grad) < gtol
     assert rel_l2(rd.grad, rr.grad.permute(0, 2, 3, 1).reshape(-1, Cout)) < gtol
