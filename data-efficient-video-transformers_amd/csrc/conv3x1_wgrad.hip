@@ -1,0 +1,271 @@
+// conv3x1_wgrad.hip -- weight gradient of the temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (video_resnet.py:30-31: a
+// (3, 1, 1) convolution, 144 mid planes -> 64 planes, stride 1, pad 1) from LDS-resident sliding windows.
+//
+//   dW[co][ci][kt] = sum over clips n, frames t and pixels p of dz[n, t, p, co] * x[n, t + kt - 1, p, ci]
+//
+// The implicit form (gemm256.hip, mn-major operands) gathers x once per temporal tap through the CU's vector-memory path:
+// 1,220 MB fetched per launch for 438 MB of operands (profiles/r04_frametransformer_pmc_traffic.md, traffic ratio 2.37),
+// 205 us at 28 clips of 12 x 56^2.  Here a workgroup owns a SEGMENT of S pixels of one clip over ALL its T frames: it stages
+// the (T + 2) x S x 144 window of x (frames -1 and T are zero rows) and the T x S x 64 tile of dz ONCE each, and the three
+// taps are three constant position offsets (0, S, 2 S) into the same window -- conv3x3_wgrad.hip's scheme with a halo in the
+// frame direction only, so no input element is fetched twice, not even by a neighbouring tile.
+//
+//   * dz image: [position][64 channels], 128-byte rows, the 32-byte-unit swizzle of conv3x3_wgrad.hip.
+//   * x image: [position][144 channels] in rows of TEN 32-byte units (320 bytes): nine channel blocks of 16 plus one unit of
+//     padding, block cb of position k stored at unit cb + ((k >> 3) & 1).  A 32-lane half of ds_read_b64_tr_b16 touches the
+//     positions {q, 8 + q} + 4 hf: 320-byte rows put positions q = 0 .. 3 on banks 0 / 16 / 32 / 48 (+ 8 each), the shift by
+//     one unit moves positions 8 + q to banks 8 / 24 / 40 / 56 -- the eight 8-bank groups of one LDS cycle, conflict-free.
+//     (No linear row pitch does that: positions k and k + 8 are 8 rows apart and 8 x pitch is a multiple of 256 bytes for
+//     every pitch that is a multiple of 32.)  The DMA is lane-linear, so the layout lives on the per-lane source address:
+//     slot = 16 bytes, 20 slots per position, two of them zero padding.
+//   * Output [co 64][tap * 144 + ci] = 4 x 27 MFMA blocks; wave w owns column blocks w, w + 8, w + 16 (and w + 24 for
+//     w < 3) for all four co blocks: 12 - 16 MFMAs per 32 positions from 4 + 3 (4) fragment reads; accumulators in registers
+//     over the workgroup's whole tile sequence; next tile's images stream into second buffers under the current tile's MFMAs.
+//   * Persistent grid; ONE fp32 partial [432][64] per workgroup, summed and scattered into the parameter's own
+//     [co][ci][kt] layout by the family's split-K reduce (dvt_splitk_pending with conv_taps = 3, conv_cin = 144).
+#include "common.h"
+
+namespace {
+
+constexpr int kCI = 144, kCO = 64, kNW = 8;
+constexpr int kCB = kCI / 16;                // 9 input-channel blocks
+constexpr int kXU = kCB + 1;                 // 32-byte units per x position (one of padding)
+constexpr int kXRow = kXU * 32;              // 320 bytes
+constexpr int kM = 3 * kCI;                  // 432 slab rows: tap * 144 + ci
+constexpr int kNB = 3 * kCB;                 // 27 column blocks
+constexpr int kMaxXP = 6, kMaxZP = 2;        // DMA pieces (1 KiB) per wave: x window <= 48 KiB, dz tile <= 16 KiB
+
+struct TwParams {
+  const void* x;        // [N, T, L, 144]
+  const void* dz;       // [N, T, L, 64]
+  float* slab;          // [grid][432][64]
+  int N, T, L, S, segs, ntiles;
+  int KP;               // T * S: positions of a dz tile (multiple of 32)
+  int xpos;             // (T + 2) * S: positions of an x window
+  int x_bytes, z_bytes; // image sizes (multiples of 1 KiB)
+};
+
+__device__ __attribute__((aligned(16))) unsigned int tw_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int tw_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }   // conv3x3_wgrad.hip's cw_swz
+
+template <typename E>
+__global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int S = p.S;
+  char* xb[2] = {smem, smem + p.x_bytes};
+  char* zb[2] = {smem + 2 * p.x_bytes, smem + 2 * p.x_bytes + p.z_bytes};
+  const E* xg = (const E*)p.x;
+  const E* zg = (const E*)p.dz;
+  const int xp = p.x_bytes >> 10, zp = p.z_bytes >> 10;
+
+  // ---- per-lane coordinates of this wave's DMA pieces (fixed for the launch)
+  // x: frame row << 20 | pixel of the segment << 8 | channel (multiple of 8) of the 16-byte chunk, bit 31 = never loaded
+  // dz: frame << 20 | pixel << 8 | source chunk << 1 | valid
+  unsigned xq[kMaxXP];
+  int zq[kMaxZP];
+#pragma unroll
+  for (int i = 0; i < kMaxXP; ++i) {
+    const int piece = wid + kNW * i;
+    const int sl = piece * 64 + lane;
+    const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
+    const int cb = (h >> 1) - ((pos >> 3) & 1);
+    const int tt = pos / S, sx = pos - tt * S;
+    const bool ok = piece < xp && pos < p.xpos && cb >= 0 && cb < kCB;
+    xq[i] = ok ? ((unsigned)tt << 20) | ((unsigned)sx << 8) | (unsigned)(cb * 16 + (h & 1) * 8) : 0x80000000u;
+  }
+  const int c16 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < kMaxZP; ++i) {
+    const int piece = wid + kNW * i;
+    const int pos = (piece * 64 + lane) >> 3;
+    const int t = pos / S, sx = pos - t * S;
+    const int ok = (piece < zp && pos < p.KP) ? 1 : 0;
+    zq[i] = (t << 20) | (sx << 8) | (((((c16 >> 1) ^ tw_swz(pos)) << 1) | (c16 & 1)) << 1) | ok;
+  }
+  auto load_tile = [&](int tile, int b) {
+    const int n = tile / p.segs, sg = tile - n * p.segs;
+    const int64_t pix0 = (int64_t)n * p.T * p.L + (int64_t)sg * S;          // pixel (frame 0, first pixel of the segment)
+#pragma unroll
+    for (int i = 0; i < kMaxXP; ++i) {
+      const int piece = wid + kNW * i;
+      if (piece < xp) {                          // wave-uniform
+        const int frame = (int)((xq[i] >> 20) & 0x7FF) - 1;
+        const bool ok = (int)xq[i] >= 0 && (unsigned)frame < (unsigned)p.T;
+        const E* src = ok ? xg + (pix0 + (int64_t)frame * p.L + ((xq[i] >> 8) & 0xFFF)) * kCI + (xq[i] & 0xFF)
+                          : reinterpret_cast<const E*>(tw_zero16);
+        dvt_dma16(src, xb[b] + piece * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxZP; ++i) {
+      const int piece = wid + kNW * i;
+      if (piece < zp) {
+        const E* src = (zq[i] & 1) ? zg + (pix0 + (int64_t)(zq[i] >> 20) * p.L + ((zq[i] >> 8) & 0xFFF)) * kCO + ((zq[i] >> 1) & 7) * 8
+                                   : reinterpret_cast<const E*>(tw_zero16);
+        dvt_dma16(src, zb[b] + piece * 1024);
+      }
+    }
+  };
+
+  // this wave's column blocks nb = wid + 8 j: tap = nb / 9 (position offset tap * S), ci block = nb % 9.  A k-step adds 32
+  // positions, which changes neither bit 1 nor bit 3 of a position: the swizzle terms are fixed for the whole launch.
+  const int cnt = wid < kNB - 3 * kNW ? 4 : 3;            // wave-uniform (waves 0 .. 2: four blocks)
+  int zo[4][2], xo[4][2];
+  {
+    const int q = li >> 2, pp = li & 3;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = 8 * g + 4 * hf + q;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) zo[m][hf] = k * 128 + ((m ^ tw_swz(k)) << 5) + 8 * pp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = min(wid + kNW * j, kNB - 1), tap = nb / kCB, cb = nb - tap * kCB;
+        const int kx = k + tap * S;
+        xo[j][hf] = kx * kXRow + ((cb + ((kx >> 3) & 1)) << 5) + 8 * pp;
+      }
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nks = p.KP >> 5;
+  for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
+    const char* cx = xb[it & 1];
+    const char* cz = zb[it & 1];
+    if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x, (it + 1) & 1);
+    V8 zf[2][4], xf[2][4];
+    auto rd = [&](int ks, V8* zv, V8* xv) {
+      const char* bz = cz + ks * (32 * 128);
+      const char* bx = cx + ks * (32 * kXRow);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        zv[m] = __builtin_shufflevector(Elem16<E>::tr_read(bz + zo[m][0]), Elem16<E>::tr_read(bz + zo[m][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < 3 || cnt == 4)
+          xv[j] = __builtin_shufflevector(Elem16<E>::tr_read(bx + xo[j][0]), Elem16<E>::tr_read(bx + xo[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    rd(0, zf[0], xf[0]);
+    for (int ks = 0; ks < nks; ks += 2) {        // two steps per trip: the fragment buffers alternate without indexing
+      if (ks + 1 < nks) rd(ks + 1, zf[1], xf[1]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < 3 || cnt == 4) acc[m][j] = Elem16<E>::mma(zf[0][m], xf[0][j], acc[m][j]);
+      if (ks + 1 < nks) {
+        if (ks + 2 < nks) rd(ks + 2, zf[0], xf[0]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < 3 || cnt == 4) acc[m][j] = Elem16<E>::mma(zf[1][m], xf[1][j], acc[m][j]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
+    __builtin_amdgcn_s_barrier();                                  // and everybody is done with this tile's
+  }
+
+  // ---- this workgroup's partial: slab[blockIdx][m = tap * 144 + 16 cb + li][n = 16 mb + 4 g .. + 3]
+  // (mma(dz fragment, x fragment): lane (g, li) holds C[co = 16 mb + 4 g + r][ci = 16 cb + li])
+  float* out = p.slab + (int64_t)blockIdx.x * kM * kCO;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j >= cnt) break;
+    const int nb = wid + kNW * j, tap = nb / kCB, cb = nb - tap * kCB;
+    float* row = out + (int64_t)(tap * kCI + cb * 16 + li) * kCO + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[m][j];
+  }
+}
+
+// pixels per segment and the two image sizes for T frames of L pixels
+int tw_plan(int T, int L, TwParams* q) {
+  if (T < 1 || L < 1 || T + 2 > 2047) return 0;
+  for (int S = 16; S >= 2; --S) {
+    if (L % S || (T * S) % 32 || S > 4095) continue;
+    const int KP = T * S, xpos = (T + 2) * S;
+    const int xbytes = (xpos * kXRow + 1023) & ~1023, zbytes = KP * 128;     // (KP % 32 == 0: zbytes is whole KiB)
+    if (2 * (xbytes + zbytes) > 160 * 1024) continue;
+    if ((xbytes >> 10) > kNW * kMaxXP || (zbytes >> 10) > kNW * kMaxZP) continue;
+    q->S = S; q->KP = KP; q->xpos = xpos; q->x_bytes = xbytes; q->z_bytes = zbytes; q->segs = L / S;
+    return 1;
+  }
+  return 0;
+}
+
+int tw_grid(int64_t N, const TwParams& q) {
+  const int64_t ntiles = N * q.segs;
+  return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype) {
+  TwParams q;
+  return N > 0 && Cin == kCI && Cout == kCO && dvt_is_16bit(dtype) && tw_plan(T, L, &q) && N * q.segs < ((int64_t)1 << 31) &&
+                 N * T * L < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L) {
+  TwParams q;
+  if (N <= 0 || !tw_plan(T, L, &q)) return 0;
+  return (size_t)tw_grid(N, q) * kM * kCO * sizeof(float);
+}
+
+int dvt_conv3x1_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int T, int L, int accumulate,
+                      int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && dz && dw && workspace && N > 0 && T > 0 && L > 0, "dvt_conv3x1_wgrad: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(dz) && dvt_aligned16(dw) && dvt_aligned16(workspace),
+              "dvt_conv3x1_wgrad: buffers must be 16-byte aligned");
+  DVT_REQUIRE(!defer_reduce || pending, "dvt_conv3x1_wgrad: defer_reduce needs a pending descriptor to fill");
+  if (!dvt_conv3x1_wgrad_supported(N, T, L, kCI, kCO, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x1_wgrad: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
+                    "(T * S) %% 32 == 0 and two (window + gradient tile) pairs in 160 KiB of LDS");
+  TwParams p;
+  tw_plan(T, L, &p);
+  p.x = x; p.dz = dz; p.slab = (float*)workspace;
+  p.N = (int)N; p.T = T; p.L = L;
+  p.ntiles = (int)(N * p.segs);
+  const int grid = tw_grid(N, p);
+  const int lds = 2 * (p.x_bytes + p.z_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DVT_BF16) {
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x1_wgrad_kernel<bf16>, 160 * 1024);
+    hipLaunchKernelGGL((conv3x1_wgrad_kernel<bf16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  } else {
+    static DvtLdsAttr set;
+    dvt_lds_attr(set, (const void*)conv3x1_wgrad_kernel<f16>, 160 * 1024);
+    hipLaunchKernelGGL((conv3x1_wgrad_kernel<f16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  }
+  DVT_LAUNCH_CHECK("dvt_conv3x1_wgrad");
+  // the slabs are summed by the family's split-K reduce, which scatters [tap * 144 + ci][co] into the parameter's [co][ci][3]
+  dvt_splitk_pending q{};
+  q.slab = p.slab; q.splits = grid; q.valid = 1; q.M = kM; q.N = kCO; q.C = dw; q.ldc = kCO;
+  q.accumulate = accumulate; q.cs_accumulate = 0; q.cs_slab = nullptr; q.cs_out = nullptr;
+  q.conv_cin = kCI; q.conv_taps = 3; q.conv_cin_l = 0; q.conv_cout_l = 0;
+  if (defer_reduce) {
+    *pending = q;
+    return DVT_OK;
+  }
+  return dvt_splitk_reduce_pending(&q, stream);
+}
+
+}  // extern "C"

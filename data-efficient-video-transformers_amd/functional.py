@@ -1337,6 +1337,8 @@ def _packed_class_weight(w: Tensor, cout_l: int, cin_l: int, kh: int, kw: int, c
 # weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
 HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
 HALO_WGRAD_COUT = (64, 144) if os.environ.get("DVT_HALO_WGRAD_WIDE", "1") != "0" else (64,)
+# weight gradient of the (3, 1) temporal convolutions 144 -> 64 from LDS sliding windows (csrc/conv3x1_wgrad.hip)
+WINDOW_WGRAD = os.environ.get("DVT_WINDOW_WGRAD", "1") != "0"
 
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
@@ -1568,6 +1570,11 @@ class _ConvBnAct(torch.autograd.Function):
                 # layer 1 of ResNet-18 (and, in 64-channel groups of dz, of R(2+1)D-18: 64 -> 144): input patch and gradient
                 # tile staged once per R rows, the nine taps read from LDS
                 pend = ops.conv3x3_c64_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True, Cout=Cout)
+            elif (WINDOW_WGRAD and HALO_CONV and (kh, kw) == (3, 1) and not padded and ops._pair(stride) == (1, 1)
+                    and ops._pair(pad) == (1, 0) and ops.conv3x1_wgrad_supported(xc, dz, N, H, W, Cin, Cout)):
+                # the temporal half of R(2+1)D-18's layer-1 pairs (144 mid planes -> 64): a segment of pixels over all frames
+                # staged once, the three taps read from LDS (the implicit form gathered x once per tap)
+                pend = ops.conv3x1_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True)
             else:
                 _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
                                                     master=dw_master, accumulate=acc_w, logical=(Cout_l, Cin_l))

@@ -1384,6 +1384,35 @@ def conv3x3_c64_wgrad(x: Tensor, dz: Tensor, N: int, H: int, W: int, master: Ten
     return None
 
 
+def conv3x1_wgrad_supported(x: Tensor, dz: Tensor, N: int, T: int, Lp: int, Cin: int, Cout: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
+        return False
+    if not (x.is_contiguous() and dz.is_contiguous() and x.shape == (N * T * Lp, Cin) and dz.shape == (N * T * Lp, Cout)):
+        return False
+    return bool(L.load().dvt_conv3x1_wgrad_supported(N, T, Lp, Cin, Cout, dt(x)))
+
+
+def conv3x1_wgrad(x: Tensor, dz: Tensor, N: int, T: int, Lp: int, master: Tensor, *, accumulate: bool = False,
+                  defer_reduce: bool = False):
+    """Weight gradient of the (3, 1) temporal convolution 144 -> 64 over the [T, H*W] view of N clips from LDS-resident
+    sliding windows (dvt_conv3x1_wgrad), summed into ``master`` (f32 [64, 144, 3(, 1, 1)]; += when accumulate).
+    defer_reduce: -> pending, as ``conv3x3_c64_wgrad``."""
+    _need_cuda(x, dz, master)
+    assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == 64 * 144 * 3
+    lib = L.load()
+    pend = L.SplitKPending()
+    nbytes = int(lib.dvt_conv3x1_wgrad_workspace_bytes(N, T, Lp))
+    ws = _deferred_workspace(nbytes, x.device, pend) if defer_reduce else workspace(nbytes, x.device, slot="conv3_wgrad")
+    nb = (x.numel() + dz.numel()) * x.element_size() + master.numel() * 4
+    with _timed(("conv", "window3x1_wgrad", 432, 64, N * T * Lp, nb), 2.0 * N * T * Lp * 64 * 432):
+        L.check(lib.dvt_conv3x1_wgrad(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, T, Lp, int(accumulate),
+                                      int(defer_reduce), C.byref(pend), dt(x), _stream()), "dvt_conv3x1_wgrad")
+    if defer_reduce:
+        pend._keep = (ws, master)
+        return pend
+    return None
+
+
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,
                     want_stats: bool = False, trim_w: int = 0, carry=None, residual: Optional[Tensor] = None,
                     out: Optional[Tensor] = None, out_hw=None, out_rows: Optional[Tensor] = None, residual_compact: bool = False):

@@ -624,6 +624,15 @@ int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* worksp
  * 64 channels); defer_reduce defers the LAST group's reduce. */
 int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cout,
                                int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
+/* Weight gradient of the temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (torchvision r2plus1d_18 as used by
+ * frame_transformer.py:64-74: a (3, 1, 1) convolution, 144 mid planes -> 64, stride 1, pad 1) from LDS-resident sliding
+ * windows: x [N, T, L, 144] (the mid activation, L = H * W pixels per frame), dz [N, T, L, 64], dw f32 [64][144][3] (the
+ * Conv3d parameter's own layout; += when accumulate).  A workgroup stages a segment of S pixels over all T + 2 frames once
+ * and the three taps read it at three position offsets; workspace / defer_reduce / pending as dvt_conv3x3_c64_wgrad. */
+int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
+size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L);
+int dvt_conv3x1_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int T, int L, int accumulate,
+                      int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */

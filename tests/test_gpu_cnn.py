@@ -877,6 +877,37 @@ def test_conv3x3_c64_weight_gradient_with_more_output_channels(dvt, device, dtyp
     assert rel_l2(acc - old, ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4)])
+def test_temporal_weight_gradient_from_lds_sliding_windows(dvt, device, dtype, N, T, H, W):
+    """dvt_conv3x1_wgrad: weight gradient of the (3, 1, 1) temporal convolution 144 -> 64 of R(2+1)D-18's layer 1
+    (torchvision r2plus1d_18, frame_transformer.py:64-74) with a segment of pixels over all frames staged once in LDS and the
+    three taps read at three position offsets, against fp32 on the same 16-bit operands and against the implicit kernel it
+    replaces; more tiles than workgroups, a map of a single tile column, accumulate, deferred reduce."""
+    ops = dvt.ops
+    Lp = H * W
+    g = torch.Generator().manual_seed(N * 100 + T + Lp)
+    x = torch.randn(N * T * Lp, 144, generator=g).to(dtype).cuda()
+    dz = (torch.randn(N * T * Lp, 64, generator=g) / (N * T * Lp) ** 0.5).to(dtype).cuda()
+    assert ops.conv3x1_wgrad_supported(x, dz, N, T, Lp, 144, 64)
+    dw = torch.full((64, 144, 3, 1), float("nan"), device="cuda")
+    ops.conv3x1_wgrad(x, dz, N, T, Lp, dw)
+    xf, zf = x.float().view(N, T, Lp, 144), dz.float().view(N, T, Lp, 64)
+    ref = torch.zeros(64, 144, 3, device="cuda")
+    for kt in range(3):                                   # dW[co][ci][kt] = sum dz[n, t, p, co] * x[n, t + kt - 1, p, ci]
+        lo, hi = max(0, 1 - kt), min(T, T + 1 - kt)
+        ref[:, :, kt] = torch.einsum("ntpo,ntpi->oi", zf[:, lo:hi], xf[:, lo + kt - 1:hi + kt - 1])
+    assert torch.isfinite(dw).all() and rel_l2(dw.view(64, 144, 3), ref) < 2e-5
+    imp = torch.empty(64, 144, 3, 1, device="cuda")
+    ops.conv2d_implicit_wgrad(x, dz, N, 144, T, Lp, 64, (3, 1), 1, (1, 0), master=imp)
+    assert rel_l2(dw, imp) < 2e-5
+    old = torch.randn(64, 144, 3, 1, generator=g).cuda()
+    acc = old.clone()
+    pend = ops.conv3x1_wgrad(x, dz, N, T, Lp, acc, accumulate=True, defer_reduce=True)
+    ops.splitk_reduce_pending(pend)
+    assert rel_l2(acc.view(64, 144, 3) - old.view(64, 144, 3), ref) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
 def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
