@@ -367,6 +367,8 @@ def cnn_roofline(summ, nprof, workload):
             name = "conv3x3_stream (LDS halo patch, streamed weights; 64 -> 144 forward and 144 -> 64 data gradient of R(2+1)D layer 1)"
         elif kind == "halo3x3_c64_wgrad":
             name = "conv3x3_c64 weight gradient (LDS halo patches; one partial per workgroup, summed by the split-K reduce)"
+        elif kind == "window3x1_wgrad":
+            name = "conv3x1 temporal weight gradient 144 -> 64 (LDS sliding windows over all frames of a pixel segment)"
         else:
             name = f"implicit forward / data gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'}"
         f = fams.setdefault(name, [0.0, 0.0, 0, 0.0, kind])
@@ -384,7 +386,8 @@ def cnn_roofline(summ, nprof, workload):
         except Exception:
             pmc = {}
     pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
-               "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream"}
+               "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream",
+               "window3x1_wgrad": "conv3x1_wgrad"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
