@@ -76,6 +76,11 @@ class ConvDesc(C.Structure):
                 ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_rows", C.c_void_p), ("residual_compact", C.c_int32)]
 
 
+class BnAffine(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("c_valid", C.c_int32), ("relu", C.c_int32)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("cout_l", "cin_l", "kh", "kw", "cout_p", "cin_p", "ld", "kind", "dtype",
@@ -226,7 +231,10 @@ SIGNATURES = {
     "dvt_conv3x3_c64_wgrad_supported": (c_int, [c_i64, c_int, c_int, c_int]),
     "dvt_conv3x1_wgrad_supported": (c_int, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "dvt_conv3x1_wgrad_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int]),
-    "dvt_conv3x1_wgrad": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, C.POINTER(SplitKPending), c_int, c_p]),
+    "dvt_conv3x1_wgrad": (c_int, [c_p, C.POINTER(BnAffine), c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, C.POINTER(SplitKPending), c_int, c_p]),
+    "dvt_conv3x1_fwd_supported": (c_int, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "dvt_conv3x1_fwd_stats_parts": (c_i64, [c_i64, c_int, c_int]),
+    "dvt_conv3x1_fwd": (c_int, [c_p, C.POINTER(BnAffine), c_p, c_i64, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_conv3x3_c64_wgrad_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int]),
     "dvt_conv3x3_c64_wgrad": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, C.POINTER(SplitKPending), c_int, c_p]),
     "dvt_conv3x3_c64_stats_parts": (c_i64, [c_i64, c_int, c_int]),

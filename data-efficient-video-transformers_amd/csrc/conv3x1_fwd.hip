@@ -1,0 +1,269 @@
+// conv3x1_fwd.hip -- forward of the temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (video_resnet.py:30-31: a (3, 1, 1)
+// convolution, 144 mid planes -> 64 planes, stride 1, pad 1) from the LDS window of conv3x1_window.h.
+//
+//   z[n, t, p, co] = sum over kt, ci of x[n, t + kt - 1, p, ci] * W[co][kt * 144 + ci]
+//
+// The implicit GEMM (gemm256.hip, per-lane taps) gathers every pixel of the 144-plane map once per temporal tap (152 - 160 us
+// per layer at 28 clips of 12 x 56^2, 303 MB of input).  Here a workgroup owns a segment of S pixels over all T frames,
+// stages the (T + 2) x S x 144 window once and reads the three taps at the position offsets 0 / S / 2S:
+//   * eight waves = 4 output-channel blocks of 16 x 2 halves of the tile's 16-position blocks; a wave's share of the weights
+//     (16 output channels x 432: 12 x 16-byte + 3 x 8-byte fragments, 54 VGPRs) is loaded ONCE per launch and stays in
+//     registers, so the only LDS traffic of the main loop is one x row fragment per MFMA (ds_read_b128 / ds_read_b64 on the
+//     window image, conflict-free);
+//   * 144 channels per tap = four 16x16x32 steps + one 16x16x16 step;
+//   * optional virtual BatchNorm: the map is the spatial convolution's output z and relu(z * s + t) is formed in the staged
+//     window (window_transform), once per tile -- the normalised 144-plane activation then never exists in HBM;
+//   * epilogue: the tile's outputs go through an LDS staging image and leave as whole 128-byte pixel rows; the column sums /
+//     sums of squares of the STORED values for the BatchNorm behind the layer are carried per thread over the workgroup's
+//     whole tile sequence (a thread always stores the same 8 channels) and reduced once per launch.
+#include "conv3x1_window.h"
+
+namespace {
+
+using namespace dvt_window;
+
+struct TfParams {
+  const void* x;        // [N, T, L, 144]
+  const void* w;        // [64][ldw] k-major, k = tap * 144 + ci
+  void* y;              // [N, T, L, 64]
+  float* bn_partial;    // [grid][2][64] or nullptr
+  Window w_;
+  Affine aff;
+  int ntiles, ldw;
+};
+
+template <typename E> struct Mma16f;
+template <> struct Mma16f<bf16> {
+  static __device__ __forceinline__ f32x4 mma(bf16x4 a, bf16x4 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16f<f16> {
+  static __device__ __forceinline__ f32x4 mma(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int kMaxPB = 4;                    // 16-position blocks per wave (tile <= 128 positions)
+
+// NPB = 16-position blocks per wave (KP / 32), a template parameter: with a run-time count every block of the unrolled k
+// loop became a branch and the accumulators were copied around them (1,100 v_mov_b64 in the listing)
+template <typename E, int NPB>
+__global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  using V4 = typename Elem16<E>::v4;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const Window& w = p.w_;
+  const int S = w.S;
+  // (the two window buffers are addressed as smem + offset, never through a pointer picked at run time: a `char* xb[2]`
+  //  selected by it & 1 lost its LDS address space and every fragment read became a flat_load)
+  char* stage = smem + 2 * w.x_bytes;                                            // [KP][64] outputs of a tile, 128-byte rows
+  float* st = reinterpret_cast<float*>(stage + w.KP * 128);                      // [2][144] folded affine
+  const E* xg = (const E*)p.x;
+  const bool affine = p.aff.mean != nullptr;
+  if (affine) window_affine_table(p.aff, st);
+  unsigned xq[kMaxXP];
+  window_coords(w, wid, lane, xq);
+  auto load_tile = [&](int tile, int b) {
+    const int n = tile / w.segs, sg = tile - n * w.segs;
+    window_load<E>(w, xg, (int64_t)n * w.T * w.L + (int64_t)sg * S, xq, wid, smem + b * w.x_bytes);
+  };
+
+  // ---- this wave: output channels [16 u, 16 u + 16), position blocks pb0 .. pb0 + npb - 1
+  const int u = wid & 3, half = wid >> 2;
+  constexpr int npb = NPB;
+  const int pb0 = half * npb;                                                    // (KP == 32 NPB)
+  // weights of the wave's 16 output channels, in registers for the whole launch: lane (g, li) <-> row 16 u + li, k = .. + 8 g
+  V8 wf[3][4];
+  V4 wr[3];
+  {
+    const E* wrow = (const E*)p.w + (int64_t)(16 * u + li) * p.ldw;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[kt][kk] = *reinterpret_cast<const V8*>(wrow + kt * kCI + kk * 32 + g * 8);
+      wr[kt] = *reinterpret_cast<const V4*>(wrow + kt * kCI + 128 + g * 4);
+    }
+  }
+  // byte offset of this lane's x fragments inside a window, per tap: row = position 16 pb0 + li + S kt, 16-byte fragment kk =
+  // channels 32 kk + 8 g -> block 2 kk + (g >> 1) (+ 1 where bit 3 of the position is set), half g & 1; the 8-byte fragment =
+  // channels 128 + 4 g.  Position block b and k-step kk add the compile-time constants 16 b x 320 and 64 kk (16 positions
+  // leave bit 3 alone), which the reads carry in their offset field: three registers per lane instead of sixty hoisted ones.
+  int xo[3], xo4[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int pos = pb0 * 16 + li + kt * S, b3 = (pos >> 3) & 1;
+    xo[kt] = pos * kXRow + (((g >> 1) + b3) << 5) + ((g & 1) << 4);
+    xo4[kt] = pos * kXRow + ((8 + b3) << 5) + (g << 3);
+  }
+
+  float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int nst = wid * 8 < w.KP ? (w.KP - wid * 8 + 63) >> 6 : 0;        // output rows (= stores) per thread and tile, wave-uniform
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (affine) {
+    window_transform<E>(w, smem, st, p.aff.relu);
+    __syncthreads();
+  }
+  for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
+    const int cxo = (it & 1) * w.x_bytes;
+    if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x, (it + 1) & 1);
+    f32x4 acc[NPB];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      // fragments of every position block first, then the MFMAs by k-step across the blocks: a 16x16x16 step that follows the
+      // 16x16x32 step on the SAME accumulator back to back read two of its four result registers early (tap 0, channels
+      // 96 .. 127 of the middle block came out partly missing) -- dependent MFMAs of different shapes are kept apart
+      V8 xf[2][NPB];                             // (double buffer over the k-steps: the next step's reads under this step's MFMAs)
+      V4 x4[NPB];
+      auto rdx = [&](int kk, V8* dst) {
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) dst[b] = *reinterpret_cast<const V8*>(smem + cxo + xo[kt] + b * (16 * kXRow) + kk * 64);
+      };
+      rdx(0, xf[0]);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk + 1 < 4) {
+          rdx(kk + 1, xf[(kk + 1) & 1]);
+        } else {
+#pragma unroll
+          for (int b = 0; b < NPB; ++b) x4[b] = *reinterpret_cast<const V4*>(smem + cxo + xo4[kt] + b * (16 * kXRow));
+        }
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) acc[b] = Elem16<E>::mma(wf[kt][kk], xf[kk & 1][b], acc[b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < NPB; ++b) acc[b] = Mma16f<E>::mma(wr[kt], x4[b], acc[b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the tile's outputs: lane (g, li) holds z[position (pb0 + b) * 16 + li][16 u + 4 g .. + 3]
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      V4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (E)acc[b][r];
+      const int pos = (pb0 + b) * 16 + li;
+      *reinterpret_cast<V4*>(stage + pos * 128 + (((2 * u + (g >> 1)) ^ (pos & 7)) << 4) + ((g & 1) << 3)) = o;
+    }
+    __syncthreads();                               // staging complete
+    {
+      const int n = tile / w.segs, sg = tile - n * w.segs;
+      const int64_t pix0 = (int64_t)n * w.T * w.L + (int64_t)sg * S;
+      E* yg = (E*)p.y;
+      const int c = threadIdx.x & 7;               // this thread's 8 channels, the same for every tile
+      for (int r = threadIdx.x >> 3; r < w.KP; r += (kNW * 64) >> 3) {
+        const V8 v = *reinterpret_cast<const V8*>(stage + r * 128 + ((c ^ (r & 7)) << 4));
+        const int t = r / S, sx = r - t * S;
+        *reinterpret_cast<V8*>(yg + (pix0 + (int64_t)t * w.L + sx) * kCO + c * 8) = v;
+        if (p.bn_partial) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float f = (float)v[k];
+            bs[k] += f;
+            bq[k] = fmaf(f, f, bq[k]);
+          }
+        }
+      }
+    }
+    // the next window has landed; this tile's stores (issued behind its requests, at most two per thread: vmcnt counts in
+    // issue order) stay in flight -- waiting for them as well cost ~3 us per tile, 130 us per launch
+    if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (nst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                              // everybody is done with this tile's window and staging
+    if (affine && tile + (int)gridDim.x < p.ntiles) {
+      window_transform<E>(w, smem + ((it + 1) & 1) * w.x_bytes, st, p.aff.relu);
+      __syncthreads();
+    }
+  }
+  if (p.bn_partial) {                              // threads with equal (tid & 7) hold the same 8 channels: fixed-order sum
+    float* red = reinterpret_cast<float*>(smem);   // [2][512][8] = 32 KiB over the window buffers (all reads of them are done)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[(0 * kNW * 64 + threadIdx.x) * 8 + k] = bs[k];
+      red[(1 * kNW * 64 + threadIdx.x) * 8 + k] = bq[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kCO) {
+      const int stat = threadIdx.x >> 6, ch = threadIdx.x & 63, c = ch >> 3, k = ch & 7;
+      float t = 0.f;
+      for (int j = 0; j < (kNW * 64) >> 3; ++j) t += red[(stat * kNW * 64 + j * 8 + c) * 8 + k];
+      p.bn_partial[((int64_t)blockIdx.x * 2 + stat) * kCO + ch] = t;
+    }
+  }
+}
+
+int tf_plan(int T, int L, Window* q) {
+  if (!window_plan(T, L, q, 0, 128, 2)) return 0;
+  return (q->KP >> 5) <= kMaxPB && 2 * q->x_bytes >= 2 * kNW * 64 * 8 * 4;      // (the statistics scratch overlays the windows)
+}
+
+int tf_grid(int64_t N, const Window& q) {
+  const int64_t ntiles = N * q.segs;
+  return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
+}
+
+template <typename E, int NPB>
+void tf_launch(const TfParams& p, int grid, int lds, hipStream_t st) {
+  static DvtLdsAttr set;
+  dvt_lds_attr(set, (const void*)conv3x1_fwd_kernel<E, NPB>, 160 * 1024);
+  hipLaunchKernelGGL((conv3x1_fwd_kernel<E, NPB>), dim3(grid), dim3(kNW * 64), lds, st, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvt_conv3x1_fwd_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype) {
+  Window q;
+  return N > 0 && Cin == kCI && Cout == kCO && dvt_is_16bit(dtype) && tf_plan(T, L, &q) && N * q.segs < ((int64_t)1 << 31) &&
+                 N * T * L < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L) {
+  Window q;
+  if (N <= 0 || !tf_plan(T, L, &q)) return 0;
+  return tf_grid(N, q);                            // one partial row per workgroup of the persistent grid
+}
+
+int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w, int64_t ldw, void* y, float* stats_partial,
+                    int64_t N, int T, int L, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && w && y && N >= 0 && T > 0 && L > 0 && ldw >= 3 * kCI && ldw % 8 == 0, "dvt_conv3x1_fwd: bad arguments");
+  DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y) && dvt_aligned16(stats_partial),
+              "dvt_conv3x1_fwd: buffers must be 16-byte aligned");
+  if (N == 0) return DVT_OK;
+  if (!dvt_conv3x1_fwd_supported(N, T, L, kCI, kCO, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x1_fwd: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
+                    "(T * S) %% 32 == 0, T * S <= 128 and two windows + the output staging in 160 KiB of LDS");
+  TfParams p{};
+  tf_plan(T, L, &p.w_);
+  p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.ldw = (int)ldw;
+  p.ntiles = (int)(N * p.w_.segs);
+  if (x_affine && x_affine->mean) {
+    DVT_REQUIRE(x_affine->invstd && x_affine->gamma && x_affine->beta && x_affine->c_valid >= 0 && x_affine->c_valid <= kCI,
+                "dvt_conv3x1_fwd: x_affine needs mean, invstd, gamma, beta and 0 <= c_valid <= 144");
+    p.aff = Affine{x_affine->mean, x_affine->invstd, x_affine->gamma, x_affine->beta,
+                   x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
+  }
+  const int grid = tf_grid(N, p.w_);
+  const int lds = 2 * p.w_.x_bytes + p.w_.KP * 128 + 2 * kCI * (int)sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const bool h = dtype == DVT_F16;
+  switch (p.w_.KP >> 5) {
+    case 1: h ? tf_launch<f16, 1>(p, grid, lds, st) : tf_launch<bf16, 1>(p, grid, lds, st); break;
+    case 2: h ? tf_launch<f16, 2>(p, grid, lds, st) : tf_launch<bf16, 2>(p, grid, lds, st); break;
+    case 3: h ? tf_launch<f16, 3>(p, grid, lds, st) : tf_launch<bf16, 3>(p, grid, lds, st); break;
+    default: h ? tf_launch<f16, 4>(p, grid, lds, st) : tf_launch<bf16, 4>(p, grid, lds, st); break;
+  }
+  DVT_LAUNCH_CHECK("dvt_conv3x1_fwd");
+  return DVT_OK;
+}
+
+}  // extern "C"

@@ -23,29 +23,23 @@
 //     over the workgroup's whole tile sequence; next tile's images stream into second buffers under the current tile's MFMAs.
 //   * Persistent grid; ONE fp32 partial [432][64] per workgroup, summed and scattered into the parameter's own
 //     [co][ci][kt] layout by the family's split-K reduce (dvt_splitk_pending with conv_taps = 3, conv_cin = 144).
-#include "common.h"
+#include "conv3x1_window.h"
 
 namespace {
 
-constexpr int kCI = 144, kCO = 64, kNW = 8;
-constexpr int kCB = kCI / 16;                // 9 input-channel blocks
-constexpr int kXU = kCB + 1;                 // 32-byte units per x position (one of padding)
-constexpr int kXRow = kXU * 32;              // 320 bytes
+using namespace dvt_window;
 constexpr int kM = 3 * kCI;                  // 432 slab rows: tap * 144 + ci
 constexpr int kNB = 3 * kCB;                 // 27 column blocks
-constexpr int kMaxXP = 6, kMaxZP = 2;        // DMA pieces (1 KiB) per wave: x window <= 48 KiB, dz tile <= 16 KiB
+constexpr int kMaxZP = 2;                    // dz DMA pieces (1 KiB) per wave: tile <= 16 KiB
 
 struct TwParams {
-  const void* x;        // [N, T, L, 144]
+  const void* x;        // [N, T, L, 144]: the normalised mid activation, or (aff.mean != nullptr) the convolution output z in front of it
   const void* dz;       // [N, T, L, 64]
   float* slab;          // [grid][432][64]
-  int N, T, L, S, segs, ntiles;
-  int KP;               // T * S: positions of a dz tile (multiple of 32)
-  int xpos;             // (T + 2) * S: positions of an x window
-  int x_bytes, z_bytes; // image sizes (multiples of 1 KiB)
+  Window w;
+  Affine aff;
+  int ntiles, z_bytes;
 };
-
-__device__ __attribute__((aligned(16))) unsigned int tw_zero16[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ int tw_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }   // conv3x3_wgrad.hip's cw_swz
 
@@ -56,57 +50,40 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int S = p.S;
-  char* xb[2] = {smem, smem + p.x_bytes};
-  char* zb[2] = {smem + 2 * p.x_bytes, smem + 2 * p.x_bytes + p.z_bytes};
+  const Window& w = p.w;
+  const int S = w.S;
+  char* xb[2] = {smem, smem + w.x_bytes};
+  char* zb[2] = {smem + 2 * w.x_bytes, smem + 2 * w.x_bytes + p.z_bytes};
+  float* st = reinterpret_cast<float*>(smem + 2 * w.x_bytes + 2 * p.z_bytes);      // [2][144] folded affine
   const E* xg = (const E*)p.x;
   const E* zg = (const E*)p.dz;
-  const int xp = p.x_bytes >> 10, zp = p.z_bytes >> 10;
+  const int zp = p.z_bytes >> 10;
+  const bool affine = p.aff.mean != nullptr;                                       // (kernel-uniform)
+  if (affine) window_affine_table(p.aff, st);
 
-  // ---- per-lane coordinates of this wave's DMA pieces (fixed for the launch)
-  // x: frame row << 20 | pixel of the segment << 8 | channel (multiple of 8) of the 16-byte chunk, bit 31 = never loaded
-  // dz: frame << 20 | pixel << 8 | source chunk << 1 | valid
+  // ---- per-lane coordinates of this wave's DMA pieces (fixed for the launch); dz: frame << 20 | pixel << 8 | source chunk << 1 | valid
   unsigned xq[kMaxXP];
   int zq[kMaxZP];
-#pragma unroll
-  for (int i = 0; i < kMaxXP; ++i) {
-    const int piece = wid + kNW * i;
-    const int sl = piece * 64 + lane;
-    const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
-    const int cb = (h >> 1) - ((pos >> 3) & 1);
-    const int tt = pos / S, sx = pos - tt * S;
-    const bool ok = piece < xp && pos < p.xpos && cb >= 0 && cb < kCB;
-    xq[i] = ok ? ((unsigned)tt << 20) | ((unsigned)sx << 8) | (unsigned)(cb * 16 + (h & 1) * 8) : 0x80000000u;
-  }
+  window_coords(w, wid, lane, xq);
   const int c16 = lane & 7;
 #pragma unroll
   for (int i = 0; i < kMaxZP; ++i) {
     const int piece = wid + kNW * i;
     const int pos = (piece * 64 + lane) >> 3;
     const int t = pos / S, sx = pos - t * S;
-    const int ok = (piece < zp && pos < p.KP) ? 1 : 0;
+    const int ok = (piece < zp && pos < w.KP) ? 1 : 0;
     zq[i] = (t << 20) | (sx << 8) | (((((c16 >> 1) ^ tw_swz(pos)) << 1) | (c16 & 1)) << 1) | ok;
   }
   auto load_tile = [&](int tile, int b) {
-    const int n = tile / p.segs, sg = tile - n * p.segs;
-    const int64_t pix0 = (int64_t)n * p.T * p.L + (int64_t)sg * S;          // pixel (frame 0, first pixel of the segment)
-#pragma unroll
-    for (int i = 0; i < kMaxXP; ++i) {
-      const int piece = wid + kNW * i;
-      if (piece < xp) {                          // wave-uniform
-        const int frame = (int)((xq[i] >> 20) & 0x7FF) - 1;
-        const bool ok = (int)xq[i] >= 0 && (unsigned)frame < (unsigned)p.T;
-        const E* src = ok ? xg + (pix0 + (int64_t)frame * p.L + ((xq[i] >> 8) & 0xFFF)) * kCI + (xq[i] & 0xFF)
-                          : reinterpret_cast<const E*>(tw_zero16);
-        dvt_dma16(src, xb[b] + piece * 1024);
-      }
-    }
+    const int n = tile / w.segs, sg = tile - n * w.segs;
+    const int64_t pix0 = (int64_t)n * w.T * w.L + (int64_t)sg * S;          // pixel (frame 0, first pixel of the segment)
+    window_load<E>(w, xg, pix0, xq, wid, xb[b]);
 #pragma unroll
     for (int i = 0; i < kMaxZP; ++i) {
       const int piece = wid + kNW * i;
       if (piece < zp) {
-        const E* src = (zq[i] & 1) ? zg + (pix0 + (int64_t)(zq[i] >> 20) * p.L + ((zq[i] >> 8) & 0xFFF)) * kCO + ((zq[i] >> 1) & 7) * 8
-                                   : reinterpret_cast<const E*>(tw_zero16);
+        const E* src = (zq[i] & 1) ? zg + (pix0 + (int64_t)(zq[i] >> 20) * w.L + ((zq[i] >> 8) & 0xFFF)) * kCO + ((zq[i] >> 1) & 7) * 8
+                                   : reinterpret_cast<const E*>(window_zero16);
         dvt_dma16(src, zb[b] + piece * 1024);
       }
     }
@@ -141,8 +118,12 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   if (tile < p.ntiles) load_tile(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (affine) {                                  // the first window: z -> relu(z * s + t) in place
+    window_transform<E>(w, xb[0], st, p.aff.relu);
+    __syncthreads();
+  }
 
-  const int nks = p.KP >> 5;
+  const int nks = w.KP >> 5;
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
     const char* cx = xb[it & 1];
     const char* cz = zb[it & 1];
@@ -178,6 +159,10 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
     __builtin_amdgcn_s_barrier();                                  // and everybody is done with this tile's
+    if (affine && tile + (int)gridDim.x < p.ntiles) {
+      window_transform<E>(w, xb[(it + 1) & 1], st, p.aff.relu);
+      __syncthreads();
+    }
   }
 
   // ---- this workgroup's partial: slab[blockIdx][m = tap * 144 + 16 cb + li][n = 16 mb + 4 g .. + 3]
@@ -193,22 +178,13 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   }
 }
 
-// pixels per segment and the two image sizes for T frames of L pixels
-int tw_plan(int T, int L, TwParams* q) {
-  if (T < 1 || L < 1 || T + 2 > 2047) return 0;
-  for (int S = 16; S >= 2; --S) {
-    if (L % S || (T * S) % 32 || S > 4095) continue;
-    const int KP = T * S, xpos = (T + 2) * S;
-    const int xbytes = (xpos * kXRow + 1023) & ~1023, zbytes = KP * 128;     // (KP % 32 == 0: zbytes is whole KiB)
-    if (2 * (xbytes + zbytes) > 160 * 1024) continue;
-    if ((xbytes >> 10) > kNW * kMaxXP || (zbytes >> 10) > kNW * kMaxZP) continue;
-    q->S = S; q->KP = KP; q->xpos = xpos; q->x_bytes = xbytes; q->z_bytes = zbytes; q->segs = L / S;
-    return 1;
-  }
-  return 0;
+// pixels per segment and the image sizes for T frames of L pixels (two windows + two dz tiles + the affine table in LDS)
+int tw_plan(int T, int L, Window* q) {
+  if (!window_plan(T, L, q, 128, 0, 2)) return 0;
+  return ((q->KP * 128) >> 10) <= kNW * kMaxZP;
 }
 
-int tw_grid(int64_t N, const TwParams& q) {
+int tw_grid(int64_t N, const Window& q) {
   const int64_t ntiles = N * q.segs;
   return (int)(ntiles < dvt_num_cus() ? ntiles : dvt_num_cus());
 }
@@ -218,19 +194,19 @@ int tw_grid(int64_t N, const TwParams& q) {
 extern "C" {
 
 int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype) {
-  TwParams q;
+  Window q;
   return N > 0 && Cin == kCI && Cout == kCO && dvt_is_16bit(dtype) && tw_plan(T, L, &q) && N * q.segs < ((int64_t)1 << 31) &&
                  N * T * L < ((int64_t)1 << 31) ? 1 : 0;
 }
 
 size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L) {
-  TwParams q;
+  Window q;
   if (N <= 0 || !tw_plan(T, L, &q)) return 0;
   return (size_t)tw_grid(N, q) * kM * kCO * sizeof(float);
 }
 
-int dvt_conv3x1_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int T, int L, int accumulate,
-                      int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
+int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* dz, float* dw, void* workspace, int64_t N, int T,
+                      int L, int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream) {
   DVT_REQUIRE(x && dz && dw && workspace && N > 0 && T > 0 && L > 0, "dvt_conv3x1_wgrad: bad arguments");
   DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(dz) && dvt_aligned16(dw) && dvt_aligned16(workspace),
               "dvt_conv3x1_wgrad: buffers must be 16-byte aligned");
@@ -238,13 +214,19 @@ int dvt_conv3x1_wgrad(const void* x, const void* dz, float* dw, void* workspace,
   if (!dvt_conv3x1_wgrad_supported(N, T, L, kCI, kCO, dtype))
     DVT_UNSUPPORTED("dvt_conv3x1_wgrad: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
                     "(T * S) %% 32 == 0 and two (window + gradient tile) pairs in 160 KiB of LDS");
-  TwParams p;
-  tw_plan(T, L, &p);
+  TwParams p{};
+  tw_plan(T, L, &p.w);
   p.x = x; p.dz = dz; p.slab = (float*)workspace;
-  p.N = (int)N; p.T = T; p.L = L;
-  p.ntiles = (int)(N * p.segs);
-  const int grid = tw_grid(N, p);
-  const int lds = 2 * (p.x_bytes + p.z_bytes);
+  p.z_bytes = p.w.KP * 128;
+  p.ntiles = (int)(N * p.w.segs);
+  if (x_affine && x_affine->mean) {
+    DVT_REQUIRE(x_affine->invstd && x_affine->gamma && x_affine->beta && x_affine->c_valid >= 0 && x_affine->c_valid <= kCI,
+                "dvt_conv3x1_wgrad: x_affine needs mean, invstd, gamma, beta and 0 <= c_valid <= 144");
+    p.aff = Affine{x_affine->mean, x_affine->invstd, x_affine->gamma, x_affine->beta,
+                   x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
+  }
+  const int grid = tw_grid(N, p.w);
+  const int lds = 2 * (p.w.x_bytes + p.z_bytes) + 2 * kCI * (int)sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVT_BF16) {
     static DvtLdsAttr set;

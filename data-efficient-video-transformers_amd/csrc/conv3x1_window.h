@@ -1,0 +1,137 @@
+// conv3x1_window.h -- the LDS "window" of the (3, 1, 1) temporal convolutions of R(2+1)D-18's layer 1 (video_resnet.py:30-31;
+// 144 mid planes <-> 64 planes), shared by the forward (conv3x1_fwd.hip) and the weight gradient (conv3x1_wgrad.hip).
+//
+// A workgroup owns a segment of S pixels of one clip over ALL its T frames and stages the (T + 2) x S x 144 window of the
+// 144-plane map once (frames -1 and T are zero rows); the three taps are the position offsets 0 / S / 2S into it.
+//   * image: [position][144 channels] in rows of TEN 32-byte units (320 bytes): nine channel blocks of 16 plus one unit of
+//     padding, block cb of position k stored at unit cb + ((k >> 3) & 1).  A 32-lane half of ds_read_b64_tr_b16 touches the
+//     positions {q, 8 + q} + 4 hf: 320-byte rows put positions q = 0 .. 3 on banks 0 / 16 / 32 / 48 (+ 8 each) and the
+//     one-unit shift moves positions 8 + q to banks 8 / 24 / 40 / 56 -- the eight 8-bank groups of one LDS cycle.  (No
+//     linear pitch does that: positions k and k + 8 are 8 rows apart, a multiple of 256 bytes for every 32-byte-multiple
+//     pitch.)  The same image serves ds_read_b128 row fragments (16 positions x 16 bytes: four 16-lane access groups, each
+//     over 64 distinct banks).  The DMA is lane-linear, so the layout lives on the per-lane source address: slot = 16
+//     bytes, 20 slots per position, two of them zero padding.
+//   * optional "virtual" BatchNorm: the map in HBM is the convolution output z of the layer in front;
+//     the normalised activation y = relu(z * s + t) -- the formula and the rounding of dvt_bn_apply_fwd (BnAffine::apply,
+//     conv.hip) -- is formed in the staged window, once per tile, by window_transform; the two zero rows stay zero.
+#pragma once
+#include "common.h"
+
+namespace dvt_window {
+
+constexpr int kCI = 144, kCO = 64, kNW = 8;
+constexpr int kCB = kCI / 16;                // 9 input-channel blocks
+constexpr int kXU = kCB + 1;                 // 32-byte units per position (one of padding)
+constexpr int kXRow = kXU * 32;              // 320 bytes
+constexpr int kMaxXP = 6;                    // window DMA pieces (1 KiB) per wave: window <= 48 KiB
+
+// geometry of a launch (host: window_plan)
+struct Window {
+  int T, L, S, segs;    // frames, pixels per frame, pixels per segment, segments per frame
+  int KP;               // T * S: positions of an output / gradient tile (multiple of 32)
+  int xpos;             // (T + 2) * S: positions of a window
+  int x_bytes;          // window image size (multiple of 1 KiB)
+};
+
+// the BatchNorm (+ ReLU) in front of the map, or mean == nullptr (the map already holds the normalised activation)
+struct Affine {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  int c_valid, relu;
+};
+
+inline int window_plan(int T, int L, Window* q, int extra_bytes_per_buffer, int extra_bytes_once, int nbuf) {
+  if (T < 1 || L < 1 || T + 2 > 2047) return 0;
+  for (int S = 16; S >= 2; --S) {
+    if (L % S || (T * S) % 32) continue;
+    const int KP = T * S, xpos = (T + 2) * S;
+    const int xbytes = (xpos * kXRow + 1023) & ~1023;
+    if (nbuf * (xbytes + extra_bytes_per_buffer * KP) + extra_bytes_once * KP + 4096 > 160 * 1024) continue;
+    if ((xbytes >> 10) > kNW * kMaxXP) continue;
+    q->T = T; q->L = L; q->S = S; q->segs = L / S; q->KP = KP; q->xpos = xpos; q->x_bytes = xbytes;
+    return 1;
+  }
+  return 0;
+}
+
+#ifdef __HIPCC__
+__device__ __attribute__((aligned(16))) static unsigned int window_zero16[4] = {0u, 0u, 0u, 0u};
+
+// per-lane coordinates of this wave's window DMA pieces (fixed for the launch):
+// frame row << 20 | pixel of the segment << 8 | channel (multiple of 8) of the 16-byte chunk, bit 31 = never loaded
+__device__ __forceinline__ void window_coords(const Window& w, int wid, int lane, unsigned (&xq)[kMaxXP]) {
+  const int xp = w.x_bytes >> 10;
+#pragma unroll
+  for (int i = 0; i < kMaxXP; ++i) {
+    const int piece = wid + kNW * i;
+    const int sl = piece * 64 + lane;
+    const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
+    const int cb = (h >> 1) - ((pos >> 3) & 1);
+    const int tt = pos / w.S, sx = pos - tt * w.S;
+    const bool ok = piece < xp && pos < w.xpos && cb >= 0 && cb < kCB;
+    xq[i] = ok ? ((unsigned)tt << 20) | ((unsigned)sx << 8) | (unsigned)(cb * 16 + (h & 1) * 8) : 0x80000000u;
+  }
+}
+
+// request this wave's pieces of the window of (clip pixel base pix0 = frame 0, first pixel of the segment)
+template <typename E>
+__device__ __forceinline__ void window_load(const Window& w, const E* xg, int64_t pix0, const unsigned (&xq)[kMaxXP], int wid,
+                                            char* dst) {
+  const int xp = w.x_bytes >> 10;
+#pragma unroll
+  for (int i = 0; i < kMaxXP; ++i) {
+    const int piece = wid + kNW * i;
+    if (piece < xp) {                            // wave-uniform
+      const int frame = (int)((xq[i] >> 20) & 0x7FF) - 1;
+      const bool ok = (int)xq[i] >= 0 && (unsigned)frame < (unsigned)w.T;
+      const E* src = ok ? xg + (pix0 + (int64_t)frame * w.L + ((xq[i] >> 8) & 0xFFF)) * kCI + (xq[i] & 0xFF)
+                        : reinterpret_cast<const E*>(window_zero16);
+      dvt_dma16(src, dst + piece * 1024);
+    }
+  }
+}
+
+// st[0][c] = invstd * gamma, st[1][c] = beta - mean * st[0][c]: the folded affine of BnAffine::init (conv.hip)
+__device__ __forceinline__ void window_affine_table(const Affine& a, float* st) {
+  for (int c = threadIdx.x; c < kCI; c += blockDim.x) {
+    const float g = c < a.c_valid ? a.gamma[c] : 0.f, b = c < a.c_valid ? a.beta[c] : 0.f;
+    const float s = a.invstd[c] * g;
+    st[c] = s;
+    st[kCI + c] = fmaf(-a.mean[c], s, b);
+  }
+}
+
+// y = relu?(z * s + t) on every live 16-byte slot of a staged window (all threads; barriers are the caller's)
+template <typename E>
+__device__ __forceinline__ void window_transform(const Window& w, char* img_, const float* st_, int relu) {
+  using V8 = typename Elem16<E>::v8;
+  typedef __attribute__((address_space(3))) char lds_char;     // (callers pick the buffer at run time: keep the accesses ds_*)
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  lds_char* const img = (lds_char*)img_;
+  lds_cfloat* const st = (lds_cfloat*)st_;
+  const int nslots = w.xpos * (2 * kXU);
+  for (int sl = threadIdx.x; sl < nslots; sl += blockDim.x) {
+    const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
+    const int cb = (h >> 1) - ((pos >> 3) & 1);
+    const int tt = pos / w.S;
+    if (cb < 0 || cb >= kCB || tt == 0 || tt > w.T) continue;      // padding slots; the zero rows of frames -1 and T
+    const int c0 = cb * 16 + (h & 1) * 8;
+    typedef __attribute__((address_space(3))) V8 lds_v8;
+    typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+    V8 v = *(lds_v8*)(img + sl * 16);
+    const f32x4 s0 = *(lds_cf4*)(st + c0), s1 = *(lds_cf4*)(st + c0 + 4);
+    const f32x4 t0 = *(lds_cf4*)(st + kCI + c0), t1 = *(lds_cf4*)(st + kCI + c0 + 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float y = fmaf((float)v[k], k < 4 ? s0[k & 3] : s1[k & 3], k < 4 ? t0[k & 3] : t1[k & 3]);
+      if (relu) y = fmaxf(y, 0.f);
+      v[k] = (E)y;
+    }
+    *(lds_v8*)(img + sl * 16) = v;
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace dvt_window

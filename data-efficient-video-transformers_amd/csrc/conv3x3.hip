@@ -48,7 +48,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
   const int PW = p.W + 2, npos = (p.R + 2) * PW;
   const int npieces = p.patch_bytes >> 10;
   char* wsm = smem;
-  char* pb[2] = {smem + kWBytes, smem + kWBytes + p.patch_bytes};
+  // the two patch buffers are smem + an offset: a `char* pb[2]` picked by it & 1 lost its LDS address space, and every x
+  // fragment read of the main loop was a flat_load (counted on vmcnt AND lgkmcnt: each wait for a fragment also waited for
+  // the next patch's DMA)
+  auto patch = [&](int b) -> char* { return smem + kWBytes + b * p.patch_bytes; };
   const E* xg = (const E*)p.x;
 
   // ---- per-lane patch coordinates of this wave's pieces (fixed for the whole launch)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
     }
   }
   int tile = blockIdx.x;
-  if (tile < p.ntiles) load_patch(tile, pb[0]);
+  if (tile < p.ntiles) load_patch(tile, patch(0));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
   // workgroup; per-tile trees over the accumulators' 16 pixel lanes cost 47 us of a 128 us launch).
   float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
-    const char* cur = pb[it & 1];
-    if (tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x, pb[(it + 1) & 1]);
+    const int cur = kWBytes + (it & 1) * p.patch_bytes;
+    if (tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x, patch((it + 1) & 1));
 
     f32x4 acc[4][2];
 #pragma unroll
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) wo[u] = *reinterpret_cast<const V8*>(wb[kk][u] + tap * 128);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) xv[t] = *reinterpret_cast<const V8*>(cur + ki * prow + xo[t][kj][kk]);
+      for (int t = 0; t < 2; ++t) xv[t] = *reinterpret_cast<const V8*>(smem + cur + ki * prow + xo[t][kj][kk]);
     };
     rd(0, xf[0], wf[0]);
     rd(1, xf[1], wf[1]);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv3Params p) {
     const int valid = rows_ok * p.W;             // pixels of this tile that exist
     E* yt = (E*)p.y + ((int64_t)(n * p.H + h0) * p.W) * kC;
     const E* rt = p.residual ? (const E*)p.residual + ((int64_t)(n * p.H + h0) * p.W) * kC : nullptr;
-    char* stg = const_cast<char*>(cur) + wid * 2048;
+    char* stg = smem + cur + wid * 2048;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;

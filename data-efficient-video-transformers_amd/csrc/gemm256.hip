@@ -618,7 +618,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
       const bool mine = WROWS % 32 == 0 || ps * 32 + (lane >> 3) + 8 * j < WROWS;   // rows past the wave's 112 are the next wave row's
       if (mine && m < p.M && n_ok) {
         if (OUT == OUT_SLAB) {
-          store8<float>(p.slab + ((int64_t)zsl * p.M + m) * p.N + n, v[j]);   // re-read from cache by the reduce: streaming stores cost 10 %
+          // (re-read from cache by the reduce: streaming stores cost 10 %.  Stored through an explicit global pointer: the
+          //  compiler had lost p.slab's address space and emitted flat_store, which also counts on lgkmcnt)
+          typedef __attribute__((address_space(1))) f32x4 gf4;
+          gf4* o = (gf4*)(p.slab + ((int64_t)zsl * p.M + m) * p.N + n);
+          o[0] = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
+          o[1] = f32x4{v[j][4], v[j][5], v[j][6], v[j][7]};
         } else if (OUT == OUT_F32) {
           float* o = (float*)p.C + (int64_t)m * p.ldc + n;
 #pragma unroll

@@ -1339,6 +1339,12 @@ HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
 HALO_WGRAD_COUT = (64, 144) if os.environ.get("DVT_HALO_WGRAD_WIDE", "1") != "0" else (64,)
 # weight gradient of the (3, 1) temporal convolutions 144 -> 64 from LDS sliding windows (csrc/conv3x1_wgrad.hip)
 WINDOW_WGRAD = os.environ.get("DVT_WINDOW_WGRAD", "1") != "0"
+# ... and their forward (csrc/conv3x1_fwd.hip)
+WINDOW_FWD = os.environ.get("DVT_WINDOW_FWD", "1") != "0"
+# "virtual" BatchNorm between the two halves of such a pair: the spatial half leaves its output z and hands (mean, invstd,
+# gamma, beta) on; the temporal half's window kernels form relu(z * s + t) in LDS -- the normalised 144-plane activation is
+# never written (models/video_resnet.py decides per pair; needs both window kernels)
+WINDOW_VIRTUAL_BN = os.environ.get("DVT_WINDOW_VIRTUAL_BN", "1") != "0"
 
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
@@ -1351,7 +1357,12 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
-                cpad=0, dx_frames=None, pool=False, fork=None):
+                cpad=0, dx_frames=None, pool=False, fork=None, in_affine=None, defer_apply=False):
+        # in_affine = (mean, invstd, gamma32, beta32, c_valid, relu): x is the OUTPUT z of the convolution in front and the
+        # BatchNorm (+ ReLU) between the two layers is applied inside this layer's kernels (csrc/conv3x1_window.h); only the
+        # window kernels of the (3, 1) temporal 144 -> 64 layers take it.  defer_apply: the mirror image on the producer's
+        # side -- no bn_apply_fwd launch; the Function returns (z, mean, invstd) and the caller hands the affine on.
+        ctx.in_affine = in_affine
         # fork: the layer's input has a second consumer, the block's shortcut (custom_resnet.py:38-54), handed out by THIS
         # Function as a second output so that its gradient arrives here and joins the data gradient inside the kernel that
         # produces it (residual epilogue of the implicit / halo convolution, second operand of col2im) instead of in an add
@@ -1443,7 +1454,19 @@ class _ConvBnAct(torch.autograd.Function):
                 and ops._pair(pad) == (1, 1) and ops.conv3x3_c64_supported(xc, wp, N, H, W))
         stream = (HALO_CONV and implicit and not halo and ld == K and (kh, kw) == (3, 3) and (sh, sw) == (1, 1)
                   and ops._pair(pad) == (1, 1) and ops.conv3x3_stream_supported(xc, wp, N, H, W, Cin, Cout))
-        if stream:                                # layer 1 of R(2+1)D-18, 64 -> 144: halo patch, weights streamed through LDS
+        window = (WINDOW_FWD and HALO_CONV and implicit and not padded and (kh, kw) == (3, 1) and (sh, sw) == (1, 1)
+                  and ops._pair(pad) == (1, 0) and ops.conv3x1_fwd_supported(xc, wp, N, H, W, Cin, Cout))
+        if in_affine is not None and not window:
+            raise RuntimeError("in_affine (virtual BatchNorm in front of the layer) needs the window kernels of the (3, 1) "
+                               "temporal 144 -> 64 convolution")
+        if window:                                # temporal half of R(2+1)D-18's layer-1 pairs: a pixel segment over all frames in LDS
+            col = None
+            halo = stream = False
+            if training and FUSE_BN_STATS:
+                z, stats_partial, stats_parts = ops.conv3x1_fwd(xc, wp, N, H, W, want_stats=True, affine=in_affine)
+            else:
+                z = ops.conv3x1_fwd(xc, wp, N, H, W, affine=in_affine)
+        elif stream:                              # layer 1 of R(2+1)D-18, 64 -> 144: halo patch, weights streamed through LDS
             col = None
             if training and FUSE_BN_STATS:
                 z, stats_partial, stats_parts = ops.conv3x3_stream(xc, wp, N, H, W, Cin, Cout, want_stats=True)
@@ -1484,6 +1507,8 @@ class _ConvBnAct(torch.autograd.Function):
         res = None if residual is None else residual.contiguous()
         if res is not None and res.shape[1] != Cout:
             raise ValueError("residual width must equal the (padded) output width")
+        if defer_apply and (res is not None or pool or dtype not in (torch.bfloat16, torch.float16)):
+            raise RuntimeError("defer_apply is for plain 16-bit conv -> BatchNorm (-> ReLU) layers")
         pooled = bool(pool) and res is None and Cout % 8 == 0
         if pool and not pooled:
             raise ValueError("pool=True needs a layer without a residual branch and a multiple of 8 output channels")
@@ -1495,6 +1520,8 @@ class _ConvBnAct(torch.autograd.Function):
             if cval:
                 raise ValueError("pool=True is for layers without channel padding")
             y, pidx = ops.bn_relu_maxpool_fwd(z, mean, invstd, g32, b32, N, Cout, Ho, Wo, relu)
+        elif defer_apply:
+            y = z                                 # the consumer forms relu(z * s + t) in its staged window
         elif relu and res is not None and Cout % 8 == 0 and any(ctx.needs_input_grad):
             y, rmask = ops.bn_apply_fwd(z, mean, invstd, g32, b32, res, relu, want_mask=True, c_valid=cval)
         else:
@@ -1518,16 +1545,22 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.w4 = w4.detach() if (implicit and pair is not None) else None
         ctx.wg_implicit = wg_implicit
         ctx.logical = (Cout_l, Cin_l, padded)
+        ctx.defer_apply = bool(defer_apply)
+        tail = ()
+        if defer_apply:                            # (mean, invstd) ride behind the data outputs
+            ctx.mark_non_differentiable(mean, invstd)
+            y, tail = y.view(y.shape), (mean, invstd)
         if fork is None:
-            return y
+            return (y,) + tail if tail else y
         if nchw or stem8:
             raise ValueError("fork is for NHWC feature maps (residual blocks), not the stem")
         if fork == "alias":
-            return y, x.view(x.shape)
-        return y, ops.im2col(xc, False, N, Cin, H, W, 1, int(fork), 0, Cin, xc.dtype)
+            return (y, x.view(x.shape)) + tail
+        return (y, ops.im2col(xc, False, N, Cin, H, W, 1, int(fork), 0, Cin, xc.dtype)) + tail
 
     @staticmethod
-    def backward(ctx, dy, dshort=None):
+    def backward(ctx, dy, *more):
+        dshort = more[0] if (ctx.fork is not None and more) else None     # (behind it, under defer_apply: mean and invstd's)
         xc, wp, z, y, mean, invstd, g32, col, b32, pidx, rmask = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
@@ -1570,12 +1603,14 @@ class _ConvBnAct(torch.autograd.Function):
                 # layer 1 of ResNet-18 (and, in 64-channel groups of dz, of R(2+1)D-18: 64 -> 144): input patch and gradient
                 # tile staged once per R rows, the nine taps read from LDS
                 pend = ops.conv3x3_c64_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True, Cout=Cout)
-            elif (WINDOW_WGRAD and HALO_CONV and (kh, kw) == (3, 1) and not padded and ops._pair(stride) == (1, 1)
+            elif ((WINDOW_WGRAD or ctx.in_affine is not None) and HALO_CONV and (kh, kw) == (3, 1) and not padded and ops._pair(stride) == (1, 1)
                     and ops._pair(pad) == (1, 0) and ops.conv3x1_wgrad_supported(xc, dz, N, H, W, Cin, Cout)):
                 # the temporal half of R(2+1)D-18's layer-1 pairs (144 mid planes -> 64): a segment of pixels over all frames
                 # staged once, the three taps read from LDS (the implicit form gathered x once per tap)
-                pend = ops.conv3x1_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True)
+                pend = ops.conv3x1_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True, affine=ctx.in_affine)
             else:
+                if ctx.in_affine is not None:
+                    raise RuntimeError("in_affine: the window weight-gradient kernel does not take this geometry")
                 _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
                                                     master=dw_master, accumulate=acc_w, logical=(Cout_l, Cin_l))
             unpack = dwp = None
@@ -1719,7 +1754,7 @@ class _ConvBnAct(torch.autograd.Function):
         ops.splitk_reduce_pending(pend)          # nobody carried it (no data gradient wanted, or the halo kernel computed it)
         emit_dw()
         dw = dw_box[0]
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
@@ -1733,20 +1768,35 @@ def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, rel
 
 
 def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual=None, dtype=torch.bfloat16,
-                    cpad: int = 0, dx_frames=None, pool: bool = False, fork=None):
+                    cpad: int = 0, dx_frames=None, pool: bool = False, fork=None, in_affine=None, defer_apply: bool = False):
     """Same with an explicit 2-D kernel geometry (k, stride, pad: ints or (h, w) pairs); ``weight`` may be a
     Conv3d weight whose singleton kernel axis is dropped by the caller's choice of ``k``
-    (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container."""
+    (factorised R(2+1)D convolutions).  ``bn``: BatchNorm2d/3d parameter container.
+    defer_apply: no BatchNorm-apply pass -- returns (z, affine) with affine = (mean, invstd, gamma, beta, c_valid, relu) for the
+    ``in_affine`` of the layer behind, whose kernels then form the normalised activation in LDS (see _ConvBnAct)."""
     N, Cin, H, W, nchw = geom
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    if defer_apply:
+        joins = fork is not None and torch.is_grad_enabled() and x.requires_grad
+        outs = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                                (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad,
+                                dx_frames, pool, fork if joins else None, in_affine, True)
+        z, (mean, invstd) = outs[0], outs[-2:]
+        cout_l = weight.shape[0]
+        affine = (mean, invstd, _f32(bn.weight), _f32(bn.bias), cout_l if z.shape[1] != cout_l else 0, relu)
+        if fork is None:
+            return z, affine
+        second = outs[1] if joins else (x if fork == "alias" else subsample_nhwc(x, N, Cin, H, W, int(fork)))
+        return (z, second), affine
     if fork is not None and not (torch.is_grad_enabled() and x.requires_grad):       # nothing to join: hand the shortcut its input
         y = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
-                             (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool)
+                             (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool,
+                             None, in_affine)
         return y, (x if fork == "alias" else subsample_nhwc(x, N, Cin, H, W, int(fork)))
     return _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
                             (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad, dx_frames, pool,
-                            fork)
+                            fork, in_affine)
 
 
 class _Subsample(torch.autograd.Function):

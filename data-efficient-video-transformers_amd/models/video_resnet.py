@@ -57,28 +57,52 @@ def _mid_cpad(conv, frames, H, W, dtype):
     return CPAD
 
 
-def _spatial(fm, conv, bn, relu, dtype, fork=None):
+def _spatial(fm, conv, bn, relu, dtype, fork=None, defer=False):
     """(1,k,k) conv + BN(+ReLU) on an NDHWC matrix: 2-D conv over N*T frames.  fork="alias": the map has a second consumer
     (the block's shortcut); the layer hands it out as a second result so that the shortcut's gradient joins this layer's
-    data gradient inside the kernel that writes it (F._ConvBnAct) -> (fm, alias)."""
+    data gradient inside the kernel that writes it (F._ConvBnAct) -> (fm, alias).  defer: the BatchNorm (+ ReLU) is NOT
+    applied here -- the map returned is the convolution's output z and the third result the affine the temporal half behind
+    applies inside its window kernels (F.WINDOW_VIRTUAL_BN) -> (fm, alias or None, affine)."""
     y, N, T, H, W = fm
     k, s, p = conv.kernel_size[1:], conv.stride[1:], conv.padding[1:]
-    out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
-                            cpad=_mid_cpad(conv, N * T, H, W, dtype), fork=fork)
     Ho, Wo = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    cpad = _mid_cpad(conv, N * T, H, W, dtype)
+    if defer:
+        out, affine = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
+                                        cpad=cpad, fork=fork, defer_apply=True)
+        if fork is not None:
+            return (out[0], N, T, Ho, Wo), out[1], affine
+        return (out, N, T, Ho, Wo), None, affine
+    out = F.conv_bn_act_raw(y, conv.weight, bn, (N * T, y.shape[1], H, W, False), k, s, p, relu=relu, dtype=dtype,
+                            cpad=cpad, fork=fork)
     if fork is not None:
         return (out[0], N, T, Ho, Wo), out[1]
     return (out, N, T, Ho, Wo)
 
 
-def _temporal(fm, conv, bn, relu, dtype, residual=None):
-    """(3,1,1) conv + BN(+res)(+ReLU): a (kt,1) conv over the [T, H*W] view of each clip."""
+def _temporal(fm, conv, bn, relu, dtype, residual=None, in_affine=None):
+    """(3,1,1) conv + BN(+res)(+ReLU): a (kt,1) conv over the [T, H*W] view of each clip.  in_affine: fm holds the spatial
+    half's convolution output and this is the BatchNorm (+ ReLU) between the halves (see _spatial(defer=True))."""
     y, N, T, H, W = fm
     kt, st, pt = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     out = F.conv_bn_act_raw(y, conv.weight, bn, (N, y.shape[1], T, H * W, False), (kt, 1), (st, 1), (pt, 0),
-                            relu=relu, residual=residual, dtype=dtype, cpad=CPAD)
+                            relu=relu, residual=residual, dtype=dtype, cpad=CPAD, in_affine=in_affine)
     To = (T + 2 * pt - kt) // st + 1
     return (out, N, To, H, W)
+
+
+def _virtual_bn_pair(pair, N, T, H, W, dtype) -> bool:
+    """Can the BatchNorm + ReLU between the two halves of this Conv2Plus1D stay virtual?  Needs the window kernels of the
+    temporal half (144 mid planes -> 64, (3, 1, 1) / 1 / pad 1, a segment length that fits) and un-padded mid planes."""
+    sp, tm = pair[0], pair[3]
+    if not (F.WINDOW_VIRTUAL_BN and F.WINDOW_FWD and F.HALO_CONV and dtype in (torch.bfloat16, torch.float16)):
+        return False
+    if not (sp.out_channels == 144 and tm.in_channels == 144 and tm.out_channels == 64 and tuple(tm.kernel_size) == (3, 1, 1)
+            and tuple(tm.stride) == (1, 1, 1) and tuple(tm.padding) == (1, 0, 0) and tuple(sp.stride) == (1, 1, 1)):
+        return False
+    if _mid_cpad(sp, N * T, H, W, dtype) != 16:           # (144 stays 144 only on the streamed-weight path)
+        return False
+    return ops.conv3x1_window_geometry(N, T, H * W, 144, 64, dtype)
 
 
 class BasicBlock(nn.Module):
@@ -97,8 +121,13 @@ class BasicBlock(nn.Module):
     def forward_ndhwc(self, fm, dtype):
         y, N, T, H, W = fm
         c1, c2 = self.conv1[0], self.conv2[0]
-        out, y = _spatial(fm, c1[0], c1[1], True, dtype, fork="alias")      # y: the block input again, for the shortcut
-        out = _temporal(out, c1[3], self.conv1[1], True, dtype)
+        if _virtual_bn_pair(c1, N, T, H, W, dtype):
+            # the spatial half leaves its output z; the BatchNorm + ReLU between the halves runs inside the temporal half's kernels
+            out, y, aff = _spatial(fm, c1[0], c1[1], True, dtype, fork="alias", defer=True)
+            out = _temporal(out, c1[3], self.conv1[1], True, dtype, in_affine=aff)
+        else:
+            out, y = _spatial(fm, c1[0], c1[1], True, dtype, fork="alias")      # y: the block input again, for the shortcut
+            out = _temporal(out, c1[3], self.conv1[1], True, dtype)
         residual = y
         if self.downsample is not None:
             ds, dbn = self.downsample[0], self.downsample[1]
@@ -109,6 +138,10 @@ class BasicBlock(nn.Module):
             r = F.subsample_nhwc(r, N, C, T, Hs * Ws, (st[0], 1))                        # temporal stride
             Ts = (T - 1) // st[0] + 1
             residual = F.conv_bn_act_raw(r, ds.weight, dbn, (N * Ts, C, Hs, Ws, False), 1, 1, 0, relu=False, dtype=dtype)
+        _, N2, T2, H2, W2 = out
+        if _virtual_bn_pair(c2, N2, T2, H2, W2, dtype):
+            out, _, aff = _spatial(out, c2[0], c2[1], True, dtype, defer=True)
+            return _temporal(out, c2[3], self.conv2[1], True, dtype, residual=residual, in_affine=aff)
         out = _spatial(out, c2[0], c2[1], True, dtype)
         return _temporal(out, c2[3], self.conv2[1], True, dtype, residual=residual)     # out += residual; relu
 

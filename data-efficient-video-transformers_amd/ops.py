@@ -1392,25 +1392,80 @@ def conv3x1_wgrad_supported(x: Tensor, dz: Tensor, N: int, T: int, Lp: int, Cin:
     return bool(L.load().dvt_conv3x1_wgrad_supported(N, T, Lp, Cin, Cout, dt(x)))
 
 
+def _bn_affine(affine):
+    """affine = (mean, invstd, gamma, beta, c_valid, relu) of the BatchNorm in front of a map, or None -> (struct, keep-alive)."""
+    if affine is None:
+        return None, None
+    mean, invstd, gamma, beta, c_valid, relu = affine
+    _need_cuda(mean, invstd, gamma, beta)
+    for t in (mean, invstd, gamma, beta):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    a = L.BnAffine()
+    a.mean, a.invstd, a.gamma, a.beta = mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.c_valid, a.relu = int(c_valid or 0), int(bool(relu))
+    return a, (mean, invstd, gamma, beta)
+
+
 def conv3x1_wgrad(x: Tensor, dz: Tensor, N: int, T: int, Lp: int, master: Tensor, *, accumulate: bool = False,
-                  defer_reduce: bool = False):
+                  defer_reduce: bool = False, affine=None):
     """Weight gradient of the (3, 1) temporal convolution 144 -> 64 over the [T, H*W] view of N clips from LDS-resident
     sliding windows (dvt_conv3x1_wgrad), summed into ``master`` (f32 [64, 144, 3(, 1, 1)]; += when accumulate).
-    defer_reduce: -> pending, as ``conv3x3_c64_wgrad``."""
+    affine: x is the convolution output in front of the BatchNorm (+ ReLU) whose (mean, invstd, gamma, beta, c_valid, relu)
+    this is; the normalised activation is formed in the staged window.  defer_reduce: -> pending, as ``conv3x3_c64_wgrad``."""
     _need_cuda(x, dz, master)
     assert master.dtype == torch.float32 and master.is_contiguous() and master.numel() == 64 * 144 * 3
     lib = L.load()
     pend = L.SplitKPending()
+    aff, keep = _bn_affine(affine)
     nbytes = int(lib.dvt_conv3x1_wgrad_workspace_bytes(N, T, Lp))
     ws = _deferred_workspace(nbytes, x.device, pend) if defer_reduce else workspace(nbytes, x.device, slot="conv3_wgrad")
     nb = (x.numel() + dz.numel()) * x.element_size() + master.numel() * 4
     with _timed(("conv", "window3x1_wgrad", 432, 64, N * T * Lp, nb), 2.0 * N * T * Lp * 64 * 432):
-        L.check(lib.dvt_conv3x1_wgrad(x.data_ptr(), dz.data_ptr(), master.data_ptr(), ws.data_ptr(), N, T, Lp, int(accumulate),
-                                      int(defer_reduce), C.byref(pend), dt(x), _stream()), "dvt_conv3x1_wgrad")
+        L.check(lib.dvt_conv3x1_wgrad(x.data_ptr(), None if aff is None else C.byref(aff), dz.data_ptr(), master.data_ptr(),
+                                      ws.data_ptr(), N, T, Lp, int(accumulate), int(defer_reduce), C.byref(pend), dt(x), _stream()),
+                "dvt_conv3x1_wgrad")
     if defer_reduce:
-        pend._keep = (ws, master)
+        pend._keep = (ws, master, keep)
         return pend
     return None
+
+
+def conv3x1_window_geometry(N: int, T: int, Lp: int, Cin: int, Cout: int, dtype: torch.dtype) -> bool:
+    """Do BOTH window kernels of the (3, 1) temporal convolution (forward and weight gradient) take this geometry?  (No
+    tensors needed: models/video_resnet.py asks before it decides to keep a BatchNorm virtual.)"""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    lib = L.load()
+    return bool(lib.dvt_conv3x1_fwd_supported(N, T, Lp, Cin, Cout, _DT[dtype])) and \
+        bool(lib.dvt_conv3x1_wgrad_supported(N, T, Lp, Cin, Cout, _DT[dtype]))
+
+
+def conv3x1_fwd_supported(x: Tensor, wp: Tensor, N: int, T: int, Lp: int, Cin: int, Cout: int) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
+        return False
+    if not (x.is_contiguous() and wp.is_contiguous() and x.shape == (N * T * Lp, Cin) and wp.dim() == 2 and wp.shape[0] == Cout
+            and wp.shape[1] >= 3 * Cin and wp.shape[1] % 8 == 0):
+        return False
+    return bool(L.load().dvt_conv3x1_fwd_supported(N, T, Lp, Cin, Cout, dt(x)))
+
+
+def conv3x1_fwd(x: Tensor, wp: Tensor, N: int, T: int, Lp: int, want_stats: bool = False, affine=None):
+    """(3, 1) temporal convolution 144 -> 64 over the [T, H*W] view of N clips from LDS-resident sliding windows
+    (dvt_conv3x1_fwd): x [N*T*Lp, 144], wp [64, >= 432] (column kt * 144 + ci) -> [N*T*Lp, 64]; want_stats: also the partial
+    column sums for ``bn_stats_from_partials``; affine as ``conv3x1_wgrad``."""
+    _need_cuda(x, wp)
+    lib = L.load()
+    y = torch.empty((N * T * Lp, 64), dtype=x.dtype, device=x.device)
+    aff, _keep = _bn_affine(affine)
+    partial, parts = None, 0
+    if want_stats:
+        parts = int(lib.dvt_conv3x1_fwd_stats_parts(N, T, Lp))
+        partial = workspace((parts + 64) * 2 * 64 * 4, x.device, slot="bn_partial")
+    nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()
+    with _timed(("conv", "window3x1_fwd", N * T * Lp, 64, 432, nb), 2.0 * N * T * Lp * 64 * 432):
+        L.check(lib.dvt_conv3x1_fwd(x.data_ptr(), None if aff is None else C.byref(aff), wp.data_ptr(), wp.shape[1], y.data_ptr(),
+                                    _p(partial), N, T, Lp, dt(x), _stream()), "dvt_conv3x1_fwd")
+    return (y, partial, parts) if want_stats else y
 
 
 def conv2d_implicit(x: Tensor, wp: Tensor, N: int, Cc: int, H: int, W: int, Cout: int, k, stride, pad,

@@ -624,15 +624,32 @@ int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* worksp
  * 64 channels); defer_reduce defers the LAST group's reduce. */
 int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cout,
                                int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
-/* Weight gradient of the temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (torchvision r2plus1d_18 as used by
- * frame_transformer.py:64-74: a (3, 1, 1) convolution, 144 mid planes -> 64, stride 1, pad 1) from LDS-resident sliding
- * windows: x [N, T, L, 144] (the mid activation, L = H * W pixels per frame), dz [N, T, L, 64], dw f32 [64][144][3] (the
- * Conv3d parameter's own layout; += when accumulate).  A workgroup stages a segment of S pixels over all T + 2 frames once
- * and the three taps read it at three position offsets; workspace / defer_reduce / pending as dvt_conv3x3_c64_wgrad. */
+/* The temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (torchvision r2plus1d_18 as used by frame_transformer.py:64-74: a
+ * (3, 1, 1) convolution, 144 mid planes -> 64, stride 1, pad 1) from LDS-resident sliding windows: a workgroup stages a
+ * segment of S pixels of one clip over all T + 2 frames once and the three taps read it at three position offsets.
+ * x [N, T, L, 144] (L = H * W pixels per frame), w [64][ldw] (dvt_conv_weight_pack, column kt * 144 + ci), y / dz
+ * [N, T, L, 64], dw f32 [64][144][3] (the Conv3d parameter's own layout; += when accumulate).
+ * x_affine (optional, both entry points): x is the OUTPUT z of the spatial convolution in front and the BatchNorm (+ ReLU)
+ * between the two halves -- y = relu(z * invstd * gamma + (beta - mean * invstd * gamma)), the formula and rounding of
+ * dvt_bn_apply_fwd -- is applied to the staged window: the normalised 144-plane activation never exists in HBM.
+ * stats_partial (forward): [dvt_conv3x1_fwd_stats_parts + 64][2][64] f32 partial column sums of the stored output for
+ * dvt_bn_stats_from_partials.  workspace / defer_reduce / pending (weight gradient) as dvt_conv3x3_c64_wgrad. */
+typedef struct dvt_bn_affine {
+  const float* mean;     /* [C] */
+  const float* invstd;   /* [C] */
+  const float* gamma;    /* [c_valid] */
+  const float* beta;     /* [c_valid] */
+  int32_t c_valid;       /* channels gamma / beta have (0: all) */
+  int32_t relu;
+} dvt_bn_affine;
+int dvt_conv3x1_fwd_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
+int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L);
+int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w, int64_t ldw, void* y, float* stats_partial,
+                    int64_t N, int T, int L, int dtype, dvt_stream_t stream);
 int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
 size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L);
-int dvt_conv3x1_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int T, int L, int accumulate,
-                      int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
+int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* dz, float* dw, void* workspace, int64_t N, int T,
+                      int L, int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */

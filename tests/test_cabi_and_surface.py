@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
     assert sorted(dvt_amd._lib.SIGNATURES) == names
 
 
+def test_no_kernel_of_the_library_lost_an_address_space():
+    """FLAT loads / stores are what the compiler emits for a pointer whose address space it could not prove (an LDS buffer
+    picked from a run-time-indexed pointer array): they count on vmcnt AND lgkmcnt, so every LDS fragment wait also waits for
+    the outstanding global loads.  The halo convolution's main loop ran that way for two rounds; tools/check_flat_ops.py
+    disassembles the built code object so that it cannot come back unseen."""
+    import importlib.util
+    import dvt_amd
+    dvt_amd.build_extension(verbose=False)
+    spec = importlib.util.spec_from_file_location("check_flat_ops", os.path.join(ROOT, "tools", "check_flat_ops.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ops = mod.flat_ops(dvt_amd._lib.LIB_PATH)
+    assert len(ops) > 300                                                   # the disassembly found the kernels
+    bad = {k: v for k, v in ops.items() if v and not any(a in k for a in mod.ALLOWED)}
+    assert not bad, f"kernels with FLAT memory instructions: {bad}"
+
+
 def test_version_and_error_channel_without_gpu():
     import dvt_amd
     lib = dvt_amd._lib.load()

@@ -908,6 +908,43 @@ def test_temporal_weight_gradient_from_lds_sliding_windows(dvt, device, dtype, N
     assert rel_l2(acc.view(64, 144, 3) - old.view(64, 144, 3), ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4)])
+def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, device, dtype, N, T, H, W):
+    """dvt_conv3x1_fwd: the (3, 1, 1) temporal convolution 144 -> 64 of R(2+1)D-18's layer 1 from a window of all frames of a
+    pixel segment, weights in registers -- against conv2d in fp32 on the same operands, with the BatchNorm partial sums of the
+    stored output; and x_affine (both entry points): handed the spatial convolution's OUTPUT z and the BatchNorm + ReLU between
+    the two halves, forward and weight gradient give bit for bit what they give on the materialised activation
+    dvt_bn_apply_fwd writes (same formula, same rounding, zero rows of frames -1 and T kept zero)."""
+    ops = dvt.ops
+    Lp = H * W
+    g = torch.Generator().manual_seed(N * 31 + T + Lp)
+    z = torch.randn(N * T * Lp, 144, generator=g).to(dtype).cuda()
+    w = (torch.randn(64, 144, 3, 1, generator=g) * (2.0 / (144 * 3)) ** 0.5).cuda()
+    wp = ops.conv_weight_pack(w, ops.conv2d_implicit_k(144, 64, (3, 1)), dtype)
+    assert ops.conv3x1_fwd_supported(z, wp, N, T, Lp, 144, 64)
+    y, partial, parts = ops.conv3x1_fwd(z, wp, N, T, Lp, want_stats=True)
+    zr = z.float().view(N, T, Lp, 144).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(zr, w.to(dtype).float(), None, 1, (1, 0)).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert y.shape == ref.shape and rel_l2(y, ref) < (5e-3 if dtype == torch.bfloat16 else 8e-4)
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, y.shape[0], 64, None, None, 1e-5, 0.1)
+    assert torch.allclose(mean, y.float().mean(0), atol=2e-3) and rel_l2(invstd, (y.float().var(0, unbiased=False) + 1e-5).rsqrt()) < 2e-3
+    assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp), y)
+    # the BatchNorm + ReLU in front, virtual: (mean, invstd, gamma, beta) of a 144-plane layer
+    m0, is0 = (0.2 * torch.randn(144, generator=g)).cuda(), (1 + 0.3 * torch.rand(144, generator=g)).cuda()
+    ga, be = (1 + 0.2 * torch.randn(144, generator=g)).cuda(), (0.3 * torch.randn(144, generator=g)).cuda()
+    act = ops.bn_apply_fwd(z, m0, is0, ga, be, None, True)                       # the materialised activation
+    aff = (m0, is0, ga, be, 0, True)
+    assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp, affine=aff), ops.conv3x1_fwd(act, wp, N, T, Lp))
+    dz = (torch.randn(N * T * Lp, 64, generator=g) / (N * T * Lp) ** 0.5).to(dtype).cuda()
+    a, b = torch.empty(64, 144, 3, 1, device="cuda"), torch.empty(64, 144, 3, 1, device="cuda")
+    ops.conv3x1_wgrad(z, dz, N, T, Lp, a, affine=aff)
+    ops.conv3x1_wgrad(act, dz, N, T, Lp, b)
+    assert torch.equal(a, b)
+    nr = ops.bn_apply_fwd(z, m0, is0, ga, be, None, False)                       # without the ReLU
+    assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp, affine=(m0, is0, ga, be, 0, False)), ops.conv3x1_fwd(nr, wp, N, T, Lp))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
 def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
