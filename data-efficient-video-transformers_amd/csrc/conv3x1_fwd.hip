@@ -60,10 +60,10 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
   // (the two window buffers are addressed as smem + offset, never through a pointer picked at run time: a `char* xb[2]`
   //  selected by it & 1 lost its LDS address space and every fragment read became a flat_load)
   char* stage = smem + 2 * w.x_bytes;                                            // [KP][64] outputs of a tile, 128-byte rows
-  float* st = reinterpret_cast<float*>(stage + w.KP * 128);                      // [2][144] folded affine
   const E* xg = (const E*)p.x;
   const bool affine = p.aff.mean != nullptr;
-  if (affine) window_affine_table(p.aff, st);
+  AffineRegs st{};
+  if (affine) window_affine_regs(p.aff, st);
   unsigned xq[kMaxXP];
   window_coords(w, wid, lane, xq);
   auto load_tile = [&](int tile, int b) {
@@ -253,7 +253,7 @@ int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w,
                    x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
   }
   const int grid = tf_grid(N, p.w_);
-  const int lds = 2 * p.w_.x_bytes + p.w_.KP * 128 + 2 * kCI * (int)sizeof(float);
+  const int lds = 2 * p.w_.x_bytes + p.w_.KP * 128;
   hipStream_t st = (hipStream_t)stream;
   const bool h = dtype == DVT_F16;
   switch (p.w_.KP >> 5) {

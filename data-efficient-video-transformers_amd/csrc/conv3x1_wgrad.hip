@@ -54,12 +54,12 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   const int S = w.S;
   char* xb[2] = {smem, smem + w.x_bytes};
   char* zb[2] = {smem + 2 * w.x_bytes, smem + 2 * w.x_bytes + p.z_bytes};
-  float* st = reinterpret_cast<float*>(smem + 2 * w.x_bytes + 2 * p.z_bytes);      // [2][144] folded affine
   const E* xg = (const E*)p.x;
   const E* zg = (const E*)p.dz;
   const int zp = p.z_bytes >> 10;
   const bool affine = p.aff.mean != nullptr;                                       // (kernel-uniform)
-  if (affine) window_affine_table(p.aff, st);
+  AffineRegs st{};
+  if (affine) window_affine_regs(p.aff, st);
 
   // ---- per-lane coordinates of this wave's DMA pieces (fixed for the launch); dz: frame << 20 | pixel << 8 | source chunk << 1 | valid
   unsigned xq[kMaxXP];
@@ -226,7 +226,7 @@ int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* 
                    x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
   }
   const int grid = tw_grid(N, p.w);
-  const int lds = 2 * (p.w.x_bytes + p.z_bytes) + 2 * kCI * (int)sizeof(float);
+  const int lds = 2 * (p.w.x_bytes + p.z_bytes);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVT_BF16) {
     static DvtLdsAttr set;

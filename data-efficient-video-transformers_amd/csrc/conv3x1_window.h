@@ -93,43 +93,50 @@ __device__ __forceinline__ void window_load(const Window& w, const E* xg, int64_
   }
 }
 
-// st[0][c] = invstd * gamma, st[1][c] = beta - mean * st[0][c]: the folded affine of BnAffine::init (conv.hip)
-__device__ __forceinline__ void window_affine_table(const Affine& a, float* st) {
-  for (int c = threadIdx.x; c < kCI; c += blockDim.x) {
+// The virtual BatchNorm of a staged window: y = relu?(z * s + t) with s = invstd * gamma, t = beta - mean * s (the folded
+// affine of BnAffine::init, conv.hip) on every live 16-byte slot.  A thread owns ONE channel group for the whole launch
+// (thread = 18 q + slot: channel block slot >> 1, half slot & 1; positions q, q + 28, q + 56 ...), so its 8 scales / shifts
+// sit in registers and a pass is one LDS read, 8 fma / max, one LDS write -- the first form (any thread, any slot: two
+// integer divisions and four table reads per slot) cost ~50 us of a 157 us launch.
+constexpr int kTfSlots = 2 * kCB;                       // 18 live 16-byte slots per position
+constexpr int kTfPos = (kNW * 64) / kTfSlots;           // 28 positions per pass (504 of the 512 threads)
+struct AffineRegs {
+  float s[8], t[8];
+  int pos0, slot_off;                                    // first position (>= xpos: idle thread); byte offset of the slot in a row
+};
+__device__ __forceinline__ void window_affine_regs(const Affine& a, AffineRegs& r) {
+  const int q = threadIdx.x / kTfSlots, slot = threadIdx.x - q * kTfSlots;
+  const int c0 = (slot >> 1) * 16 + (slot & 1) * 8;
+  r.pos0 = q < kTfPos ? q : (1 << 30);
+  r.slot_off = slot * 16;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + k;
     const float g = c < a.c_valid ? a.gamma[c] : 0.f, b = c < a.c_valid ? a.beta[c] : 0.f;
-    const float s = a.invstd[c] * g;
-    st[c] = s;
-    st[kCI + c] = fmaf(-a.mean[c], s, b);
+    r.s[k] = a.invstd[c] * g;
+    r.t[k] = fmaf(-a.mean[c], r.s[k], b);
   }
 }
 
-// y = relu?(z * s + t) on every live 16-byte slot of a staged window (all threads; barriers are the caller's)
+// (all threads; barriers are the caller's; the zero rows of frames -1 and T stay zero)
 template <typename E>
-__device__ __forceinline__ void window_transform(const Window& w, char* img_, const float* st_, int relu) {
+__device__ __forceinline__ void window_transform(const Window& w, char* img_, const AffineRegs& r, int relu) {
   using V8 = typename Elem16<E>::v8;
   typedef __attribute__((address_space(3))) char lds_char;     // (callers pick the buffer at run time: keep the accesses ds_*)
-  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  typedef __attribute__((address_space(3))) V8 lds_v8;
   lds_char* const img = (lds_char*)img_;
-  lds_cfloat* const st = (lds_cfloat*)st_;
-  const int nslots = w.xpos * (2 * kXU);
-  for (int sl = threadIdx.x; sl < nslots; sl += blockDim.x) {
-    const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
-    const int cb = (h >> 1) - ((pos >> 3) & 1);
-    const int tt = pos / w.S;
-    if (cb < 0 || cb >= kCB || tt == 0 || tt > w.T) continue;      // padding slots; the zero rows of frames -1 and T
-    const int c0 = cb * 16 + (h & 1) * 8;
-    typedef __attribute__((address_space(3))) V8 lds_v8;
-    typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
-    V8 v = *(lds_v8*)(img + sl * 16);
-    const f32x4 s0 = *(lds_cf4*)(st + c0), s1 = *(lds_cf4*)(st + c0 + 4);
-    const f32x4 t0 = *(lds_cf4*)(st + kCI + c0), t1 = *(lds_cf4*)(st + kCI + c0 + 4);
+  const int lo = w.S, hi = (w.T + 1) * w.S;
+  for (int pos = r.pos0; pos < hi; pos += kTfPos) {
+    if (pos < lo) continue;
+    lds_v8* const at = (lds_v8*)(img + pos * kXRow + (((pos >> 3) & 1) << 5) + r.slot_off);
+    V8 v = *at;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float y = fmaf((float)v[k], k < 4 ? s0[k & 3] : s1[k & 3], k < 4 ? t0[k & 3] : t1[k & 3]);
+      float y = fmaf((float)v[k], r.s[k], r.t[k]);
       if (relu) y = fmaxf(y, 0.f);
       v[k] = (E)y;
     }
-    *(lds_v8*)(img + sl * 16) = v;
+    *at = v;
   }
 }
 #endif  // __HIPCC__
