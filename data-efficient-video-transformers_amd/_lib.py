@@ -245,6 +245,9 @@ SIGNATURES = {
     "dvt_conv3x3_stream": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv3x1_stream_supported": (c_int, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "dvt_conv3x1_stream": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_conv3x1_stream_bn_bwd_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int]),
+    "dvt_conv3x1_stream_bn_bwd": (c_int, [c_p, c_p, c_p, C.POINTER(BnAffine), c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int,
+                                          c_int, c_int, c_p]),
     "dvt_conv_weight_pairs": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv_weight_pairs_bwd": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv2d_implicit": (c_int, [C.POINTER(ConvDesc), c_p]),

@@ -46,6 +46,12 @@ int dvt_num_cus();
 // hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel PER DEVICE: one flag per (call site, device),
 // atomic (two host threads racing on a first call both set it: idempotent), the return code recorded -- the launch behind a
 // failed call fails as well and DVT_LAUNCH_CHECK reports it.
+// conv.hip: reduction of BatchNorm-backward partial rows produced by another translation unit's kernel
+namespace dvt_internal {
+void bn_bwd_finalize(hipStream_t st, const float* partial, int nparts, int C, float* loc, int accumulate, float* dgamma,
+                     float* dbeta, int c_valid);
+}
+
 struct DvtLdsAttr { unsigned long long done = 0ull; };
 static inline void dvt_lds_attr(DvtLdsAttr& f, const void* kernel, int bytes) {
   int dev = 0;

@@ -636,6 +636,21 @@ static void bn_finalize_launch(hipStream_t st, const float* partial, int nparts,
                        inv_rows, eps, o0, o1, run_mean, run_var, momentum, unbias, accumulate, pub0, pub1, c_valid);
 }
 
+}  // namespace
+
+// For the kernels of other translation units that produce the backward sums themselves (conv3x3_stream.hip's fused data
+// gradient + BatchNorm backward): partial rows [nparts][2][C] = (sum dz, sum dz * xhat) -> loc[0][C] = sum dz * xhat,
+// loc[1][C] = sum dz, and the caller's dgamma / dbeta overwritten or accumulated.
+namespace dvt_internal {
+void bn_bwd_finalize(hipStream_t st, const float* partial, int nparts, int C, float* loc, int accumulate, float* dgamma,
+                     float* dbeta, int c_valid) {
+  bn_finalize_launch<1>(st, partial, nparts, C, 0.f, 0.f, loc, loc + C, (float*)nullptr, (float*)nullptr, 0.f, 0.f, accumulate,
+                        dgamma, dbeta, c_valid);
+}
+}  // namespace dvt_internal
+
+namespace {
+
 // Fold many partial rows (one per 128 output rows of a convolution: thousands) into gridDim.y rows that bn_finalize can
 // sum: block = 32 columns x 32 part lanes over its contiguous range of parts, four loads in flight, fixed order.
 __global__ __launch_bounds__(1024) void bn_partial_fold_kernel(const float* __restrict__ partial, int nparts, int C,

@@ -69,6 +69,12 @@ struct StreamParams {
   int hb;                // images per outer block: pixel 0 of image n = (n / hb) * pitch_n + (n % hb) * pitch_h
   int64_t pitch_n;
   int pitch_h, row_pitch;   // pixels between the image's rows (W for a dense NHWC frame)
+  // BatchNorm backward of the layer in FRONT of this data gradient, fused (MODE 1 / 2 of the kernel, dvt_conv3x1_stream_bn_bwd):
+  const void* bz;           // [.., CO] the convolution output z that BatchNorm normalised (same pixel layout as y)
+  const float *bmean, *binvstd, *bgamma, *bbeta;
+  const float* bloc;        // MODE 2: [2][CO] this launch pair's own sum dz * xhat, sum dz (bn_finalize)
+  float inv_rows;
+  int brelu, btraining;
 };
 
 __device__ __attribute__((aligned(16))) unsigned int conv3s_zero16[4] = {0u, 0u, 0u, 0u};
@@ -96,7 +102,14 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
-template <typename E, int CI, int CO, int NTAP>
+// MODE 0: the convolution.  MODE 1 / 2 (the 144-wide outputs only): the convolution is the DATA GRADIENT d of a layer whose
+// input was relu(BatchNorm(z)) and the BatchNorm backward runs in its epilogue instead of in two passes over a stored d:
+//   MODE 1  nothing is stored; per channel sum dz and sum dz * xhat (dz = d under the ReLU mask recomputed from z) leave as
+//           partial rows [grid * 7][2][CO] (the layout bn_finalize sums);
+//   MODE 2  the same d again (this layer is cheap: 108 MFMAs per tile against 64 KiB of output), and
+//           gamma * invstd * (dz - sum dz / rows - xhat * sum dz xhat / rows) is what gets stored.
+// The z rows of a tile are requested before its main loop and consumed in its epilogue.
+template <typename E, int CI, int CO, int NTAP, int MODE = 0>
 __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams p) {
   typedef SC<CI, CO, NTAP> C;
   using V8 = typename Elem16<E>::v8;
@@ -306,6 +319,67 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
 
   float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   (void)bs; (void)bq;
+  // ---- fused BatchNorm backward.  Per channel (a table in LDS behind the patch buffers, filled before B_0):
+  //   sc, sh   the folded forward affine (BnAffine::init, conv.hip): relu mask = z * sc + sh > 0, the decision every route takes
+  //   MODE 1:  is, mis   xhat = z * is + mis
+  //   MODE 2:  A, B, C0  gamma * invstd * (dz - sum dz / rows - xhat * sum dz xhat / rows) = A dz + B z + C0
+  // A lane stores the same 16-byte chunk (8 channels) of every pixel row it handles; its constants are read from the table at
+  // the start of each tile's epilogue (the main loop has no registers to spare for them).
+  constexpr int kCH = CO / 8, kPPP = 64 / kCH, kPS = (16 + kPPP - 1) / kPPP;   // chunks per pixel, pixels per pass, passes per 16 pixels
+  constexpr int kNTab = MODE == 2 ? 5 : 4;
+  float* const btab = reinterpret_cast<float*>(smem + 3 * kWStage + 2 * kPatch + (C::STG_DEDICATED ? kNC * kStgWave : 0));
+  const int r3e = lane / kCH, c18e = lane - r3e * kCH;
+  if constexpr (MODE != 0) {
+    static_assert(CO != 64, "the fused BatchNorm backward rides the 144-wide epilogue");
+    for (int c = threadIdx.x; c < CO; c += kNC * 64) {
+      const float mu = p.bmean[c], is = p.binvstd[c], gmm = p.bgamma[c];
+      const float sc = is * gmm;
+      btab[c] = sc;
+      btab[CO + c] = fmaf(-mu, sc, p.bbeta[c]);
+      if (MODE == 1) {
+        btab[2 * CO + c] = is;
+        btab[3 * CO + c] = -mu * is;
+      } else {
+        const float kb = p.btraining ? p.bloc[CO + c] * p.inv_rows : 0.f;      // sum dz / rows
+        const float kg = p.btraining ? p.bloc[c] * p.inv_rows : 0.f;           // sum dz xhat / rows
+        const float gi = gmm * is;
+        btab[2 * CO + c] = gi;
+        btab[3 * CO + c] = -gi * kg * is;
+        btab[4 * CO + c] = gi * (kg * is * mu - kb);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // pixel offset (from the tile's first pixel) of the row this lane stores in pass ps of half t; -1: none
+  auto out_pix = [&](int t, int ps, int valid) __attribute__((always_inline)) -> int64_t {
+    const int px = ps * kPPP + r3e;
+    const int mpx0 = wid * 32 + t * 16 + px;
+    if (!(r3e < kPPP && px < 16 && mpx0 < valid)) return -1;
+    int mpx = mpx0;
+    asm volatile("" : "+v"(mpx));
+    int64_t po = mpx;
+    if (NTAP != 9) {
+      const int r = (int)__umulhi((unsigned)mpx, p.magic_w);
+      po = (int64_t)r * p.row_pitch + (mpx - r * p.W);
+    }
+    return po;
+  };
+  V8 zq[MODE != 0 ? 2 : 1][MODE != 0 ? kPS : 1];
+  (void)zq;
+  // z rows of half t of a tile, requested at the start of its epilogue (under the staging of half 0; holding them across the
+  // main loop -- 24 registers per half -- spilled, and a spill reload in the producer's path waits for every DMA in flight)
+  auto request_z = [&](int tile_, int t) __attribute__((always_inline)) {
+    const int n = tile_ / p.tiles_per_img, h0 = (tile_ - n * p.tiles_per_img) * p.R;
+    const int valid = min(p.R, p.H - h0) * p.W;
+    const int nq = n / p.hb;
+    const int64_t pix0 = nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)h0 * p.row_pitch;
+    const E* zt = (const E*)p.bz + pix0 * CO;
+#pragma unroll
+    for (int ps = 0; ps < kPS; ++ps) {
+      const int64_t po = out_pix(t, ps, valid);
+      zq[t][ps] = *reinterpret_cast<const V8*>(zt + (po >= 0 ? po : 0) * CO + c18e * 8);
+    }
+  };
   int tile = blockIdx.x;
   __builtin_amdgcn_s_barrier();                                     // B_0
   rd(patch_of(0, 0), 0, 0);
@@ -359,6 +433,19 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     const int64_t pix0 = nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)h0 * p.row_pitch;   // the tile's first pixel
     E* yt = (E*)p.y + pix0 * CO;
     char* stg = (C::STG_DEDICATED ? pbuf + 2 * kPatch : pbuf + ((it * NCH + NCH - 1) & 1) * kPatch) + wid * kStgWave;
+    float bk[MODE != 0 ? kNTab : 1][8];
+    (void)bk;
+    if constexpr (MODE != 0) {
+      request_z(tile, 0);
+      request_z(tile, 1);
+      const int c = (r3e < kPPP ? c18e : 0) * 8;
+#pragma unroll
+      for (int a = 0; a < kNTab; ++a) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(btab + a * CO + c), hi = *reinterpret_cast<const f32x4*>(btab + a * CO + c + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bk[a][k] = lo[k]; bk[a][4 + k] = hi[k]; }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;
@@ -403,7 +490,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
         for (int ps = 0; ps < (16 + PPP - 1) / PPP; ++ps) {
           const int px = ps * PPP + r3;
           if (r3 < PPP && px < 16 && m0 + px < valid) {
-            const V8 v = *reinterpret_cast<const V8*>(stg + px * (CO * 2) + c18 * 16);
+            V8 v = *reinterpret_cast<const V8*>(stg + px * (CO * 2) + c18 * 16);
             int mpx = m0 + px;
             asm volatile("" : "+v"(mpx));          // (the 12 tile-invariant 64-bit store offsets stay out of loop-carried registers)
             int64_t po = mpx;                      // pixel offset from the tile's first: rows of the tile are row_pitch apart
@@ -411,13 +498,31 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
               const int r = (int)__umulhi((unsigned)mpx, p.magic_w);
               po = (int64_t)r * p.row_pitch + (mpx - r * p.W);
             }
-            *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
-            if (p.bn_partial) {
+            if constexpr (MODE != 0) {
+              // v = the data gradient as it would have been stored (rounded to E); z decides the mask and gives xhat
+              const V8 zv = zq[t][ps];
 #pragma unroll
               for (int k = 0; k < 8; ++k) {
-                const float f = (float)v[k];
-                bs[k] += f;
-                bq[k] = fmaf(f, f, bq[k]);
+                const float xf = (float)zv[k];
+                const bool on = !p.brelu || fmaf(xf, bk[0][k], bk[1][k]) > 0.f;
+                const float dzv = on ? (float)v[k] : 0.f;
+                if (MODE == 1) {
+                  bs[k] += dzv;
+                  bq[k] = fmaf(dzv, fmaf(xf, bk[2][k], bk[3][k]), bq[k]);
+                } else {
+                  v[k] = (E)fmaf(bk[2][k], dzv, fmaf(bk[MODE == 2 ? 3 : 0][k], xf, bk[MODE == 2 ? 4 : 0][k]));
+                }
+              }
+              if (MODE == 2) *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
+            } else {
+              *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
+              if (p.bn_partial) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const float f = (float)v[k];
+                  bs[k] += f;
+                  bq[k] = fmaf(f, f, bq[k]);
+                }
               }
             }
           }
@@ -493,11 +598,24 @@ int plan_t(int T, int L, Plan* o, int* S) {
   return (int64_t)(o->R + 2) * L * 64 + (int64_t)bs * 64 < ((int64_t)1 << 24);   // the producer's 24-bit patch offsets
 }
 
-template <typename E, int CI, int CO, int NTAP>
+template <typename E, int CI, int CO, int NTAP, int MODE = 0>
 void launch(const StreamParams& p, int lds, int grid, hipStream_t st) {
   static DvtLdsAttr set;
-    dvt_lds_attr(set, (const void*)conv3x3_stream_kernel<E, CI, CO, NTAP>, 160 * 1024);
-  hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO, NTAP>), dim3(grid), dim3(512), lds, st, p);
+  dvt_lds_attr(set, (const void*)conv3x3_stream_kernel<E, CI, CO, NTAP, MODE>, 160 * 1024);
+  hipLaunchKernelGGL((conv3x3_stream_kernel<E, CI, CO, NTAP, MODE>), dim3(grid), dim3(512), lds, st, p);
+}
+
+// geometry of the (3, 1) form over N clips of T frames x L pixels
+int params_t(StreamParams* p, Plan* pl, int64_t N, int T, int L) {
+  int S = 0;
+  if (!plan_t(T, L, pl, &S)) return 0;
+  p->hb = L / S;                                    // images: (clip, column segment)
+  p->N = (int)(N * p->hb); p->H = T; p->W = S; p->R = pl->R; p->PW = pl->PW; p->SPR = pl->SPR; p->magic = pl->magic;
+  p->magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)S - 1) / (uint64_t)S);
+  p->pitch_n = (int64_t)T * L; p->pitch_h = S; p->row_pitch = L;
+  p->tiles_per_img = (int)dvt_cdiv(T, pl->R);
+  p->ntiles = (int)(N * p->hb * p->tiles_per_img);
+  return 1;
 }
 
 }  // namespace
@@ -563,21 +681,57 @@ int dvt_conv3x1_stream(const void* x, const void* w, void* y, int64_t N, int T, 
   if (!dvt_conv3x1_stream_supported(N, T, L, Cin, Cout, dtype))
     DVT_UNSUPPORTED("dvt_conv3x1_stream: needs a 16-bit dtype, (Cin, Cout) = (64, 144) and a divisor of L that fills half a 224-pixel tile");
   Plan pl;
-  int S = 0;
-  plan_t(T, L, &pl, &S);
-  StreamParams p;
+  StreamParams p{};
+  params_t(&p, &pl, N, T, L);
   p.x = x; p.w = w; p.y = y; p.bn_partial = nullptr; p.residual = nullptr;
-  p.hb = L / S;                                    // images: (clip, column segment)
-  p.N = (int)(N * p.hb); p.H = T; p.W = S; p.R = pl.R; p.PW = pl.PW; p.SPR = pl.SPR; p.magic = pl.magic;
-  p.magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)S - 1) / (uint64_t)S);
-  p.pitch_n = (int64_t)T * L; p.pitch_h = S; p.row_pitch = L;
-  p.tiles_per_img = (int)dvt_cdiv(T, pl.R);
-  p.ntiles = (int)(N * p.hb * p.tiles_per_img);
   const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVT_BF16) launch<bf16, 64, 144, 3>(p, pl.lds, grid, st);
   else launch<f16, 64, 144, 3>(p, pl.lds, grid, st);
   DVT_LAUNCH_CHECK("dvt_conv3x1_stream");
+  return DVT_OK;
+}
+
+size_t dvt_conv3x1_stream_bn_bwd_workspace_bytes(int64_t N, int T, int L) {
+  (void)N; (void)T; (void)L;
+  return ((size_t)dvt_num_cus() * kNC * 2 + 2) * 144 * sizeof(float) + 64;     // partial rows of the persistent grid + [2][144]
+}
+
+int dvt_conv3x1_stream_bn_bwd(const void* dy, const void* w, const void* z, const dvt_bn_affine* bn, void* dz, float* dgamma,
+                              float* dbeta, void* workspace, int64_t N, int T, int L, int training, int accumulate, int dtype,
+                              dvt_stream_t stream) {
+  DVT_REQUIRE(dy && w && z && bn && dz && dgamma && dbeta && workspace && N >= 0 && T > 0 && L > 0,
+              "dvt_conv3x1_stream_bn_bwd: bad arguments");
+  DVT_REQUIRE(bn->mean && bn->invstd && bn->gamma && bn->beta && (bn->c_valid == 0 || bn->c_valid == 144),
+              "dvt_conv3x1_stream_bn_bwd: the BatchNorm needs mean, invstd, gamma, beta over all 144 channels");
+  DVT_REQUIRE(dvt_aligned16(dy) && dvt_aligned16(w) && dvt_aligned16(z) && dvt_aligned16(dz) && dvt_aligned16(workspace),
+              "dvt_conv3x1_stream_bn_bwd: buffers must be 16-byte aligned");
+  if (N == 0) return DVT_OK;
+  if (!dvt_conv3x1_stream_supported(N, T, L, 64, 144, dtype))
+    DVT_UNSUPPORTED("dvt_conv3x1_stream_bn_bwd: needs a 16-bit dtype and a divisor of L that fills half a 224-pixel tile");
+  Plan pl;
+  StreamParams p{};
+  params_t(&p, &pl, N, T, L);
+  const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
+  float* part = (float*)workspace;
+  float* loc = part + (size_t)dvt_num_cus() * kNC * 2 * 144;
+  p.x = dy; p.w = w; p.y = dz; p.residual = nullptr; p.bn_partial = part;
+  p.bz = z; p.bmean = bn->mean; p.binvstd = bn->invstd; p.bgamma = bn->gamma; p.bbeta = bn->beta; p.bloc = loc;
+  p.brelu = bn->relu; p.btraining = training;
+  p.inv_rows = 1.0f / (float)(N * T * L);
+  hipStream_t st = (hipStream_t)stream;
+  // pass 1: the sums (nothing stored); their fixed-order reduction; pass 2: the same data gradient again, corrected and stored
+  const int lds = pl.lds + 5 * 144 * (int)sizeof(float);            // + the per-channel constants table
+  DVT_REQUIRE(lds <= 160 * 1024, "dvt_conv3x1_stream_bn_bwd: no LDS left for the BatchNorm constants");
+  if (dtype == DVT_BF16) launch<bf16, 64, 144, 3, 1>(p, lds, grid, st);
+  else launch<f16, 64, 144, 3, 1>(p, lds, grid, st);
+  DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(sums)");
+  dvt_internal::bn_bwd_finalize(st, part, grid * kNC, 144, loc, accumulate, dgamma, dbeta, 144);
+  DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(finalize)");
+  p.bn_partial = nullptr;
+  if (dtype == DVT_BF16) launch<bf16, 64, 144, 3, 2>(p, lds, grid, st);
+  else launch<f16, 64, 144, 3, 2>(p, lds, grid, st);
+  DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(apply)");
   return DVT_OK;
 }
 

@@ -1345,6 +1345,9 @@ WINDOW_FWD = os.environ.get("DVT_WINDOW_FWD", "1") != "0"
 # gamma, beta) on; the temporal half's window kernels form relu(z * s + t) in LDS -- the normalised 144-plane activation is
 # never written (models/video_resnet.py decides per pair; needs both window kernels)
 WINDOW_VIRTUAL_BN = os.environ.get("DVT_WINDOW_VIRTUAL_BN", "1") != "0"
+# the backward of that virtual BatchNorm inside the temporal half's data gradient (ops.conv3x1_stream_bn_bwd: the 144-plane
+# gradient is computed twice and never stored) instead of a stored gradient + two BatchNorm passes over it
+FUSED_MID_BN_BWD = os.environ.get("DVT_FUSED_MID_BN_BWD", "1") != "0"
 
 class _ConvBnAct(torch.autograd.Function):
     """y = relu?( BN(conv(x)) (+ residual) ).  x: NHWC matrix [N*H*W, Cin], or the raw NCHW
@@ -1357,12 +1360,17 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, run_mean, run_var, geom, relu, training, momentum, eps, dtype,
-                cpad=0, dx_frames=None, pool=False, fork=None, in_affine=None, defer_apply=False):
+                cpad=0, dx_frames=None, pool=False, fork=None, in_affine=None, defer_apply=False, link=None):
         # in_affine = (mean, invstd, gamma32, beta32, c_valid, relu): x is the OUTPUT z of the convolution in front and the
         # BatchNorm (+ ReLU) between the two layers is applied inside this layer's kernels (csrc/conv3x1_window.h); only the
         # window kernels of the (3, 1) temporal 144 -> 64 layers take it.  defer_apply: the mirror image on the producer's
         # side -- no bn_apply_fwd launch; the Function returns (z, mean, invstd) and the caller hands the affine on.
         ctx.in_affine = in_affine
+        # link (defer_apply side; the consumer finds it as in_affine[6]): a dict shared by the two Functions of a virtual pair.
+        # The consumer's backward may run THIS layer's BatchNorm backward inside its own data gradient (FUSED_MID_BN_BWD): it
+        # then finds the gradient sinks of gamma / beta here, leaves dgamma / dbeta and sets "done", and this layer's backward
+        # takes the incoming gradient as dz.
+        ctx.link = link
         # fork: the layer's input has a second consumer, the block's shortcut (custom_resnet.py:38-54), handed out by THIS
         # Function as a second output so that its gradient arrives here and joins the data gradient inside the kernel that
         # produces it (residual epilogue of the implicit / halo convolution, second operand of col2im) instead of in an add
@@ -1538,6 +1546,8 @@ class _ConvBnAct(torch.autograd.Function):
                               col if keep_col else None, b32 if ((relu and not keep_y) or pooled) else None, pidx, rmask)
         ctx.cfg = (geom, Cout, ld, direct, relu, training, residual is not None, tuple(w.shape), dtype)
         ctx.sinks = (_sink(w), _sink(gamma), _sink(beta))
+        if link is not None:
+            link["sinks"], link["training"], link["done"], link["grads"] = (ctx.sinks[1], ctx.sinks[2]), training, False, (None, None)
         ctx.x_needs = x.requires_grad
         ctx.x_shape, ctx.x_dtype = tuple(x.shape), x.dtype
         ctx.implicit = implicit
@@ -1578,7 +1588,12 @@ class _ConvBnAct(torch.autograd.Function):
                 return dz_, None, dg_, db_
             return ops.bn_bwd(dy, z, y, mean, invstd, g32, relu, training, has_res, beta=b32, mask=rmask, c_valid=cval, **kw)
 
-        if sg is not None and sb is not None and sg.fresh != sb.fresh:
+        if ctx.link is not None and ctx.link.get("done"):
+            # the consumer's data gradient already went through this layer's BatchNorm backward (and emitted dgamma / dbeta)
+            dz, dres = dy, None
+            dgam, dbet = ctx.link["grads"]
+            ctx.link["done"] = False
+        elif sg is not None and sb is not None and sg.fresh != sb.fresh:
             dz, dres, dgam, dbet = bn_backward()
             _emit_into(sg, dgam); _emit_into(sb, dbet)
             dgam = dbet = None
@@ -1693,7 +1708,25 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = ops.conv3x3_stream(dz, wd, N, Ho, Wo, Cout, Cin, residual=join_alias())
             elif (HALO_CONV and (kh, kw) == (3, 1) and pd == (1, 0) and (joined[0] or ctx.fork != "alias")
                     and ops.conv3x1_stream_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
-                dx = ops.conv3x1_stream(dz, wd, N, Ho, Wo, Cout, Cin)      # temporal half of layer 1's Conv2Plus1D: 64 -> 144
+                lk = ctx.in_affine[6] if (ctx.in_affine is not None and len(ctx.in_affine) > 6) else None
+                if FUSED_MID_BN_BWD and lk is not None and lk.get("sinks") is not None and not ctx.in_affine[4]:
+                    # the input is the spatial half's z under a virtual BatchNorm: its backward runs inside this data gradient
+                    sgm, sbm = lk["sinks"]
+                    if sgm is not None and sbm is not None and sgm.fresh == sbm.fresh:
+                        dx, _, _ = ops.conv3x1_stream_bn_bwd(dz, wd, xc, ctx.in_affine[:6], N, Ho, Wo, lk["training"],
+                                                             dgamma=sgm.buf.view(-1), dbeta=sbm.buf.view(-1),
+                                                             accumulate=not sgm.fresh)
+                        sgm.mark_written(); sbm.mark_written()
+                        lk["grads"] = (None, None)
+                    else:
+                        dx, dgm, dbm = ops.conv3x1_stream_bn_bwd(dz, wd, xc, ctx.in_affine[:6], N, Ho, Wo, lk["training"])
+                        if sgm is not None and sbm is not None:
+                            _emit_into(sgm, dgm); _emit_into(sbm, dbm)
+                            dgm = dbm = None
+                        lk["grads"] = (dgm, dbm)
+                    lk["done"] = True
+                else:
+                    dx = ops.conv3x1_stream(dz, wd, N, Ho, Wo, Cout, Cin)  # temporal half of layer 1's Conv2Plus1D: 64 -> 144
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
                                          residual=join_alias())   # [N*H*W, Cin], no dcol / col2im
@@ -1754,7 +1787,7 @@ class _ConvBnAct(torch.autograd.Function):
         ops.splitk_reduce_pending(pend)          # nobody carried it (no data gradient wanted, or the halo kernel computed it)
         emit_dw()
         dw = dw_box[0]
-        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgam, dbet, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, *, relu: bool, residual=None,
@@ -1779,12 +1812,13 @@ def conv_bn_act_raw(x, weight, bn, geom, k, stride, pad, *, relu: bool, residual
     momentum = 0.1 if bn.momentum is None else bn.momentum
     if defer_apply:
         joins = fork is not None and torch.is_grad_enabled() and x.requires_grad
+        link = {}
         outs = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
                                 (N, Cin, H, W, k, stride, pad, nchw), relu, training, momentum, bn.eps, dtype, cpad,
-                                dx_frames, pool, fork if joins else None, in_affine, True)
+                                dx_frames, pool, fork if joins else None, in_affine, True, link)
         z, (mean, invstd) = outs[0], outs[-2:]
         cout_l = weight.shape[0]
-        affine = (mean, invstd, _f32(bn.weight), _f32(bn.bias), cout_l if z.shape[1] != cout_l else 0, relu)
+        affine = (mean, invstd, _f32(bn.weight), _f32(bn.bias), cout_l if z.shape[1] != cout_l else 0, relu, link)
         if fork is None:
             return z, affine
         second = outs[1] if joins else (x if fork == "alias" else subsample_nhwc(x, N, Cin, H, W, int(fork)))

@@ -1347,6 +1347,31 @@ def conv3x1_stream(x: Tensor, wp: Tensor, N: int, T: int, HW: int, Cin: int, Cou
     return y
 
 
+def conv3x1_stream_bn_bwd(dy: Tensor, wp: Tensor, z: Tensor, affine, N: int, T: int, HW: int, training: bool, *,
+                          dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None, accumulate: bool = False):
+    """Data gradient of the (3, 1) temporal convolution 144 -> 64 (as ``conv3x1_stream``) with the backward of the BatchNorm
+    (+ ReLU) in front of that layer fused in (dvt_conv3x1_stream_bn_bwd): dy [N*T*HW, 64], z [N*T*HW, 144] the spatial half's
+    output, affine = (mean, invstd, gamma, beta, c_valid, relu) of the BatchNorm that normalised it
+    -> (dz [N*T*HW, 144], dgamma, dbeta).  The 144-plane data gradient is never stored (computed twice instead)."""
+    _need_cuda(dy, wp, z)
+    assert dy.dtype == z.dtype and z.shape == (N * T * HW, 144) and dy.shape == (N * T * HW, 64)
+    aff, keep = _bn_affine(affine)
+    if dgamma is None:
+        assert not accumulate
+        dgamma = torch.empty((144,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((144,), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    lib = L.load()
+    ws = workspace(lib.dvt_conv3x1_stream_bn_bwd_workspace_bytes(N, T, HW), z.device)
+    esz = z.element_size()
+    nb = 2 * (dy.numel() + z.numel() + wp.numel()) * esz + dz.numel() * esz
+    with _timed(("conv", "stream3x1_bn_bwd", N * T * HW, 144, 3 * 64, nb), 2 * 2.0 * N * T * HW * 144 * 3 * 64):
+        L.check(lib.dvt_conv3x1_stream_bn_bwd(dy.data_ptr(), wp.data_ptr(), z.data_ptr(), C.byref(aff), dz.data_ptr(),
+                                              dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, T, HW, int(training),
+                                              int(accumulate), dt(z), _stream()), "dvt_conv3x1_stream_bn_bwd")
+    return dz, dgamma, dbeta
+
+
 def conv3x3_c64_wgrad_supported(x: Tensor, dz: Tensor, N: int, H: int, W: int, Cout: int = 64) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or dz.dtype != x.dtype:
         return False
@@ -1396,7 +1421,7 @@ def _bn_affine(affine):
     """affine = (mean, invstd, gamma, beta, c_valid, relu) of the BatchNorm in front of a map, or None -> (struct, keep-alive)."""
     if affine is None:
         return None, None
-    mean, invstd, gamma, beta, c_valid, relu = affine
+    mean, invstd, gamma, beta, c_valid, relu = affine[:6]
     _need_cuda(mean, invstd, gamma, beta)
     for t in (mean, invstd, gamma, beta):
         assert t.dtype == torch.float32 and t.is_contiguous()

@@ -669,6 +669,17 @@ int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_parti
 int dvt_conv3x1_stream_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
 int dvt_conv3x1_stream(const void* x, const void* w, void* y, int64_t N, int T, int L, int Cin, int Cout, int dtype,
                        dvt_stream_t stream);
+/* The same data gradient with the backward of the BatchNorm (+ ReLU) in FRONT of the temporal half fused in (the mid-plane
+ * BatchNorm of Conv2Plus1D, video_resnet.py:30-31 of torchvision's layout; reference frame_transformer.py:64-74): dy [N*T*L, 64]
+ * is the temporal convolution's output gradient, z [N*T*L, 144] the spatial half's output that `bn` normalised, dz [N*T*L, 144]
+ * receives gamma * invstd * (d - sum d / rows - xhat * sum d xhat / rows) with d = (dy (*) w) under the ReLU mask recomputed
+ * from z (training == 0: gamma * invstd * d); dgamma / dbeta [144] overwritten or accumulated.  The data gradient itself is
+ * never stored: it is computed twice (sums, then the corrected gradient), which replaces a write and two reads of a
+ * 144-plane map by one read of the 64-plane dy.  Same geometry as dvt_conv3x1_stream (dvt_conv3x1_stream_supported). */
+size_t dvt_conv3x1_stream_bn_bwd_workspace_bytes(int64_t N, int T, int L);
+int dvt_conv3x1_stream_bn_bwd(const void* dy, const void* w, const void* z, const dvt_bn_affine* bn, void* dz, float* dgamma,
+                              float* dbeta, void* workspace, int64_t N, int T, int L, int training, int accumulate, int dtype,
+                              dvt_stream_t stream);
 int dvt_conv2d_implicit_supported(const dvt_conv_desc* desc);
 /* Row length K of the packed weights w[Cout][K] the forward call expects: kh*kw*C -- rounded up to the kernel's k-tile in
  * the stem form C == 8 (the columns past kh*kw*8 must be zero: dvt_conv_weight_pack with ld = K writes them so). */

@@ -945,6 +945,72 @@ def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, d
     assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp, affine=(m0, is0, ga, be, 0, False)), ops.conv3x1_fwd(nr, wp, N, T, Lp))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (1, 8, 4, 4)])
+def test_temporal_data_gradient_with_the_mid_batchnorm_backward_fused(dvt, device, dtype, training, N, T, H, W):
+    """dvt_conv3x1_stream_bn_bwd: the data gradient of the (3, 1, 1) temporal convolution 144 -> 64 with the backward of the
+    BatchNorm + ReLU in front of that layer (the mid-plane BatchNorm of Conv2Plus1D) in its epilogue -- the 144-plane gradient
+    is computed twice (sums, then the corrected gradient) and never stored -- against the composition it replaces on the same
+    operands: dvt_conv3x1_stream, then dvt_bn_bwd with the mask recomputed from z.  dgamma / dbeta sum the same rounded values
+    in another order; dz differs by the association of the fp32 correction (A dz + B z + C0) before the one rounding."""
+    ops = dvt.ops
+    Lp = H * W
+    g = torch.Generator().manual_seed(N * 17 + T + Lp)
+    rows = N * T * Lp
+    z = torch.randn(rows, 144, generator=g).to(dtype).cuda()
+    dy = (torch.randn(rows, 64, generator=g) / rows ** 0.5).to(dtype).cuda()
+    w = (torch.randn(64, 144, 3, 1, generator=g) * (2.0 / (144 * 3)) ** 0.5).cuda()
+    wd = ops.conv_weight_pack_dgrad(w, dtype)
+    if not ops.conv3x1_stream_supported(dy, wd, N, T, Lp, 64, 144):
+        pytest.skip("no segment length of this map fills half a 224-pixel tile")
+    m0, is0 = (0.2 * torch.randn(144, generator=g)).cuda(), (1 + 0.3 * torch.rand(144, generator=g)).cuda()
+    ga, be = (1 + 0.2 * torch.randn(144, generator=g)).cuda(), (0.3 * torch.randn(144, generator=g)).cuda()
+    d = ops.conv3x1_stream(dy, wd, N, T, Lp, 64, 144)
+    want, _, wg, wb = ops.bn_bwd(d, z, None, m0, is0, ga, True, training, False, beta=be)
+    got, gg, gb = ops.conv3x1_stream_bn_bwd(dy, wd, z, (m0, is0, ga, be, 0, True), N, T, Lp, training)
+    assert rel_l2(gg, wg) < 2e-5 and rel_l2(gb, wb) < 2e-5
+    assert rel_l2(got, want) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    # accumulate: += into the caller's dgamma / dbeta
+    ag, ab = torch.ones(144, device="cuda"), torch.full((144,), 2.0, device="cuda")
+    got2, _, _ = ops.conv3x1_stream_bn_bwd(dy, wd, z, (m0, is0, ga, be, 0, True), N, T, Lp, training, dgamma=ag, dbeta=ab,
+                                           accumulate=True)
+    assert torch.equal(got2, got) and rel_l2(ag - 1, gg) < 1e-5 and rel_l2(ab - 2, gb) < 1e-5
+    # without the ReLU
+    want3, _, wg3, _ = ops.bn_bwd(d, z, None, m0, is0, ga, False, training, False)
+    got3, gg3, _ = ops.conv3x1_stream_bn_bwd(dy, wd, z, (m0, is0, ga, be, 0, False), N, T, Lp, training)
+    assert rel_l2(gg3, wg3) < 2e-5 and rel_l2(got3, want3) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+
+
+def test_r2plus1d_block_backward_with_and_without_the_fused_mid_batchnorm(dvt, device, monkeypatch):
+    """models/video_resnet.BasicBlock (layer 1 of R(2+1)D-18, frame_transformer.py:64-74): with the virtual BatchNorm between the
+    halves of each Conv2Plus1D, the backward of that BatchNorm runs inside the temporal half's data gradient
+    (functional.FUSED_MID_BN_BWD) or as dvt_bn_bwd over the stored gradient -- same input gradient, same parameter gradients
+    (the mid BatchNorm's dgamma / dbeta included)."""
+    from dvt_amd.models import video_resnet as vr
+    F = dvt.functional
+    torch.manual_seed(11)
+    blk = vr.BasicBlock(64, 64, vr.Conv2Plus1D).cuda().train()
+    N, T, H, W = 2, 12, 8, 7
+    x0 = torch.randn(N * T * H * W, 64).to(torch.bfloat16).cuda()
+    gy = (torch.randn(N * T * H * W, 64) / 50).to(torch.bfloat16).cuda()
+    assert vr._virtual_bn_pair(blk.conv1[0], N, T, H, W, torch.bfloat16)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(F, "FUSED_MID_BN_BWD", fused)
+        for p_ in blk.parameters():
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = blk.forward_ndhwc((x, N, T, H, W), torch.bfloat16)[0]
+        out.backward(gy)
+        res.append((x.grad.float().clone(), {n: p_.grad.clone() for n, p_ in blk.named_parameters()}))
+    (dx0, g0), (dx1, g1) = res
+    assert rel_l2(dx1, dx0) < 1e-2
+    assert set(g0) == set(g1) and len(g0) == 12
+    for n in g0:
+        assert rel_l2(g1[n], g0[n]) < (1e-2 if n.endswith("weight") and g0[n].dim() > 1 else 2e-2), n
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
 def test_col2im_joins_a_compact_downsample_gradient(dvt, device, dtype, H, W):
