@@ -369,6 +369,8 @@ def cnn_roofline(summ, nprof, workload):
             name = "conv3x3_c64 weight gradient (LDS halo patches; one partial per workgroup, summed by the split-K reduce)"
         elif kind == "window3x1_wgrad":
             name = "conv3x1 temporal weight gradient 144 -> 64 (LDS sliding windows over all frames of a pixel segment)"
+        elif kind == "stream3x1_bn_bwd":
+            name = "conv3x1 temporal data gradient 64 -> 144 with the mid-plane BatchNorm backward in its epilogue (computed twice: sums, then the corrected gradient; the 144-plane gradient is never stored)"
         elif kind == "window3x1_fwd":
             name = "conv3x1 temporal forward 144 -> 64 (LDS sliding windows; the spatial half's BatchNorm + ReLU applied in the window)"
         else:
@@ -389,7 +391,7 @@ def cnn_roofline(summ, nprof, workload):
             pmc = {}
     pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
                "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream",
-               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd"}
+               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "stream3x1_bn_bwd": "conv3x3_stream"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
