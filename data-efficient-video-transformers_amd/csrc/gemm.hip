@@ -1102,7 +1102,20 @@ static int conv_fwd_cfg(int64_t rows, int cout, int c, int taps) {
       // 72 k-tiles of 0.2 us MFMA work each took 3 us)
       return dvt_cdiv(rows, 128) * dvt_cdiv(cout, 128) <= cus ? 10 : 9;
     }
-    if (cfg == 0 && t128 > cus && t128 <= 2 * cus && c % 32 == 0) return 1;
+  }
+  {
+    // per-shape sweep of every configuration on the layer 2 - 4 shapes of both encoders (tools/dev/conv_cfg_sweep.py with a
+    // forced-configuration build; gpurun_out/r5_conv_cfg_sweep2.log; in the step: frametransformer -0.06 ms, pyramid -0.04 ms,
+    // gpurun_out/r5_ab_tuned.log).  It also retired the round-3 rule "256 x 128 x 32 for one to two workgroups per CU of
+    // 256-wide tiles" (ResNet-18 layer 3: 78 us against 68 on the 256 x 256 tile it replaced).
+    //  * 65..128 output channels, K a whole number of 64-deep k-tiles: 128 x 128 x 64, two per CU, beats 256 x 128 x 32 on
+    //    every such shape (R(2+1)D layer 2 data gradients 141 -> 116, 57 -> 51 us; ResNet-18 layer 2 92 -> 87)
+    if (cfg == 1 && ((int64_t)taps * c) % 64 == 0 && c % 8 == 0) return 9;
+    //  * widths whose last 256-wide tile column is mostly padding (288 mid planes): 256 x 128 x 32 (200 -> 178, 89 -> 71 us)
+    if (cfg == 0 && c % 32 == 0) {
+      const int w256 = (cout + 255) / 256 * 256, w128 = (cout + 127) / 128 * 128;
+      if (w256 * 4 > w128 * 5) return 1;
+    }
   }
   if (cfg == 0 && dvt_cdiv(rows, 256) * dvt_cdiv(cout, 256) * 4 < cus * 3) return c % 64 == 0 ? 7 : 1;
   return cfg;
