@@ -1,5 +1,5 @@
 """Dev probe: forward / data-gradient convolutions of R(2+1)D-18's layers 2 - 3 at the frametransformer shapes under every tile
-configuration of the implicit GEMM (needs a build with the DVT_FORCE_CONV_CFG switch in gemm.hip: conv_fwd_cfg)."""
+configuration of the implicit GEMM (needs a build with tools/dev/force_conv_cfg.patch applied: the DVT_FORCE_CONV_CFG switch of conv_fwd_cfg)."""
 import os, subprocess, sys, json
 SHAPES = [  # name, frames, Cin, H, W, Cout, k, pad, stride
     ("L2 spatial 128->288", 168, 128, 28, 28, 288, (3, 3), (1, 1), 1),
