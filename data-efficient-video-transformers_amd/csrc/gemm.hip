@@ -1078,6 +1078,9 @@ int dvt_gemm(const dvt_gemm_desc* d, dvt_stream_t stream) {
 // no epilogue to overlap) is faster on the 64-deep form of that tile (cfg 7: layer 2 of ResNet-18 104 -> 93 us, forward
 // 92 -> 97 us).
 static int conv_cfg(int cout, int c, bool wgrad = false) {
+  // (weight gradient of a width whose last 256-wide tile column is mostly padding -- 288 mid planes: 202 -> 183 us on the
+  //  256 x 128 x 32 form; every other width keeps what the sweep tools/dev/conv_wgrad_cfg_sweep.py found it on already)
+  if (wgrad && cout > 128 && ((cout + 255) / 256 * 256) * 4 > ((cout + 127) / 128 * 128) * 5) return 1;
   // (the weight gradient's k-tile runs over output pixels, not channels: its 64-deep forms take any C % 8 == 0)
   return cout <= 64 ? (c % 64 == 0 || wgrad ? 6 : 4) : cout <= 128 ? (wgrad ? 7 : 1) : 0;
 }
