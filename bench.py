@@ -391,12 +391,14 @@ def cnn_roofline(summ, nprof, workload):
             pmc = {}
     pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
                "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream",
-               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "stream3x1_bn_bwd": "conv3x3_stream"}
+               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "stream3x1_bn_bwd": "conv3x1_stream_bn_bwd"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
         tf = fl / (ms * 1e-3) / 1e12
         traffic = (pmc.get(pmc_key[kind], {}) or {}).get("hbm_bytes_corrected")
+        if traffic and kind == "stream3x1_bn_bwd":
+            traffic *= 2                     # one operator = two kernel launches (sums pass + apply pass); the family averages both
         alg_kind = sum(v[3] for v in fams.values() if v[4] == kind) / max(1, sum(v[2] for v in fams.values() if v[4] == kind))
         out["conv_families"][name] = {"ms_per_step": round(ms / nprof, 3), "launches_per_step": cnt // nprof,
                                       "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),

@@ -51,6 +51,10 @@ def conv_family(name):
     """Kernels of the per-frame CNN encoder: the implicit-GEMM convolution (gemm_dma_kernel with A_CONV = true: forward /
     data gradient when A is k-major, weight gradient when both operands are mn-major) and the LDS-halo 3x3 kernel."""
     if "conv3x3_stream_kernel" in name:
+        # MODE 1 / 2 of the (3, 1) form: the two passes of the fused data gradient + BatchNorm backward (one operator = one
+        # launch of each; bench.py doubles the family's per-launch average)
+        if re.search(r"Li64ELi144ELi3ELi[12]E", name) or re.search(r"64, 144, 3, [12]>", name):
+            return "conv3x1_stream_bn_bwd"
         return "conv3x3_stream"
     if "conv3x3_c64_wgrad_kernel" in name:
         return "conv3x3_c64_wgrad"
