@@ -1590,12 +1590,15 @@ static int bn_vc(int C) {
   return 1 << bn_vc_log2(C);
 }
 
-// Row partition: about 2048 workgroups in total (8 per CU), at least 4 passes of the row lanes per workgroup.
+// Row partition: about 1024 workgroups in total (4 per CU), at least 4 passes of the row lanes per workgroup.  (2048 until
+// round 5: the column-statistics kernel streams as fast with 1024 -- tools/dev/bn_colstats_price.hip: 5.9 TB/s either way -- and
+// the finalize launch behind it, 37 of them per frametransformer step, reads half the partial rows: 7.5 -> ~5 us each;
+// same box, frametransformer 15.98 -> 15.86 ms, pyramid 13.36 -> 13.29; 512 gives the gain back in the statistics kernel.)
 static int bn_parts(int64_t rows, int C, int* rpb) {
   const int vc = bn_vc(C);
   const int64_t gx = dvt_cdiv(C, 8 * vc);
   const int nrl = 256 / vc;
-  int64_t parts = 2048 / gx;
+  int64_t parts = 1024 / gx;
   const int64_t cap = rows / (4 * nrl);
   if (parts > cap) parts = cap;
   if (parts < 1) parts = 1;
