@@ -233,6 +233,258 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic_kernel(const AttnPar
   }
 }
 
+// ======================================================================= short sequences, any head width
+// The reference's default FrameTransformer runs a 4-layer encoder over 14 + 1 chunk tokens (frame_transformer.py:83-121;
+// d = 896, 8 heads of 112): the generic kernels above give every (b, h, query) a wave whose lanes walk dh serially with
+// 2-byte loads -- 25 us per launch for 392 dot products of 448 (d = 896 in 2 heads), and the backward is three launches
+// (delta, dq, dk / dv).  Here ONE WORKGROUP owns a whole (b, h): Q, K, V (and dO) are staged in LDS as fp32 rows of dh + 1
+// floats (an odd pitch: the lanes of a score pass read different rows at the same column, conflict-free), the Lq x Lk
+// score matrix lives in LDS, and the backward recomputes the softmax and produces dQ, dK and dV in the same launch (no lse,
+// no delta workspace).  Same arithmetic as the generic kernels: fp32 FMA, the dropout multiplier of attn_drop on the
+// normalised probabilities.  LDS per workgroup: (3 or 4) L (dh + 1) + (1 or 2) L (L + 1) floats; L <= 32, dh <= 512.
+constexpr int kSmallL = 32, kSmallDh = 512;
+
+// rows of a [L][dh] operand (row stride sl elements) -> fp32 LDS rows of pitch dhp (a multiple of 4 floats).  16-byte
+// loads, four in flight per thread, when the rows allow it: one 2-byte load per trip of a rolled loop serialised a DRAM
+// round trip per element.
+template <typename T>
+__device__ __forceinline__ void small_stage(float* dst, const T* src, int L, int dh, int64_t sl, int dhp, int tid, int NT) {
+  constexpr int VE = 16 / (int)sizeof(T);                       // elements per 16-byte load
+  typedef T vec_t __attribute__((ext_vector_type(VE)));
+  const bool vec = dh % VE == 0 && sl % VE == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  if (vec) {
+    const int vpr = dh / VE, nv = L * vpr;
+    for (int base = 0; base < nv; base += 4 * NT) {
+      vec_t v[4];
+      int r[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * NT + tid;
+        r[u] = idx / vpr; c[u] = (idx - r[u] * vpr) * VE;
+        if (idx < nv) v[u] = *reinterpret_cast<const vec_t*>(src + (int64_t)r[u] * sl + c[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (base + u * NT + tid < nv) {
+#pragma unroll
+          for (int k = 0; k < VE; k += 4)
+            *reinterpret_cast<f32x4*>(dst + r[u] * dhp + c[u] + k) =
+                f32x4{to_f32<T>(v[u][k]), to_f32<T>(v[u][k + 1]), to_f32<T>(v[u][k + 2]), to_f32<T>(v[u][k + 3])};
+        }
+      }
+    }
+  } else {
+    for (int idx = tid; idx < L * dh; idx += NT) {
+      const int i = idx / dh, e = idx - i * dh;
+      dst[i * dhp + e] = to_f32<T>(src[(int64_t)i * sl + e]);
+    }
+  }
+  for (int idx = tid; idx < L * (dhp - dh); idx += NT) {          // the pad columns are read by the 4-wide dot products
+    const int i = idx / (dhp - dh), e = dh + idx - i * (dhp - dh);
+    dst[i * dhp + e] = 0.f;
+  }
+}
+
+// pitches: operand rows dh rounded up to 4 floats + 4 (16-byte aligned rows for ds_read_b128, consecutive rows 4 banks
+// apart); score rows Lk rounded up to 4 floats + 4
+__host__ __device__ inline int small_dhp(int dh) { return ((dh + 3) & ~3) + 4; }
+__host__ __device__ inline int small_lp(int Lk) { return ((Lk + 3) & ~3) + 4; }
+
+// scores of all (i, j) pairs: a pair's dot product is cut into P = 1, 2 or 4 column ranges so that every thread of the
+// workgroup has one (196 pairs on 512 threads: two threads per pair); partial sums into part[P][Lq][LP].  16-byte LDS
+// reads: with 4-byte reads the 448-long products of the frametransformer's encoder were 5.5 us of LDS instruction issue.
+template <bool WITH_DP>
+__device__ __forceinline__ void small_scores(const float* qs, const float* ks, const float* gs, const float* vs, float* part,
+                                             float* dpart, int Lq, int Lk, int dh, int dhp, int LP, int P, int tid, int NT) {
+  const int npair = Lq * Lk, span = (((dh + P - 1) / P) + 3) & ~3, dh4 = (dh + 3) & ~3;
+  for (int idx = tid; idx < npair * P; idx += NT) {
+    const int pr = idx / P, pt = idx - pr * P;
+    const int i = pr / Lk, j = pr - i * Lk;
+    const int e0 = pt * span, e1 = min(dh4, e0 + span);
+    const float* qi = qs + i * dhp;
+    const float* kj = ks + j * dhp;
+    const float* gi = WITH_DP ? gs + i * dhp : nullptr;
+    const float* vj = WITH_DP ? vs + j * dhp : nullptr;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; e += 4) {                             // (pad columns are zero)
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qi + e), c = *reinterpret_cast<const f32x4*>(kj + e);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = fmaf(a[u], c[u], s[u]);
+      if (WITH_DP) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(gi + e), y = *reinterpret_cast<const f32x4*>(vj + e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = fmaf(x[u], y[u], d[u]);
+      }
+    }
+    part[(pt * Lq + i) * LP + j] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (WITH_DP) dpart[(pt * Lq + i) * LP + j] = (d[0] + d[1]) + (d[2] + d[3]);
+  }
+}
+
+// column ranges per pair: as many as give every thread work, at most 4 (the partial matrices live in LDS)
+__host__ __device__ inline int small_parts(int Lq, int Lk, int NT) {
+  const int np = Lq * Lk;
+  return np * 4 <= NT ? 4 : np * 2 <= NT ? 2 : 1;
+}
+
+// out[r][e] = sum_c m[r][c] * col[c] for this thread's column e: the matrix rows (pitch LP, zero beyond nc) are broadcast
+// from LDS four at a time, the column sits in registers
+#define DVT_SMALL_MATCOL(acc, mrow, col, nc)                                         \
+  do {                                                                               \
+    f32x4 t_ = {0.f, 0.f, 0.f, 0.f};                                                 \
+    _Pragma("unroll") for (int c4_ = 0; c4_ < kSmallL; c4_ += 4) {                   \
+      if (c4_ < (nc)) {                                                              \
+        const f32x4 m_ = *reinterpret_cast<const f32x4*>((mrow) + c4_);              \
+        t_[0] = fmaf(m_[0], (col)[c4_], t_[0]); t_[1] = fmaf(m_[1], (col)[c4_ + 1], t_[1]); \
+        t_[2] = fmaf(m_[2], (col)[c4_ + 2], t_[2]); t_[3] = fmaf(m_[3], (col)[c4_ + 3], t_[3]); \
+      }                                                                              \
+    }                                                                                \
+    (acc) = (t_[0] + t_[1]) + (t_[2] + t_[3]);                                       \
+  } while (0)
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_small_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int64_t bh = blockIdx.x;
+  const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  const int dhp = small_dhp(p.dh), LP = small_lp(p.Lk), P = small_parts(p.Lq, p.Lk, NT);
+  float* qs = lds_f;
+  float* ks = qs + p.Lq * dhp;
+  float* vs = ks + p.Lk * dhp;
+  float* sc = vs + p.Lk * dhp;                      // [P][Lq][LP] partial scores; [0] becomes the probabilities
+  const T* q = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+  const T* k = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* v = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  T* o = (T*)p.out + b * p.o_sb + h * p.o_sh;
+  small_stage<T>(qs, q, p.Lq, p.dh, p.q_sl, dhp, tid, NT);
+  small_stage<T>(ks, k, p.Lk, p.dh, p.k_sl, dhp, tid, NT);
+  small_stage<T>(vs, v, p.Lk, p.dh, p.v_sl, dhp, tid, NT);
+  __syncthreads();
+  small_scores<false>(qs, ks, nullptr, nullptr, sc, nullptr, p.Lq, p.Lk, p.dh, dhp, LP, P, tid, NT);
+  __syncthreads();
+  // softmax: 32 lanes per query row (key j on lane j; Lk <= 32), the row's maximum / sum by xor-shuffles inside the half wave
+  for (int i = tid >> 5; i < p.Lq; i += NT >> 5) {
+    const int j = tid & 31;
+    float sv = -INFINITY;
+    if (j < p.Lk) {
+      sv = 0.f;
+      for (int pt = 0; pt < P; ++pt) sv += sc[(pt * p.Lq + i) * LP + j];
+      sv *= p.scale;
+    }
+    float m = sv;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    const float e = j < p.Lk ? expf(sv - m) : 0.f;
+    float l = e;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 32);
+    // (dropped probabilities leave the normaliser untouched; columns Lk .. LP - 1 of a row are zero for the 4-wide reads)
+    if (j < LP) sc[i * LP + j] = j < p.Lk ? e * attn_drop(p, b, h, i, j) * (1.0f / l) : 0.f;
+    if (j == 0) p.lse[bh * p.Lq + i] = m + logf(l);
+  }
+  __syncthreads();
+  // O = P V: a thread owns an output column e, V's column in registers, the probabilities broadcast from LDS
+  for (int e = tid; e < p.dh; e += NT) {
+    float vc[kSmallL];
+#pragma unroll
+    for (int j = 0; j < kSmallL; ++j) vc[j] = j < p.Lk ? vs[j * dhp + e] : 0.f;
+    for (int i = 0; i < p.Lq; ++i) {
+      float acc;
+      DVT_SMALL_MATCOL(acc, sc + i * LP, vc, p.Lk);
+      o[(int64_t)i * p.o_sl + e] = from_f32<T>(acc);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_small_bwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int64_t bh = blockIdx.x;
+  const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  const int dhp = small_dhp(p.dh), LP = small_lp(p.Lk), LQ = small_lp(p.Lq), P = small_parts(p.Lq, p.Lk, NT);
+  float* qs = lds_f;
+  float* gs = qs + p.Lq * dhp;                       // dO
+  float* ks = gs + p.Lq * dhp;
+  float* vs = ks + p.Lk * dhp;
+  float* pm = vs + p.Lk * dhp;                       // [P][Lq][LP]: partial scores; [0]: dS
+  float* dm = pm + P * p.Lq * LP;                    // [P][Lq][LP]: partial dP
+  float* pt_ = dm + P * p.Lq * LP;                   // [Lk][LQ]: dropped probabilities, transposed (dV's operand)
+  float* dt_ = pt_ + p.Lk * LQ;                      // [Lk][LQ]: dS, transposed (dK's operand)
+  const T* q = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+  const T* k = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* v = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  const T* g = (const T*)p.d_o + b * p.o_sb + h * p.o_sh;
+  T* dq = (T*)p.dq + b * p.q_sb + h * p.q_sh;
+  T* dk = (T*)p.dk + b * p.k_sb + h * p.k_sh;
+  T* dv = (T*)p.dv + b * p.v_sb + h * p.v_sh;
+  small_stage<T>(qs, q, p.Lq, p.dh, p.q_sl, dhp, tid, NT);
+  small_stage<T>(gs, g, p.Lq, p.dh, p.o_sl, dhp, tid, NT);
+  small_stage<T>(ks, k, p.Lk, p.dh, p.k_sl, dhp, tid, NT);
+  small_stage<T>(vs, v, p.Lk, p.dh, p.v_sl, dhp, tid, NT);
+  for (int idx = tid; idx < 2 * p.Lk * LQ; idx += NT) pt_[idx] = 0.f;       // (pad columns of the transposed matrices)
+  __syncthreads();
+  small_scores<true>(qs, ks, gs, vs, pm, dm, p.Lq, p.Lk, p.dh, dhp, LP, P, tid, NT);
+  __syncthreads();
+  for (int i = tid >> 5; i < p.Lq; i += NT >> 5) {   // 32 lanes per query row
+    const int j = tid & 31;
+    float sv = -INFINITY, dp = 0.f;
+    if (j < p.Lk) {
+      sv = 0.f;
+      for (int pt = 0; pt < P; ++pt) {
+        sv += pm[(pt * p.Lq + i) * LP + j];
+        dp += dm[(pt * p.Lq + i) * LP + j];
+      }
+      sv *= p.scale;
+    }
+    float m = sv;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    const float e = j < p.Lk ? expf(sv - m) : 0.f;
+    float l = e;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 32);
+    const float pr = e * (1.0f / l);
+    const float dr = j < p.Lk ? attn_drop(p, b, h, i, j) : 0.f;
+    const float dpd = dp * dr;                       // dP * drop
+    float delta = pr * dpd;                          // sum_j: = sum_e dO[i][e] O[i][e]
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) delta += __shfl_xor(delta, off, 32);
+    const float dsv = j < p.Lk ? pr * (dpd - delta) * p.scale : 0.f;
+    if (j < LP) pm[i * LP + j] = dsv;                // dS (rows: dQ's operand), zero beyond Lk
+    if (j < p.Lk) {
+      dt_[j * LQ + i] = dsv;
+      pt_[j * LQ + i] = pr * dr;                     // dropped probability
+    }
+  }
+  __syncthreads();
+  // a thread owns a column e of the head: dQ[:, e] from K's column, dK[:, e] / dV[:, e] from Q's and dO's columns
+  for (int e = tid; e < p.dh; e += NT) {
+    float c0[kSmallL], c1[kSmallL];
+#pragma unroll
+    for (int j = 0; j < kSmallL; ++j) c0[j] = j < p.Lk ? ks[j * dhp + e] : 0.f;
+    for (int i = 0; i < p.Lq; ++i) {
+      float acc;
+      DVT_SMALL_MATCOL(acc, pm + i * LP, c0, p.Lk);
+      dq[(int64_t)i * p.q_sl + e] = from_f32<T>(acc);
+    }
+#pragma unroll
+    for (int i = 0; i < kSmallL; ++i) {
+      c0[i] = i < p.Lq ? gs[i * dhp + e] : 0.f;
+      c1[i] = i < p.Lq ? qs[i * dhp + e] : 0.f;
+    }
+    for (int j = 0; j < p.Lk; ++j) {
+      float av, ak;
+      DVT_SMALL_MATCOL(av, pt_ + j * LQ, c0, p.Lq);
+      DVT_SMALL_MATCOL(ak, dt_ + j * LQ, c1, p.Lq);
+      dv[(int64_t)j * p.v_sl + e] = from_f32<T>(av);
+      dk[(int64_t)j * p.k_sl + e] = from_f32<T>(ak);
+    }
+  }
+}
+#undef DVT_SMALL_MATCOL
+
 // ======================================================================= one query per (b, h), dh = 64
 // The last layer of a stack is read at row 0 only (src/models/vit.py:119-120, :126), so its attention has ONE query per
 // (sequence, head): a matrix-vector problem, bound by streaming K and V once (HBM), no MFMA.  One wave per (b, h): a
@@ -1367,6 +1619,24 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     DVT_LAUNCH_CHECK("dvt_attention_fwd(mfma)");
     return DVT_OK;
   }
+  const int nt_s = p.Lq * p.dh >= 4096 ? 512 : 256;
+  const size_t lds_s = ((size_t)(p.Lq + 2 * p.Lk) * small_dhp(p.dh) +
+                        (size_t)small_parts(p.Lq, p.Lk, nt_s) * p.Lq * small_lp(p.Lk)) * sizeof(float);
+  if (p.Lq <= kSmallL && p.Lk <= kSmallL && p.dh <= kSmallDh && lds_s <= (size_t)kMaxLds) {   // short sequences: a workgroup per (b, h)
+    const dim3 grid((unsigned)(p.B * p.H)), block(nt_s);
+#define DVT_ATTN_SMALL_FWD(T)                                                   \
+  do {                                                                          \
+    set_lds(attn_small_fwd_kernel<T>, lds_s);                                   \
+    hipLaunchKernelGGL((attn_small_fwd_kernel<T>), grid, block, lds_s, st, p);  \
+  } while (0)
+    if (d->dtype == DVT_F32) DVT_ATTN_SMALL_FWD(float);
+    else if (d->dtype == DVT_BF16) DVT_ATTN_SMALL_FWD(bf16);
+    else if (d->dtype == DVT_F16) DVT_ATTN_SMALL_FWD(f16);
+    else DVT_UNSUPPORTED("dvt_attention_fwd: dtype %d not supported", d->dtype);
+#undef DVT_ATTN_SMALL_FWD
+    DVT_LAUNCH_CHECK("dvt_attention_fwd(short)");
+    return DVT_OK;
+  }
   const size_t lds = (size_t)4 * (p.dh + p.Lk) * sizeof(float);
   if (lds > (size_t)kMaxLds) DVT_UNSUPPORTED("dvt_attention_fwd: Lk = %d, dh = %d exceed the LDS budget", p.Lk, p.dh);
   const int64_t rows = (int64_t)p.B * p.H * p.Lq;
@@ -1460,6 +1730,25 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
 #undef DVT_ATTN_BWD_DQ
 #undef DVT_ATTN_BWD_DKV
     DVT_LAUNCH_CHECK("dvt_attention_bwd(dkdv)");
+    return DVT_OK;
+  }
+  const int nt_s = p.Lq * p.dh >= 4096 ? 512 : 256;
+  const size_t lds_s = ((size_t)2 * (p.Lq + p.Lk) * small_dhp(p.dh) +
+                        (size_t)2 * small_parts(p.Lq, p.Lk, nt_s) * p.Lq * small_lp(p.Lk) +
+                        (size_t)2 * p.Lk * small_lp(p.Lq)) * sizeof(float);
+  if (p.Lq <= kSmallL && p.Lk <= kSmallL && p.dh <= kSmallDh && lds_s <= (size_t)kMaxLds) {   // short sequences: dQ, dK, dV of a (b, h) in one launch
+    const dim3 grid((unsigned)(p.B * p.H)), block(nt_s);
+#define DVT_ATTN_SMALL_BWD(T)                                                   \
+  do {                                                                          \
+    set_lds(attn_small_bwd_kernel<T>, lds_s);                                   \
+    hipLaunchKernelGGL((attn_small_bwd_kernel<T>), grid, block, lds_s, st, p);  \
+  } while (0)
+    if (d->dtype == DVT_F32) DVT_ATTN_SMALL_BWD(float);
+    else if (d->dtype == DVT_BF16) DVT_ATTN_SMALL_BWD(bf16);
+    else if (d->dtype == DVT_F16) DVT_ATTN_SMALL_BWD(f16);
+    else DVT_UNSUPPORTED("dvt_attention_bwd: dtype %d not supported", d->dtype);
+#undef DVT_ATTN_SMALL_BWD
+    DVT_LAUNCH_CHECK("dvt_attention_bwd(short)");
     return DVT_OK;
   }
   DVT_REQUIRE(d->workspace, "dvt_attention_bwd: workspace (dvt_attention_bwd_workspace_bytes) required");

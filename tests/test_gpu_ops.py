@@ -535,6 +535,9 @@ ATTN_CASES = [
     # B, H, Lq, Lk, dh
     (2, 2, 17, 17, 64), (2, 3, 33, 33, 64), (1, 2, 197, 197, 64), (2, 2, 5, 40, 64),
     (1, 1, 64, 64, 64), (2, 2, 14, 14, 32), (1, 2, 15, 14, 448), (1, 4, 14, 15, 224),
+    # short sequences of any head width (one workgroup per (b, h), csrc/attention.hip: attn_small_*): the frametransformer's
+    # 15-token encoder at 8 heads, widths that are no multiple of 8 / of 4, the largest shape the kernels take, one query
+    (2, 8, 15, 15, 112), (1, 3, 9, 11, 100), (1, 2, 7, 5, 30), (1, 2, 32, 32, 128), (2, 1, 1, 7, 20), (1, 1, 32, 32, 512),
     (2, 2, 325, 325, 64),          # long-clip tokens per frame (288^2): > 80 KiB of LDS, one 11-wave workgroup per CU
     (1, 2, 40, 600, 64),
     # every compile-time key / query count of the register-resident forward (<= 224 keys) and the unrolled backward
