@@ -220,6 +220,7 @@ SIGNATURES = {
     "dvt_device_delay": (c_int, [C.c_uint64, c_p]),
     "dvt_zero": (c_int, [c_p, C.c_size_t, c_p]),
     "dvt_dropout": (c_int, [c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_p]),
+    "dvt_dropout_fused": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_p, C.c_uint64, c_int, c_int, c_p]),
     "dvt_rng_advance": (c_int, [c_p, C.c_uint64, c_p]),
     "dvt_conv_weight_pack_dgrad": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "dvt_pad3_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),

@@ -2088,6 +2088,56 @@ class _Dropout(torch.autograd.Function):
         return ops.dropout(dy.contiguous(), ctx.p, ctx.state, ctx.off), None
 
 
+class _DropoutAdd(torch.autograd.Function):
+    """res + dropout(x): one launch (the mask of ``_Dropout`` at the same RNG site)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p):
+        st = _rng.tensor(x.device)
+        ctx.p, ctx.off, ctx.state = p, _rng.take(x.numel()), st
+        return ops.dropout_fused(x, p, st, ctx.off, residual=res.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return ops.dropout(dy, ctx.p, ctx.state, ctx.off), dy, None
+
+
+class _ReluDropout(torch.autograd.Function):
+    """dropout(relu(x)): one launch forward, one backward (gated by the saved output: no mask is re-drawn)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        st = _rng.tensor(x.device)
+        y = ops.dropout_fused(x, p, st, _rng.take(x.numel()), relu=True)
+        ctx.p = p
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.dropout_fused(dy.contiguous(), ctx.p, None, 0, gate=y), None
+
+
+def dropout_add(x: Tensor, res: Tensor, p: float, training: bool) -> Tensor:
+    """res + nn.Dropout(p)(x) (the residual connections of nn.TransformerEncoderLayer in training mode)."""
+    if not training or p <= 0.0:
+        return add(res, x)
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _DropoutAdd.apply(x, res, float(p))
+
+
+def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    """nn.Dropout(p)(relu(x)) (the feed-forward hidden state of nn.TransformerEncoderLayer in training mode)."""
+    if not training or p <= 0.0:
+        return relu(x)
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _ReluDropout.apply(x, float(p))
+
+
 def dropout(x: Tensor, p: float, training: bool) -> Tensor:
     """nn.Dropout(p)(x): identity unless ``training`` and p > 0."""
     if not training or p <= 0.0:

@@ -101,11 +101,13 @@ class EncoderLayer(nn.Module):
             x, xr = F.fork(x)
             sa = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
                               prenorm=False, residual=False, b_qkv=a.in_proj_bias, seq_first=True, attn_dropout=self.p)
-            x = F.layernorm(F.add(xr, F.dropout(sa, self.p, True)), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            # (dropout fused with the residual add / with the ReLU in front of it: the same masks at the same RNG sites, 3
+            #  launches fewer per layer forward and one fewer backward -- each ~4.7 us of a 28-row step)
+            x = F.layernorm(F.dropout_add(sa, xr, self.p, True), self.norm1.weight, self.norm1.bias, self.norm1.eps)
             x, xr = F.fork(x)
-            h = F.dropout(F.relu(F.linear(x, self.linear1.weight, self.linear1.bias)), self.p, True)
-            y = F.dropout(F.linear(h, self.linear2.weight, self.linear2.bias), self.p, True)
-            return F.layernorm(F.add(xr, y), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            h = F.relu_dropout(F.linear(x, self.linear1.weight, self.linear1.bias), self.p, True)
+            y = F.linear(h, self.linear2.weight, self.linear2.bias)
+            return F.layernorm(F.dropout_add(y, xr, self.p, True), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = F.attn_block(x, None, None, a.in_proj_weight, a.out_proj.weight, a.out_proj.bias, self.nhead,
                          prenorm=False, residual=True, b_qkv=a.in_proj_bias, seq_first=True)
         x = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)

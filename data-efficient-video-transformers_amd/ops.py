@@ -1089,6 +1089,21 @@ def dropout(x: Tensor, p: float, rng_state: Tensor, call_offset: int) -> Tensor:
     return y
 
 
+def dropout_fused(x: Tensor, p: float, rng_state: Optional[Tensor], call_offset: int, *, residual: Optional[Tensor] = None,
+                  relu: bool = False, gate: Optional[Tensor] = None) -> Tensor:
+    """y = residual? + keep * relu?(x) / (1 - p) with the mask of ``dropout`` at (rng_state, call_offset); or, with ``gate``
+    (the forward's output) and no rng_state, the backward of the relu form: gate != 0 ? x / (1 - p) : 0 (dvt_dropout_fused)."""
+    _need_cuda(x, residual, gate, rng_state)
+    x = x.contiguous()
+    assert (rng_state is None) != (gate is None)
+    for t in (residual, gate):
+        assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
+    y = torch.empty_like(x)
+    L.check(L.load().dvt_dropout_fused(x.data_ptr(), _p(residual), _p(gate), y.data_ptr(), x.numel(), p, _p(rng_state),
+                                       call_offset, int(relu), dt(x), _stream()), "dvt_dropout_fused")
+    return y
+
+
 def rng_advance_(rng_state: Tensor, delta: int) -> None:
     L.check(L.load().dvt_rng_advance(rng_state.data_ptr(), delta, _stream()), "dvt_rng_advance")
 

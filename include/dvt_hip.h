@@ -106,6 +106,14 @@ int dvt_zero(void* dst, size_t nbytes, dvt_stream_t stream);
  * device, so a captured hipGraph draws new masks on every replay.  torch's own generator stream is not reproduced. */
 int dvt_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* rng_state, uint64_t call_offset, int dtype,
                 dvt_stream_t stream);
+/* The same mask fused with its neighbours in nn.TransformerEncoderLayer's training-mode forward (frame_transformer.py:39-47:
+ * x + dropout1(sa), dropout(relu(linear1 x)), x + dropout2(ff)):  y = residual? + keep * relu?(x) / (1 - p), residual nullable,
+ * relu 0 / 1, mask drawn exactly like dvt_dropout at (rng_state, call_offset).  With rng_state == NULL and `gate` given (the
+ * backward of the relu form, gate = the forward's output): y = gate != 0 ? x / (1 - p) : 0 -- no mask is re-drawn, an element
+ * the mask dropped and one the ReLU zeroed both pass no gradient.  Exactly one of rng_state and gate is non-NULL.  The
+ * backward of the residual form is dvt_dropout on dy (and dy itself for the residual). */
+int dvt_dropout_fused(const void* x, const void* residual, const void* gate, void* y, int64_t n, float p,
+                      const uint64_t* rng_state, uint64_t call_offset, int relu, int dtype, dvt_stream_t stream);
 int dvt_rng_advance(uint64_t* rng_state, uint64_t delta, dvt_stream_t stream);
 
 /* ---------------------------------------------------------------- patchify

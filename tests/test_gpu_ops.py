@@ -1021,6 +1021,34 @@ def test_dropout_philox(dvt, device, dtype):
     assert float((k4[:, 0] * k4[:, 1]).mean()) == pytest.approx(0.49, abs=0.02)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_fused_with_residual_and_relu(dvt, device, dtype):
+    """dvt_dropout_fused: res + dropout(x) and dropout(relu(x)) (the training-mode sites of nn.TransformerEncoderLayer,
+    frame_transformer.py:39-47) in one launch each draw the SAME mask as dvt_dropout at the same RNG site, and their backward
+    passes equal the unfused compositions'."""
+    F = dvt.functional
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(28, 896, generator=g).to(dtype).cuda()
+    r0 = torch.randn(28, 896, generator=g).to(dtype).cuda()
+    gy = torch.randn(28, 896, generator=g).to(dtype).cuda()
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    out = {}
+    for fused in (False, True):
+        F.manual_seed(11)
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        a = F.dropout_add(x, r, 0.5, True) if fused else F.add(r, F.dropout(x, 0.5, True))
+        x2 = x0.clone().requires_grad_(True)
+        b = F.relu_dropout(x2, 0.5, True) if fused else F.dropout(F.relu(x2), 0.5, True)
+        torch.autograd.backward([a, b], [gy, gy])
+        out[fused] = (a.detach().float(), b.detach().float(), x.grad.float(), r.grad.float(), x2.grad.float())
+    for u, f in zip(out[False], out[True]):
+        assert float((u - f).abs().max()) <= tol * max(1.0, float(u.abs().max()))
+    a, b = out[True][0], out[True][1]
+    assert abs(float(((a - r0.float()) != 0).float().mean()) - 0.5) < 0.03          # half of the elements survive
+    assert torch.equal(out[True][1] != 0, out[False][1] != 0)                         # the same mask
+    assert torch.equal(F.dropout_add(x0, r0, 0.5, False), F.add(r0, x0)) and torch.equal(F.relu_dropout(x0, 0.0, True), F.relu(x0))
+
+
 def test_dropout_training_step_and_checkpoint_consistency(dvt, device):
     """ViViT with dropout > 0 in train mode runs end to end, and activation checkpointing replays the same masks
     (gradients identical with and without recomputation)."""
