@@ -817,6 +817,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const dvt_split
   store8<float>(o, acc);
 }
 
+// The convolution-scatter reduce of a LARGE weight gradient as a launch of its own (layers whose data gradient is itself
+// split-K and carries nothing; R(2+1)D layers 3 - 4: [4608][1152] x 2 slices = 42 MB of slabs).  The element-order form
+// above writes 8 floats per thread, each 41 KB from the next (parameter layout [co][ci][tap], product layout
+// [tap * Cin + ci][co]): 56 us per launch at 0.75 TB/s.  Here a workgroup owns 32 input channels x all taps x 32 output
+// channels: the slab rows are read along co (128-byte segments, slices summed in slice order = the same bits), transposed
+// through LDS, and written as 32 x taps contiguous floats per output channel: six launches of 16 - 56 us -> 6 - 15 us each,
+// frametransformer 15.58 -> 15.42 ms same box.  (Carried reduces keep the element-order form in the carrier's grid tail:
+// performing them here instead measured 0 .. +0.1 ms, `gpurun_out/r5_ab_nocarry.log`.)
+constexpr int kScCi = 32, kScCo = 32;
+__global__ __launch_bounds__(256) void splitk_reduce_conv_tiled_kernel(const dvt_splitk_pending q) {
+  extern __shared__ float sc_tile[];                 // [taps * 32][33]
+  const int taps = q.conv_taps, cin = q.conv_cin;
+  const int cin_l = q.conv_cin_l > 0 ? q.conv_cin_l : q.conv_cin, cout_l = q.conv_cout_l > 0 ? q.conv_cout_l : (int)q.N;
+  const int ci0 = blockIdx.x * kScCi, co0 = blockIdx.y * kScCo;
+  const int64_t MN = q.M * q.N;
+  const int nrows = taps * kScCi;
+  for (int r = threadIdx.x >> 3; r < nrows; r += 32) {                    // 8 lanes x 4 floats per row
+    const int tap = r / kScCi, cil = r - tap * kScCi, c4 = (threadIdx.x & 7) * 4;
+    const int64_t m = (int64_t)tap * cin + ci0 + cil;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (ci0 + cil < cin && co0 + c4 < q.N) {
+      const float* src = q.slab + m * q.N + co0 + c4;
+      for (int z = 0; z < q.splits; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)z * MN);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sc_tile[r * (kScCo + 1) + c4 + k] = acc[k];
+  }
+  __syncthreads();
+  // per output channel: (ci, tap) pairs of this tile are contiguous in the parameter
+  const int nout = kScCi * taps;
+  for (int idx = threadIdx.x; idx < kScCo * nout; idx += 256) {
+    const int col = idx / nout, j = idx - col * nout;
+    const int cil = j / taps, tap = j - cil * taps;
+    const int co = co0 + col, ci = ci0 + cil;
+    if (co < cout_l && ci < cin_l) {
+      float* o = q.C + ((int64_t)co * cin_l + ci) * taps + tap;
+      const float v = sc_tile[(tap * kScCi + cil) * (kScCo + 1) + col];
+      *o = q.accumulate ? *o + v : v;
+    }
+  }
+}
+
 static int launch_pending_reduce(const dvt_splitk_pending* q, hipStream_t st) {
   if (!q || !q->valid) return DVT_OK;
   if (q->splits >= 64 && !q->cs_slab && q->M * q->N <= ((int64_t)1 << 20)) {
@@ -828,6 +873,13 @@ static int launch_pending_reduce(const dvt_splitk_pending* q, hipStream_t st) {
   int64_t blocks = dvt_cdiv(nvec, 256);
   const int64_t cap = (int64_t)dvt_num_cus() * 8;
   if (blocks > cap) blocks = cap;
+  if (q->conv_taps > 0 && !q->cs_slab && q->N % 4 == 0 && q->M * q->N >= ((int64_t)1 << 20) &&
+      q->M == (int64_t)q->conv_taps * q->conv_cin && (size_t)q->conv_taps * kScCi * (kScCo + 1) * 4 <= 64 * 1024) {
+    const dim3 grid((unsigned)dvt_cdiv(q->conv_cin, kScCi), (unsigned)dvt_cdiv(q->N, kScCo));
+    hipLaunchKernelGGL(splitk_reduce_conv_tiled_kernel, grid, dim3(256), (size_t)q->conv_taps * kScCi * (kScCo + 1) * 4, st, *q);
+    DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce, convolution scatter, tiled)");
+    return DVT_OK;
+  }
   if (q->conv_taps > 0) {
     hipLaunchKernelGGL(splitk_reduce_pending_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *q);
     DVT_LAUNCH_CHECK("dvt_gemm(splitk reduce, convolution scatter)");
