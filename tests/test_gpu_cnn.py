@@ -740,6 +740,10 @@ def test_implicit_gemm_with_taps_that_split_a_k_tile(dvt, device, dtype, geom):
     (3, 256, 7, 7, 512, 3, 1, 1),          # 147 pixels: not a multiple of the k-tile (ragged last k-tile: zeros past the end)
     (7, 64, 6, 6, 64, 3, 1, 1),            # 252 pixels, 64-deep k-tiles
     (5, 128, 9, 5, 128, (3, 1), (2, 1), (1, 0)),   # temporal (3,1,1) / 2 of R(2+1)D over a [T, H*W] view: 125 output rows
+    # products of more than 2^20 entries: the stand-alone scatter reduce goes through LDS-transposed tiles of 32 ci x taps x
+    # 32 co (gemm.hip: splitk_reduce_conv_tiled_kernel) -- ragged tiles on both sides, and the 3-tap temporal form
+    (2, 264, 6, 6, 520, 3, 1, 1),
+    (2, 576, 4, 9, 640, (3, 1), 1, (1, 0)),
 ])
 def test_implicit_gemm_weight_gradient_matches_explicit_path(dvt, device, dtype, geom):
     ops = dvt.ops
