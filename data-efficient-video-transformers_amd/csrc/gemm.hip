@@ -631,7 +631,9 @@ bool small_regime(const dvt_gemm_desc* d) {
   if (tm == 0) return false;
   // The panel kernel never splits K: a deep product on a handful of tiles (the weight gradient of a narrow
   // convolution, K = output pixels) belongs to the split-K path.
-  if (d->K > 2048 && dvt_cdiv(d->M, tm) * dvt_cdiv(d->N, 64) < 96) return false;
+  // (K up to 4096 stays here for a single row tile: the data gradient of the frametransformer encoder's QKV projection -- 28
+  //  rows, K = 2688 -- was a split-K launch plus its reduce, 12 us, instead of one 7 us panel launch)
+  if (d->K > (dvt_cdiv(d->M, tm) == 1 ? 4096 : 2048) && dvt_cdiv(d->M, tm) * dvt_cdiv(d->N, 64) < 96) return false;
   return true;
 }
 
