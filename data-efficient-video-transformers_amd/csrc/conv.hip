@@ -1060,18 +1060,29 @@ __global__ void col2im_scalar_kernel(const T* __restrict__ dcol, D* __restrict__
       const int64_t px = i / C;
       w = (int)(px % W); h = (int)((px / W) % H); n = px / ((int64_t)W * H);
     }
+    // Only the taps with (h + ph - ki) % sh == 0 contribute: ki = ki0, ki0 + sh, ... -- walked directly, and the (at most
+    // four) taps of a row requested together before they are added (same order of additions as the tap-by-tap form, whose
+    // `continue`s made every load wait for the one before: 34 us for the 0.9 M input-gradient elements of the
+    // frametransformer's CLS chunks)
     float acc = 0.f;
-    for (int ki = 0; ki < kh; ++ki) {
+    const int ki0 = (h + ph) % sh, kj0 = (w + pw) % sw;
+    for (int ki = ki0; ki < kh; ki += sh) {
       const int hh = h + ph - ki;
-      if (hh < 0 || hh % sh) continue;
+      if (hh < 0) break;
       const int ho = hh / sh;
       if (ho >= Ho) continue;
-      for (int kj = 0; kj < kw; ++kj) {
-        const int ww = w + pw - kj;
-        if (ww < 0 || ww % sw) continue;
-        const int wo = ww / sw;
-        if (wo >= Wo) continue;
-        acc += to_f32<T>(dcol[((n * Ho + ho) * Wo + wo) * ld + (int64_t)(ki * kw + kj) * C + c]);
+      const T* row = dcol + ((n * Ho + ho) * Wo) * ld + (int64_t)(ki * kw) * C + c;
+      for (int kj = kj0; kj < kw; kj += 4 * sw) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = kj + u * sw, ww = w + pw - kk;
+          const int wo = ww / sw;
+          const bool ok = kk < kw && ww >= 0 && wo < Wo;
+          v[u] = ok ? to_f32<T>(row[(int64_t)wo * ld + (int64_t)kk * C]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
       }
     }
     dx[i] = from_f32<D>(acc);
