@@ -52,8 +52,9 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   const int g = lane >> 4, li = lane & 15;
   const Window& w = p.w;
   const int S = w.S;
-  char* xb[2] = {smem, smem + w.x_bytes};
-  char* zb[2] = {smem + 2 * w.x_bytes, smem + 2 * w.x_bytes + p.z_bytes};
+  // two windows, then two dz tiles, addressed as smem + byte offset (a pointer picked at run time by it & 1 turned every
+  // fragment address into a 64-bit generic pointer: add, null check, select and cast per transposing read)
+  const int zbase = 2 * w.x_bytes;
   const E* xg = (const E*)p.x;
   const E* zg = (const E*)p.dz;
   const int zp = p.z_bytes >> 10;
@@ -77,14 +78,14 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   auto load_tile = [&](int tile, int b) {
     const int n = tile / w.segs, sg = tile - n * w.segs;
     const int64_t pix0 = (int64_t)n * w.T * w.L + (int64_t)sg * S;          // pixel (frame 0, first pixel of the segment)
-    window_load<E>(w, xg, pix0, xq, wid, xb[b]);
+    window_load<E>(w, xg, pix0, xq, wid, smem + b * w.x_bytes);
 #pragma unroll
     for (int i = 0; i < kMaxZP; ++i) {
       const int piece = wid + kNW * i;
       if (piece < zp) {
         const E* src = (zq[i] & 1) ? zg + (pix0 + (int64_t)(zq[i] >> 20) * w.L + ((zq[i] >> 8) & 0xFFF)) * kCO + ((zq[i] >> 1) & 7) * 8
                                    : reinterpret_cast<const E*>(window_zero16);
-        dvt_dma16(src, zb[b] + piece * 1024);
+        dvt_dma16(src, smem + zbase + b * p.z_bytes + piece * 1024);
       }
     }
   };
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (affine) {                                  // the first window: z -> relu(z * s + t) in place
-    window_transform<E>(w, xb[0], st, p.aff.relu);
+    window_transform<E>(w, smem, st, p.aff.relu);
     __syncthreads();
   }
 
   const int nks = w.KP >> 5;
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
-    const char* cx = xb[it & 1];
-    const char* cz = zb[it & 1];
+    const char* cx = smem + (it & 1) * w.x_bytes;
+    const char* cz = smem + zbase + (it & 1) * p.z_bytes;
     if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x, (it + 1) & 1);
     V8 zf[2][4], xf[2][4];
     auto rd = [&](int ks, V8* zv, V8* xv) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
     __builtin_amdgcn_s_barrier();                                  // and everybody is done with this tile's
     if (affine && tile + (int)gridDim.x < p.ntiles) {
-      window_transform<E>(w, xb[(it + 1) & 1], st, p.aff.relu);
+      window_transform<E>(w, smem + ((it + 1) & 1) * w.x_bytes, st, p.aff.relu);
       __syncthreads();
     }
   }

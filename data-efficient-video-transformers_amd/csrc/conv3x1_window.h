@@ -119,24 +119,47 @@ __device__ __forceinline__ void window_affine_regs(const Affine& a, AffineRegs& 
 }
 
 // (all threads; barriers are the caller's; the zero rows of frames -1 and T stay zero)
+// Four positions per thread in flight; the arithmetic as packed pairs (v_pk_fma_f32) and the ReLU on the ROUNDED 16-bit
+// pairs as a signed-integer maximum with zero (v_pk_max_i16: rounding keeps the sign, so relu(round(y)) == round(relu(y))
+// bit for bit, -0 included): ~20 vector instructions per slot instead of ~45.  The launch did not get shorter for it
+// (160 us either way in tools/dev/tf_probe.py): with the parts of the forward kernel switched off one at a time the phases of
+// a tile ADD UP -- 27 us loop + barriers, 30 transform, 58 fragment reads + MFMAs, 28 epilogue, 28 exposed window requests
+// of a 170 us launch -- i.e. a phase costs its barrier-to-barrier latency chain (LDS round trip, drain, barrier) rather than
+// its instruction count, and one workgroup per CU has nothing to overlap it with.
 template <typename E>
 __device__ __forceinline__ void window_transform(const Window& w, char* img_, const AffineRegs& r, int relu) {
   using V8 = typename Elem16<E>::v8;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) char lds_char;     // (callers pick the buffer at run time: keep the accesses ds_*)
   typedef __attribute__((address_space(3))) V8 lds_v8;
   lds_char* const img = (lds_char*)img_;
   const int lo = w.S, hi = (w.T + 1) * w.S;
-  for (int pos = r.pos0; pos < hi; pos += kTfPos) {
-    if (pos < lo) continue;
-    lds_v8* const at = (lds_v8*)(img + pos * kXRow + (((pos >> 3) & 1) << 5) + r.slot_off);
-    V8 v = *at;
+  constexpr int kU = 4;
+  for (int pos0 = r.pos0; pos0 < hi; pos0 += kU * kTfPos) {
+    V8 v[kU];
+    lds_v8* at[kU];
+    bool live[kU];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float y = fmaf((float)v[k], r.s[k], r.t[k]);
-      if (relu) y = fmaxf(y, 0.f);
-      v[k] = (E)y;
+    for (int u = 0; u < kU; ++u) {
+      const int pos = pos0 + u * kTfPos;
+      live[u] = pos >= lo && pos < hi;
+      at[u] = (lds_v8*)(img + pos * kXRow + (((pos >> 3) & 1) << 5) + r.slot_off);
+      if (live[u]) v[u] = *at[u];
     }
-    *at = v;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (!live[u]) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2 x = {(float)v[u][2 * k], (float)v[u][2 * k + 1]};
+        const f32x2 y = __builtin_elementwise_fma(x, f32x2{r.s[2 * k], r.s[2 * k + 1]}, f32x2{r.t[2 * k], r.t[2 * k + 1]});
+        v[u][2 * k] = (E)y[0];
+        v[u][2 * k + 1] = (E)y[1];
+      }
+      if (relu) v[u] = __builtin_bit_cast(V8, __builtin_elementwise_max(__builtin_bit_cast(i16x8, v[u]), i16x8{0, 0, 0, 0, 0, 0, 0, 0}));
+      *at[u] = v[u];
+    }
   }
 }
 #endif  // __HIPCC__

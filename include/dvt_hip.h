@@ -627,9 +627,10 @@ size_t dvt_conv3x3_c64_wgrad_workspace_bytes(int64_t N, int H, int W);
 int dvt_conv3x3_c64_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int accumulate,
                           int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 /* The same with Cout output channels (>= 64 in steps of 16: the 64 -> 144 spatial half of R(2+1)D-18's layer-1 Conv2Plus1D,
- * video_resnet.py:25): the kernel runs once per 64-channel group of dz (the last group's blocks of 16 only), each group's
- * partials summed into its rows of dw f32 [Cout][64][3][3] before the next launch reuses the workspace (same size as for
- * 64 channels); defer_reduce defers the LAST group's reduce. */
+ * video_resnet.py:25): the kernel runs once per group of dz channels -- groups of 64, the last one up to 80 wide (144 = 64 +
+ * 80: a 16-channel launch of its own would re-stage every input patch for a ninth of the work) --, each group's partials
+ * summed into its rows of dw f32 [Cout][64][3][3] before the next launch reuses the workspace (the size
+ * dvt_conv3x3_c64_wgrad_workspace_bytes reports covers the widest group); defer_reduce defers the LAST group's reduce. */
 int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* workspace, int64_t N, int H, int W, int Cout,
                                int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
 /* The temporal half of R(2+1)D-18's layer-1 Conv2Plus1D (torchvision r2plus1d_18 as used by frame_transformer.py:64-74: a

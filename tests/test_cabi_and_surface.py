@@ -40,10 +40,14 @@ def test_no_kernel_of_the_library_lost_an_address_space():
     spec = importlib.util.spec_from_file_location("check_flat_ops", os.path.join(ROOT, "tools", "check_flat_ops.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    ops = mod.flat_ops(dvt_amd._lib.LIB_PATH)
+    gen = {}
+    ops = mod.flat_ops(dvt_amd._lib.LIB_PATH, gen)
     assert len(ops) > 300                                                   # the disassembly found the kernels
     bad = {k: v for k, v in ops.items() if v and not any(a in k for a in mod.ALLOWED)}
     assert not bad, f"kernels with FLAT memory instructions: {bad}"
+    # the milder form: ds_* accesses whose address is a generic pointer converted (null check + select) per access
+    badg = {k: v for k, v in gen.items() if v > mod.GENERIC_LIMIT and not any(a in k for a in mod.ALLOWED + mod.ALLOWED_GENERIC)}
+    assert not badg, f"kernels converting generic pointers to LDS addresses in bulk: {badg}"
 
 
 def test_version_and_error_channel_without_gpu():

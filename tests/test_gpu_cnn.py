@@ -857,10 +857,12 @@ def test_conv3x3_c64_weight_gradient_from_lds_halo_patches(dvt, device, dtype, N
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,H,W,Cout", [(3, 56, 56, 144), (2, 13, 20, 144), (300, 8, 8, 144), (2, 28, 28, 80), (2, 28, 28, 128)])
+@pytest.mark.parametrize("N,H,W,Cout", [(3, 56, 56, 144), (2, 13, 20, 144), (300, 8, 8, 144), (2, 28, 28, 80), (2, 28, 28, 128), (2, 28, 28, 96),
+                                         (1, 14, 14, 160)])
 def test_conv3x3_c64_weight_gradient_with_more_output_channels(dvt, device, dtype, N, H, W, Cout):
     """dvt_conv3x3_c64_wgrad_wide (the 64 -> 144 spatial half of R(2+1)D-18's layer-1 Conv2Plus1D): the halo-patch kernel once
-    per 64-channel group of a dz whose rows are Cout channels long (the 16-channel tail on one block of 16), every group summed
+    per channel group of a dz whose rows are Cout channels long (groups of 64, a last group of up to 80 on five blocks of 16 with
+    the fifth block's own LDS image, narrower tails on the 64-wide kernel), every group summed
     into its rows of the parameter layout over the same workspace; against torch's fp32 conv2d weight gradient on the same
     operands; accumulate through a deferred reduce of the last group."""
     ops = dvt.ops
@@ -882,7 +884,7 @@ def test_conv3x3_c64_weight_gradient_with_more_output_channels(dvt, device, dtyp
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4)])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4), (5, 16, 4, 6)])
 def test_temporal_weight_gradient_from_lds_sliding_windows(dvt, device, dtype, N, T, H, W):
     """dvt_conv3x1_wgrad: weight gradient of the (3, 1, 1) temporal convolution 144 -> 64 of R(2+1)D-18's layer 1
     (torchvision r2plus1d_18, frame_transformer.py:64-74) with a segment of pixels over all frames staged once in LDS and the
@@ -913,7 +915,7 @@ def test_temporal_weight_gradient_from_lds_sliding_windows(dvt, device, dtype, N
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4)])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4), (5, 16, 4, 6)])
 def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, device, dtype, N, T, H, W):
     """dvt_conv3x1_fwd: the (3, 1, 1) temporal convolution 144 -> 64 of R(2+1)D-18's layer 1 from a window of all frames of a
     pixel segment, weights in registers -- against conv2d in fp32 on the same operands, with the BatchNorm partial sums of the
