@@ -57,6 +57,8 @@ __device__ __forceinline__ int cw_tail_slot(int k) { return (k & ~12) | ((k & 4)
 // MB: output-channel blocks of 16 this launch computes (4: a whole 64-channel group; 5: the last 80 of a 144-wide dz -- a
 // 16-channel launch of its own re-staged every input patch for a ninth of the work, 70 us against the group's 115; 1: a
 // 16-channel tail).  The slab rows are SN = 80 floats for MB = 5, else 64.
+template <int N> struct IntC { static constexpr int value = N; };
+
 template <typename E, int MB>
 __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,6 +171,10 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
   __syncthreads();
 
   const int nks = p.KP >> 5;
+  // The tile sequence with the wave's count of column blocks as a compile-time constant (instantiated for 5 and 4, picked per
+  // wave; both forms pass the same barriers): as a run-time test it put a branch around every row's fifth MFMA.
+  auto run = [&](auto CNT) {
+  constexpr int NJ = decltype(CNT)::value;
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
     const int cx = (it & 1) * p.patch_bytes;
     const int cz = zbase + (it & 1) * p.dz_bytes;
@@ -187,8 +193,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
     auto rdx = [&](int ks, V8* xv) {
       const char* bx = smem + cx + ks * 4096;
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < 4 || cnt == 5)
+      for (int j = 0; j < NJ; ++j)
           xv[j] = __builtin_shufflevector(Elem16<E>::tr_read(bx + xo[j][0]), Elem16<E>::tr_read(bx + xo[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
     };
     // MFMAs of step ks; row m's dz fragment of the next step is requested behind row m -- unconditionally (the last step
@@ -198,8 +203,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-          if (j < 4 || cnt == 5) acc[m][j] = Elem16<E>::mma(zf[m], xv[j], acc[m][j]);
+        for (int j = 0; j < NJ; ++j) acc[m][j] = Elem16<E>::mma(zf[m], xv[j], acc[m][j]);
         rdz(kn, m);
       }
     };
@@ -217,6 +221,9 @@ __global__ __launch_bounds__(kNW * 64) void conv3x3_c64_wgrad_kernel(const CwPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
     __builtin_amdgcn_s_barrier();                                  // and everybody is done with this tile's
   }
+  };
+  if (cnt == 5) run(IntC<5>{});
+  else run(IntC<4>{});
 
   // ---- this workgroup's partial: slab[blockIdx][m = tap * 64 + 16 cb + li][n = 16 mb + 4 g .. + 3] (rows of SN floats)
   // (mma(dz fragment, x fragment): lane (g, li) holds C[co = 16 mb + 4 g + r][ci = 16 cb + li])

@@ -1190,6 +1190,10 @@ static int conv_fwd_split(int64_t rows, int cout, int c, int taps, int64_t K) {
   const int64_t tiles = dvt_cdiv(rows, 128) * dvt_cdiv(cout, 128), cus = dvt_num_cus();
   const int64_t nk = K / 64;
   if (tiles * 5 > cus * 4 || nk < 24) return 1;    // four fifths of the CUs busy already, or too shallow to be worth a reduce
+  // shallow AND wide: the fp32 slabs (rows x cout x 4 bytes per slice, written and read back) outweigh the shorter chain
+  // (R(2+1)D layer 4's temporal data gradients 512 -> 1152 / 960 at 24 k-tiles: 33 -> 28, 37 -> 28 us unsplit;
+  // tools/dev/conv_split_sweep.py, gpurun_out/r5_split_sweep3.log)
+  if (nk < 36 && cout > 512) return 1;
   // about one and a half workgroups per CU (same-box sweep on the frametransformer step, gpurun_out/r5_sweep_split2.log:
   // 17.57 ms unsplit; 17.38 - 17.43 at one per CU, 17.34 - 17.39 at 1.5, 17.44 - 17.45 at two)
   int64_t s = (3 * cus / 2 + tiles - 1) / tiles;
