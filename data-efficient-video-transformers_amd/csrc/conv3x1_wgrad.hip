@@ -43,6 +43,8 @@ struct TwParams {
 
 __device__ __forceinline__ int tw_swz(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }   // conv3x3_wgrad.hip's cw_swz
 
+template <int N> struct IntC { static constexpr int value = N; };
+
 template <typename E>
 __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   }
 
   const int nks = w.KP >> 5;
+  // the tile sequence with the wave's count of column blocks as a compile-time constant (instantiated for 4 and 3, picked per
+  // wave; both forms pass the same barriers) -- as a run-time test it put a branch around every row's fourth MFMA
+  auto run = [&](auto CNT) {
+  constexpr int NJ = decltype(CNT)::value;
   for (int it = 0; tile < p.ntiles; ++it, tile += gridDim.x) {
     const char* cx = smem + (it & 1) * w.x_bytes;
     const char* cz = smem + zbase + (it & 1) * p.z_bytes;
@@ -137,8 +143,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
       for (int m = 0; m < 4; ++m)
         zv[m] = __builtin_shufflevector(Elem16<E>::tr_read(bz + zo[m][0]), Elem16<E>::tr_read(bz + zo[m][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < 3 || cnt == 4)
+      for (int j = 0; j < NJ; ++j)
           xv[j] = __builtin_shufflevector(Elem16<E>::tr_read(bx + xo[j][0]), Elem16<E>::tr_read(bx + xo[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
     };
     rd(0, zf[0], xf[0]);
@@ -147,15 +152,13 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < 3 || cnt == 4) acc[m][j] = Elem16<E>::mma(zf[0][m], xf[0][j], acc[m][j]);
+        for (int j = 0; j < NJ; ++j) acc[m][j] = Elem16<E>::mma(zf[0][m], xf[0][j], acc[m][j]);
       if (ks + 1 < nks) {
         if (ks + 2 < nks) rd(ks + 2, zf[0], xf[0]);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < 3 || cnt == 4) acc[m][j] = Elem16<E>::mma(zf[1][m], xf[1][j], acc[m][j]);
+          for (int j = 0; j < NJ; ++j) acc[m][j] = Elem16<E>::mma(zf[1][m], xf[1][j], acc[m][j]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile's images have landed
@@ -165,6 +168,9 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
       __syncthreads();
     }
   }
+  };
+  if (cnt == 4) run(IntC<4>{});
+  else run(IntC<3>{});
 
   // ---- this workgroup's partial: slab[blockIdx][m = tap * 144 + 16 cb + li][n = 16 mb + 4 g .. + 3]
   // (mma(dz fragment, x fragment): lane (g, li) holds C[co = 16 mb + 4 g + r][ci = 16 cb + li])
