@@ -577,16 +577,27 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
   }
   V8 rs[kNeedLd ? NPS : 1][4];
   if (kNeedLd) {
+    // (addresses as for the stores below: the lane's first row once, then wave-uniform offsets; a row past M reads the last
+    //  row instead -- loaded unconditionally, never stored)
+    const int nn = n_ok ? n : 0;
+    const int rl = wrow0 + (lane >> 3);
+    const E* const lfirst = ldp + (int64_t)(rl < p.M ? rl : p.M - 1) * ldl + nn;
+    const E* const llast = ldp + (int64_t)(p.M - 1) * ldl + nn;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int m = wrow0 + ps * 32 + (lane >> 3) + 8 * j;
-        m = m < p.M ? m : p.M - 1;                    // clamped row: loaded unconditionally, never stored
-        if (kCanMap && mapped && !p.res_compact) m = orow[kCanMap ? ps : 0][j];
-        rs[ps][j] = *reinterpret_cast<const V8*>(ldp + (int64_t)m * ldl + (n_ok ? n : 0));
+        const E* src = rl + ps * 32 + 8 * j < p.M ? lfirst + (int64_t)(ps * 32 + 8 * j) * ldl : llast;
+        if (kCanMap && mapped && !p.res_compact) src = ldp + (int64_t)orow[kCanMap ? ps : 0][j] * ldl + nn;
+        rs[ps][j] = *reinterpret_cast<const V8*>(src);
       }
   }
+  // Output addresses: the lane's first row once per tile (one 64-bit multiply), every further row a wave-uniform offset
+  // (a constant times the leading dimension: scalar unit).  Per row -- m * ldc with a per-lane m -- it was two v_mul_lo_u32
+  // and a v_mad_u64_u32 (quarter-rate) per 16-byte store, twice that where the pre-activation is stored too: a sixth of the
+  // vector work of the GELU epilogue, which is not hidden under anything.
+  const int r0 = wrow0 + (lane >> 3);
+  const int64_t cofs = (int64_t)r0 * p.ldc + n, aofs = (int64_t)r0 * p.ldaux + n;
   // fused BatchNorm statistics (convolution outputs): per-lane sums of its 8 columns over its rows of the tile.
   // {sum y, sum y^2} of the STORED output as the BatchNorm behind the convolution needs them.
   constexpr bool kCanBn = OUT == OUT_BF16 && EPI == DVT_EPI_NONE;
@@ -621,11 +632,11 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
           // (re-read from cache by the reduce: streaming stores cost 10 %.  Stored through an explicit global pointer: the
           //  compiler had lost p.slab's address space and emitted flat_store, which also counts on lgkmcnt)
           typedef __attribute__((address_space(1))) f32x4 gf4;
-          gf4* o = (gf4*)(p.slab + ((int64_t)zsl * p.M + m) * p.N + n);
+          gf4* o = (gf4*)(p.slab + ((int64_t)zsl * p.M + r0) * p.N + n + (int64_t)(ps * 32 + 8 * j) * p.N);
           o[0] = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
           o[1] = f32x4{v[j][4], v[j][5], v[j][6], v[j][7]};
         } else if (OUT == OUT_F32) {
-          float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+          float* o = (float*)p.C + cofs + (int64_t)(ps * 32 + 8 * j) * p.ldc;
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[j][k] += bias[k];
           if (p.accumulate) {
@@ -650,9 +661,12 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
               bsq[k] = fmaf(f, f, bsq[k]);
             }
           }
-          if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + (int64_t)m * p.ldaux + n, pre);
-          const int mo = (kCanMap && mapped) ? orow[kCanMap ? ps : 0][j] : m;
-          DVT_C_STORE((E*)p.C + (int64_t)mo * p.ldc + n, v[j]);
+          if (EPI == DVT_EPI_GELU && p.aux) DVT_C_STORE((E*)p.aux + aofs + (int64_t)(ps * 32 + 8 * j) * p.ldaux, pre);
+          if (kCanMap && mapped) {
+            DVT_C_STORE((E*)p.C + (int64_t)orow[kCanMap ? ps : 0][j] * p.ldc + n, v[j]);
+          } else {
+            DVT_C_STORE((E*)p.C + cofs + (int64_t)(ps * 32 + 8 * j) * p.ldc, v[j]);
+          }
         }
       }
     }
