@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvt_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 4            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)
+ABI_VERSION = 5            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_DGELU, EPI_DRELU = range(6)
 
 c_i64 = C.c_int64

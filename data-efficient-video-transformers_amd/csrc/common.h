@@ -220,6 +220,15 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   gelu_parts(x, cdf, pdf);
   return fmaf(x, pdf, cdf);
 }
+// value and derivative from the same parts: what a GEMM's GELU epilogue stores as C and as aux (the backward epilogue then
+// only multiplies -- re-evaluating the derivative from a stored pre-activation cost the backward launch what the GELU costs
+// the forward one, ~35 us at the metric shape, for two more vector instructions here)
+__device__ __forceinline__ float gelu_erf_both_f(float x, float& grad) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  grad = fmaf(x, pdf, cdf);
+  return x * cdf;
+}
 
 // ---------------------------------------------------------------- device: counter-based RNG (dropout)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

@@ -47,14 +47,10 @@ template <int ROWS> __device__ __forceinline__ int swz_mn_r(int k) {
 __device__ __forceinline__ float epi_apply(int epi, float acc, float bias, float res, float aux_in,
                                            float& aux_out) {
   switch (epi) {
-    case DVT_EPI_GELU: {
-      const float pre = acc + bias;
-      aux_out = pre;
-      return gelu_erf_f(pre);
-    }
+    case DVT_EPI_GELU: return gelu_erf_both_f(acc + bias, aux_out);   // aux = gelu'(acc + bias)
     case DVT_EPI_RELU: return fmaxf(acc + bias, 0.f);
     case DVT_EPI_RESIDUAL: return acc + bias + res;
-    case DVT_EPI_DGELU: return acc * gelu_erf_grad_f(aux_in);
+    case DVT_EPI_DGELU: return acc * aux_in;                           // (aux = the derivative the forward stored)
     case DVT_EPI_DRELU: return aux_in > 0.f ? acc : 0.f;
     default: return acc + bias;
   }
@@ -125,7 +121,7 @@ __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (
   switch (epi) {
     case DVT_EPI_GELU:
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { pre[k] = v[k] + bias[k]; v[k] = gelu_erf_f(pre[k]); }
+      for (int k = 0; k < 8; ++k) v[k] = gelu_erf_both_f(v[k] + bias[k], pre[k]);
       break;
     case DVT_EPI_RELU:
 #pragma unroll
@@ -137,7 +133,7 @@ __device__ __forceinline__ void epi_apply8(int epi, float (&v)[8], const float (
       break;
     case DVT_EPI_DGELU:
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= gelu_erf_grad_f(ld[k]);
+      for (int k = 0; k < 8; ++k) v[k] *= ld[k];
       break;
     case DVT_EPI_DRELU:
 #pragma unroll

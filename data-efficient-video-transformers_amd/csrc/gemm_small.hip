@@ -228,10 +228,10 @@ __device__ __forceinline__ void gemm_small_tile(const GemmParams& p, const int b
     EXPR;                                                    \
   }
   switch (p.epilogue) {
-    case DVT_EPI_GELU: DVT_SMALL_EPI(pre[t][u][r] = x + bi; x = gelu_erf_f(pre[t][u][r])) break;
+    case DVT_EPI_GELU: DVT_SMALL_EPI(x = gelu_erf_both_f(x + bi, pre[t][u][r])) break;
     case DVT_EPI_RELU: DVT_SMALL_EPI(x = fmaxf(x + bi, 0.f)) break;
     case DVT_EPI_RESIDUAL: DVT_SMALL_EPI(x = x + bi + ld) break;
-    case DVT_EPI_DGELU: DVT_SMALL_EPI(x *= gelu_erf_grad_f(ld)) break;
+    case DVT_EPI_DGELU: DVT_SMALL_EPI(x *= ld) break;
     case DVT_EPI_DRELU: DVT_SMALL_EPI(x = ld > 0.f ? x : 0.f) break;
     default: DVT_SMALL_EPI(x += bi) break;
   }

@@ -908,7 +908,7 @@ class _MlpBlock(torch.autograd.Function):
         w1c, w2c = _wc(w1, T), _wc(w2, T)
         M = x2.shape[0]
         if act == "gelu":
-            u = torch.empty((M, w1c.shape[0]), dtype=T, device=x.device)    # pre-activation
+            u = torch.empty((M, w1c.shape[0]), dtype=T, device=x.device)    # gelu'(pre-activation), for the backward epilogue
             h = ops.linear_fwd(xn, w1c, _f32(b1), epilogue=L.EPI_GELU, aux=u)
         else:
             u = None

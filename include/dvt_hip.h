@@ -34,8 +34,9 @@ extern "C" {
 /* Bumped whenever a descriptor struct changes layout (fields are only ever appended) or an entry point changes
  * signature.  v2: dvt_gemm_desc / dvt_conv_desc gained defer_reduce / pending / carry, dvt_splitk_pending and the
  * head-wise / folded-attention descriptors were added.  Callers MUST zero-initialise every descriptor (memset / = {0})
- * before filling it: a zero in a field this header adds later means "feature off". */
-#define DVT_ABI_VERSION 4
+ * before filling it: a zero in a field this header adds later means "feature off".  v5: the `aux` matrix of DVT_EPI_GELU /
+ * DVT_EPI_DGELU holds the activation's DERIVATIVE (was the pre-activation): a meaning changed, no layout. */
+#define DVT_ABI_VERSION 5
 
 typedef void* dvt_stream_t; /* hipStream_t */
 
@@ -247,10 +248,10 @@ int dvt_layernorm_reduce_group(const dvt_ln_pending* list, int count, dvt_stream
  */
 enum dvt_epilogue {
   DVT_EPI_NONE = 0,          /* C = acc (+ bias) */
-  DVT_EPI_GELU = 1,          /* aux = acc + bias (pre-activation, if aux != NULL); C = gelu_erf(aux) */
+  DVT_EPI_GELU = 1,          /* C = gelu_erf(acc + bias); aux (if != NULL) = gelu_erf'(acc + bias), what DVT_EPI_DGELU takes */
   DVT_EPI_RELU = 2,          /* C = relu(acc + bias) */
   DVT_EPI_RESIDUAL = 3,      /* C = acc + bias + residual */
-  DVT_EPI_DGELU = 4,         /* C = acc * gelu'(aux)   (aux = saved pre-activation) */
+  DVT_EPI_DGELU = 4,         /* C = acc * aux          (aux = the derivative saved by DVT_EPI_GELU) */
   DVT_EPI_DRELU = 5          /* C = acc * (aux > 0)    (aux = saved post-activation) */
 };
 

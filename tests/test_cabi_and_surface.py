@@ -53,7 +53,7 @@ def test_no_kernel_of_the_library_lost_an_address_space():
 def test_version_and_error_channel_without_gpu():
     import dvt_amd
     lib = dvt_amd._lib.load()
-    assert lib.dvt_version() == 4
+    assert lib.dvt_version() == 5
     # argument validation happens before any HIP call: safe on a CPU-only box
     rc = lib.dvt_cast(None, 0, None, 1, 8, None)
     assert rc == -1

@@ -31,6 +31,12 @@ def _tol(dtype):
     return F32_TOL if dtype == torch.float32 else BF16_TOL
 
 
+def _gelu_grad(x):
+    """d/dx gelu_erf(x) = Phi(x) + x phi(x): what DVT_EPI_GELU leaves in ``aux`` and DVT_EPI_DGELU multiplies by."""
+    x = x.float()
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
 def _rnd(shape, dtype, gen, scale=1.0):
     """Random tensor already rounded to ``dtype``; returns (device tensor, cpu fp32 copy)."""
     x = (torch.randn(shape, generator=gen) * scale).to(dtype)
@@ -183,10 +189,10 @@ def test_gemm_epilogues(dvt, device, dtype, K):
     res_d, res = _rnd((M, N), dtype, g)
     pre = x @ w.t() + bias
     tol = _tol(dtype)
-    # GELU with saved pre-activation
+    # GELU with its derivative saved for the backward epilogue
     aux = torch.empty((M, N), dtype=dtype, device="cuda")
     h = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_GELU, aux=aux)
-    assert rel_l2(aux, pre) < tol
+    assert rel_l2(aux, _gelu_grad(pre)) < tol
     assert rel_l2(h, O.gelu_erf(pre)) < tol
     # ReLU
     r = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RELU)
@@ -199,7 +205,7 @@ def test_gemm_epilogues(dvt, device, dtype, K):
     dy_d, dy = _rnd((M, N), dtype, g)
     uu = u.clone().requires_grad_(True)
     O.gelu_erf(uu).backward(dy @ w)
-    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d)
+    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=dvt.ops.cast(_gelu_grad(u).cuda(), dtype))
     assert rel_l2(du, uu.grad) < tol
     hpos = torch.relu(u)
     dr = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DRELU, aux=dvt.ops.cast(hpos.cuda(), dtype))
@@ -208,7 +214,7 @@ def test_gemm_epilogues(dvt, device, dtype, K):
 
 def test_gemm256_streaming_store_path(dvt, device):
     """The FF1 shape of the metric workload: its two outputs (414 MB) exceed the streaming threshold, so C and the saved
-    pre-activation are written with non-temporal stores; reference = fp32 matmul on the GPU."""
+    derivative are written with non-temporal stores; reference = fp32 matmul on the GPU."""
     L = dvt._lib
     g = torch.Generator().manual_seed(5)
     M, N, K = 50432, 2048, 512
@@ -218,7 +224,8 @@ def test_gemm256_streaming_store_path(dvt, device):
     aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     y = dvt.ops.linear_fwd(x, w, bias, epilogue=L.EPI_GELU, aux=aux)
     pre = x.float() @ w.float().t() + bias
-    assert float((aux.float() - pre).norm() / pre.norm()) < BF16_TOL
+    gp = _gelu_grad(pre)
+    assert float((aux.float() - gp).norm() / gp.norm()) < BF16_TOL
     ref = torch.nn.functional.gelu(pre)
     assert float((y.float() - ref).norm() / ref.norm()) < BF16_TOL
 
@@ -239,7 +246,7 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     assert rel_l2(y, pre) < BF16_TOL
     aux = torch.empty((M, N), dtype=dt16, device="cuda")
     h = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_GELU, aux=aux)
-    assert rel_l2(aux, pre) < BF16_TOL and rel_l2(h, O.gelu_erf(pre)) < BF16_TOL
+    assert rel_l2(aux, _gelu_grad(pre)) < BF16_TOL and rel_l2(h, O.gelu_erf(pre)) < BF16_TOL
     res_d, res = _rnd((M, N), dt16, g)
     yr = dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d)
     assert rel_l2(yr, pre + res) < BF16_TOL
@@ -249,7 +256,7 @@ def test_gemm256_lds_dma_kernel_all_layouts_and_epilogues(dvt, device, dt16):
     u_d, u = _rnd((M, K), dt16, g)
     uu = u.clone().requires_grad_(True)
     O.gelu_erf(uu).backward(dy @ w)
-    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d)
+    du = dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=dvt.ops.cast(_gelu_grad(u).cuda(), dt16))
     assert rel_l2(du, uu.grad) < BF16_TOL
     dw = dvt.ops.linear_wgrad(dy_d, x_d)                      # mn-major x mn-major, split-K
     assert rel_l2(dw, dy.t() @ x) < BF16_TOL
@@ -294,7 +301,7 @@ def test_gemm_large_m_every_row_written_exactly_once(dvt, device, M, N, K):
     aux = poison(M, N)
     h = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias, epilogue=L.EPI_GELU, aux=aux,
                      out=poison(M, N))
-    check(aux, pre, "gelu pre-activation")
+    check(aux, _gelu_grad(pre), "gelu derivative")
     check(h, torch.nn.functional.gelu(pre), "gelu")
     res_d = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
     yr = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias, epilogue=L.EPI_RESIDUAL,
@@ -308,8 +315,8 @@ def test_gemm_large_m_every_row_written_exactly_once(dvt, device, M, N, K):
     u_d = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
     uu = u_d.float().requires_grad_(True)
     torch.nn.functional.gelu(uu).backward(dx_ref)
-    du = dvt.ops.gemm(x_d, wt_d, M, N, K, a_kmajor=True, b_kmajor=False, lda=K, ldb=N, epilogue=L.EPI_DGELU, aux=u_d,
-                      out=poison(M, N))
+    du = dvt.ops.gemm(x_d, wt_d, M, N, K, a_kmajor=True, b_kmajor=False, lda=K, ldb=N, epilogue=L.EPI_DGELU,
+                      aux=_gelu_grad(u_d).to(torch.bfloat16), out=poison(M, N))
     check(du, uu.grad, "dgrad + gelu'")
 
 
@@ -339,7 +346,7 @@ def test_gemm_launch_bound_shapes_panel_streaming_kernel(dvt, device, dtype, M, 
     aux = nan16(M, N)
     h = dvt.ops.gemm(x_d, w_d, M, N, K, a_kmajor=True, b_kmajor=True, lda=K, ldb=K, bias=bias.cuda(), epilogue=L.EPI_GELU,
                      aux=aux, out=nan16(M, N))
-    check(aux, pre, "pre-activation")
+    check(aux, _gelu_grad(pre), "gelu derivative")
     check(h, O.gelu_erf(pre), "gelu")
     res_d, res = _rnd((M, N), dtype, g)
     check(dvt.ops.linear_fwd(x_d, w_d, bias.cuda(), epilogue=L.EPI_RESIDUAL, residual=res_d), pre + res, "residual")
@@ -349,7 +356,8 @@ def test_gemm_launch_bound_shapes_panel_streaming_kernel(dvt, device, dtype, M, 
     u_d, u = _rnd((M, K), dtype, g)
     uu = u.clone().requires_grad_(True)
     O.gelu_erf(uu).backward(dy @ w)
-    check(dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=u_d), uu.grad, "dgrad gelu'")
+    check(dvt.ops.linear_dgrad(dy_d, w_d, epilogue=L.EPI_DGELU, aux=dvt.ops.cast(_gelu_grad(u).cuda(), dtype)), uu.grad,
+          "dgrad gelu'")
     dw_ref = dy.t() @ x
     db = torch.full((N,), float("nan"), device="cuda")
     dw = dvt.ops.linear_wgrad(dy_d, x_d, bias_out=db)
