@@ -373,6 +373,8 @@ def cnn_roofline(summ, nprof, workload):
             name = "conv3x1 temporal data gradient 64 -> 144 with the mid-plane BatchNorm backward in its epilogue (computed twice: sums, then the corrected gradient; the 144-plane gradient is never stored)"
         elif kind == "window3x1_fwd":
             name = "conv3x1 temporal forward 144 -> 64 (LDS sliding windows; the spatial half's BatchNorm + ReLU applied in the window)"
+        elif kind == "window3x1_c64":
+            name = "conv3x1 temporal forward and data gradient 64 -> 64 of the stem (LDS sliding windows, 16-pixel segments)"
         else:
             name = f"implicit forward / data gradient, Cout {'<= 64' if N <= 64 else '65..128' if N <= 128 else '> 128'}"
         f = fams.setdefault(name, [0.0, 0.0, 0, 0.0, kind])
@@ -391,7 +393,8 @@ def cnn_roofline(summ, nprof, workload):
             pmc = {}
     pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
                "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream",
-               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "stream3x1_bn_bwd": "conv3x1_stream_bn_bwd"}
+               "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "window3x1_c64": "conv3x1_c64",
+               "stream3x1_bn_bwd": "conv3x1_stream_bn_bwd"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):

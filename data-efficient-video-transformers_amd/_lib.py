@@ -234,8 +234,8 @@ SIGNATURES = {
     "dvt_conv3x1_wgrad_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int]),
     "dvt_conv3x1_wgrad": (c_int, [c_p, C.POINTER(BnAffine), c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, C.POINTER(SplitKPending), c_int, c_p]),
     "dvt_conv3x1_fwd_supported": (c_int, [c_i64, c_int, c_int, c_int, c_int, c_int]),
-    "dvt_conv3x1_fwd_stats_parts": (c_i64, [c_i64, c_int, c_int]),
-    "dvt_conv3x1_fwd": (c_int, [c_p, C.POINTER(BnAffine), c_p, c_i64, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
+    "dvt_conv3x1_fwd_stats_parts": (c_i64, [c_i64, c_int, c_int, c_int]),
+    "dvt_conv3x1_fwd": (c_int, [c_p, C.POINTER(BnAffine), c_p, c_i64, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_p]),
     "dvt_conv3x3_c64_wgrad_workspace_bytes": (C.c_size_t, [c_i64, c_int, c_int]),
     "dvt_conv3x3_c64_wgrad": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, C.POINTER(SplitKPending), c_int, c_p]),
     "dvt_conv3x3_c64_stats_parts": (c_i64, [c_i64, c_int, c_int]),

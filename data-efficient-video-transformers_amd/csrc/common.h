@@ -48,6 +48,11 @@ int dvt_num_cus();
 // failed call fails as well and DVT_LAUNCH_CHECK reports it.
 // conv.hip: reduction of BatchNorm-backward partial rows produced by another translation unit's kernel
 namespace dvt_internal {
+// conv3x1_c64.hip: the 64 -> 64 form of the (3, 1, 1) window convolution, behind dvt_conv3x1_fwd (conv3x1_fwd.hip)
+int conv3x1_c64_supported(int64_t N, int T, int L, int dtype);
+int64_t conv3x1_c64_stats_parts(int64_t N, int T, int L);
+int conv3x1_c64_fwd(const void* x, const void* w, int64_t ldw, void* y, float* stats_partial, int64_t N, int T, int L, int dtype,
+                    hipStream_t st);
 void bn_bwd_finalize(hipStream_t st, const float* partial, int nparts, int C, float* loc, int accumulate, float* dgamma,
                      float* dbeta, int c_valid);
 }

@@ -222,23 +222,36 @@ void tf_launch(const TfParams& p, int grid, int lds, hipStream_t st) {
 extern "C" {
 
 int dvt_conv3x1_fwd_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype) {
+  if (Cin == 64 && Cout == 64) return dvt_internal::conv3x1_c64_supported(N, T, L, dtype);
   Window q;
   return N > 0 && Cin == kCI && Cout == kCO && dvt_is_16bit(dtype) && tf_plan(T, L, &q) && N * q.segs < ((int64_t)1 << 31) &&
                  N * T * L < ((int64_t)1 << 31) ? 1 : 0;
 }
 
-int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L) {
+int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L, int Cin) {
+  if (Cin == 64) return dvt_internal::conv3x1_c64_stats_parts(N, T, L);
   Window q;
   if (N <= 0 || !tf_plan(T, L, &q)) return 0;
   return tf_grid(N, q);                            // one partial row per workgroup of the persistent grid
 }
 
 int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w, int64_t ldw, void* y, float* stats_partial,
-                    int64_t N, int T, int L, int dtype, dvt_stream_t stream) {
-  DVT_REQUIRE(x && w && y && N >= 0 && T > 0 && L > 0 && ldw >= 3 * kCI && ldw % 8 == 0, "dvt_conv3x1_fwd: bad arguments");
+                    int64_t N, int T, int L, int Cin, int dtype, dvt_stream_t stream) {
+  DVT_REQUIRE(x && w && y && N >= 0 && T > 0 && L > 0 && (Cin == kCI || Cin == 64) && ldw >= 3 * Cin && ldw % 8 == 0,
+              "dvt_conv3x1_fwd: bad arguments");
   DVT_REQUIRE(dvt_aligned16(x) && dvt_aligned16(w) && dvt_aligned16(y) && dvt_aligned16(stats_partial),
               "dvt_conv3x1_fwd: buffers must be 16-byte aligned");
   if (N == 0) return DVT_OK;
+  if (Cin == 64) {                                 // the stem's temporal half (and its data gradient): conv3x1_c64.hip
+    DVT_REQUIRE(!(x_affine && x_affine->mean), "dvt_conv3x1_fwd: x_affine is for the 144-channel form");
+    if (!dvt_internal::conv3x1_c64_supported(N, T, L, dtype))
+      DVT_UNSUPPORTED("dvt_conv3x1_fwd (64 channels): needs a 16-bit dtype and a segment length S <= 16 with L %% S == 0, "
+                      "(T * S) %% 32 == 0, T * S <= 192 and two windows + the output staging in 160 KiB of LDS");
+    const int rc = dvt_internal::conv3x1_c64_fwd(x, w, ldw, y, stats_partial, N, T, L, dtype, (hipStream_t)stream);
+    if (rc != DVT_OK) return rc;
+    DVT_LAUNCH_CHECK("dvt_conv3x1_fwd(64 channels)");
+    return DVT_OK;
+  }
   if (!dvt_conv3x1_fwd_supported(N, T, L, kCI, kCO, dtype))
     DVT_UNSUPPORTED("dvt_conv3x1_fwd: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
                     "(T * S) %% 32 == 0, T * S <= 128 and two windows + the output staging in 160 KiB of LDS");

@@ -1462,7 +1462,9 @@ class _ConvBnAct(torch.autograd.Function):
                 and ops._pair(pad) == (1, 1) and ops.conv3x3_c64_supported(xc, wp, N, H, W))
         stream = (HALO_CONV and implicit and not halo and ld == K and (kh, kw) == (3, 3) and (sh, sw) == (1, 1)
                   and ops._pair(pad) == (1, 1) and ops.conv3x3_stream_supported(xc, wp, N, H, W, Cin, Cout))
-        window = (WINDOW_FWD and HALO_CONV and implicit and not padded and (kh, kw) == (3, 1) and (sh, sw) == (1, 1)
+        # (the 64 -> 64 form also takes a zero-extended input: the stem's 45 mid planes stored as 64)
+        window = (WINDOW_FWD and HALO_CONV and implicit and (not padded or (Cin == 64 and Cout == Cout_l == 64))
+                  and (kh, kw) == (3, 1) and (sh, sw) == (1, 1)
                   and ops._pair(pad) == (1, 0) and ops.conv3x1_fwd_supported(xc, wp, N, H, W, Cin, Cout))
         if in_affine is not None and not window:
             raise RuntimeError("in_affine (virtual BatchNorm in front of the layer) needs the window kernels of the (3, 1) "
@@ -1727,6 +1729,9 @@ class _ConvBnAct(torch.autograd.Function):
                     lk["done"] = True
                 else:
                     dx = ops.conv3x1_stream(dz, wd, N, Ho, Wo, Cout, Cin)  # temporal half of layer 1's Conv2Plus1D: 64 -> 144
+            elif (WINDOW_FWD and HALO_CONV and (kh, kw) == (3, 1) and pd == (1, 0) and Cin == 64 and Cout == 64
+                    and (joined[0] or ctx.fork != "alias") and ops.conv3x1_fwd_supported(dz, wd, N, Ho, Wo, Cout, Cin)):
+                dx = ops.conv3x1_fwd(dz, wd, N, Ho, Wo)           # the stem's temporal half: the window kernel on the data-gradient pack
             elif ops.conv2d_implicit_supported(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd):
                 dx = ops.conv2d_implicit(dz, wd, N, Cout, Ho, Wo, Cin, k, 1, pd, carry=pend,
                                          residual=join_alias())   # [N*H*W, Cin], no dcol / col2im

@@ -1490,21 +1490,23 @@ def conv3x1_fwd_supported(x: Tensor, wp: Tensor, N: int, T: int, Lp: int, Cin: i
 
 
 def conv3x1_fwd(x: Tensor, wp: Tensor, N: int, T: int, Lp: int, want_stats: bool = False, affine=None):
-    """(3, 1) temporal convolution 144 -> 64 over the [T, H*W] view of N clips from LDS-resident sliding windows
-    (dvt_conv3x1_fwd): x [N*T*Lp, 144], wp [64, >= 432] (column kt * 144 + ci) -> [N*T*Lp, 64]; want_stats: also the partial
-    column sums for ``bn_stats_from_partials``; affine as ``conv3x1_wgrad``."""
+    """(3, 1) temporal convolution 144 -> 64 (or 64 -> 64: the stem's temporal half / its data gradient) over the [T, H*W] view
+    of N clips from LDS-resident sliding windows (dvt_conv3x1_fwd): x [N*T*Lp, Cin], wp [64, >= 3 * Cin] (column kt * Cin + ci)
+    -> [N*T*Lp, 64]; want_stats: also the partial column sums for ``bn_stats_from_partials``; affine (144 channels only) as
+    ``conv3x1_wgrad``."""
     _need_cuda(x, wp)
     lib = L.load()
+    Cin = x.shape[1]
     y = torch.empty((N * T * Lp, 64), dtype=x.dtype, device=x.device)
     aff, _keep = _bn_affine(affine)
     partial, parts = None, 0
     if want_stats:
-        parts = int(lib.dvt_conv3x1_fwd_stats_parts(N, T, Lp))
+        parts = int(lib.dvt_conv3x1_fwd_stats_parts(N, T, Lp, Cin))
         partial = workspace((parts + 64) * 2 * 64 * 4, x.device, slot="bn_partial")
     nb = (x.numel() + wp.numel() + y.numel()) * x.element_size()
-    with _timed(("conv", "window3x1_fwd", N * T * Lp, 64, 432, nb), 2.0 * N * T * Lp * 64 * 432):
+    with _timed(("conv", "window3x1_fwd" if Cin == 144 else "window3x1_c64", N * T * Lp, 64, 3 * Cin, nb), 2.0 * N * T * Lp * 64 * 3 * Cin):
         L.check(lib.dvt_conv3x1_fwd(x.data_ptr(), None if aff is None else C.byref(aff), wp.data_ptr(), wp.shape[1], y.data_ptr(),
-                                    _p(partial), N, T, Lp, dt(x), _stream()), "dvt_conv3x1_fwd")
+                                    _p(partial), N, T, Lp, Cin, dt(x), _stream()), "dvt_conv3x1_fwd")
     return (y, partial, parts) if want_stats else y
 
 

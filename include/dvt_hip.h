@@ -643,7 +643,10 @@ int dvt_conv3x3_c64_wgrad_wide(const void* x, const void* dz, float* dw, void* w
  * between the two halves -- y = relu(z * invstd * gamma + (beta - mean * invstd * gamma)), the formula and rounding of
  * dvt_bn_apply_fwd -- is applied to the staged window: the normalised 144-plane activation never exists in HBM.
  * stats_partial (forward): [dvt_conv3x1_fwd_stats_parts + 64][2][64] f32 partial column sums of the stored output for
- * dvt_bn_stats_from_partials.  workspace / defer_reduce / pending (weight gradient) as dvt_conv3x3_c64_wgrad. */
+ * dvt_bn_stats_from_partials.  workspace / defer_reduce / pending (weight gradient) as dvt_conv3x3_c64_wgrad.
+ * The forward also takes Cin = 64 (since ABI v5): the temporal half of the STEM, Conv3d(45, 64, (3, 1, 1)) with its 45 mid
+ * planes stored zero-padded to 64 -- x [N, T, L, 64], w [64][ldw] with column kt * 64 + ci, no x_affine -- and, given the
+ * data-gradient pack of the weights (dvt_conv_weight_pack_dgrad), that layer's data gradient. */
 typedef struct dvt_bn_affine {
   const float* mean;     /* [C] */
   const float* invstd;   /* [C] */
@@ -653,9 +656,9 @@ typedef struct dvt_bn_affine {
   int32_t relu;
 } dvt_bn_affine;
 int dvt_conv3x1_fwd_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
-int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L);
+int64_t dvt_conv3x1_fwd_stats_parts(int64_t N, int T, int L, int Cin);
 int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w, int64_t ldw, void* y, float* stats_partial,
-                    int64_t N, int T, int L, int dtype, dvt_stream_t stream);
+                    int64_t N, int T, int L, int Cin, int dtype, dvt_stream_t stream);
 int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int dtype);
 size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L);
 int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* dz, float* dw, void* workspace, int64_t N, int T,

@@ -952,6 +952,50 @@ def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, d
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 8), (3, 12, 56, 56), (40, 12, 4, 8), (1, 8, 4, 4), (5, 16, 4, 6), (2, 4, 7, 8), (1, 12, 2, 4),
+                                     (3, 20, 2, 4)])
+def test_stem_temporal_convolution_from_lds_sliding_windows(dvt, device, dtype, N, T, H, W):
+    """dvt_conv3x1_fwd with 64 input channels: the temporal half of R(2+1)D-18's stem (torchvision r2plus1d_18 as used by
+    frame_transformer.py:64-74: Conv3d(45, 64, (3, 1, 1)), the 45 mid planes stored zero-padded to 64) from a window of all
+    frames of a 16-pixel segment -- against conv2d in fp32 on the same operands and the implicit kernel it replaces, with the
+    BatchNorm partial sums of the stored output; and on the data-gradient pack of the weights (what the layer's backward
+    launches) against the implicit data gradient.  Segments of 16, 12 and 8 pixels, one to six position blocks per wave, more
+    tiles than workgroups."""
+    ops = dvt.ops
+    Lp = H * W
+    g = torch.Generator().manual_seed(N * 13 + T + Lp)
+    x = torch.randn(N * T * Lp, 64, generator=g).to(dtype)
+    x[:, 45:] = 0                                                      # the padded planes
+    x = x.cuda()
+    w = torch.zeros(64, 64, 3, 1)
+    w[:, :45] = torch.randn(64, 45, 3, 1, generator=g) * (2.0 / (45 * 3)) ** 0.5
+    w = w.cuda()
+    wp = ops.conv_weight_pack(w, ops.conv2d_implicit_k(64, 64, (3, 1)), dtype)
+    assert ops.conv3x1_fwd_supported(x, wp, N, T, Lp, 64, 64)
+    y, partial, parts = ops.conv3x1_fwd(x, wp, N, T, Lp, want_stats=True)
+    xr = x.float().view(N, T, Lp, 64).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xr, w.to(dtype).float(), None, 1, (1, 0)).permute(0, 2, 3, 1).reshape(-1, 64)
+    tol = 5e-3 if dtype == torch.bfloat16 else 8e-4
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all() and rel_l2(y, ref) < tol
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, y.shape[0], 64, None, None, 1e-5, 0.1)
+    assert torch.allclose(mean, y.float().mean(0), atol=2e-3) and rel_l2(invstd, (y.float().var(0, unbiased=False) + 1e-5).rsqrt()) < 2e-3
+    assert torch.equal(ops.conv3x1_fwd(x, wp, N, T, Lp), y)
+    imp = ops.conv2d_implicit(x, wp, N, 64, T, Lp, 64, (3, 1), 1, (1, 0))
+    assert rel_l2(y, imp) < tol
+    # the layer's data gradient: the same kernel on the rotated / transposed pack
+    dz = torch.randn(N * T * Lp, 64, generator=g).to(dtype).cuda()
+    wd = ops.conv_weight_pack_dgrad(w, dtype)
+    assert ops.conv3x1_fwd_supported(dz, wd, N, T, Lp, 64, 64)
+    dx = ops.conv3x1_fwd(dz, wd, N, T, Lp)
+    dr = dz.float().view(N, T, Lp, 64).permute(0, 3, 1, 2).requires_grad_(False)
+    xg = xr.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xg, w.to(dtype).float(), None, 1, (1, 0)).backward(dr)
+    dref = xg.grad.permute(0, 2, 3, 1).reshape(-1, 64)
+    assert rel_l2(dx, dref) < tol and float(dx[:, 45:].float().abs().max()) == 0.0
+    assert rel_l2(dx, ops.conv2d_implicit(dz, wd, N, 64, T, Lp, 64, (3, 1), 1, (1, 0))) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (1, 8, 4, 4)])
 def test_temporal_data_gradient_with_the_mid_batchnorm_backward_fused(dvt, device, dtype, training, N, T, H, W):

@@ -62,6 +62,8 @@ def conv_family(name):
         return "conv3x1_wgrad"
     if "conv3x1_fwd_kernel" in name:
         return "conv3x1_fwd"
+    if "conv3x1_c64_kernel" in name:
+        return "conv3x1_c64"
     if "conv3x3_c64_kernel" in name:
         return "conv3x3_c64"
     if "gemm_dma_kernel" not in name:
