@@ -13,7 +13,9 @@
 //   * 144 channels per tap = four 16x16x32 steps + one 16x16x16 step;
 //   * optional virtual BatchNorm: the map is the spatial convolution's output z and relu(z * s + t) is formed in the staged
 //     window (window_transform), once per tile -- the normalised 144-plane activation then never exists in HBM;
-//   * epilogue: the tile's outputs go through an LDS staging image and leave as whole 128-byte pixel rows; the column sums /
+//   * epilogue: the tile's outputs go through an LDS staging image -- laid over the tile's own, by then consumed, window, so
+//     that two windows of 16-pixel segments fit (2 x 70 KiB at 12 frames; with a staging area of its own the segment was 8
+//     pixels: twice the tiles, 170 -> 159 us isolated) -- and leave as whole 128-byte pixel rows; the column sums /
 //     sums of squares of the STORED values for the BatchNorm behind the layer are carried per thread over the workgroup's
 //     whole tile sequence (a thread always stores the same 8 channels) and reduced once per launch.
 #include "conv3x1_window.h"
@@ -43,7 +45,8 @@ template <> struct Mma16f<f16> {
   static __device__ __forceinline__ f32x4 mma(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int kMaxPB = 4;                    // 16-position blocks per wave (tile <= 128 positions)
+constexpr int kMaxPB = 6;                    // 16-position blocks per wave (tile <= 192 positions: 16 pixels x 12 frames)
+constexpr int kFMaxXP = 9;                   // window DMA pieces per wave: window <= 72 KiB
 
 // NPB = 16-position blocks per wave (KP / 32), a template parameter: with a run-time count every block of the unrolled k
 // loop became a branch and the accumulators were copied around them (1,100 v_mov_b64 in the listing)
@@ -59,16 +62,15 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
   const int S = w.S;
   // (the two window buffers are addressed as smem + offset, never through a pointer picked at run time: a `char* xb[2]`
   //  selected by it & 1 lost its LDS address space and every fragment read became a flat_load)
-  char* stage = smem + 2 * w.x_bytes;                                            // [KP][64] outputs of a tile, 128-byte rows
   const E* xg = (const E*)p.x;
   const bool affine = p.aff.mean != nullptr;
   AffineRegs st{};
   if (affine) window_affine_regs(p.aff, st);
-  unsigned xq[kMaxXP];
-  window_coords(w, wid, lane, xq);
+  unsigned xq[kFMaxXP];
+  window_coords<kFMaxXP>(w, wid, lane, xq);
   auto load_tile = [&](int tile, int b) {
     const int n = tile / w.segs, sg = tile - n * w.segs;
-    window_load<E>(w, xg, (int64_t)n * w.T * w.L + (int64_t)sg * S, xq, wid, smem + b * w.x_bytes);
+    window_load<E, kFMaxXP>(w, xg, (int64_t)n * w.T * w.L + (int64_t)sg * S, xq, wid, smem + b * w.x_bytes);
   };
 
   // ---- this wave: output channels [16 u, 16 u + 16), position blocks pb0 .. pb0 + npb - 1
@@ -143,7 +145,12 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
       for (int b = 0; b < NPB; ++b) acc[b] = Mma16f<E>::mma(wr[kt], x4[b], acc[b]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- the tile's outputs: lane (g, li) holds z[position (pb0 + b) * 16 + li][16 u + 4 g .. + 3]
+    // ---- the tile's outputs: lane (g, li) holds z[position (pb0 + b) * 16 + li][16 u + 4 g .. + 3].  The staging image
+    // [KP][64] (128-byte rows) OVERLAYS the tile's own window, which nobody reads any more behind this barrier: two windows
+    // of 16-pixel segments (2 x 70 KiB at 12 frames) then fit, i.e. half as many tiles -- and a tile's cost here is its
+    // chain of phases more than its bytes (conv3x1_window.h)
+    __syncthreads();
+    char* const stage = smem + cxo;
 #pragma unroll
     for (int b = 0; b < NPB; ++b) {
       V4 o;
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
     }
     // the next window has landed; this tile's stores (issued behind its requests, at most two per thread: vmcnt counts in
     // issue order) stay in flight -- waiting for them as well cost ~3 us per tile, 130 us per launch
-    if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (nst == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if (nst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                              // everybody is done with this tile's window and staging
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
 }
 
 int tf_plan(int T, int L, Window* q) {
-  if (!window_plan(T, L, q, 0, 128, 2)) return 0;
+  if (!window_plan(T, L, q, 0, 0, 2, kNW * kFMaxXP)) return 0;   // (the output staging overlays a window)
   return (q->KP >> 5) <= kMaxPB && 2 * q->x_bytes >= 2 * kNW * 64 * 8 * 4;      // (the statistics scratch overlays the windows)
 }
 
@@ -254,7 +262,7 @@ int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w,
   }
   if (!dvt_conv3x1_fwd_supported(N, T, L, kCI, kCO, dtype))
     DVT_UNSUPPORTED("dvt_conv3x1_fwd: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
-                    "(T * S) %% 32 == 0, T * S <= 128 and two windows + the output staging in 160 KiB of LDS");
+                    "(T * S) %% 32 == 0, T * S <= 192 and two windows in 160 KiB of LDS");
   TfParams p{};
   tf_plan(T, L, &p.w_);
   p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.ldw = (int)ldw;
@@ -266,14 +274,16 @@ int dvt_conv3x1_fwd(const void* x, const dvt_bn_affine* x_affine, const void* w,
                    x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
   }
   const int grid = tf_grid(N, p.w_);
-  const int lds = 2 * p.w_.x_bytes + p.w_.KP * 128;
+  const int lds = 2 * p.w_.x_bytes;
   hipStream_t st = (hipStream_t)stream;
   const bool h = dtype == DVT_F16;
   switch (p.w_.KP >> 5) {
     case 1: h ? tf_launch<f16, 1>(p, grid, lds, st) : tf_launch<bf16, 1>(p, grid, lds, st); break;
     case 2: h ? tf_launch<f16, 2>(p, grid, lds, st) : tf_launch<bf16, 2>(p, grid, lds, st); break;
     case 3: h ? tf_launch<f16, 3>(p, grid, lds, st) : tf_launch<bf16, 3>(p, grid, lds, st); break;
-    default: h ? tf_launch<f16, 4>(p, grid, lds, st) : tf_launch<bf16, 4>(p, grid, lds, st); break;
+    case 4: h ? tf_launch<f16, 4>(p, grid, lds, st) : tf_launch<bf16, 4>(p, grid, lds, st); break;
+    case 5: h ? tf_launch<f16, 5>(p, grid, lds, st) : tf_launch<bf16, 5>(p, grid, lds, st); break;
+    default: h ? tf_launch<f16, 6>(p, grid, lds, st) : tf_launch<bf16, 6>(p, grid, lds, st); break;
   }
   DVT_LAUNCH_CHECK("dvt_conv3x1_fwd");
   return DVT_OK;

@@ -42,14 +42,16 @@ struct Affine {
   int c_valid, relu;
 };
 
-inline int window_plan(int T, int L, Window* q, int extra_bytes_per_buffer, int extra_bytes_once, int nbuf) {
+// (max_pieces: 1 KiB DMA pieces the workgroup's waves carry between them)
+inline int window_plan(int T, int L, Window* q, int extra_bytes_per_buffer, int extra_bytes_once, int nbuf,
+                       int max_pieces = kNW * kMaxXP) {
   if (T < 1 || L < 1 || T + 2 > 2047) return 0;
   for (int S = 16; S >= 2; --S) {
     if (L % S || (T * S) % 32) continue;
     const int KP = T * S, xpos = (T + 2) * S;
     const int xbytes = (xpos * kXRow + 1023) & ~1023;
     if (nbuf * (xbytes + extra_bytes_per_buffer * KP) + extra_bytes_once * KP + 4096 > 160 * 1024) continue;
-    if ((xbytes >> 10) > kNW * kMaxXP) continue;
+    if ((xbytes >> 10) > max_pieces) continue;
     q->T = T; q->L = L; q->S = S; q->segs = L / S; q->KP = KP; q->xpos = xpos; q->x_bytes = xbytes;
     return 1;
   }
@@ -61,10 +63,11 @@ __device__ __attribute__((aligned(16))) static unsigned int window_zero16[4] = {
 
 // per-lane coordinates of this wave's window DMA pieces (fixed for the launch):
 // frame row << 20 | pixel of the segment << 8 | channel (multiple of 8) of the 16-byte chunk, bit 31 = never loaded
-__device__ __forceinline__ void window_coords(const Window& w, int wid, int lane, unsigned (&xq)[kMaxXP]) {
+template <int MAXP = kMaxXP>
+__device__ __forceinline__ void window_coords(const Window& w, int wid, int lane, unsigned (&xq)[MAXP]) {
   const int xp = w.x_bytes >> 10;
 #pragma unroll
-  for (int i = 0; i < kMaxXP; ++i) {
+  for (int i = 0; i < MAXP; ++i) {
     const int piece = wid + kNW * i;
     const int sl = piece * 64 + lane;
     const int pos = sl / (2 * kXU), h = sl - pos * (2 * kXU);
@@ -76,12 +79,12 @@ __device__ __forceinline__ void window_coords(const Window& w, int wid, int lane
 }
 
 // request this wave's pieces of the window of (clip pixel base pix0 = frame 0, first pixel of the segment)
-template <typename E>
-__device__ __forceinline__ void window_load(const Window& w, const E* xg, int64_t pix0, const unsigned (&xq)[kMaxXP], int wid,
+template <typename E, int MAXP = kMaxXP>
+__device__ __forceinline__ void window_load(const Window& w, const E* xg, int64_t pix0, const unsigned (&xq)[MAXP], int wid,
                                             char* dst) {
   const int xp = w.x_bytes >> 10;
 #pragma unroll
-  for (int i = 0; i < kMaxXP; ++i) {
+  for (int i = 0; i < MAXP; ++i) {
     const int piece = wid + kNW * i;
     if (piece < xp) {                            // wave-uniform
       const int frame = (int)((xq[i] >> 20) & 0x7FF) - 1;
