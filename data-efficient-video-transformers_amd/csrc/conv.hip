@@ -1287,6 +1287,60 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_k3s2p1_kernel(const T* __
   const int c = m.cg << 3;
   BnAffine<T> af;
   af.init(mean, invstd, gamma, beta, c, C);
+  // 16-bit maps under a ReLU (the stem: the only caller in the workloads): the launch is bound by VECTOR work (3.2 M outputs x
+  // 64 channels x 9 taps of affine + ReLU + rounding + compare / select: 154 us against ~100 us of HBM time), so the maximum
+  // and its tap are found as ONE unsigned key per element: (rounded value's 16 bits << 16) | (15 - tap).  Non-negative
+  // 16-bit floats order like unsigned integers, equal values prefer the earlier tap through the low bits, taps outside the
+  // image are key 0 and lose to every tap inside (low bits >= 7).  Same output and argmax as the compare form below.
+  if constexpr (sizeof(T) == 2) if (relu) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((ext_vector_type(2))) T T2;
+    for (int64_t r = m.row; r < outs; r += m.lanes) {
+      const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+      const int64_t n = r / ((int64_t)Wo * Ho);
+      typedef __attribute__((ext_vector_type(8))) T T8;
+      T8 v[9];
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj) {
+          const int h = min(max(ho * 2 - 1 + ki, 0), H - 1), w = min(max(wo * 2 - 1 + kj, 0), W - 1);
+          v[ki * 3 + kj] = *reinterpret_cast<const T8*>(z + ((n * H + h) * W + w) * C + c);
+        }
+      unsigned best[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj) {
+          const int tap = ki * 3 + kj;
+          const int h = ho * 2 - 1 + ki, w = wo * 2 - 1 + kj;
+          const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+          const unsigned low = ok ? 15u - tap : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 x = {(float)v[tap][2 * e], (float)v[tap][2 * e + 1]};
+            const f32x2 y = __builtin_elementwise_fma(x, f32x2{af.s[2 * e], af.s[2 * e + 1]}, f32x2{af.t[2 * e], af.t[2 * e + 1]});
+            T2 q = {(T)y[0], (T)y[1]};
+            q = __builtin_bit_cast(T2, __builtin_elementwise_max(__builtin_bit_cast(i16x2, q), i16x2{0, 0}));   // ReLU on the rounded pair
+            unsigned pk = __builtin_bit_cast(unsigned, q);
+            pk = ok ? pk : 0u;
+            best[2 * e] = max(best[2 * e], (pk << 16) | low);
+            best[2 * e + 1] = max(best[2 * e + 1], (pk & 0xFFFF0000u) | low);
+          }
+        }
+      T8 o;
+      unsigned long long packed = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = __builtin_bit_cast(T, (unsigned short)(best[e] >> 16));
+        packed |= (unsigned long long)(15u - (best[e] & 15u)) << (8 * e);
+      }
+      *reinterpret_cast<T8*>(y + r * C + c) = o;
+      *reinterpret_cast<unsigned long long*>(idx + r * C + c) = packed;
+    }
+    return;
+  }
   for (int64_t r = m.row; r < outs; r += m.lanes) {
     const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
     const int64_t n = r / ((int64_t)Wo * Ho);

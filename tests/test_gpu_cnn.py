@@ -177,7 +177,7 @@ def test_batchnorm_row_streaming_kernels_and_relu_mask(dvt, device, dtype, rows,
     assert rel_l2(dz_r.float(), dz_s.float()) < 1e-4 and rel_l2(dg_r, dg_s) < 1e-5 and rel_l2(db_r, db_s) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("H,W", [(9, 11), (12, 16)])
 def test_bn_relu_maxpool_in_one_pass_matches_the_three_ops(dvt, device, dtype, H, W):
     """The stem's bn1 -> relu -> maxpool(3, 2, 1) (custom_resnet.py:100-105,138-142) as one forward pass and a BatchNorm
@@ -202,6 +202,13 @@ def test_bn_relu_maxpool_in_one_pass_matches_the_three_ops(dvt, device, dtype, H
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert rel_l2(dz.float(), dz_ref.float()) < tol
     assert rel_l2(dg, dg_ref) < tol and rel_l2(db, db_ref) < tol
+    # many ties (a map of zeros and ones under the ReLU): the first maximal tap of every window
+    zt = (torch.rand(N * H * W, C, generator=g) < 0.3).to(dtype).cuda()
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    yt = ops.bn_apply_fwd(zt, zero, one, one, zero, None, True)
+    pt_ref, it_ref = ops.maxpool_fwd(yt, N, C, H, W, 3, 2, 1)
+    pt, it = ops.bn_relu_maxpool_fwd(zt, zero, one, one, zero, N, C, H, W, True)
+    assert torch.equal(pt, pt_ref) and torch.equal(it, it_ref)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
