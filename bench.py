@@ -159,9 +159,9 @@ def cpu_baseline(cfg, batch=8, timed_steps=3):
     ts = sorted(step(batch) for _ in range(timed_steps))
     dt = ts[len(ts) // 2]
     return {"value": round(batch / dt, 4), "unit": "clips/s", "cores": best, "kind": "port",
-            "sample": f"oracle (pure-torch fp32 restatement of src/models/vit.py) fwd+BCE+bwd at the metric shape, B={batch} "
-                      f"(T={cfg['T']}, {cfg['image']}^2, d={cfg['d']}), 1 warm-up + {timed_steps} timed steps, median "
-                      f"{dt:.2f} s/step at {best} threads",
+            "sample": f"oracle fp32 fwd+BCE+bwd, metric shape B={batch}, 1 warm-up + {timed_steps} timed steps, median "
+                      f"{dt:.2f} s/step, {best} threads",
+            "oracle": "pure-torch fp32 restatement of src/models/vit.py (oracle/clip_path.py), pinned by tests/golden",
             "host_logical_cpus": cores, "threads": f"pinned at {best} of a shared host's {cores}",
             "survey_cross_check": "the imported reference itself: 0.69 clips/s at B=8 on 8 cores, fp32 (BASELINE.md section 2)"}
 
@@ -601,6 +601,9 @@ def run_workload(args, workload, rank, world, use_dist, comm, *, steps, warmup, 
     if roofline and workload in ("pyramid", "crossmodal", "frametransformer"):      # the CNN encoder's kernels
         summ, nprof, _ = profile_pass(ops, step, elapsed / steps * 1e3, steps)
         roof = cnn_roofline(summ, nprof, "frametransformer" if workload == "frametransformer" else "pyramid")
+    elif roofline and workload == "longclip":       # configs[4]: the HBM-bandwidth report
+        summ, nprof, _ = profile_pass(ops, step, elapsed / steps * 1e3, steps)
+        roof = longclip_roofline(summ, nprof, round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
     elif roofline:
         summ, nprof, bracket_us = profile_pass(ops, step, elapsed / steps * 1e3, steps)
         fam, hbm, big = {}, {}, {}
@@ -780,6 +783,131 @@ def launch_ranks(args, argv):
         raise SystemExit(f"[bench] rank exit codes {rcs}; JSON line {'missing' if line is None else 'present'}")
     print(line, flush=True)
 
+DETAIL_DEFAULT = os.path.join("profiles", "r06_bench_detail.json")
+LINE_LIMIT = 6000      # the driver keeps the last 8 KB of stdout: the ONE line must fit with room to spare
+
+
+def _short(s, n=110):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def longclip_roofline(summ, nprof, peak_gib):
+    """BASELINE configs[4] / SURVEY 8(d) config 5: HBM GB/s of the streaming kernels of the long-clip step (LayerNorm,
+    pos-add / CLS assembly, patchify, the GELU-epilogue GEMM's own traffic) and of the N = 325 attention pair, each as
+    algorithmic bytes per launch / live HIP-event launch time, against the HBM peak; peak activation memory."""
+    from dvt_amd import _lib as L
+    ker = {}
+    for key, (ms, units, cnt) in summ.items():
+        if key[0] == "hbm":
+            k = ker.setdefault(key[1], {"ms": 0.0, "bytes": 0.0, "n": 0, "flops": 0.0, "big": 0})
+            if key[2] >= k["big"]:                  # per kernel: report its largest launch shape (the space stack's)
+                if key[2] > k["big"]:
+                    k.update(ms=0.0, bytes=0.0, n=0, flops=0.0, big=key[2])
+                k["ms"] += ms; k["bytes"] += units; k["n"] += cnt
+                if len(key) > 3:
+                    k["flops"] += key[3] * cnt
+        elif key[0] == "gemm" and key[6] == L.EPI_GELU and key[3] * key[4] * key[5] >= (1 << 30):
+            k = ker.setdefault("ff1_gemm_gelu_epilogue", {"ms": 0.0, "bytes": 0.0, "n": 0, "flops": 0.0, "big": 0})
+            k["ms"] += ms; k["bytes"] += float(key[7]) * cnt; k["n"] += cnt; k["flops"] += units
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": {}, "peak_activation_GiB": peak_gib}
+    for name, k in sorted(ker.items(), key=lambda kv: -kv[1]["ms"]):
+        if k["ms"] <= 0:
+            continue
+        gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        e = {"us": round(k["ms"] * 1e3 / k["n"], 1), "n": k["n"] // nprof, "GBps": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 3)}
+        if k["flops"]:
+            e["mfma_frac"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 3)
+        out["kernels"][name] = e
+    stream = {n: k for n, k in ker.items() if not k["flops"] and k["ms"] > 0}
+    if stream:                                       # the dominant pure-streaming kernel carries achieved / frac
+        dom = max(stream, key=lambda n: stream[n]["ms"])
+        out["kernel"] = dom
+        out["achieved"] = out["kernels"][dom]["GBps"]
+        out["frac"] = out["kernels"][dom]["frac"]
+        out["traffic"] = None
+    return out
+
+
+def compact_line(out):
+    """The ONE line the driver records: every workload's value / ms_per_step, the dominant kernel's roofline and the CPU
+    baseline, short enough for the driver's 8 KB tail; everything else goes to the detail file."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in out}
+    cfg = dict(out.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload", ""), 118)
+    line["config"] = cfg
+    r = out.get("roofline")
+    if r:
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                "traffic_ratio", "launches", "avg_launch_us", "peak_activation_GiB")
+        line["roofline"] = {k: (_short(r[k], 72) if isinstance(r[k], str) else r[k]) for k in keep if k in r}
+        fk = (r.get("same_kernel_full_k") or {}).get("frac")
+        if fk is not None:
+            line["roofline"]["same_kernel_4096_cubed_frac"] = fk
+        if "kernels" in r:
+            line["roofline"]["kernels"] = r["kernels"]
+    for k in ("launch", "executed_mfma_frac", "model_mfma_frac", "final_loss", "optimizer_ms_per_step", "peak_hbm_GiB", "step_ms"):
+        if out.get(k) is not None:
+            line[k] = _short(out[k], 60) if isinstance(out[k], str) else out[k]
+    ge = out.get("gradient_exchange")
+    if ge:
+        line["gradient_exchange"] = {k: ge[k] for k in ("world", "dtype", "bucket_mb", "through", "eager_ms_per_step",
+                                                        "graph_ms_per_step", "graph_ms_per_step_without_exchange",
+                                                        "exposed_allreduce_ms_per_step", "allreduce_bytes_per_step") if k in ge}
+        line["gradient_exchange"]["devices"] = sorted({d.split(": ", 1)[1].rsplit(" pid", 1)[0] for d in ge.get("rank_devices") or []})
+    sec = out.get("secondary")
+    if sec:
+        line["secondary"] = {}
+        for wl, s in sec.items():
+            if "error" in s:
+                line["secondary"][wl] = {"error": _short(s["error"], 100)}
+                continue
+            e = {k: s[k] for k in ("value", "unit", "ms_per_step", "dtype", "peak_hbm_GiB") if k in s}
+            e["launch"] = "graph" if str(s.get("launch", "")).startswith("hipGraph") else "eager"
+            rr = s.get("roofline")
+            if rr and "kernels" in rr:               # longclip: the HBM report configs[4] asks for
+                e["roofline"] = {k: rr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernels",
+                                                    "peak_activation_GiB") if k in rr}
+            elif rr:
+                e["roofline"] = {"bound": rr.get("bound"), "kernel": _short(rr.get("kernel", ""), 60), "frac": rr.get("frac")}
+                fams = rr.get("conv_families") or {}
+                if fams:
+                    e["roofline"]["conv_frac_min"] = min(f["frac"] for f in fams.values())
+                    tr = [f["traffic_ratio"] for f in fams.values() if f.get("traffic_ratio")]
+                    e["roofline"]["traffic_ratio_max"] = max(tr) if tr else None
+                bn = rr.get("hbm_kernels") or {}
+                if bn:
+                    e["roofline"]["batchnorm_ms"] = round(sum(b["ms_per_step"] for b in bn.values()), 3)
+            line["secondary"][wl] = e
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: (_short(cb[k], 118) if isinstance(cb[k], str) else cb[k])
+                                for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+    return line
+
+
+def emit(out, detail_path):
+    """Write the full record to the detail file (tracked under profiles/ when the run is the builder's own) and print the
+    compact line, which names that file."""
+    line = compact_line(out)
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, detail_path)) or ".", exist_ok=True)
+            with open(os.path.join(ROOT, detail_path), "w") as fh:
+                json.dump(out, fh, indent=1)
+            line["detail"] = detail_path
+        except OSError as e:                          # a read-only tree must not take the line down
+            line["detail"] = f"not written ({type(e).__name__})"
+    txt = json.dumps(line, separators=(",", ":"))
+    for drop in ("step_ms", "optimizer_ms_per_step", "final_loss", "launch"):      # never expected; the limit is a contract
+        if len(txt) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    print(txt, flush=True)
+    return txt
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -822,6 +950,9 @@ def main():
                     "Linears as two launches (ops.PAIR_LAUNCH)")
     ap.add_argument("--attn-two-pass", action="store_true", help="A/B switch: attention backward as the dq + dk/dv kernel pair "
                     "instead of the one-pass kernel (ops.ATTN_BWD_TWO_PASS)")
+    ap.add_argument("--detail-out", default=DETAIL_DEFAULT, help="file (relative to the repository root) that receives the FULL "
+                    "record -- per-family rooflines, per-kernel HBM rates, bucket timeline; the printed line is the compact form "
+                    "and names this file; '' writes none")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test (runs without a GPU): every rank joins "
                     "the process group, sums its rank over the group and rank 0 prints a JSON line with n_gpus = world")
     args = ap.parse_args()
@@ -895,7 +1026,8 @@ def main():
             release_gpu_memory()
             try:
                 r = run_workload(args, wl, rank, world, False, None, steps=3, warmup=1,
-                                 roofline=wl in ("pyramid", "frametransformer") and not args.no_roofline, secondary=True)
+                                 roofline=wl in ("pyramid", "frametransformer", "longclip") and not args.no_roofline,
+                                 secondary=True)
                 sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "launch", "peak_hbm_GiB",
                                              "final_loss", "roofline") if k in r}
                 sec[wl]["workload"] = r["config"]["workload"]
@@ -907,7 +1039,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == "vivit":
             out["cpu_baseline"] = cpu_baseline(dict(image=224, patch=16, classes=19, T=32, d=512, depth=4, heads=8, dh=64))
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_out)
     if _LIVE["comm"] is not None:
         _LIVE["comm"].destroy()
     if use_dist:

@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvt_hip.so")
+# (DVT_LIB_PATH: development A/B of another build of the same ABI -- tools/dev/ab_libs.sh; the product loads the in-tree library)
+LIB_PATH = os.environ.get("DVT_LIB_PATH") or os.path.join(_HERE, "libdvt_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 ABI_VERSION = 5            # == DVT_ABI_VERSION of include/dvt_hip.h (bumped with every descriptor layout change)

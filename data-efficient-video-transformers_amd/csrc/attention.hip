@@ -1588,7 +1588,7 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)dvt_cdiv((int64_t)p.B * p.H, 4)), block(256);
     const size_t lds = (size_t)4 * p.Lkp * sizeof(float);
     DVT_DISPATCH_16BIT(d->dtype, E, {
-      set_lds(attn_fwd_q1_kernel<E>, lds);
+      if (int rc_ = set_lds(attn_fwd_q1_kernel<E>, lds)) return rc_;
       hipLaunchKernelGGL((attn_fwd_q1_kernel<E>), grid, block, lds, st, p);
     });
     DVT_LAUNCH_CHECK("dvt_attention_fwd(q1)");
@@ -1602,7 +1602,7 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)(p.B * p.H)), block(64 * W);
 #define DVT_ATTN_FWD_RES(NKP)                                                               \
   case NKP:                                                                                 \
-    set_lds(attn_fwd_mfma_res_kernel<E, NKP>, lds);                                         \
+    if (int rc_ = set_lds(attn_fwd_mfma_res_kernel<E, NKP>, lds)) return rc_;                                         \
     hipLaunchKernelGGL((attn_fwd_mfma_res_kernel<E, NKP>), grid, block, lds, st, p);        \
     break
     DVT_DISPATCH_16BIT(d->dtype, E, {
@@ -1611,7 +1611,7 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
         DVT_ATTN_FWD_RES(5); DVT_ATTN_FWD_RES(6); DVT_ATTN_FWD_RES(7); DVT_ATTN_FWD_RES(8);
         DVT_ATTN_FWD_RES(9); DVT_ATTN_FWD_RES(10); DVT_ATTN_FWD_RES(11);
         default:
-          set_lds(attn_fwd_mfma_kernel<E>, lds);
+          if (int rc_ = set_lds(attn_fwd_mfma_kernel<E>, lds)) return rc_;
           hipLaunchKernelGGL((attn_fwd_mfma_kernel<E>), grid, block, lds, st, p);
       }
     });
@@ -1626,7 +1626,7 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)(p.B * p.H)), block(nt_s);
 #define DVT_ATTN_SMALL_FWD(T)                                                   \
   do {                                                                          \
-    set_lds(attn_small_fwd_kernel<T>, lds_s);                                   \
+    if (int rc_ = set_lds(attn_small_fwd_kernel<T>, lds_s)) return rc_;                                   \
     hipLaunchKernelGGL((attn_small_fwd_kernel<T>), grid, block, lds_s, st, p);  \
   } while (0)
     if (d->dtype == DVT_F32) DVT_ATTN_SMALL_FWD(float);
@@ -1642,13 +1642,13 @@ int dvt_attention_fwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   const int64_t rows = (int64_t)p.B * p.H * p.Lq;
   const dim3 grid((unsigned)dvt_cdiv(rows, 4)), block(256);
   if (d->dtype == DVT_F32) {
-    set_lds(attn_fwd_generic_kernel<float>, lds);
+    if (int rc_ = set_lds(attn_fwd_generic_kernel<float>, lds)) return rc_;
     hipLaunchKernelGGL((attn_fwd_generic_kernel<float>), grid, block, lds, st, p);
   } else if (d->dtype == DVT_BF16) {
-    set_lds(attn_fwd_generic_kernel<bf16>, lds);
+    if (int rc_ = set_lds(attn_fwd_generic_kernel<bf16>, lds)) return rc_;
     hipLaunchKernelGGL((attn_fwd_generic_kernel<bf16>), grid, block, lds, st, p);
   } else if (d->dtype == DVT_F16) {
-    set_lds(attn_fwd_generic_kernel<f16>, lds);
+    if (int rc_ = set_lds(attn_fwd_generic_kernel<f16>, lds)) return rc_;
     hipLaunchKernelGGL((attn_fwd_generic_kernel<f16>), grid, block, lds, st, p);
   } else {
     DVT_UNSUPPORTED("dvt_attention_fwd: dtype %d not supported", d->dtype);
@@ -1676,7 +1676,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)(p.B * p.H)), block(64 * waves);
 #define DVT_ATTN_BWD_FUSED(N)                                                               \
   case N:                                                                                   \
-    set_lds(attn_bwd_fused_kernel<E, N>, lds);                                              \
+    if (int rc_ = set_lds(attn_bwd_fused_kernel<E, N>, lds)) return rc_;                                              \
     hipLaunchKernelGGL((attn_bwd_fused_kernel<E, N>), grid, block, lds, st, p);             \
     break
     DVT_DISPATCH_16BIT(d->dtype, E, {
@@ -1701,12 +1701,12 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const size_t lds_q = with_patches(img_q, wq, pq), lds_kv = with_patches(img_kv, wkv, pkv);
 #define DVT_ATTN_BWD_DQ(NKP)                                                                \
   case NKP:                                                                                 \
-    set_lds(attn_bwd_dq_mfma_kernel<E, NKP>, lds_q);                                        \
+    if (int rc_ = set_lds(attn_bwd_dq_mfma_kernel<E, NKP>, lds_q)) return rc_;                                        \
     hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, NKP>), grid, block_q, lds_q, st, pq);     \
     break
 #define DVT_ATTN_BWD_DKV(NQP)                                                               \
   case NQP:                                                                                 \
-    set_lds(attn_bwd_dkv_mfma_kernel<E, NQP>, lds_kv);                                      \
+    if (int rc_ = set_lds(attn_bwd_dkv_mfma_kernel<E, NQP>, lds_kv)) return rc_;                                      \
     hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, NQP>), grid, block_kv, lds_kv, st, pkv);  \
     break
     DVT_DISPATCH_16BIT(d->dtype, E, {
@@ -1715,7 +1715,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
         DVT_ATTN_BWD_DQ(5); DVT_ATTN_BWD_DQ(6); DVT_ATTN_BWD_DQ(7); DVT_ATTN_BWD_DQ(8);
         DVT_ATTN_BWD_DQ(9); DVT_ATTN_BWD_DQ(10); DVT_ATTN_BWD_DQ(11);
         default:
-          set_lds(attn_bwd_dq_mfma_kernel<E, 0>, lds_q);
+          if (int rc_ = set_lds(attn_bwd_dq_mfma_kernel<E, 0>, lds_q)) return rc_;
           hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 0>), grid, block_q, lds_q, st, pq);
       }
       switch (p.Lqp >> 5) {                      // unrolled query loop up to 352 queries
@@ -1723,7 +1723,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
         DVT_ATTN_BWD_DKV(5); DVT_ATTN_BWD_DKV(6); DVT_ATTN_BWD_DKV(7); DVT_ATTN_BWD_DKV(8);
         DVT_ATTN_BWD_DKV(9); DVT_ATTN_BWD_DKV(10); DVT_ATTN_BWD_DKV(11);
         default:
-          set_lds(attn_bwd_dkv_mfma_kernel<E, 0>, lds_kv);
+          if (int rc_ = set_lds(attn_bwd_dkv_mfma_kernel<E, 0>, lds_kv)) return rc_;
           hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, 0>), grid, block_kv, lds_kv, st, pkv);
       }
     });
@@ -1740,7 +1740,7 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
     const dim3 grid((unsigned)(p.B * p.H)), block(nt_s);
 #define DVT_ATTN_SMALL_BWD(T)                                                   \
   do {                                                                          \
-    set_lds(attn_small_bwd_kernel<T>, lds_s);                                   \
+    if (int rc_ = set_lds(attn_small_bwd_kernel<T>, lds_s)) return rc_;                                   \
     hipLaunchKernelGGL((attn_small_bwd_kernel<T>), grid, block, lds_s, st, p);  \
   } while (0)
     if (d->dtype == DVT_F32) DVT_ATTN_SMALL_BWD(float);
@@ -1761,8 +1761,8 @@ int dvt_attention_bwd(const dvt_attn_desc* d, dvt_stream_t stream) {
   const dim3 block(256);
 #define DVT_ATTN_BWD_GENERIC(T)                                                                   \
   do {                                                                                            \
-    set_lds(attn_bwd_dq_generic_kernel<T>, lds_q);                                                \
-    set_lds(attn_bwd_dkv_generic_kernel<T>, lds_kv);                                              \
+    if (int rc_ = set_lds(attn_bwd_dq_generic_kernel<T>, lds_q)) return rc_;                                                \
+    if (int rc_ = set_lds(attn_bwd_dkv_generic_kernel<T>, lds_kv)) return rc_;                                              \
     hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)dvt_cdiv(qrows, 4)), block, 0, st, p); \
     hipLaunchKernelGGL((attn_bwd_dq_generic_kernel<T>), dim3((unsigned)dvt_cdiv(qrows, 4)), block, lds_q, st, p); \
     hipLaunchKernelGGL((attn_bwd_dkv_generic_kernel<T>), dim3((unsigned)dvt_cdiv(krows, 4)), block, lds_kv, st, p); \

@@ -45,6 +45,24 @@ template <> struct Mma16f<f16> {
   static __device__ __forceinline__ f32x4 mma(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 };
 
+// A 16x16x16 MFMA whose SrcC is the vDst of the 16x16x32 MFMA issued right before it (or the reverse) is not interlocked:
+// the listing has the two back to back with no s_nop (hipcc 7.2 counts "same vDst as SrcC" as the hardware's back-to-back
+// accumulate case whatever the two opcodes are), and the second one then read two of its four accumulator registers before
+// the first had written them (conv3x1_fwd<.., 1>: `v_mfma_f32_16x16x32 v[4:7] .. ; s_waitcnt lgkmcnt(0) ; v_mfma_f32_16x16x16
+// v[4:7], .., v[4:7]`).  With NPB position blocks per wave the k-step-major order puts NPB - 1 independent MFMAs between the
+// two; below four blocks that distance is made up with wait states: 16 of them (`s_nop 15` = 64 cycles) outlast the 16-cycle
+// issue + write-back of either shape.  tests: test_temporal_forward_with_one_two_and_five_position_blocks_per_wave (the
+// unfenced build, -DDVT_NO_MFMA_SHAPE_FENCE, fails it at NPB = 1: profiles/r06_mfma_shape_hazard.md).
+template <int NPB>
+__device__ __forceinline__ void mfma_shape_fence() {
+#ifndef DVT_NO_MFMA_SHAPE_FENCE
+  if constexpr (NPB < 4) {
+    asm volatile("s_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+}
+
 constexpr int kMaxPB = 6;                    // 16-position blocks per wave (tile <= 192 positions: 16 pixels x 12 frames)
 constexpr int kFMaxXP = 9;                   // window DMA pieces per wave: window <= 72 KiB
 
@@ -141,9 +159,11 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_fwd_kernel(const TfParams p)
         for (int b = 0; b < NPB; ++b) acc[b] = Elem16<E>::mma(wf[kt][kk], xf[kk & 1][b], acc[b]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      mfma_shape_fence<NPB>();
 #pragma unroll
       for (int b = 0; b < NPB; ++b) acc[b] = Mma16f<E>::mma(wr[kt], x4[b], acc[b]);
       __builtin_amdgcn_sched_barrier(0);
+      mfma_shape_fence<NPB>();                     // (the next tap's first 16x16x32 step takes the same accumulators)
     }
     // ---- the tile's outputs: lane (g, li) holds z[position (pb0 + b) * 16 + li][16 u + 4 g .. + 3].  The staging image
     // [KP][64] (128-byte rows) OVERLAYS the tile's own window, which nobody reads any more behind this barrier: two windows

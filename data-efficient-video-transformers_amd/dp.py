@@ -309,12 +309,18 @@ class FlatParameters:
             self._packed_version[key] = version
             ops.conv_weight_pack_group([entry])
             return dst
-        if self._packed_version.get(key) != version:
-            self._packed_version[key] = version
-            self._packed_valid = False
         if not self._packed_valid:
+            # every form in one launch; each entry's source shares its parameter's version counter (detach()), so the
+            # versions recorded here are the ones this launch has seen
             ops.conv_weight_pack_group([en for _, en in self._packed.values()])
+            for k, (_, en) in self._packed.items():
+                self._packed_version[k] = en[0]._version
             self._packed_valid = True
+        if self._packed_version.get(key) != version:
+            # an edit behind the store's back SINCE the last refresh: this entry alone (invalidating all of
+            # them here made K stale forms cost K full-group launches)
+            ops.conv_weight_pack_group([e[1]])
+            self._packed_version[key] = version
         return e[0]
 
     # ------------------------------------------------------------------ per-step protocol

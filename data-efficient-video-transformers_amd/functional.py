@@ -1626,9 +1626,14 @@ class _ConvBnAct(torch.autograd.Function):
                 # staged once, the three taps read from LDS (the implicit form gathered x once per tap)
                 pend = ops.conv3x1_wgrad(xc, dz, N, H, W, dw_master, accumulate=acc_w, defer_reduce=True, affine=ctx.in_affine)
             else:
+                xw = xc
                 if ctx.in_affine is not None:
-                    raise RuntimeError("in_affine: the window weight-gradient kernel does not take this geometry")
-                _, pend = ops.conv2d_implicit_wgrad(xc, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
+                    # the forward kept the BatchNorm in front virtual, and the window weight-gradient kernel refuses what it
+                    # is handed now (a switch flipped between forward and backward, a gradient the kernel cannot take):
+                    # materialise relu(bn(z)) once -- what the forward skipped -- and take the implicit kernel
+                    am, ai, ag, ab, acv, arelu = ctx.in_affine[:6]
+                    xw = ops.bn_apply_fwd(xc.contiguous(), am, ai, ag, ab, None, bool(arelu), c_valid=int(acv))
+                _, pend = ops.conv2d_implicit_wgrad(xw, dz, N, Cin, H, W, Cout, k, stride, pad, ctx.trim, defer_reduce=True,
                                                     master=dw_master, accumulate=acc_w, logical=(Cout_l, Cin_l))
             unpack = dwp = None
         elif ctx.wg_implicit:

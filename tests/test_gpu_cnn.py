@@ -921,8 +921,31 @@ def test_temporal_weight_gradient_from_lds_sliding_windows(dvt, device, dtype, N
     assert rel_l2(acc.view(64, 144, 3) - old.view(64, 144, 3), ref) < 2e-5
 
 
+def _window_position_blocks(T, Lp):
+    """16-position blocks per wave of the window forward for a clip geometry (csrc/conv3x1_window.h: window_plan picks the
+    longest segment S <= 16 with Lp % S == 0 and (T * S) % 32 == 0 whose two windows fit; blocks = T * S / 32)."""
+    for S in range(16, 1, -1):
+        if Lp % S or (T * S) % 32:
+            continue
+        xbytes = (((T + 2) * S * 320) + 1023) & ~1023
+        if 2 * xbytes + 4096 > 160 * 1024 or (xbytes >> 10) > 72:
+            continue
+        return T * S // 32 if 2 * xbytes >= 32768 else 0        # (tf_plan: the statistics scratch overlays the two windows)
+    return 0
+
+
+# one to six position blocks per wave: with one or two, the 16x16x16 tail of a tap follows the tap's last 16x16x32 step on
+# the SAME accumulator with at most one other MFMA in between (ADVICE r5; csrc/conv3x1_fwd.hip: mfma_shape_fence)
+_WINDOW_FWD_GEOMS = [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4), (5, 16, 4, 6), (2, 8, 7, 8), (2, 20, 2, 4),
+                     (3, 2, 4, 4), (300, 2, 4, 8)]
+
+
+def test_window_forward_geometries_cover_every_block_count():
+    assert {_window_position_blocks(T, H * W) for _, T, H, W in _WINDOW_FWD_GEOMS} == {1, 2, 3, 4, 5, 6}
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (40, 12, 8, 8), (1, 8, 4, 4), (5, 16, 4, 6)])
+@pytest.mark.parametrize("N,T,H,W", _WINDOW_FWD_GEOMS)
 def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, device, dtype, N, T, H, W):
     """dvt_conv3x1_fwd: the (3, 1, 1) temporal convolution 144 -> 64 of R(2+1)D-18's layer 1 from a window of all frames of a
     pixel segment, weights in registers -- against conv2d in fp32 on the same operands, with the BatchNorm partial sums of the
@@ -950,10 +973,11 @@ def test_temporal_forward_from_lds_sliding_windows_with_virtual_batchnorm(dvt, d
     aff = (m0, is0, ga, be, 0, True)
     assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp, affine=aff), ops.conv3x1_fwd(act, wp, N, T, Lp))
     dz = (torch.randn(N * T * Lp, 64, generator=g) / (N * T * Lp) ** 0.5).to(dtype).cuda()
-    a, b = torch.empty(64, 144, 3, 1, device="cuda"), torch.empty(64, 144, 3, 1, device="cuda")
-    ops.conv3x1_wgrad(z, dz, N, T, Lp, a, affine=aff)
-    ops.conv3x1_wgrad(act, dz, N, T, Lp, b)
-    assert torch.equal(a, b)
+    if ops.conv3x1_wgrad_supported(z, dz, N, T, Lp, 144, 64):
+        a, b = torch.empty(64, 144, 3, 1, device="cuda"), torch.empty(64, 144, 3, 1, device="cuda")
+        ops.conv3x1_wgrad(z, dz, N, T, Lp, a, affine=aff)
+        ops.conv3x1_wgrad(act, dz, N, T, Lp, b)
+        assert torch.equal(a, b)
     nr = ops.bn_apply_fwd(z, m0, is0, ga, be, None, False)                       # without the ReLU
     assert torch.equal(ops.conv3x1_fwd(z, wp, N, T, Lp, affine=(m0, is0, ga, be, 0, False)), ops.conv3x1_fwd(nr, wp, N, T, Lp))
 
@@ -1039,6 +1063,52 @@ def test_temporal_data_gradient_with_the_mid_batchnorm_backward_fused(dvt, devic
     assert rel_l2(gg3, wg3) < 2e-5 and rel_l2(got3, want3) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("N,T,H,W", [(2, 12, 8, 7), (3, 12, 56, 56), (1, 8, 4, 4)])
+def test_fused_mid_batchnorm_backward_against_fp32_autograd(dvt, device, dtype, training, N, T, H, W):
+    """dvt_conv3x1_stream_bn_bwd against an INDEPENDENT fp32 chain on the same 16-bit operands: torch's
+    batch_norm -> relu -> conv2d (the (3, 1, 1) temporal convolution of torchvision's Conv2Plus1D, frame_transformer.py:64-74,
+    over the [T, H*W] view) differentiated by autograd -- dz, dgamma, dbeta.  Training mode: the statistics handed to the
+    kernel are the batch statistics of z (what the forward's statistics kernels produce), eval mode: arbitrary running ones."""
+    ops = dvt.ops
+    Lp = H * W
+    g = torch.Generator().manual_seed(N * 19 + T + Lp)
+    rows = N * T * Lp
+    z = torch.randn(rows, 144, generator=g).to(dtype).cuda()
+    dy = (torch.randn(rows, 64, generator=g) / rows ** 0.5).to(dtype).cuda()
+    w = (torch.randn(64, 144, 3, 1, generator=g) * (2.0 / (144 * 3)) ** 0.5).cuda()
+    wd = ops.conv_weight_pack_dgrad(w, dtype)
+    if not ops.conv3x1_stream_supported(dy, wd, N, T, Lp, 64, 144):
+        pytest.skip("no segment length of this map fills half a 224-pixel tile")
+    ga, be = (1 + 0.2 * torch.randn(144, generator=g)).cuda(), (0.3 * torch.randn(144, generator=g)).cuda()
+    eps = 1e-5
+    if training:
+        z64 = z.double()
+        mean = z64.mean(0)
+        var = (z64 - mean).pow(2).mean(0)
+        m0, is0 = mean.float(), (var + eps).rsqrt().float()
+    else:
+        m0, is0 = (0.2 * torch.randn(144, generator=g)).cuda(), (1 + 0.3 * torch.rand(144, generator=g)).cuda()
+    got, gg, gb = ops.conv3x1_stream_bn_bwd(dy, wd, z, (m0, is0, ga, be, 0, True), N, T, Lp, training)
+    # the fp32 chain: [N, 144, T, Lp] maps, the temporal convolution as a (3, 1) conv2d with padding (1, 0)
+    zf = z.float().view(N, T, Lp, 144).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    gaf, bef = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    if training:
+        bn = TF.batch_norm(zf, None, None, gaf, bef, True, 0.1, eps)
+    else:
+        bn = TF.batch_norm(zf, m0.clone(), (1.0 / is0.double() ** 2 - eps).float(), gaf, bef, False, 0.1, eps)
+    out = TF.conv2d(torch.relu(bn), w.to(dtype).float(), None, 1, (1, 0))
+    out.backward(dy.float().view(N, T, Lp, 64).permute(0, 3, 1, 2))
+    want = zf.grad.permute(0, 2, 3, 1).reshape(rows, 144)
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
+    assert torch.isfinite(got.float()).all() and rel_l2(got, want) < tol
+    # dgamma / dbeta: the kernel sums the 144-plane gradient ROUNDED to the map's 16-bit type (what the unfused composition
+    # stores and bn_bwd then reads), the fp32 chain the unrounded one: the element type's tolerance, not fp32's
+    # (measured 1.4e-3 - 1.9e-3 in bf16, 1.9e-4 - 2.3e-4 in fp16)
+    assert rel_l2(gg, gaf.grad) < tol and rel_l2(gb, bef.grad) < tol
+
+
 def test_r2plus1d_block_backward_with_and_without_the_fused_mid_batchnorm(dvt, device, monkeypatch):
     """models/video_resnet.BasicBlock (layer 1 of R(2+1)D-18, frame_transformer.py:64-74): with the virtual BatchNorm between the
     halves of each Conv2Plus1D, the backward of that BatchNorm runs inside the temporal half's data gradient
@@ -1066,6 +1136,18 @@ def test_r2plus1d_block_backward_with_and_without_the_fused_mid_batchnorm(dvt, d
     assert set(g0) == set(g1) and len(g0) == 12
     for n in g0:
         assert rel_l2(g1[n], g0[n]) < (1e-2 if n.endswith("weight") and g0[n].dim() > 1 else 2e-2), n
+    # a switch flipped BETWEEN forward and backward (the forward has kept the mid BatchNorm virtual; the window and halo
+    # kernels are then refused in backward): the backward materialises relu(bn(z)) and takes the implicit kernels -- same
+    # gradients, no error
+    for p_ in blk.parameters():
+        p_.grad = None
+    x = x0.clone().requires_grad_(True)
+    out = blk.forward_ndhwc((x, N, T, H, W), torch.bfloat16)[0]
+    monkeypatch.setattr(F, "HALO_CONV", False)
+    out.backward(gy)
+    assert rel_l2(x.grad, dx0) < 1e-2
+    for n, p_ in blk.named_parameters():
+        assert rel_l2(p_.grad, g0[n]) < (1e-2 if n.endswith("weight") and g0[n].dim() > 1 else 2e-2), n
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1254,3 +1336,43 @@ def test_conv_epilogue_batchnorm_statistics(dvt, device, N, C, H, W, Cout, k, st
     assert float((mean - mean_ref).abs().max()) < 2e-3 * float(zf.std()) + 1e-6
     assert float((invstd / invstd_ref - 1).abs().max()) < 2e-3
     assert float((rm1 - rm2).abs().max()) < 1e-3 and float((rv1 / rv2 - 1).abs().max()) < 1e-3
+
+
+def test_packed_weights_follow_edits_behind_the_stores_back(dvt, device, monkeypatch):
+    """dp.FlatParameters.packed_weight: the cached GEMM-operand forms of the convolution weights are refreshed by
+    ONE grouped launch after an optimizer step, and an edit the store did not make (load_state_dict, an in-place op under
+    no_grad) repacks the forms of THAT parameter only -- one single-entry launch each, not a full-group launch per stale key --
+    with outputs equal to a freshly built model holding the same weights."""
+    from dvt_amd.dp import FlatParameters
+    from dvt_amd.models.custom_resnet import resnet18
+    ops = dvt.ops
+    torch.manual_seed(5)
+    net = resnet18(False, compute_dtype=torch.bfloat16).cuda().train()
+    flat = FlatParameters(net, compute_dtype=torch.bfloat16)
+    x = torch.randn(2, 3, 64, 64).cuda()
+    calls = []
+    real = ops.conv_weight_pack_group
+    monkeypatch.setattr(ops, "conv_weight_pack_group", lambda entries: (calls.append(len(entries)), real(entries))[1])
+    net(x)                                                   # first use: every form is created (one single-entry launch each)
+    nforms = len(flat._packed)
+    assert nforms >= 15 and calls == [1] * nforms
+    calls.clear()
+    net(x)
+    assert calls == []                                       # nothing changed: no launch
+    flat.invalidate_packed()                                 # what an optimizer step does
+    net(x)
+    assert calls == [nforms]                                 # one grouped launch
+    calls.clear()
+    other = resnet18(False, compute_dtype=torch.bfloat16).cuda().train()
+    with torch.no_grad():
+        for p_ in other.parameters():
+            p_.mul_(1.5)
+    net.load_state_dict(other.state_dict())                  # bumps every parameter's version behind the store's back
+    want = other(x)
+    got = net(x)
+    assert all(c == 1 for c in calls) and len(calls) == nforms, calls      # K single-entry launches, not K x K work
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    calls.clear()
+    net(x)
+    assert calls == []

@@ -45,6 +45,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             out[name] = None
     print("RESULT " + json.dumps(out))
     sys.exit(0)
+# fail fast on a product build: without tools/dev/force_conv_cfg.patch the switch does not exist and every column would
+# silently measure the product configuration
+_root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+with open(os.path.join(_root, "data-efficient-video-transformers_amd", "libdvt_hip.so"), "rb") as _fh:
+    if b"DVT_FORCE_WGRAD_CFG" not in _fh.read():
+        sys.exit("conv_wgrad_cfg_sweep.py: libdvt_hip.so was built without tools/dev/force_conv_cfg.patch (DVT_FORCE_WGRAD_CFG is not in it)")
 res = {}
 for cfg in ["product", "0", "7", "1", "6"]:
     env = dict(os.environ)
