@@ -1,7 +1,7 @@
 """Dev probe: upper bound of running the step as two independent half-batch chains on two streams inside one hipGraph
 (two model replicas of B = 4 each, each with its own optimizer step) against one chain of B = 8."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import dvt_amd
 from dvt_amd.dp import FlatParameters
 from dvt_amd.models.vit import ViViT
