@@ -144,7 +144,8 @@ class GradSink:
     collective.  Such a *late* write is redirected transparently: ``buf`` / ``fresh`` then name a per-sink side buffer,
     which ``FlatParameters.finish_backward`` all-reduces by itself and adds to the reduced gradient."""
 
-    __slots__ = ("_buf", "_fresh", "bucket", "owner", "index", "unwritten", "_late", "_late_fresh", "late_written")
+    __slots__ = ("_buf", "_fresh", "bucket", "owner", "index", "unwritten", "_late", "_late_fresh", "late_written",
+                 "_zeroed", "_uncounted")
 
     def __init__(self, buf: torch.Tensor, bucket: int, owner: "FlatParameters", index: int):
         self._buf = buf         # view shaped like the parameter
@@ -156,6 +157,8 @@ class GradSink:
         self._late = None       # side buffer for writes that arrive after the bucket's all-reduce was launched
         self._late_fresh = True
         self.late_written = False
+        self._zeroed = False    # the slice holds zeros written by finish_backward and nobody has written it since
+        self._uncounted = False  # this step's bucket count does not wait for it (nobody wrote it in the previous step)
 
     def _is_late(self) -> bool:
         o = self.owner
@@ -181,7 +184,9 @@ class GradSink:
         if self._fresh:
             self._fresh = False
             self.unwritten = False
-            self.owner._on_first_write(self)
+            self._zeroed = False
+            if not self._uncounted:          # (a parameter the bucket did not wait for: nothing to count down)
+                self.owner._on_first_write(self)
 
 
 def sink_of(p) -> Optional[GradSink]:
@@ -326,13 +331,25 @@ class FlatParameters:
     # ------------------------------------------------------------------ per-step protocol
     def zero_grad(self) -> None:
         """Marks every sink fresh (first write overwrites): no memset pass."""
+        self._pending = list(self.bucket_size)
         for s in self.sinks:
             s._fresh = True
             s._late_fresh = True
             s.late_written = False
-        self._pending = list(self.bucket_size)
+            # A parameter nobody wrote in the previous step (a dead branch of the model: custom_resnet.py:149-153's avgpool + fc,
+            # TPN.py:22's unused 1 x 1 convolution) will most likely not be written in this one either: its bucket does not
+            # wait for it -- it waited until finish_backward, i.e. the whole bucket was exchanged AFTER backward (pyramid:
+            # 21 MB at +0.02 ms).  The slice still holds the zeros of the last finish_backward.  Should it be written after
+            # all: before the bucket's launch the write lands in place as usual, after it through the late-write redirect.
+            # (Every rank runs the same model, so every rank takes the same decision: the collectives stay in one order.)
+            s._uncounted = s.unwritten and s._zeroed
+            if s._uncounted:
+                self._pending[s.bucket] -= 1
         self._launched = [False] * len(self.bucket_ranges)
         self._handles = []
+        for b, n in enumerate(self._pending):      # (a bucket of dead parameters only: exchanged at finish_backward as before)
+            if n <= 0:
+                self._pending[b] = 1 << 30
 
     def _launch_bucket(self, b: int) -> None:
         if self._launched[b] or self.defer_exchange:
@@ -376,7 +393,9 @@ class FlatParameters:
         unwritten = []
         for s in self.sinks:
             if s._fresh:
-                s._buf.zero_()   # memset of a slice nobody wrote this step (rare)
+                if not s._zeroed:            # (still zero from the last step otherwise -- and its bucket may be in flight)
+                    s._buf.zero_()           # memset of a slice nobody wrote this step (rare)
+                    s._zeroed = True
                 s._fresh = False
                 s.unwritten = True
                 unwritten.append(s.index)

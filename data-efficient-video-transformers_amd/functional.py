@@ -1572,6 +1572,13 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *more):
+        if _ln_pending_sinks:
+            # backward has left the transformer for the per-frame CNN encoder: whatever LayerNorm dgamma / dbeta reduces are
+            # still deferred (the launch-bound zone's, a token LayerNorm of the front-end) are performed NOW, not at the end of
+            # the step -- under data parallelism their gradient buckets then exchange beside the encoder's whole backward
+            # instead of after it (frametransformer at one rank: 68 MB of buckets moved from -0.09 .. -0.01 ms before the end
+            # of backward to its start, bench.py --force-dist)
+            ln_flush()
         dshort = more[0] if (ctx.fork is not None and more) else None     # (behind it, under defer_apply: mean and invstd's)
         xc, wp, z, y, mean, invstd, g32, col, b32, pidx, rmask = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg

@@ -156,11 +156,12 @@ def _plan_worker(rank, world, port, out):
     twice = "space_transformer.norm.weight"          # written again after its bucket has been launched (late buffer)
     never = "temporal_token"                         # nobody writes it in step 0 (zero fill + skip mask)
     launched_at = {}
-    for step in range(2):
+    i_never = [k for k, _ in named].index(never)
+    for step in range(3):                            # steps 0, 1: `never` unwritten; step 2: written after all
         flat.zero_grad()
         for i in range(len(named) - 1, -1, -1):      # backward completion order
             k, p = named[i]
-            if k == never and step == 0:
+            if k == never and step < 2:
                 continue
             s = p._dvt_sink
             val = (rank + 1) * (i + 1) * 1e-3 * flat.loss_scale * (0.25 if k == twice else 1.0)
@@ -169,6 +170,9 @@ def _plan_worker(rank, world, port, out):
             s.mark_written()
             if step == 0:
                 launched_at[i] = sum(flat._launched)
+        # the bucket of a never-written parameter: in step 0 it waits for finish_backward; from step 1 on nobody expects the
+        # parameter any more and the bucket leaves with its last WRITTEN parameter (its slice holds step 0's zeros)
+        assert flat._launched[flat.sinks[i_never].bucket] == (step > 0), step
         s = dict(named)[twice]._dvt_sink               # the second write: its bucket's all-reduce is in flight
         i2 = [k for k, _ in named].index(twice)
         assert flat._launched[s.bucket] and s.fresh    # (fresh now names the late buffer)
@@ -176,11 +180,12 @@ def _plan_worker(rank, world, port, out):
         s.mark_written()
         assert s.late_written
         flat.finish_backward()
-        if step == 0:
-            i = [k for k, _ in named].index(never)
+        if step < 2:
+            i = i_never
             assert flat.sinks[i].unwritten and flat.skip_mask is not None and int(flat.skip_mask.sum()) == (named[i][1].numel() + 63) // 64
-        else:
-            assert flat.skip_mask is None
+            assert float(named[i][1].grad.abs().max()) == 0.0
+        else:                 # written in step 2 after all: in place (its bucket had not left yet) or through the late path
+            assert flat.skip_mask is None and not flat.sinks[i_never].unwritten
     if rank == 0:
         torch.save({"ranges": flat.bucket_ranges, "offsets": flat.offsets, "total": flat.total,
                     "launched_at": launched_at, "bucket_size": flat.bucket_size,
