@@ -229,6 +229,9 @@ SIGNATURES = {
     "dvt_conv2d_implicit_supported": (c_int, [C.POINTER(ConvDesc)]),
     "dvt_conv2d_implicit_k": (c_i64, [C.POINTER(ConvDesc)]),
     "dvt_nchw_to_nhwc_pad": (c_int, [c_p, c_int, c_p, c_int, c_i64, c_int, c_int, c_int, c_int, c_p]),
+    "dvt_conv_stem7_supported": (c_int, [c_i64, c_int, c_int, c_int]),
+    "dvt_conv_stem7_stats_parts": (c_i64, [c_i64, c_int, c_int]),
+    "dvt_conv_stem7": (c_int, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_int, c_int, c_int, c_p]),
     "dvt_conv3x3_c64_supported": (c_int, [c_i64, c_int, c_int, c_int]),
     "dvt_conv3x3_c64_wgrad_supported": (c_int, [c_i64, c_int, c_int, c_int]),
     "dvt_conv3x1_wgrad_supported": (c_int, [c_i64, c_int, c_int, c_int, c_int, c_int]),

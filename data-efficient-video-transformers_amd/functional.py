@@ -1334,6 +1334,8 @@ def _packed_class_weight(w: Tensor, cout_l: int, cin_l: int, kh: int, kw: int, c
     return sink.owner.packed_weight((sink.index, 2, cout_p, cin_p, (sh, sw, rh, rw), dtype), make, w._version)
 
 
+# the 7x7 / 2 stem from an LDS halo patch with the weights in registers (csrc/conv_stem.hip) instead of the implicit gather
+STEM_HALO = os.environ.get("DVT_STEM_HALO", "1") != "0"
 # weight gradient of the 64 -> 64 3x3 layers from LDS halo patches (csrc/conv3x3_wgrad.hip) instead of the implicit gather
 HALO_WGRAD = os.environ.get("DVT_HALO_WGRAD", "1") != "0"
 HALO_WGRAD_COUT = (64, 144) if os.environ.get("DVT_HALO_WGRAD_WIDE", "1") != "0" else (64,)
@@ -1469,7 +1471,18 @@ class _ConvBnAct(torch.autograd.Function):
         if in_affine is not None and not window:
             raise RuntimeError("in_affine (virtual BatchNorm in front of the layer) needs the window kernels of the (3, 1) "
                                "temporal 144 -> 64 convolution")
-        if window:                                # temporal half of R(2+1)D-18's layer-1 pairs: a pixel segment over all frames in LDS
+        # the pixel-pair stem (7x7 / 2 / 3 on 3-channel frames, 64 output channels incl. zero extension) from an LDS halo patch
+        stem_halo = (STEM_HALO and HALO_CONV and implicit and pair is not None and Cout == 64 and (kh, kw) == (7, 4)
+                     and (sh, sw) == (2, 1) and ops._pair(pad) == (3, 2) and ctx.trim == 1
+                     and ops.conv_stem7_supported(xc, wp, N, H, W))
+        if stem_halo:
+            col = None
+            halo = stream = window = False
+            if training and FUSE_BN_STATS:
+                z, stats_partial, stats_parts = ops.conv_stem7(xc, wp, N, H, W, want_stats=True)
+            else:
+                z = ops.conv_stem7(xc, wp, N, H, W)
+        elif window:                                # temporal half of R(2+1)D-18's layer-1 pairs: a pixel segment over all frames in LDS
             col = None
             halo = stream = False
             if training and FUSE_BN_STATS:

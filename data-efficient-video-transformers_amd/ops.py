@@ -1278,6 +1278,35 @@ def conv_weight_pairs_bwd(dwp: Tensor, Cout: int, Cin: int, kh: int, kw: int, pw
     return out
 
 
+def conv_stem7_supported(xp: Tensor, wp: Tensor, N: int, H: int, Wp: int) -> bool:
+    """Does dvt_conv_stem7 take this stem?  xp: the pixel-pair map [N*H*Wp, 8] (nchw_to_nhwc_pad(.., 4)), wp [64, >= 224]."""
+    if not xp.is_cuda or xp.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != xp.dtype:
+        return False
+    if not (xp.is_contiguous() and wp.is_contiguous() and xp.numel() == N * H * Wp * 8 and wp.dim() == 2 and wp.shape[0] == 64
+            and wp.shape[1] >= 224 and wp.shape[1] % 8 == 0):
+        return False
+    return bool(L.load().dvt_conv_stem7_supported(N, H, Wp, dt(xp)))
+
+
+def conv_stem7(xp: Tensor, wp: Tensor, N: int, H: int, Wp: int, want_stats: bool = False):
+    """The 7x7 / 2 / 3 stem on the pixel-pair map from an LDS halo patch, weights in registers (dvt_conv_stem7): same result
+    and statistics contract as conv2d_implicit with the pair geometry ((7, 4) / (2, 1) / (3, 2), trim_w = 1).
+    -> z [N * (H/2) * Wp, 64] (, partial, parts)."""
+    _need_cuda(xp, wp)
+    Ho = H // 2
+    y = torch.empty((N * Ho * Wp, 64), dtype=xp.dtype, device=xp.device)
+    lib = L.load()
+    partial, parts = None, 0
+    if want_stats:
+        parts = int(lib.dvt_conv_stem7_stats_parts(N, H, Wp))
+        partial = workspace((parts + 64) * 2 * 64 * 4, xp.device, slot="bn_partial")
+    nb = (xp.numel() + y.numel() + wp.numel()) * xp.element_size()
+    with _timed(("conv", "stem7", N * Ho * Wp, 64, 224, nb), 2.0 * N * Ho * Wp * 64 * 224):
+        L.check(lib.dvt_conv_stem7(xp.data_ptr(), wp.data_ptr(), wp.shape[1], y.data_ptr(), _p(partial), N, H, Wp, dt(xp),
+                                   _stream()), "dvt_conv_stem7")
+    return (y, partial, parts) if want_stats else y
+
+
 def conv3x3_c64_supported(x: Tensor, wp: Tensor, N: int, H: int, W: int) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
         return False

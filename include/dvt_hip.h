@@ -663,6 +663,16 @@ int dvt_conv3x1_wgrad_supported(int64_t N, int T, int L, int Cin, int Cout, int 
 size_t dvt_conv3x1_wgrad_workspace_bytes(int64_t N, int T, int L);
 int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* dz, float* dw, void* workspace, int64_t N, int T,
                       int L, int accumulate, int defer_reduce, dvt_splitk_pending* pending, int dtype, dvt_stream_t stream);
+/* The 7x7 / stride 2 / pad 3 stem on 3-channel frames, 64 output channels (reference custom_resnet.py:100 `conv1`; the
+ * (1, 7, 7) spatial half of torchvision's R(2+1)D stem behind frame_transformer.py:64-74, its 45 planes zero-extended to 64),
+ * from an LDS halo patch with the weights in registers.  x_pairs: the pixel-pair map [N, H, Wp = W / 2, 8] of
+ * dvt_nchw_to_nhwc_pad(.., 4); w: [64][ldw] with column (ki * 4 + kj) * 8 + c8 (dvt_conv_weight_pairs + dvt_conv_weight_pack,
+ * ldw >= 224); y: [N * (H / 2) * Wp, 64] -- the same result as dvt_conv2d_implicit with the pair geometry (kernel (7, 4),
+ * stride (2, 1), pad (3, 2), trim_w 1).  stats_partial: [dvt_conv_stem7_stats_parts + 64][2][64] or NULL. */
+int dvt_conv_stem7_supported(int64_t N, int H, int Wp, int dtype);
+int64_t dvt_conv_stem7_stats_parts(int64_t N, int H, int Wp);
+int dvt_conv_stem7(const void* x_pairs, const void* w, int64_t ldw, void* y, float* stats_partial, int64_t N, int H, int Wp,
+                   int dtype, dvt_stream_t stream);
 int64_t dvt_conv3x3_c64_stats_parts(int64_t N, int H, int W);
 int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,
                     int dtype, dvt_stream_t stream);   /* residual (optional): added to the output rows, like dvt_conv_desc.residual */

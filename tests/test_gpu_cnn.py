@@ -1380,3 +1380,37 @@ def test_packed_weights_follow_edits_behind_the_stores_back(dvt, device, monkeyp
     calls.clear()
     net(x)
     assert calls == []
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(3, 224, 224, 64), (2, 112, 112, 45), (5, 32, 32, 64), (2, 36, 20, 64), (300, 16, 16, 64),
+                                        (1, 64, 48, 64)])
+def test_stem_convolution_from_an_lds_halo_patch(dvt, device, dtype, N, H, W, Cout):
+    """dvt_conv_stem7: the 7x7 / 2 / 3 stem on 3-channel frames (custom_resnet.py:100 `conv1`; with 45 planes zero-extended to
+    64 the (1, 7, 7) spatial half of the R(2+1)D stem behind frame_transformer.py:64-74) from an LDS halo patch of the
+    pixel-pair map with the weights in registers -- against conv2d in fp32 on the same 16-bit operands, with the BatchNorm
+    partial sums of the stored output, and against the implicit GEMM it replaces (same pair geometry: (7, 4) / (2, 1) /
+    (3, 2), trim 1).  Whole frames per tile, ragged last tiles, more tiles than workgroups, rows narrower than a block."""
+    ops = dvt.ops
+    g = torch.Generator().manual_seed(N * 7 + H + W + Cout)
+    x = torch.randn(N, 3, H, W, generator=g).to(dtype).cuda()
+    w = (torch.randn(Cout, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5).cuda()
+    xp = ops.nchw_to_nhwc_pad(x, dtype, 4)                                  # [N*H*(W/2), 8]
+    w4 = w.reshape(Cout, 3, 49)
+    if Cout != 64:
+        w4 = ops.pad3_f32(w4, Cout, 3, 49, 64, 3)
+    wpairs = ops.conv_weight_pairs(w4, 64, 3, 7, 7, 3, 4)                   # [64, 8, 7, 4]
+    wp = ops.conv_weight_pack(wpairs, ops.conv2d_implicit_k(8, 64, (7, 4)), dtype)
+    Wp, Ho = W // 2, H // 2
+    assert ops.conv_stem7_supported(xp, wp, N, H, Wp)
+    z, partial, parts = ops.conv_stem7(xp, wp, N, H, Wp, want_stats=True)
+    ref = TF.conv2d(x.float(), w.to(dtype).float(), None, 2, 3).permute(0, 2, 3, 1).reshape(-1, Cout)
+    tol = 5e-3 if dtype == torch.bfloat16 else 8e-4
+    assert z.shape == (N * Ho * Wp, 64) and torch.isfinite(z.float()).all()
+    assert rel_l2(z[:, :Cout], ref) < tol and float(z[:, Cout:].float().abs().max() if Cout < 64 else 0.0) == 0.0
+    mean, invstd = ops.bn_stats_from_partials(partial, parts, z.shape[0], 64, None, None, 1e-5, 0.1)
+    assert torch.allclose(mean, z.float().mean(0), atol=2e-3)
+    assert rel_l2(invstd, (z.float().var(0, unbiased=False) + 1e-5).rsqrt()) < 2e-3
+    assert torch.equal(ops.conv_stem7(xp, wp, N, H, Wp), z)
+    imp = ops.conv2d_implicit(xp, wp, N, 8, H, Wp, 64, (7, 4), (2, 1), (3, 2), trim_w=1)
+    assert imp.shape == z.shape and rel_l2(z, imp) < tol
