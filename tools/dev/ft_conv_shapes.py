@@ -1,6 +1,6 @@
 """Dev probe: per-shape convolution / BatchNorm time of one FrameTransformer(vid) training step (HIP-event brackets, ops.set_profiler)."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import dvt_amd
 from dvt_amd import ops
 from dvt_amd.models.frame_transformer import FrameTransformer
@@ -31,5 +31,10 @@ torch.cuda.synchronize()
 ops.set_profiler(None)
 rows = [(ms, k, n) for k, (ms, fl, n) in prof.summary().items() if k[0] in ("conv", "hbm")]
 rows.sort(reverse=True)
-for ms, k, n in rows[:90]:
-    print(f"{ms*1e3/n:9.1f} us x{n:3d}  {k}")
+tot = 0.0
+for ms, k, n in rows[:120]:
+    fl = prof.summary()[k][1]
+    frac = (fl / (ms * 1e-3) / 1e12 / 2500.0) if k[0] == "conv" else 0.0
+    tot += ms
+    print(f"{ms*1e3/n:9.1f} us x{n:3d}  total {ms*1e3:8.1f} us  frac {frac:5.3f}  {k}")
+print("sum ms", tot)
