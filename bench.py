@@ -373,6 +373,8 @@ def cnn_roofline(summ, nprof, workload):
             name = "conv3x1 temporal data gradient 64 -> 144 with the mid-plane BatchNorm backward in its epilogue (computed twice: sums, then the corrected gradient; the 144-plane gradient is never stored)"
         elif kind == "window3x1_fwd":
             name = "conv3x1 temporal forward 144 -> 64 (LDS sliding windows; the spatial half's BatchNorm + ReLU applied in the window)"
+        elif kind == "stem7":
+            name = "conv_stem7 (7x7 / 2 stem on 3-channel frames: LDS halo patch of the pixel-pair map, weights in registers)"
         elif kind == "window3x1_c64":
             name = "conv3x1 temporal forward and data gradient 64 -> 64 of the stem (LDS sliding windows, 16-pixel segments)"
         else:
@@ -394,12 +396,12 @@ def cnn_roofline(summ, nprof, workload):
     pmc_key = {"implicit": "conv_implicit", "wgrad": "conv_wgrad", "halo3x3_c64": "conv3x3_c64",
                "halo3x3_c64_wgrad": "conv3x3_c64_wgrad", "halo3x3_stream": "conv3x3_stream",
                "window3x1_wgrad": "conv3x1_wgrad", "window3x1_fwd": "conv3x1_fwd", "window3x1_c64": "conv3x1_c64",
-               "stream3x1_bn_bwd": "conv3x1_stream_bn_bwd"}
+               "stream3x1_bn_bwd": "conv3x1_stream_bn_bwd", "stem7": "conv_stem7"}
     out = {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "conv_families": {}, "hbm_kernels": {},
            "traffic_source": pfile}
     for name, (ms, fl, cnt, nb, kind) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
         tf = fl / (ms * 1e-3) / 1e12
-        traffic = (pmc.get(pmc_key[kind], {}) or {}).get("hbm_bytes_corrected")
+        traffic = (pmc.get(pmc_key.get(kind, kind), {}) or {}).get("hbm_bytes_corrected")
         if traffic and kind == "stream3x1_bn_bwd":
             traffic *= 2                     # one operator = two kernel launches (sums pass + apply pass); the family averages both
         alg_kind = sum(v[3] for v in fams.values() if v[4] == kind) / max(1, sum(v[2] for v in fams.values() if v[4] == kind))

@@ -64,6 +64,8 @@ def conv_family(name):
         return "conv3x1_fwd"
     if "conv3x1_c64_kernel" in name:
         return "conv3x1_c64"
+    if "conv_stem_kernel" in name:
+        return "conv_stem7"
     if "conv3x3_c64_kernel" in name:
         return "conv3x3_c64"
     if "gemm_dma_kernel" not in name:
