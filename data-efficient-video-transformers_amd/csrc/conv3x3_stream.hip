@@ -54,6 +54,11 @@ template <int CI_, int CO_, int NTAP_> struct SC;
 // stage positions GPOS .. SPC - 1 and the last group the batch of the chunk's own first stage.
 template <> struct SC<64, 144, 9> { enum { CK = 64, NCH = 1, TPS = 1, PPG = 7, GPOS = 3, NG = 7, STG_DEDICATED = 0 }; };
 template <> struct SC<144, 64, 9> { enum { CK = 48, NCH = 3, TPS = 3, PPG = 17, GPOS = 2, NG = 2, STG_DEDICATED = 1 }; };
+// Layer 2 of R(2+1)D-18 (video_resnet.py: Conv2Plus1D 128 -> 288 mid planes -> 128 on 28 x 28 maps; round 6): the same two
+// kernels with more input chunks per tile, launched once per 144- / 64-wide group of the output channels (the group's rows
+// of the weights, its columns of y / the residual / the statistics rows: StreamParams.ldy, ldp).
+template <> struct SC<128, 144, 9> { enum { CK = 64, NCH = 2, TPS = 1, PPG = 7, GPOS = 3, NG = 7, STG_DEDICATED = 0 }; };
+template <> struct SC<288, 64, 9> { enum { CK = 48, NCH = 6, TPS = 3, PPG = 17, GPOS = 2, NG = 2, STG_DEDICATED = 1 }; };
 // NTAP = 3: a (3, 1) filter over rows `row_pitch` pixels apart (the temporal half of Conv2Plus1D over the [T, H*W] view of a clip,
 // as the data gradient 64 -> 144): three stages per tile, no column halo; the whole patch rides the batch of the tile's first
 // stage (62 DMA instructions, one below the vmcnt range).
@@ -76,6 +81,8 @@ struct StreamParams {
   int hb;                // images per outer block: pixel 0 of image n = (n / hb) * pitch_n + (n % hb) * pitch_h
   int64_t pitch_n;
   int pitch_h, row_pitch;   // pixels between the image's rows (W for a dense NHWC frame)
+  int ldy, ldp;             // elements between the pixel rows of y / z / the residual (CO, or the full width when this launch
+                            // writes one channel group of a wider map); floats between the two statistics rows of a partial
   // BatchNorm backward of the layer in FRONT of this data gradient, fused (MODE 1 / 2 of the kernel, dvt_conv3x1_stream_bn_bwd):
   const void* bz;           // [.., CO] the convolution output z that BatchNorm normalised (same pixel layout as y)
   const float *bmean, *binvstd, *bgamma, *bbeta;
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     }
     auto issue_weights = [&](int sg) __attribute__((always_inline)) {             // stage position sg of a tile
       char* dst = wring + (sg % 3) * kWStage;
-      const E* base = CK == 64 ? wg + sg * CI : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;   // (CK == 64: stage = tap)
+      // (CK == 64: stage = one tap of one 64-channel chunk; CK == 48: a tap row of one 48-channel chunk)
+      const E* base = CK == 64 ? wg + (sg % SPC) * CI + (sg / SPC) * CK : wg + (sg % 3) * 3 * CI + (sg / 3) * CK;
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
         int o = woff[i];
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
   auto rd = [&](const char* pb, int sg, int j) __attribute__((always_inline)) {
     const char* wb = wring + (sg % 3) * kWStage;
     if constexpr (CK == 64) {
-      const int ki = NTAP == 9 ? sg / 3 : sg, kj = NTAP == 9 ? sg % 3 : 0;
+      const int tp = sg % SPC;
+      const int ki = NTAP == 9 ? tp / 3 : tp, kj = NTAP == 9 ? tp % 3 : 0;
 #pragma unroll
       for (int u = 0; u < NB; ++u) wf8[j][u] = *reinterpret_cast<const V8*>(wb + wo[j] + u * 2048);
 #pragma unroll
@@ -382,11 +391,11 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     const int valid = min(p.R, p.H - h0) * p.W;
     const int nq = n / p.hb;
     const int64_t pix0 = nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)h0 * p.row_pitch;
-    const E* zt = (const E*)p.bz + pix0 * CO;
+    const E* zt = (const E*)p.bz + pix0 * p.ldy;
 #pragma unroll
     for (int ps = 0; ps < kPS; ++ps) {
       const int64_t po = out_pix(t, ps, valid);
-      zq[t][ps] = *reinterpret_cast<const V8*>(zt + (po >= 0 ? po : 0) * CO + c18e * 8);
+      zq[t][ps] = *reinterpret_cast<const V8*>(zt + (po >= 0 ? po : 0) * p.ldy + c18e * 8);
     }
   };
   int tile = blockIdx.x;
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     const int valid = rows_ok * p.W;
     const int nq = n / p.hb;
     const int64_t pix0 = nq * p.pitch_n + (int64_t)(n - nq * p.hb) * p.pitch_h + (int64_t)h0 * p.row_pitch;   // the tile's first pixel
-    E* yt = (E*)p.y + pix0 * CO;
+    E* yt = (E*)p.y + pix0 * p.ldy;
     char* stg = (C::STG_DEDICATED ? pbuf + 2 * kPatch : pbuf + ((it * NCH + NCH - 1) & 1) * kPatch) + wid * kStgWave;
     float bk[MODE != 0 ? kNTab : 1][8];
     (void)bk;
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
     for (int t = 0; t < 2; ++t) {
       const int m0 = wid * 32 + t * 16;
       if constexpr (CO == 64) {
-        const E* rt = p.residual ? (const E*)p.residual + pix0 * CO : nullptr;      // (dense frames: row_pitch == W)
+        const E* rt = p.residual ? (const E*)p.residual + pix0 * p.ldy : nullptr;   // (dense frames: row_pitch == W)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           V4 o;
@@ -475,11 +484,11 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
           V8 v = *reinterpret_cast<const V8*>(stg + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
           if (m0 + r < valid) {
             if (rt) {
-              const V8 rv = *reinterpret_cast<const V8*>(rt + (int64_t)(m0 + r) * CO + c * 8);
+              const V8 rv = *reinterpret_cast<const V8*>(rt + (int64_t)(m0 + r) * p.ldy + c * 8);
 #pragma unroll
               for (int k = 0; k < 8; ++k) v[k] = (E)((float)v[k] + (float)rv[k]);
             }
-            *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * CO + c * 8) = v;
+            *reinterpret_cast<V8*>(yt + (int64_t)(m0 + r) * p.ldy + c * 8) = v;
           }
         }
       } else {
@@ -524,9 +533,9 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
                   v[k] = (E)fmaf(bk[2][k], dzv, fmaf(bk[MODE == 2 ? 3 : 0][k], xf, bk[MODE == 2 ? 4 : 0][k]));
                 }
               }
-              if (MODE == 2) *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
+              if (MODE == 2) *reinterpret_cast<V8*>(yt + po * p.ldy + c18 * 8) = v;
             } else {
-              *reinterpret_cast<V8*>(yt + po * CO + c18 * 8) = v;
+              *reinterpret_cast<V8*>(yt + po * p.ldy + c18 * 8) = v;
               if (p.bn_partial) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -552,11 +561,11 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(const StreamParams 
         bq[k] += __shfl(bq[k], lane + CH, 64) + __shfl(bq[k], lane + 2 * CH, 64);
       }
       if (lane < CH) {
-        float* pr = p.bn_partial + ((int64_t)blockIdx.x * kNC + wid) * 2 * CO + lane * 8;
+        float* pr = p.bn_partial + ((int64_t)blockIdx.x * kNC + wid) * 2 * p.ldp + lane * 8;
         *reinterpret_cast<f32x4*>(pr) = f32x4{bs[0], bs[1], bs[2], bs[3]};
         *reinterpret_cast<f32x4*>(pr + 4) = f32x4{bs[4], bs[5], bs[6], bs[7]};
-        *reinterpret_cast<f32x4*>(pr + CO) = f32x4{bq[0], bq[1], bq[2], bq[3]};
-        *reinterpret_cast<f32x4*>(pr + CO + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
+        *reinterpret_cast<f32x4*>(pr + p.ldp) = f32x4{bq[0], bq[1], bq[2], bq[3]};
+        *reinterpret_cast<f32x4*>(pr + p.ldp + 4) = f32x4{bq[4], bq[5], bq[6], bq[7]};
       }
     }
   }
@@ -586,9 +595,12 @@ int plan_for(int H, int W, Plan* o) {
   return o->lds <= 160 * 1024;
 }
 
+// -> number of output-channel groups (launches) of the pair, 0 = not taken
 int plan_any(int Cin, int Cout, int H, int W, Plan* o) {
   if (Cin == 64 && Cout == 144) return plan_for<64, 144, 9>(H, W, o);
   if (Cin == 144 && Cout == 64) return plan_for<144, 64, 9>(H, W, o);
+  if (Cin == 128 && Cout == 288) return plan_for<128, 144, 9>(H, W, o) ? 2 : 0;
+  if (Cin == 288 && Cout == 128) return plan_for<288, 64, 9>(H, W, o) ? 2 : 0;
   return 0;
 }
 
@@ -624,6 +636,7 @@ int params_t(StreamParams* p, Plan* pl, int64_t N, int T, int L) {
   p->N = (int)(N * p->hb); p->H = T; p->W = S; p->R = pl->R; p->PW = pl->PW; p->SPR = pl->SPR; p->magic = pl->magic;
   p->magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)S - 1) / (uint64_t)S);
   p->pitch_n = (int64_t)T * L; p->pitch_h = S; p->row_pitch = L;
+  p->ldy = 144; p->ldp = 144;
   p->tiles_per_img = (int)dvt_cdiv(T, pl->R);
   p->ntiles = (int)(N * p->hb * p->tiles_per_img);
   return 1;
@@ -652,13 +665,15 @@ int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_parti
               "dvt_conv3x3_stream: buffers must be 16-byte aligned");
   if (N == 0) return DVT_OK;
   if (!dvt_conv3x3_stream_supported(N, H, W, Cin, Cout, dtype))
-    DVT_UNSUPPORTED("dvt_conv3x3_stream: needs a 16-bit dtype, (Cin, Cout) = (64, 144) or (144, 64) and a patch of 224 / W rows within its LDS buffer");
-  DVT_REQUIRE(!(stats_partial && Cout == 64) && !(residual && Cout != 64),
-              "dvt_conv3x3_stream: statistics come with the 144-wide output, the residual with the 64-wide one");
+    DVT_UNSUPPORTED("dvt_conv3x3_stream: needs a 16-bit dtype, (Cin, Cout) = (64, 144), (144, 64), (128, 288) or (288, 128) and a patch of 224 / W rows within its LDS buffer");
+  DVT_REQUIRE(!(stats_partial && Cout % 144) && !(residual && Cout % 64),
+              "dvt_conv3x3_stream: statistics come with the 144- / 288-wide output, the residual with the 64- / 128-wide one");
   Plan pl;
-  plan_any(Cin, Cout, H, W, &pl);
-  StreamParams p;
+  const int groups = plan_any(Cin, Cout, H, W, &pl);
+  const int cog = Cout / groups;                      // output channels per launch: 144 or 64
+  StreamParams p{};
   p.x = x; p.w = w; p.y = y; p.bn_partial = stats_partial; p.residual = residual;
+  p.ldy = Cout; p.ldp = Cout;
   p.N = (int)N; p.H = H; p.W = W; p.R = pl.R; p.PW = pl.PW; p.SPR = pl.SPR; p.magic = pl.magic;
   p.magic_w = (unsigned)((((uint64_t)1 << 32) + (uint64_t)W - 1) / (uint64_t)W);
   p.hb = 1; p.pitch_n = (int64_t)H * W; p.pitch_h = 0; p.row_pitch = W;
@@ -666,12 +681,16 @@ int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_parti
   p.ntiles = (int)(N * p.tiles_per_img);
   const int grid = p.ntiles < dvt_num_cus() ? p.ntiles : dvt_num_cus();
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 64) {
-    if (dtype == DVT_BF16) launch<bf16, 64, 144, 9>(p, pl.lds, grid, st);
-    else launch<f16, 64, 144, 9>(p, pl.lds, grid, st);
-  } else {
-    if (dtype == DVT_BF16) launch<bf16, 144, 64, 9>(p, pl.lds, grid, st);
-    else launch<f16, 144, 64, 9>(p, pl.lds, grid, st);
+  const bool h = dtype == DVT_F16;
+  for (int gi = 0; gi < groups; ++gi) {               // one launch per group of output channels: its rows of w, its columns of y
+    p.w = (const char*)w + (size_t)gi * cog * 9 * Cin * 2;
+    p.y = (char*)y + (size_t)gi * cog * 2;
+    p.residual = residual ? (const char*)residual + (size_t)gi * cog * 2 : nullptr;
+    p.bn_partial = stats_partial ? stats_partial + gi * cog : nullptr;
+    if (Cin == 64) { h ? launch<f16, 64, 144, 9>(p, pl.lds, grid, st) : launch<bf16, 64, 144, 9>(p, pl.lds, grid, st); }
+    else if (Cin == 144) { h ? launch<f16, 144, 64, 9>(p, pl.lds, grid, st) : launch<bf16, 144, 64, 9>(p, pl.lds, grid, st); }
+    else if (Cin == 128) { h ? launch<f16, 128, 144, 9>(p, pl.lds, grid, st) : launch<bf16, 128, 144, 9>(p, pl.lds, grid, st); }
+    else { h ? launch<f16, 288, 64, 9>(p, pl.lds, grid, st) : launch<bf16, 288, 64, 9>(p, pl.lds, grid, st); }
   }
   DVT_LAUNCH_CHECK("dvt_conv3x3_stream");
   return DVT_OK;

@@ -7,6 +7,7 @@ falls back to torch arithmetic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -1333,10 +1334,14 @@ def conv3x3_c64(x: Tensor, wp: Tensor, N: int, H: int, W: int, want_stats: bool 
     return (y, partial, parts) if want_stats else y
 
 
+# (DVT_STREAM_LAYER2=0: layer 2's 128 <-> 288 pairs stay on the implicit GEMM -- the same-box A/B switch of round 6)
+_STREAM_PAIRS = ((64, 144), (144, 64)) + (((128, 288), (288, 128)) if os.environ.get("DVT_STREAM_LAYER2", "1") != "0" else ())
+
+
 def conv3x3_stream_supported(x: Tensor, wp: Tensor, N: int, H: int, W: int, Cin: int, Cout: int) -> bool:
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or wp.dtype != x.dtype:
         return False
-    if (Cin, Cout) not in ((64, 144), (144, 64)):
+    if (Cin, Cout) not in _STREAM_PAIRS:
         return False
     if not (x.is_contiguous() and wp.is_contiguous() and tuple(wp.shape) == (Cout, 9 * Cin) and x.shape == (N * H * W, Cin)):
         return False
@@ -1353,8 +1358,9 @@ def conv3x3_stream_geometry(N: int, H: int, W: int, Cin: int, Cout: int, dtype: 
 
 def conv3x3_stream(x: Tensor, wp: Tensor, N: int, H: int, W: int, Cin: int, Cout: int, want_stats: bool = False,
                    residual: Optional[Tensor] = None):
-    """3x3 / 1 / 1 convolution 64 -> 144 or 144 -> 64 from LDS halo patches with streamed weights (dvt_conv3x3_stream); same
-    contract as conv3x3_c64 (statistics with the 144-wide output, residual with the 64-wide one)."""
+    """3x3 / 1 / 1 convolution 64 -> 144 / 144 -> 64 (layer 1 of R(2+1)D-18) or 128 -> 288 / 288 -> 128 (layer 2) from LDS halo
+    patches with streamed weights (dvt_conv3x3_stream); same contract as conv3x3_c64 (statistics with the 144- / 288-wide
+    output, residual with the 64- / 128-wide one)."""
     _need_cuda(x, wp, residual)
     y = torch.empty((N * H * W, Cout), dtype=x.dtype, device=x.device)
     if residual is not None:

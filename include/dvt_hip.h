@@ -680,8 +680,9 @@ int dvt_conv3x3_c64(const void* x, const void* w, void* y, float* stats_partial,
  * (video_resnet.py: 64 -> 144 mid planes forward, 144 -> 64 as the data gradient with the rotated weights): the weights
  * (162 KiB) cannot stay in LDS, so they stream through a ring of 18 KiB stages issued by a producer wave while seven
  * compute waves run the taps of the staged patch (per 48-channel chunk at 144 input channels).  (Cin, Cout) = (64, 144)
- * or (144, 64); x [N*H*W, Cin], w [Cout][9 * Cin] (k = tap * Cin + c), y [N*H*W, Cout].  stats_partial: only with
- * Cout = 144, [dvt_conv3x3_stream_stats_parts + 64][2][144]; residual: only with Cout = 64. */
+ * or (144, 64) -- and (128, 288) / (288, 128), the same pair in layer 2, as one launch per 144- / 64-wide group of output
+ * channels; x [N*H*W, Cin], w [Cout][9 * Cin] (k = tap * Cin + c), y [N*H*W, Cout].  stats_partial: only with
+ * Cout = 144 / 288, [dvt_conv3x3_stream_stats_parts + 64][2][Cout]; residual: only with Cout = 64 / 128. */
 int dvt_conv3x3_stream_supported(int64_t N, int H, int W, int Cin, int Cout, int dtype);
 int64_t dvt_conv3x3_stream_stats_parts(int64_t N, int H, int W, int Cin, int Cout);
 int dvt_conv3x3_stream(const void* x, const void* w, void* y, float* stats_partial, const void* residual, int64_t N, int H, int W,

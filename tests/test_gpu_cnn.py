@@ -239,7 +239,7 @@ def test_conv3x3_c64_from_an_lds_halo_patch(dvt, device, dtype, N, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("Cin,Cout", [(64, 144), (144, 64)])
+@pytest.mark.parametrize("Cin,Cout", [(64, 144), (144, 64), (128, 288), (288, 128)])
 @pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (2, 13, 20), (1, 5, 56), (300, 8, 8), (150, 9, 40)])
 def test_conv3x3_stream_halo_patch_with_streamed_weights(dvt, device, dtype, Cin, Cout, N, H, W):
     """dvt_conv3x3_stream (the spatial half of R(2+1)D-18's layer-1 Conv2Plus1D, video_resnet.py: 64 -> 144 forward and
@@ -255,7 +255,7 @@ def test_conv3x3_stream_halo_patch_with_streamed_weights(dvt, device, dtype, Cin
     wp = ops.conv_weight_pack(w.cuda(), 9 * Cin, dtype)
     assert ops.conv3x3_stream_supported(xd, wp, N, H, W, Cin, Cout)
     tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
-    if Cout == 144:
+    if Cout % 144 == 0:
         z, partial, parts = ops.conv3x3_stream(xd, wp, N, H, W, Cin, Cout, want_stats=True)
         assert rel_l2(z.float().cpu(), ref) < tol
         mean, invstd = ops.bn_stats_from_partials(partial, parts, z.shape[0], Cout, None, None, 1e-5, 0.1)
