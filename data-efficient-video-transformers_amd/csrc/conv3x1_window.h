@@ -107,8 +107,11 @@ struct AffineRegs {
   float s[8], t[8];
   int pos0, slot_off;                                    // first position (>= xpos: idle thread); byte offset of the slot in a row
 };
-__device__ __forceinline__ void window_affine_regs(const Affine& a, AffineRegs& r) {
-  const int q = threadIdx.x / kTfSlots, slot = threadIdx.x - q * kTfSlots;
+// (tid: the thread's index among the kNW * 64 threads that transform -- threadIdx.x, or its index among the helper waves of
+//  the pipelined forward)
+__device__ __forceinline__ void window_affine_regs(const Affine& a, AffineRegs& r, int tid = -1) {
+  if (tid < 0) tid = threadIdx.x;
+  const int q = tid / kTfSlots, slot = tid - q * kTfSlots;
   const int c0 = (slot >> 1) * 16 + (slot & 1) * 8;
   r.pos0 = q < kTfPos ? q : (1 << 30);
   r.slot_off = slot * 16;

@@ -2,7 +2,7 @@
 DESIGN 4.5 came from a build with run-time switches in the kernel (DVT_TF_DBG bits: 1 no window transform, 2 no fragment
 reads / MFMAs, 4 no output staging / stores / statistics, 8 no window requests after the first two), not kept in the product."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dvt_amd import ops, _lib as L
 if os.environ.get('DVT_LIB'):
