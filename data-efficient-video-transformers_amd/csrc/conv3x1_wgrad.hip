@@ -185,10 +185,163 @@ __global__ __launch_bounds__(kNW * 64) void conv3x1_wgrad_kernel(const TwParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with the tile's phases overlapped by construction (round 6; conv3x1_fwd.hip has the forward's
+// sibling and the counters behind it): sixteen waves, ONE barrier per tile.  Waves 0 - 7 run tile i's MFMAs from buffer
+// i % 3 exactly as above; waves 8 - 15 meanwhile request window + gradient tile i + 2 into the buffer tile i - 1 has left and
+// apply the virtual BatchNorm to window i + 1, which landed before the barrier that opened the interval.  Three (window,
+// gradient tile) pairs: 3 x (35 + 12) KiB at 12 frames of 8-pixel segments.
+template <typename E>
+__global__ __launch_bounds__(2 * kNW * 64) void conv3x1_wgrad_pipe_kernel(const TwParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using V8 = typename Elem16<E>::v8;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Window& w = p.w;
+  const int S = w.S;
+  const int zbase = 3 * w.x_bytes;
+  const int n_my = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this workgroup (>= 1)
+
+  if (wid >= kNW) {
+    // ================================================================ helper waves
+    const int hw = wid - kNW, htid = threadIdx.x - kNW * 64;
+    const E* xg = (const E*)p.x;
+    const E* zg = (const E*)p.dz;
+    const int zp = p.z_bytes >> 10;
+    const bool affine = p.aff.mean != nullptr;
+    AffineRegs st{};
+    if (affine) window_affine_regs(p.aff, st, htid);
+    unsigned xq[kMaxXP];
+    int zq[kMaxZP];
+    window_coords(w, hw, lane, xq);
+    const int c16 = lane & 7;
+#pragma unroll
+    for (int i = 0; i < kMaxZP; ++i) {
+      const int piece = hw + kNW * i;
+      const int pos = (piece * 64 + lane) >> 3;
+      const int t = pos / S, sx = pos - t * S;
+      const int ok = (piece < zp && pos < w.KP) ? 1 : 0;
+      zq[i] = (t << 20) | (sx << 8) | (((((c16 >> 1) ^ tw_swz(pos)) << 1) | (c16 & 1)) << 1) | ok;
+    }
+    auto load_tile = [&](int j) {
+      const int tile = blockIdx.x + j * gridDim.x, b = j % 3;
+      const int n = tile / w.segs, sg = tile - n * w.segs;
+      const int64_t pix0 = (int64_t)n * w.T * w.L + (int64_t)sg * S;
+      window_load<E>(w, xg, pix0, xq, hw, smem + b * w.x_bytes);
+#pragma unroll
+      for (int i = 0; i < kMaxZP; ++i) {
+        const int piece = hw + kNW * i;
+        if (piece < zp) {
+          const E* src = (zq[i] & 1) ? zg + (pix0 + (int64_t)(zq[i] >> 20) * w.L + ((zq[i] >> 8) & 0xFFF)) * kCO + ((zq[i] >> 1) & 7) * 8
+                                     : reinterpret_cast<const E*>(window_zero16);
+          dvt_dma16(src, smem + zbase + b * p.z_bytes + piece * 1024);
+        }
+      }
+    };
+    load_tile(0);
+    if (n_my > 1) load_tile(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                              // P0: pairs 0 and 1 have landed
+    if (affine) window_transform<E>(w, smem, st, p.aff.relu);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                              // P1: window 0 is ready
+    for (int i = 0; i < n_my; ++i) {
+      if (i + 2 < n_my) load_tile(i + 2);                         // into the buffers tile i - 1 has left
+      if (affine && i + 1 < n_my) window_transform<E>(w, smem + ((i + 1) % 3) * w.x_bytes, st, p.aff.relu);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // pair i + 2 has landed (needed from the next interval on)
+      __syncthreads();                                            // B_{i+1}
+    }
+    return;
+  }
+
+  // ================================================================== compute waves (the MFMA phase of the kernel above)
+  const int g = lane >> 4, li = lane & 15;
+  const int cnt = wid < kNB - 3 * kNW ? 4 : 3;
+  int zo[4][2], xo[4][2];
+  {
+    const int q = li >> 2, pp = li & 3;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = 8 * g + 4 * hf + q;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) zo[m][hf] = k * 128 + ((m ^ tw_swz(k)) << 5) + 8 * pp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = min(wid + kNW * j, kNB - 1), tap = nb / kCB, cb = nb - tap * kCB;
+        const int kx = k + tap * S;
+        xo[j][hf] = kx * kXRow + ((cb + ((kx >> 3) & 1)) << 5) + 8 * pp;
+      }
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                                // P0
+  __syncthreads();                                                // P1
+  const int nks = w.KP >> 5;
+  auto run = [&](auto CNT) {
+  constexpr int NJ = decltype(CNT)::value;
+  for (int i = 0; i < n_my; ++i) {
+    const char* cx = smem + (i % 3) * w.x_bytes;
+    const char* cz = smem + zbase + (i % 3) * p.z_bytes;
+    // (sixteen waves leave 128 registers per lane: ONE set of fragments -- the second compute wave of the SIMD and the helpers
+    //  cover its LDS round trips; two sets spilled 95 registers)
+    V8 zf[4], xf[4];
+    for (int ks = 0; ks < nks; ++ks) {
+      const char* bz = cz + ks * (32 * 128);
+      const char* bx = cx + ks * (32 * kXRow);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        zf[m] = __builtin_shufflevector(Elem16<E>::tr_read(bz + zo[m][0]), Elem16<E>::tr_read(bz + zo[m][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        xf[j] = __builtin_shufflevector(Elem16<E>::tr_read(bx + xo[j][0]), Elem16<E>::tr_read(bx + xo[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[m][j] = Elem16<E>::mma(zf[m], xf[j], acc[m][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // B_{i+1}
+  }
+  };
+  if (cnt == 4) run(IntC<4>{});
+  else run(IntC<3>{});
+  float* out = p.slab + (int64_t)blockIdx.x * kM * kCO;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j >= cnt) break;
+    const int nb = wid + kNW * j, tap = nb / kCB, cb = nb - tap * kCB;
+    float* row = out + (int64_t)(tap * kCI + cb * 16 + li) * kCO + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[m][j];
+  }
+}
+
+// the pipelined form's geometry: three (window, gradient tile) pairs; 0 = not taken (the kernel above then)
+int twp_plan(int T, int L, Window* q) {
+#ifdef DVT_TW_NO_PIPE
+  return 0;
+#endif
+  if (!window_plan(T, L, q, 128, 0, 3)) return 0;
+  return ((q->KP * 128) >> 10) <= kNW * kMaxZP;
+}
+
 // pixels per segment and the image sizes for T frames of L pixels (two windows + two dz tiles + the affine table in LDS)
-int tw_plan(int T, int L, Window* q) {
+int tw_plan_two(int T, int L, Window* q) {
   if (!window_plan(T, L, q, 128, 0, 2)) return 0;
   return ((q->KP * 128) >> 10) <= kNW * kMaxZP;
+}
+
+// the launcher's choice: the pipelined form where its buffers fit (*pipe = 1), else the two-buffer kernel
+int tw_plan(int T, int L, Window* q, int* pipe = nullptr) {
+  int dummy;
+  if (!pipe) pipe = &dummy;
+  *pipe = twp_plan(T, L, q);
+  if (*pipe) return 1;
+  return tw_plan_two(T, L, q);
 }
 
 int tw_grid(int64_t N, const Window& q) {
@@ -222,7 +375,8 @@ int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* 
     DVT_UNSUPPORTED("dvt_conv3x1_wgrad: needs a 16-bit dtype, 144 -> 64 channels and a segment length S <= 16 with L %% S == 0, "
                     "(T * S) %% 32 == 0 and two (window + gradient tile) pairs in 160 KiB of LDS");
   TwParams p{};
-  tw_plan(T, L, &p.w);
+  int pipe = 0;
+  tw_plan(T, L, &p.w, &pipe);
   p.x = x; p.dz = dz; p.slab = (float*)workspace;
   p.z_bytes = p.w.KP * 128;
   p.ntiles = (int)(N * p.w.segs);
@@ -233,16 +387,27 @@ int dvt_conv3x1_wgrad(const void* x, const dvt_bn_affine* x_affine, const void* 
                    x_affine->c_valid > 0 ? x_affine->c_valid : kCI, x_affine->relu};
   }
   const int grid = tw_grid(N, p.w);
-  const int lds = 2 * (p.w.x_bytes + p.z_bytes);
   hipStream_t st = (hipStream_t)stream;
+  if (pipe) {
+    const int lds3 = 3 * (p.w.x_bytes + p.z_bytes);
+    if (dtype == DVT_BF16) {
+      static DvtLdsAttr set;
+      dvt_lds_attr(set, (const void*)conv3x1_wgrad_pipe_kernel<bf16>, 160 * 1024);
+      hipLaunchKernelGGL((conv3x1_wgrad_pipe_kernel<bf16>), dim3(grid), dim3(2 * kNW * 64), lds3, st, p);
+    } else {
+      static DvtLdsAttr set;
+      dvt_lds_attr(set, (const void*)conv3x1_wgrad_pipe_kernel<f16>, 160 * 1024);
+      hipLaunchKernelGGL((conv3x1_wgrad_pipe_kernel<f16>), dim3(grid), dim3(2 * kNW * 64), lds3, st, p);
+    }
+  } else
   if (dtype == DVT_BF16) {
     static DvtLdsAttr set;
     dvt_lds_attr(set, (const void*)conv3x1_wgrad_kernel<bf16>, 160 * 1024);
-    hipLaunchKernelGGL((conv3x1_wgrad_kernel<bf16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+    hipLaunchKernelGGL((conv3x1_wgrad_kernel<bf16>), dim3(grid), dim3(kNW * 64), 2 * (p.w.x_bytes + p.z_bytes), st, p);
   } else {
     static DvtLdsAttr set;
     dvt_lds_attr(set, (const void*)conv3x1_wgrad_kernel<f16>, 160 * 1024);
-    hipLaunchKernelGGL((conv3x1_wgrad_kernel<f16>), dim3(grid), dim3(kNW * 64), lds, st, p);
+    hipLaunchKernelGGL((conv3x1_wgrad_kernel<f16>), dim3(grid), dim3(kNW * 64), 2 * (p.w.x_bytes + p.z_bytes), st, p);
   }
   DVT_LAUNCH_CHECK("dvt_conv3x1_wgrad");
   // the slabs are summed by the family's split-K reduce, which scatters [tap * 144 + ci][co] into the parameter's [co][ci][3]
