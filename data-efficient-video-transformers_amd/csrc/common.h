@@ -55,6 +55,13 @@ int conv3x1_c64_fwd(const void* x, const void* w, int64_t ldw, void* y, float* s
                     hipStream_t st);
 void bn_bwd_finalize(hipStream_t st, const float* partial, int nparts, int C, float* loc, int accumulate, float* dgamma,
                      float* dbeta, int c_valid);
+// conv3x1_dbn.hip: the temporal data gradient 64 -> 144 + mid-plane BatchNorm backward as a window kernel with helper waves
+// (behind dvt_conv3x1_stream_bn_bwd, conv3x3_stream.hip)
+int conv3x1_dbn_supported(int64_t N, int T, int L, int dtype);
+int conv3x1_dbn_parts(int64_t N, int T, int L);
+int conv3x1_dbn_pass(int mode, const void* dy, const void* w, int64_t ldw, const void* z, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int relu, int training, float* partial, const float* loc, void* dz,
+                     int64_t N, int T, int L, int dtype, hipStream_t st);
 }
 
 struct DvtLdsAttr { unsigned long long done = 0ull; };

@@ -739,6 +739,24 @@ int dvt_conv3x1_stream_bn_bwd(const void* dy, const void* w, const void* z, cons
   if (N == 0) return DVT_OK;
   if (!dvt_conv3x1_stream_supported(N, T, L, 64, 144, dtype))
     DVT_UNSUPPORTED("dvt_conv3x1_stream_bn_bwd: needs a 16-bit dtype and a divisor of L that fills half a 224-pixel tile");
+  hipStream_t st0 = (hipStream_t)stream;
+  if (dvt_internal::conv3x1_dbn_supported(N, T, L, dtype)) {
+    // the window kernel with helper waves (conv3x1_dbn.hip): one partial row per workgroup
+    float* part0 = (float*)workspace;
+    float* loc0 = part0 + (size_t)dvt_num_cus() * kNC * 2 * 144;
+    const int parts = dvt_internal::conv3x1_dbn_parts(N, T, L);
+    int rc = dvt_internal::conv3x1_dbn_pass(1, dy, w, 3 * 64, z, bn->mean, bn->invstd, bn->gamma, bn->beta, bn->relu, training, part0,
+                                            nullptr, nullptr, N, T, L, dtype, st0);
+    if (rc != DVT_OK) return rc;
+    DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(window sums)");
+    dvt_internal::bn_bwd_finalize(st0, part0, parts, 144, loc0, accumulate, dgamma, dbeta, 144);
+    DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(finalize)");
+    rc = dvt_internal::conv3x1_dbn_pass(2, dy, w, 3 * 64, z, bn->mean, bn->invstd, bn->gamma, bn->beta, bn->relu, training, nullptr,
+                                        loc0, dz, N, T, L, dtype, st0);
+    if (rc != DVT_OK) return rc;
+    DVT_LAUNCH_CHECK("dvt_conv3x1_stream_bn_bwd(window apply)");
+    return DVT_OK;
+  }
   Plan pl;
   StreamParams p{};
   params_t(&p, &pl, N, T, L);
