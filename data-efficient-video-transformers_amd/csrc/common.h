@@ -242,28 +242,6 @@ __device__ __forceinline__ float gelu_erf_both_f(float x, float& grad) {
   return x * cdf;
 }
 
-// The same value / derivative pair for TWO elements at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 /
-// v_pk_add_f32: two lanes' worth of fp32 per issue slot): the same IEEE operations in the same order as gelu_parts, so the
-// results are bit-identical to the scalar form; only the reciprocal, the exponential, |x| and the sign insert stay one
-// instruction per element (the GELU epilogue's vector arithmetic is not hidden under anything).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_erf_both_pk(f32x2 x, f32x2& val, f32x2& grad) {
-  const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])};
-  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.23164189f, 0.23164189f}, f32x2{1.0f, 1.0f});
-  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  const f32x2 e2 = x * x * f32x2{-0.72134752044448170368f, -0.72134752044448170368f};
-  const f32x2 E = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-  f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-  p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
-  p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
-  p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
-  const f32x2 half_erf = f32x2{0.5f, 0.5f} - f32x2{0.5f, 0.5f} * (p * t) * E;
-  const f32x2 cdf = f32x2{0.5f, 0.5f} + f32x2{__builtin_copysignf(half_erf[0], x[0]), __builtin_copysignf(half_erf[1], x[1])};
-  const f32x2 pdf = f32x2{0.39894228040143267794f, 0.39894228040143267794f} * E;
-  grad = __builtin_elementwise_fma(x, pdf, cdf);
-  val = x * cdf;
-}
-
 // ---------------------------------------------------------------- device: counter-based RNG (dropout)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&out)[4]) {

@@ -648,20 +648,13 @@ __global__ __launch_bounds__(Cfg<CFG>::NW * 64, Cfg<CFG>::NW == 16 ? 4 : 2) void
           store8<float>(o, v[j]);
         } else {
           float pre[8];
-          if constexpr (EPI == DVT_EPI_GELU) {       // two elements per instruction on the packed fp32 pipe (common.h)
+          // (the GELU / GELU' arithmetic as packed fp32 pairs -- v_pk_fma_f32, half the vector instructions, bit-identical --
+          //  was built and measured in round 6: 165.3 -> 165.9 us per FF1 launch in bf16, 637 -> 655 us at the long-clip fp16
+          //  shape; the epilogue is bound by its stores, not its arithmetic: profiles/r06_gemm_epilogue.md)
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-              f32x2 val, grd;
-              gelu_erf_both_pk(f32x2{v[j][k], v[j][k + 1]} + f32x2{bias[k], bias[k + 1]}, val, grd);
-              v[j][k] = val[0]; v[j][k + 1] = val[1];
-              pre[k] = grd[0]; pre[k + 1] = grd[1];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float ld = (float)cur[j][k];
-              v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
-            }
+          for (int k = 0; k < 8; ++k) {
+            const float ld = (float)cur[j][k];
+            v[j][k] = epi_apply(EPI, v[j][k], bias[k], ld, ld, pre[k]);
           }
           if (kCanBn && do_bn) {                     // of the values as STORED (rounded to E): what the BatchNorm behind the
 #pragma unroll                                        // layer normalises, and what every other route sums (halo / streamed-weight

@@ -178,7 +178,7 @@ def main():
         with open(os.path.join(outd, name), "w") as fh:
             fh.write(f"# rocprofv3 --kernel-trace, bench.py" + (f" --workload {wl}" if wl != "bench" else "") + f" ({tag}): per-step table\n\n"
                      "Steps = intervals between consecutive `adamw_fused_kernel` launches (hipGraph replay); the last 3 averaged.\n\n")
-            trace_steps.table(tr2, 3, 80, fh, os.path.join(outd, f"{tag}_{wl}_last_step_order.txt") if wl == "bench" else None)
+            trace_steps.table(tr2, 3, 260, fh, os.path.join(outd, f"{tag}_{wl}_last_step_order.txt") if wl == "bench" else None)
     # ---- traffic
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {cmd}.  gfx950: FETCH_SIZE counts "
             "64 B per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact.  FETCH_SIZE is counted at the L2 fabric side "
