@@ -1414,3 +1414,40 @@ def test_stem_convolution_from_an_lds_halo_patch(dvt, device, dtype, N, H, W, Co
     assert torch.equal(ops.conv_stem7(xp, wp, N, H, Wp), z)
     imp = ops.conv2d_implicit(xp, wp, N, 8, H, Wp, 64, (7, 4), (2, 1), (3, 2), trim_w=1)
     assert imp.shape == z.shape and rel_l2(z, imp) < tol
+
+
+@pytest.mark.parametrize("N,T,H,W", [(28, 12, 56, 56), (300, 12, 8, 8), (7, 8, 28, 28)])
+def test_helper_wave_kernels_are_deterministic(dvt, device, N, T, H, W):
+    """The sixteen-wave kernels of round 6 (compute waves + helper waves behind one barrier per tile: conv3x1_fwd_pipe,
+    conv3x1_wgrad_pipe, conv3x1_dbn; torchvision's Conv2Plus1D behind frame_transformer.py:64-74) hand buffers between wave
+    roles through counted vmcnt waits and barriers: a missing wait shows as run-to-run differences long before it shows in a
+    tolerance.  Six launches of each on the same operands -- at the product shape, with many more tiles than workgroups, and
+    with another frame count -- must agree bit for bit, with other kernels' traffic in between."""
+    ops = dvt.ops
+    Lp = H * W
+    rows = N * T * Lp
+    g = torch.Generator().manual_seed(5 + N + T)
+    z = torch.randn(rows, 144, generator=g).to(torch.bfloat16).cuda()
+    dy = (torch.randn(rows, 64, generator=g) / 8).to(torch.bfloat16).cuda()
+    w = (torch.randn(64, 144, 3, 1, generator=g) * 0.05).cuda()
+    wp = ops.conv_weight_pack(w, ops.conv2d_implicit_k(144, 64, (3, 1)), torch.bfloat16)
+    wd = ops.conv_weight_pack_dgrad(w, torch.bfloat16)
+    m0, is0 = (0.2 * torch.randn(144, generator=g)).cuda(), (1 + 0.3 * torch.rand(144, generator=g)).cuda()
+    ga, be = (1 + 0.2 * torch.randn(144, generator=g)).cuda(), (0.3 * torch.randn(144, generator=g)).cuda()
+    aff = (m0, is0, ga, be, 0, True)
+    noise = torch.randn(1 << 22, device="cuda")
+    first = None
+    for rep in range(6):
+        y, partial, parts = ops.conv3x1_fwd(z, wp, N, T, Lp, want_stats=True, affine=aff)
+        st = partial[:parts * 2 * 64].clone()
+        dw = torch.empty(64, 144, 3, 1, device="cuda")
+        ops.conv3x1_wgrad(z, dy, N, T, Lp, dw, affine=aff)
+        outs = [y, st, dw]
+        if ops.conv3x1_stream_supported(dy, wd, N, T, Lp, 64, 144):
+            outs += list(ops.conv3x1_stream_bn_bwd(dy, wd, z, aff, N, T, Lp, True))
+        noise.mul_(1.0001)                                       # (unrelated traffic between the repetitions)
+        if first is None:
+            first = [o.clone() for o in outs]
+        else:
+            for a, b in zip(outs, first):
+                assert torch.equal(a, b), rep
