@@ -1574,6 +1574,8 @@ class _ConvBnAct(torch.autograd.Function):
         tail = ()
         if defer_apply:                            # (mean, invstd) ride behind the data outputs
             ctx.mark_non_differentiable(mean, invstd)
+            # (autograd otherwise hands backward two zero-filled [C] "gradients" for them: two fill launches per pair)
+            ctx.set_materialize_grads(False)
             y, tail = y.view(y.shape), (mean, invstd)
         if fork is None:
             return (y,) + tail if tail else y
@@ -1593,6 +1595,8 @@ class _ConvBnAct(torch.autograd.Function):
             # of backward to its start, bench.py --force-dist)
             ln_flush()
         dshort = more[0] if (ctx.fork is not None and more) else None     # (behind it, under defer_apply: mean and invstd's)
+        if dy is None or (ctx.fork is not None and dshort is None):       # (unmaterialised gradients of a defer_apply layer)
+            raise RuntimeError("_ConvBnAct.backward: an output of a deferred-BatchNorm layer received no gradient")
         xc, wp, z, y, mean, invstd, g32, col, b32, pidx, rmask = ctx.saved_tensors
         geom, Cout, ld, direct, relu, training, has_res, wshape, dtype = ctx.cfg
         N, Cin, H, W, k, stride, pad, nchw = geom
