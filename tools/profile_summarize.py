@@ -58,9 +58,11 @@ def conv_family(name):
         return "conv3x3_stream"
     if "conv3x3_c64_wgrad_kernel" in name:
         return "conv3x3_c64_wgrad"
-    if "conv3x1_wgrad_kernel" in name:
+    if "conv3x1_dbn_kernel" in name:                       # round 6: the two passes of the same operator as a window kernel
+        return "conv3x1_stream_bn_bwd"
+    if "conv3x1_wgrad_kernel" in name or "conv3x1_wgrad_pipe_kernel" in name:
         return "conv3x1_wgrad"
-    if "conv3x1_fwd_kernel" in name:
+    if "conv3x1_fwd_kernel" in name or "conv3x1_fwd_pipe_kernel" in name:
         return "conv3x1_fwd"
     if "conv3x1_c64_kernel" in name:
         return "conv3x1_c64"
