@@ -578,8 +578,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const int c = blockIdx.x * CL + cl;
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
-    // four partial rows per round trip (a rolled loop waits for each before it requests the next); same order of additions
+    // sixteen, then eight, then four partial rows per round trip (a rolled loop waits for each before it requests the next; with
+    // four per trip the 8 - 18 rows a thread owns at 1024 - 2304 partial rows were two to five dependent trips to another XCD's L2:
+    // 6.4 -> 5.7 us for the 22 launches per frametransformer step that see that many); same order of additions
     int p = pl;
+    for (; p + 15 * PL < nparts; p += 16 * PL) {
+      float a[16], b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        a[u] = partial[((int64_t)(p + PL * u) * 2 + 0) * C + c];
+        b[u] = partial[((int64_t)(p + PL * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
+    }
+    if (p + 7 * PL < nparts) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = partial[((int64_t)(p + PL * u) * 2 + 0) * C + c];
+        b[u] = partial[((int64_t)(p + PL * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
+      p += 8 * PL;
+    }
     for (; p + 3 * PL < nparts; p += 4 * PL) {
       float a[4], b[4];
 #pragma unroll
@@ -598,9 +621,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   red[0][pl][cl] = s0;
   red[1][pl][cl] = s1;
   __syncthreads();
+  // lane tree in two levels (fixed order): part lanes 0 .. 7 each add PL / 8 consecutive lanes, lane 0 adds those eight (one
+  // thread adding all PL = 128 lanes was a chain of 128 dependent double additions)
+  constexpr int PG = PL / 8;
+  if (pl < 8) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < PG; ++q) { t0 += red[0][pl * PG + q][cl]; t1 += red[1][pl * PG + q][cl]; }
+    s0 = t0; s1 = t1;
+  }
+  __syncthreads();
+  if (pl < 8) { red[0][pl][cl] = s0; red[1][pl][cl] = s1; }
+  __syncthreads();
   if (pl != 0 || c >= C) return;
   s0 = 0.0; s1 = 0.0;
-  for (int p = 0; p < PL; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { s0 += red[0][p][cl]; s1 += red[1][p][cl]; }
   if (MODE == 0) {
     const double mud = s0 * (double)inv_rows;
     const double vard = s1 * (double)inv_rows - mud * mud;
