@@ -405,9 +405,16 @@ def cnn_roofline(summ, nprof, workload):
         if traffic and kind == "stream3x1_bn_bwd":
             traffic *= 2                     # one operator = two kernel launches (sums pass + apply pass); the family averages both
         alg_kind = sum(v[3] for v in fams.values() if v[4] == kind) / max(1, sum(v[2] for v in fams.values() if v[4] == kind))
+        # the same launches against the HBM peak on their ALGORITHMIC bytes: a family of narrow outputs (Cout <= 64 at a few
+        # hundred k-columns: ~64 flops per byte) is bounded by its bytes, not by the MFMA pipe -- `bound` names the roof the
+        # family is nearer to and `roof_frac` its fraction of that one
+        gbs = nb / (ms * 1e-3) / 1e9
+        mf, hf = tf / MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
         out["conv_families"][name] = {"ms_per_step": round(ms / nprof, 3), "launches_per_step": cnt // nprof,
-                                      "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                                      "achieved": round(tf, 1), "frac": round(mf, 4),
                                       "algorithmic_MB_per_launch": round(nb / cnt / 1e6, 1),
+                                      "algorithmic_GBps": round(gbs, 1), "hbm_frac": round(hf, 4),
+                                      "bound": "hbm" if hf > mf else "mfma", "roof_frac": round(max(mf, hf), 4),
                                       "traffic_ratio": round(traffic / alg_kind, 3) if traffic else None}
     agg = {}
     for key, (ms, units, cnt) in summ.items():
@@ -876,6 +883,7 @@ def compact_line(out):
                 fams = rr.get("conv_families") or {}
                 if fams:
                     e["roofline"]["conv_frac_min"] = min(f["frac"] for f in fams.values())
+                    e["roofline"]["conv_roof_frac_min"] = min(f.get("roof_frac", f["frac"]) for f in fams.values())
                     tr = [f["traffic_ratio"] for f in fams.values() if f.get("traffic_ratio")]
                     e["roofline"]["traffic_ratio_max"] = max(tr) if tr else None
                 bn = rr.get("hbm_kernels") or {}
