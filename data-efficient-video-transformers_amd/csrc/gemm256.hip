@@ -120,6 +120,13 @@ template <int ROWS, int TK, int NW>
 struct ConvRows {
   enum { PIECES = ROWS * TK * 2 / 1024, PPW = PIECES / NW, CPR = TK / 8, RPP = 64 / CPR };
   int pix[PPW], h0[PPW], w0[PPW], coff[PPW];
+  // C % TK == 0: the k-tiles of a workgroup are requested in order, TK channels apart, and C / TK of them share a filter tap --
+  // the lane's source addresses are carried and advanced by TK; the tap's bounds checks, the pixel arithmetic and the 64-bit
+  // multiply run once per TAP instead of once per k-tile (per k-tile they were ~12 vector instructions per 1-KiB piece, one
+  // of them quarter-rate: as many issue cycles as half the k-tile's MFMAs at one wave per SIMD, profiles/r06_implicit_l34_counters.md)
+  const bf16* src_[PPW];
+  unsigned okm_;
+  int c0_ = -1, ki_ = 0, kj_ = 0;
   __device__ __forceinline__ void init(const GemmParams& p, int m0, int wid, int lane) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -135,7 +142,7 @@ struct ConvRows {
       coff[i] = ((lane % CPR) ^ swz_k<TK>(row)) * 8;
     }
   }
-  __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) const {
+  __device__ __forceinline__ void dma(const GemmParams& p, int k0, char* tile, int wid) {
     if (p.cC == 8) {
       // Stem form (the 3 image channels zero-extended to 8, custom_resnet.py:100): a 16-byte chunk is one (pixel, tap), so
       // the chunks of a k-tile are consecutive taps and every lane derives its own tap; k >= kh*kw*8 (K is rounded up
@@ -170,6 +177,7 @@ struct ConvRows {
       }
       return;
     }
+#ifdef DVT_CONV_ROWS_PER_TILE
     const int tap = k0 / p.cC, c0 = k0 - tap * p.cC;
     const int ki = tap / p.ckw, kj = tap - ki * p.ckw;
 #pragma unroll
@@ -180,6 +188,33 @@ struct ConvRows {
                            : reinterpret_cast<const bf16*>(dvt_zero16);
       dvt_dma16(src, tile + (wid * PPW + i) * 1024);
     }
+#else
+    if (c0_ < 0 || c0_ >= p.cC) {                 // (wave-uniform) the first request, or the first k-tile of the next tap
+      if (c0_ < 0) {
+        const int tap = k0 / p.cC;
+        c0_ = k0 - tap * p.cC;
+        ki_ = tap / p.ckw;
+        kj_ = tap - ki_ * p.ckw;
+      } else {
+        c0_ = 0;
+        if (++kj_ == p.ckw) { kj_ = 0; ++ki_; }
+      }
+      okm_ = 0u;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int hi = h0[i] + ki_, wi = w0[i] + kj_;
+        const bool ok = (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+        src_[i] = p.A + ((int64_t)(pix[i] + hi * p.cW + wi) * p.cC + c0_ + coff[i]);     // (formed, not read, when !ok)
+        okm_ |= ok ? 1u << i : 0u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      dvt_dma16((okm_ >> i) & 1u ? src_[i] : reinterpret_cast<const bf16*>(dvt_zero16), tile + (wid * PPW + i) * 1024);
+      src_[i] += TK;
+    }
+    c0_ += TK;
+#endif
   }
 };
 
